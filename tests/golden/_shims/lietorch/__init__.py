@@ -1,0 +1,108 @@
+"""CPU stand-in for the un-vendored ``lietorch`` (reference .gitmodules:1-3) -- GOLDEN GENERATION ONLY.
+
+Used solely by tests/golden/make_golden.py to import the reference's Python
+formulation (geom/ba.py, geom/projective_ops.py) on CPU.  Implements the SE3
+subset listed in SURVEY.md Appendix C with plain torch ops; semantics follow the
+device helpers of src/droid_kernels.cu:67-184, 886-904.  Not part of the product.
+"""
+import torch
+
+
+def _cross(a, b):
+    return torch.stack([a[..., 1] * b[..., 2] - a[..., 2] * b[..., 1],
+                        a[..., 2] * b[..., 0] - a[..., 0] * b[..., 2],
+                        a[..., 0] * b[..., 1] - a[..., 1] * b[..., 0]], -1)
+
+
+def _rot(q, X):
+    uv = 2.0 * _cross(q[..., :3], X)
+    return X + q[..., 3:4] * uv + _cross(q[..., :3], uv)
+
+
+def _qmul(a, b):
+    ax, ay, az, aw = a.unbind(-1)
+    bx, by, bz, bw = b.unbind(-1)
+    return torch.stack([aw * bx + ax * bw + ay * bz - az * by,
+                        aw * by + ay * bw + az * bx - ax * bz,
+                        aw * bz + az * bw + ax * by - ay * bx,
+                        aw * bw - ax * bx - ay * by - az * bz], -1)
+
+
+class _Group:
+    manifold_dim = 6
+    embedded_dim = 7
+
+    def __init__(self, data):
+        self.data = data
+
+    @property
+    def shape(self):
+        return self.data.shape[:-1]
+
+    @property
+    def device(self):
+        return self.data.device
+
+    def __getitem__(self, index):
+        return self.__class__(self.data[index])
+
+    def detach(self):
+        return self.__class__(self.data.detach())
+
+
+class SE3(_Group):
+    def inv(self):
+        t, q = self.data[..., :3], self.data[..., 3:]
+        qi = torch.cat([-q[..., :3], q[..., 3:]], -1)
+        return SE3(torch.cat([-_rot(qi, t), qi], -1))
+
+    def __mul__(self, other):
+        t, q = self.data[..., :3], self.data[..., 3:]
+        if isinstance(other, SE3):
+            t2, q2 = other.data[..., :3], other.data[..., 3:]
+            return SE3(torch.cat([t + _rot(q, t2), _qmul(q, q2)], -1))
+        X = other                                   # homogeneous points [...,4]
+        Y = _rot(q, X[..., :3]) + X[..., 3:4] * t
+        return torch.cat([Y, X[..., 3:4]], -1)
+
+    def adjT(self, X):
+        t, q = self.data[..., :3], self.data[..., 3:]
+        qi = torch.cat([-q[..., :3], q[..., 3:]], -1)
+        a = _rot(qi, X[..., :3])
+        b = _rot(qi, X[..., 3:]) + _rot(qi, _cross(X[..., :3], t.expand_as(X[..., :3])))
+        return torch.cat([a, b], -1)
+
+    @staticmethod
+    def exp(xi):
+        tau, phi = xi[..., :3], xi[..., 3:]
+        th2 = (phi * phi).sum(-1, keepdim=True)
+        th = th2.sqrt()
+        small = th2 < 1e-8
+        ths = torch.where(small, torch.ones_like(th), th)
+        imag = torch.where(small, 0.5 - th2 / 48.0, torch.sin(0.5 * ths) / ths)
+        real = torch.where(small, 1.0 - th2 / 8.0, torch.cos(0.5 * ths))
+        q = torch.cat([imag * phi, real], -1)
+        big = th > 1e-4
+        a = (1 - torch.cos(ths)) / (ths * ths)
+        b = (ths - torch.sin(ths)) / (ths ** 3)
+        c1 = _cross(phi, tau)
+        c2 = _cross(phi, c1)
+        t = tau + torch.where(big, a * c1 + b * c2, torch.zeros_like(c1))
+        return SE3(torch.cat([t, q], -1))
+
+    def retr(self, xi):
+        return SE3.exp(xi) * self
+
+
+class Sim3(_Group):
+    manifold_dim = 7
+    embedded_dim = 8
+
+
+class SO3(_Group):
+    manifold_dim = 3
+    embedded_dim = 4
+
+
+def cat(xs, dim=0):
+    return xs[0].__class__(torch.cat([x.data for x in xs], dim))
