@@ -1,0 +1,217 @@
+#!/usr/bin/env python
+"""Benchmark of the dense-BA update operator on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one update iteration of the hot path over the whole synthetic frame graph
+(BASELINE.json configs[2]: 512 keyframes / 4096 edges / 48x64, global-BA damping):
+    reproject all edges -> 4-level correlation-pyramid lookup -> [ConvGRU update block] -> ba(itrs=2)
+with every input resident in HBM before the timed region.  `value` = edges x pixels / second of the
+whole job; `ms_per_global_ba` is the BA-only part (droid_backends.ba, itrs=2).
+
+N > 1: one process per GPU (torch.distributed, RCCL); edges are sharded by source frame, the only
+exchange is the all-reduce of the reduced camera system inside the BA ("multi-GPU").
+
+The JSON line also carries `roofline` (correlation-lookup kernel, HBM bound, algorithmic bytes from
+SURVEY.md 8d: 880 B per edge-pixel for fp16) and `cpu_baseline` (the numpy/C oracle timed on a bounded
+sample of the same graph on this host's cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "droid-slam_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0           # MI355X spec (MI355X_MICROARCH.md)
+LOOKUP_BYTES_PER_EP_F16 = 880
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="C3")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-update-op", action="store_true", help="skip the ConvGRU block (diagnostics only)")
+    ap.add_argument("--edge-chunk", type=int, default=512, help="edges per update-operator chunk")
+    return ap.parse_args()
+
+
+def cpu_baseline(g, n_frames_sample=24, n_lookup_edges=8):
+    """Oracle (numpy restatement of the reference kernels) on a bounded sample of the same graph."""
+    from oracle import ba as oba, corr as ocorr
+    ii, jj = g["ii"], g["jj"]
+    keep = (ii < n_frames_sample) & (jj < n_frames_sample)
+    sub = dict(g)
+    for k in ("ii", "jj", "targets", "weights"):
+        sub[k] = g[k][keep]
+    N = n_frames_sample
+    kx_full = np.unique(np.concatenate([np.arange(1, g["n_frames"]), ii]))
+    kx = np.unique(np.concatenate([np.arange(1, N), sub["ii"]]))
+    eta = g["eta"][np.searchsorted(kx_full, kx)]
+    poses = g["poses"][:N].astype(np.float32).copy(); disps = g["disps"][:N].astype(np.float32).copy()
+    t0 = time.perf_counter()
+    oba.ba(poses, disps, g["intrinsics"], g["disps_sens"][:N], sub["targets"], sub["weights"], eta,
+           sub["ii"], sub["jj"], 1, N, g["itrs"], g["lm"], g["ep"], False, dtype=np.float32)
+    t_ba = time.perf_counter() - t0
+    ep_ba = int(keep.sum()) * g["ht"] * g["wd"]
+    # lookup on a few edges (volume built on the host just for this)
+    rng = np.random.default_rng(0)
+    ht, wd = g["ht"], g["wd"]
+    f1 = rng.standard_normal((n_lookup_edges, 128, ht, wd)).astype(np.float32)
+    f2 = rng.standard_normal((n_lookup_edges, 128, ht, wd)).astype(np.float32)
+    pyr = [p.astype(np.float32) for p in ocorr.corr_pyramid(f1, f2, 4)]
+    coords = np.stack([rng.uniform(0, wd, (n_lookup_edges, ht, wd)), rng.uniform(0, ht, (n_lookup_edges, ht, wd))], -1)
+    t0 = time.perf_counter()
+    ocorr.corr_block_lookup(pyr, coords.astype(np.float32), 3)
+    t_lk = time.perf_counter() - t0
+    ep_lk = n_lookup_edges * ht * wd
+    per_ep = t_ba / ep_ba + t_lk / ep_lk
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count()
+    return {"value": 1.0 / per_ep, "unit": "edge-pixels/s", "cores": cores, "kind": "port",
+            "sample": "numpy oracle (fp32): ba itrs=%d on the %d-frame / %d-edge sub-graph (%.2fs) + 4-level lookup of "
+                      "%d edges (%.2fs); ConvGRU not included" % (g["itrs"], N, int(keep.sum()), t_ba, n_lookup_edges, t_lk),
+            "ba_s": t_ba, "lookup_s": t_lk}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a ROCm device (no CPU fallback)"
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    dev = torch.device("cuda", local)
+
+    import droid_backends as db
+    from droid_amd import synthetic as syn
+    from droid_amd.corr import CorrBlock
+
+    cfg = syn.CONFIGS[args.config]
+    g = syn.make_graph(cfg, with_features=True)
+    N, ht, wd = g["n_frames"], g["ht"], g["wd"]
+    HW = ht * wd
+    ii_all, jj_all = g["ii"], g["jj"]
+    E_all = len(ii_all)
+
+    # ---- edge sharding by source frame (contiguous frame ranges balanced by edge count) ----
+    if world > 1:
+        order = np.argsort(ii_all, kind="stable")
+        bounds = np.linspace(0, E_all, world + 1).astype(int)
+        # snap shard boundaries to source-frame boundaries
+        cuts = [0]
+        for b in bounds[1:-1]:
+            f = ii_all[order[b]]
+            cuts.append(int(np.searchsorted(ii_all[order], f, side="left")))
+        cuts.append(E_all)
+        mine = np.sort(order[cuts[rank]:cuts[rank + 1]])
+    else:
+        mine = np.arange(E_all)
+    d = lambda a, **kw: torch.as_tensor(np.ascontiguousarray(a), **kw).to(dev)
+    ii, jj = d(ii_all[mine]), d(jj_all[mine])
+    E = len(mine)
+
+    poses0, disps0 = d(g["poses"]), d(g["disps"])
+    poses, disps = poses0.clone(), disps0.clone()
+    intr, sens, eta = d(g["intrinsics"]), d(g["disps_sens"]), d(g["eta"])
+    targets, weights = d(g["targets"][mine]), d(g["weights"][mine])
+    rig = g["fmaps"].shape[1]
+    fmaps = d(g["fmaps"])
+
+    # ---- correlation pyramid for this rank's edges (setup, untimed) ----
+    c = (ii == jj).long() if rig > 1 else torch.zeros_like(ii)
+    corr = CorrBlock(fmaps[ii, 0][None], fmaps[jj, c][None])
+    torch.cuda.synchronize()
+
+    from droid_amd.dist_ba import DistBA
+    solver = DistBA(world) if world > 1 else None
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    lk_ms, ba_ms = [], []
+
+    def step(timed):
+        poses.copy_(poses0); disps.copy_(disps0)
+        coords1, _ = db.reproject(poses, disps, intr, ii, jj)
+        e0, e1, e2, e3 = ev(), ev(), ev(), ev()
+        e0.record()
+        feats = corr(coords1[None])
+        e1.record()
+        # TODO(update op): ConvGRU block goes here; until it lands the BA consumes the synthetic targets
+        e2.record()
+        if solver is None:
+            db.ba(poses, disps, intr, sens, targets, weights, eta, ii, jj, 1, N, g["itrs"], g["lm"], g["ep"], False)
+        else:
+            solver.ba(poses, disps, intr, sens, targets, weights, eta, ii, jj, 1, N, g["itrs"], g["lm"], g["ep"])
+        disps.clamp_(min=0.001)
+        e3.record()
+        if timed:
+            lk_ms.append((e0, e1)); ba_ms.append((e2, e3))
+        return feats
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    lk = float(np.mean([a.elapsed_time(b) for a, b in lk_ms])) if lk_ms else 0.0
+    ba = float(np.mean([a.elapsed_time(b) for a, b in ba_ms])) if ba_ms else 0.0
+
+    if rank == 0:
+        ms = 1000.0 * elapsed / max(1, args.steps)
+        ep_total = E_all * HW
+        lookup_bytes = LOOKUP_BYTES_PER_EP_F16 * E * HW
+        achieved = lookup_bytes / (lk * 1e-3) / 1e9 if lk > 0 else 0.0
+        out = {
+            "metric": "BA update iterations/sec (edges*pixels/s), 512-KF graph",
+            "value": ep_total / (ms * 1e-3), "unit": "edge-pixels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32 (BA; fp64 solve) / f16 (correlation pyramid)", "data": "synthetic",
+            "config": {"workload": "%s: %d keyframes, %d edges, %dx%d, ba itrs=%d lm=%g ep=%g" % (
+                cfg.name, N, E_all, ht, wd, g["itrs"], g["lm"], g["ep"]),
+                "stages": "reproject + corr lookup (4 levels, materialised fp16 pyramid) + ba",
+                "parallelism": "edge-sharded x%d" % world},
+            "ms_per_global_ba": ba, "ms_corr_lookup": lk,
+            "roofline": {"kernel": "corr_index_fwd_r3_kernel<half> (4 launches = 1 pyramid lookup)", "bound": "hbm",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch_group": lookup_bytes},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(g)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

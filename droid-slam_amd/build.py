@@ -1,0 +1,107 @@
+#!/usr/bin/env python
+"""In-tree build of the MI355X library and its torch binding (no JIT cache, no cmake).
+
+  libdroid_hip.so    hipcc --offload-arch=gfx950, all csrc/*.hip     -> the C ABI (include/droid_hip.h)
+  droid_backends.so  g++ csrc/droid_backends.cpp, links libtorch + libdroid_hip
+                     -> Python module `droid_backends` (same API as reference src/droid.cpp:246-259)
+
+Both land next to this file so that the gpurun snapshot carries them to the GPU box.
+hipcc cross-compiles gfx950 code objects without a GPU.  Usage:  python build.py [--force] [--verbose]
+"""
+import os
+import subprocess
+import sys
+import sysconfig
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
+ROOT = os.path.dirname(HERE)
+LIB = os.path.join(HERE, "libdroid_hip.so")
+EXT = os.path.join(HERE, "droid_backends.so")
+ARCH = os.environ.get("DROID_HIP_ARCH", "gfx950")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+HIP_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
+             "-Wno-unused-result", "-ffp-contract=fast"]
+
+
+def _run(cmd, verbose):
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("command failed: %s\n%s" % (" ".join(cmd), r.stdout))
+    if verbose and r.stdout.strip():
+        print(r.stdout)
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def hip_sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs.append(os.path.join(ROOT, "include", "droid_hip.h"))
+    return hs
+
+
+def build_lib(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = hip_sources()
+    hdrs = headers()
+    objs = []
+    jobs = []
+    for s in srcs:
+        o = os.path.join(OBJ, os.path.basename(s)[:-4] + ".o")
+        objs.append(o)
+        if force or _newer(o, [s] + hdrs):
+            jobs.append([HIPCC] + HIP_FLAGS + ["-c", s, "-o", o])
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        list(ex.map(lambda c: _run(c, verbose), jobs))
+    if force or jobs or _newer(LIB, objs):
+        _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs, verbose)
+    return LIB
+
+
+def build_ext(force=False, verbose=False):
+    import torch
+    from torch.utils import cpp_extension as ce
+    src = os.path.join(CSRC, "droid_backends.cpp")
+    if not (force or _newer(EXT, [src, LIB] + headers())):
+        return EXT
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    inc = []
+    for p in ce.include_paths():
+        inc += ["-isystem", p]
+    inc += ["-isystem", "/opt/rocm/include", "-I", sysconfig.get_paths()["include"]]
+    abi = int(torch._C._GLIBCXX_USE_CXX11_ABI)
+    obj = os.path.join(OBJ, "droid_backends.o")
+    cxx = os.environ.get("CXX", "g++")
+    _run([cxx, "-O2", "-std=c++17", "-fPIC", "-c", src, "-o", obj,
+          "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DTORCH_EXTENSION_NAME=droid_backends",
+          "-DTORCH_API_INCLUDE_EXTENSION_H", "-D_GLIBCXX_USE_CXX11_ABI=%d" % abi,
+          "-Wno-deprecated-declarations"] + inc, verbose)
+    _run([cxx, "-shared", "-o", EXT, obj, "-L" + tlib, "-L" + HERE,
+          "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch", "-ltorch_python", "-ldroid_hip",
+          "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + tlib], verbose)
+    return EXT
+
+
+def build_all(force=False, verbose=False):
+    build_lib(force, verbose)
+    build_ext(force, verbose)
+    return LIB, EXT
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv)
+    print("built:", LIB, EXT)

@@ -1,0 +1,826 @@
+// Dense bundle adjustment on the device: Gauss-Newton over SE(3) poses and per-pixel inverse depths
+// with a Schur complement onto the poses.  Replaces ba_cuda and its kernels
+// (reference src/droid_kernels.cu:185-433 projective_transform_kernel, :863-1007 accum, :1010-1124
+// EEt6x6/Ev6x1/EvT6x1, :1126-1228 SparseBlock (Eigen, CPU, fp64), :1231-1320 schur_block,
+// :1323-1443 ba_cuda).  Index conventions: SURVEY.md Appendix A.
+//
+// MI355X design (no host round trip anywhere; the reference crosses device->host->device >= 8x/iter):
+//   prep      one block: unique source frames (depth blocks), CSR of edges by source frame -- built on
+//             the device from ii (the reference argsorts on the CPU in every accum_cuda call);
+//   build     FRAME-centric: workgroup = (source frame k, pixel strip).  Loops over k's out-edges with
+//             lane = pixel, so per-frame sums (C_k, w_k, E_i[k]) are plain register accumulations in a
+//             fixed edge order -- no segment-sum kernels, no atomics.  Uses linearity Ji = -Adj^T Jj:
+//             only Hjj (21 entries) + vj are reduced per edge (wave64 shuffles + one LDS hop), the
+//             6x6 adjoint is applied once per edge in fp64 (pose_blocks) and once per pixel for E_i;
+//   gram      Schur blocks of one depth block as a TRUE contraction over pixels: G = M^T M with
+//             M = sqrt(Q) [E_slot0 .. E_slotn | w]  (HW x (6(n+1)+1)), on the exact-fp32 MFMA
+//             (v_mfma_f32_16x16x4_f32), K split over the 4 waves, reduced in LDS, accumulated into the
+//             fp64 reduced camera system;
+//   solve     hand-written blocked right-looking Cholesky in fp64 (48x48 blocks = 8 poses), the rhs is
+//             carried as an extra block row so forward substitution is free; damping and the
+//             "failure -> zero update" semantics of SparseBlock::solve are preserved;
+//   backsub   dz = Q (w - sum_slots E^T dx) incl. the reference's row-skip quirk (EvT6x1_kernel :1114),
+//             disps updated in place; poses retracted by exp(dx) * T.
+// The reduced camera system is accumulated with fp64 atomics (order-dependent only at the 1e-16
+// level); everything else is deterministic.
+#include "common.h"
+
+namespace {
+
+using namespace dh;
+
+constexpr int NB = 48;            // Cholesky block (8 poses)
+constexpr int NBP = NB + 1;       // padded LDS leading dimension (doubles)
+constexpr int PPT = 3;            // pixels per thread in build/backsub strips
+constexpr int STRIP = 256 * PPT;  // pixels per strip
+constexpr int HP_STRIDE = 28;     // per (edge, strip) partial: 21 Hjj + 6 vj (+1 pad)
+constexpr int GS = 10;            // slots per Gram chunk: 10*6 + 1 (w) = 61 <= 64 MFMA columns
+constexpr int GCOLS = 64;
+constexpr int GLD = 65;           // LDS leading dimension of the M tile (floats)
+constexpr float ALPHA_PRIOR = 0.05f;   // src/droid_kernels.cu:1405
+
+struct BaLayout {
+  size_t kmap, kx, eoff, cursor, eidx, meta;          // int32 arrays
+  size_t Q, W, Ei, Ej, Hpart;                          // f32
+  size_t H, x, Linv;                                   // f64
+  size_t dx;                                           // f32 [P,6]
+  size_t total;
+  int P, n, nbk, npad, ld, NS, Kmax;
+};
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+BaLayout make_layout(int F, int E, int HW, int t0, int t1, int motion_only) {
+  BaLayout L{};
+  L.P = t1 - t0;
+  L.n = 6 * L.P;
+  L.nbk = (L.n + NB - 1) / NB;
+  L.npad = L.nbk * NB;
+  L.ld = L.npad;
+  L.NS = (HW + STRIP - 1) / STRIP;
+  L.Kmax = F;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+  L.kmap = take(sizeof(int) * (size_t)F);
+  L.kx = take(sizeof(int) * (size_t)F);
+  L.eoff = take(sizeof(int) * ((size_t)F + 1));
+  L.cursor = take(sizeof(int) * (size_t)F);
+  L.eidx = take(sizeof(int) * (size_t)(E > 0 ? E : 1));
+  L.meta = take(sizeof(int) * 16);
+  L.Hpart = take(sizeof(float) * (size_t)(E > 0 ? E : 1) * L.NS * HP_STRIDE);
+  if (!motion_only) {
+    L.Q = take(sizeof(float) * (size_t)F * HW);
+    L.W = take(sizeof(float) * (size_t)F * HW);
+    L.Ei = take(sizeof(float) * (size_t)F * 6 * HW);
+    L.Ej = take(sizeof(float) * (size_t)(E > 0 ? E : 1) * 6 * HW);
+  }
+  L.H = take(sizeof(double) * (size_t)(L.npad + NB) * L.ld);
+  L.x = take(sizeof(double) * (size_t)L.npad);
+  L.Linv = take(sizeof(double) * (size_t)L.nbk * NB * NB);
+  L.dx = take(sizeof(float) * (size_t)(L.P > 0 ? L.P : 1) * 6);
+  L.total = off;
+  return L;
+}
+
+// meta[0] = K (number of depth blocks), meta[1] = Cholesky failure flag, meta[2] = bad-index flag
+
+// ------------------------------------------------------------------------------------------ prep
+__global__ __launch_bounds__(1024) void ba_prep_kernel(
+    const int64_t* __restrict__ ii, int E, int F, int t0, int t1,
+    int* __restrict__ kmap, int* __restrict__ kx, int* __restrict__ eoff, int* __restrict__ cursor,
+    int* __restrict__ eidx, int* __restrict__ meta) {
+  __shared__ int s_part[1024];
+  __shared__ int s_part2[1024];
+  const int tid = threadIdx.x;
+  // kmap doubles as "present" flag, cursor as degree
+  for (int f = tid; f < F; f += 1024) { kmap[f] = (f >= t0 && f < t1) ? 1 : 0; cursor[f] = 0; }
+  if (tid == 0) { meta[1] = 0; meta[2] = 0; }
+  __syncthreads();
+  for (int e = tid; e < E; e += 1024) {
+    long f = ii[e];
+    if (f >= 0 && f < F) { kmap[f] = 1; atomicAdd(&cursor[f], 1); }
+    else meta[2] = 1;
+  }
+  __syncthreads();
+  // block scan over frames: each thread owns a contiguous chunk
+  const int chunk = (F + 1023) / 1024;
+  const int f0 = tid * chunk, f1 = min(F, f0 + chunk);
+  int np = 0, nd = 0;
+  for (int f = f0; f < f1; ++f) { np += kmap[f]; nd += kmap[f] ? cursor[f] : 0; }
+  s_part[tid] = np; s_part2[tid] = nd;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    int a = 0, b = 0;
+    if (tid >= off) { a = s_part[tid - off]; b = s_part2[tid - off]; }
+    __syncthreads();
+    s_part[tid] += a; s_part2[tid] += b;
+    __syncthreads();
+  }
+  int kbase = s_part[tid] - np, ebase = s_part2[tid] - nd;
+  for (int f = f0; f < f1; ++f) {
+    if (kmap[f]) {
+      const int d = cursor[f];
+      kx[kbase] = f; eoff[kbase] = ebase; kmap[f] = kbase; cursor[f] = 0;
+      kbase++; ebase += d;
+    } else {
+      kmap[f] = -1;
+    }
+  }
+  if (tid == 1023) { meta[0] = s_part[1023]; }
+  __syncthreads();
+  const int K = meta[0];
+  if (tid == 0) eoff[K] = s_part2[1023];
+  __syncthreads();
+  for (int e = tid; e < E; e += 1024) {
+    long f = ii[e];
+    if (f >= 0 && f < F) {
+      const int k = kmap[f];
+      const int slot = atomicAdd(&cursor[f], 1);
+      eidx[eoff[k] + slot] = e;
+    }
+  }
+  __syncthreads();
+  // stable order inside each segment (ascending edge id): insertion sort, segments are short
+  for (int k = tid; k < K; k += 1024) {
+    const int a = eoff[k], b = eoff[k + 1];
+    for (int i = a + 1; i < b; ++i) {
+      int v = eidx[i], j = i - 1;
+      while (j >= a && eidx[j] > v) { eidx[j + 1] = eidx[j]; --j; }
+      eidx[j + 1] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ build
+struct EdgeGeom { SE3f T; bool stereo; };
+
+__device__ __forceinline__ EdgeGeom edge_geom(const float* __restrict__ poses, int i, int j) {
+  EdgeGeom g;
+  g.stereo = (i == j);
+  if (g.stereo) g.T = stereo_rel();
+  else g.T = rel(load_pose(poses + 7 * (long)i), load_pose(poses + 7 * (long)j));
+  return g;
+}
+
+// per-pixel residual / Jacobian terms of one edge (reference :290-385, restated)
+struct PixTerms { float ru, rv, wu, wv, Jju[6], Jjv[6], Jzu, Jzv; };
+
+__device__ __forceinline__ PixTerms pix_terms(const SE3f& T, float X, float Y, float h,
+                                              float tu, float tv, float wwu, float wwv,
+                                              float fx, float fy, float cx, float cy) {
+  PixTerms o;
+  Vec3 R = rot(T.q, {X, Y, 1.f});
+  const float x = R.x + h * T.t.x, y = R.y + h * T.t.y, z = R.z + h * T.t.z;
+  const bool bad = z < DH_MIN_DEPTH;
+  const float d = bad ? 0.f : 1.f / z;
+  const float d2 = d * d;
+  o.wu = bad ? 0.f : 0.001f * wwu;
+  o.wv = bad ? 0.f : 0.001f * wwv;
+  o.ru = tu - (fx * d * x + cx);
+  o.rv = tv - (fy * d * y + cy);
+  o.Jju[0] = fx * (h * d); o.Jju[1] = 0.f; o.Jju[2] = fx * (-x * h * d2);
+  o.Jju[3] = fx * (-x * y * d2); o.Jju[4] = fx * (1.f + x * x * d2); o.Jju[5] = fx * (-y * d);
+  o.Jjv[0] = 0.f; o.Jjv[1] = fy * (h * d); o.Jjv[2] = fy * (-y * h * d2);
+  o.Jjv[3] = fy * (-1.f - y * y * d2); o.Jjv[4] = fy * (x * y * d2); o.Jjv[5] = fy * (x * d);
+  o.Jzu = fx * (T.t.x * d - T.t.z * (x * d2));
+  o.Jzv = fy * (T.t.y * d - T.t.z * (y * d2));
+  return o;
+}
+
+template <bool MOTION_ONLY>
+__global__ __launch_bounds__(256) void ba_build_kernel(
+    const float* __restrict__ poses, const float* __restrict__ disps, const float* __restrict__ intr,
+    const float* __restrict__ disps_sens, const float* __restrict__ targets, const float* __restrict__ weights,
+    const float* __restrict__ eta, int n_eta_rows, const int64_t* __restrict__ jj,
+    const int* __restrict__ kx, const int* __restrict__ eoff, const int* __restrict__ eidx,
+    const int* __restrict__ meta, int HW, int wd, int NS,
+    float* __restrict__ Q, float* __restrict__ W, float* __restrict__ Ei, float* __restrict__ Ej,
+    float* __restrict__ Hpart) {
+  const int k = blockIdx.x;
+  if (k >= meta[0]) return;
+  const int strip = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int f = kx[k];
+  const float fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
+  __shared__ float s_red[4][HP_STRIDE];
+
+  int px[PPT]; bool ok[PPT]; float Xn[PPT], Yn[PPT], h[PPT];
+  float Cs[PPT], Ws[PPT], Eacc[PPT][6];
+#pragma unroll
+  for (int q = 0; q < PPT; ++q) {
+    px[q] = strip * STRIP + q * 256 + tid;
+    ok[q] = px[q] < HW;
+    const int p = ok[q] ? px[q] : 0;
+    const int row = p / wd, col = p - row * wd;
+    Xn[q] = ((float)col - cx) / fx;
+    Yn[q] = ((float)row - cy) / fy;
+    h[q] = disps[(long)f * HW + p];
+    Cs[q] = 0.f; Ws[q] = 0.f;
+#pragma unroll
+    for (int n = 0; n < 6; ++n) Eacc[q][n] = 0.f;
+  }
+
+  const int e0 = eoff[k], e1 = eoff[k + 1];
+  for (int ei = e0; ei < e1; ++ei) {
+    const int e = eidx[ei];
+    const int j = (int)jj[e];
+    const EdgeGeom g = edge_geom(poses, f, j);
+    float hj[21], vj[6];
+#pragma unroll
+    for (int l = 0; l < 21; ++l) hj[l] = 0.f;
+#pragma unroll
+    for (int n = 0; n < 6; ++n) vj[n] = 0.f;
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+      const int p = ok[q] ? px[q] : 0;
+      const float tu = targets[((long)e * 2 + 0) * HW + p], tv = targets[((long)e * 2 + 1) * HW + p];
+      const float wu0 = ok[q] ? weights[((long)e * 2 + 0) * HW + p] : 0.f;
+      const float wv0 = ok[q] ? weights[((long)e * 2 + 1) * HW + p] : 0.f;
+      PixTerms t = pix_terms(g.T, Xn[q], Yn[q], h[q], tu, tv, wu0, wv0, fx, fy, cx, cy);
+      if (!MOTION_ONLY) {
+        Cs[q] += t.wu * t.Jzu * t.Jzu + t.wv * t.Jzv * t.Jzv;
+        Ws[q] += t.wu * t.ru * t.Jzu + t.wv * t.rv * t.Jzv;
+      }
+      const float wu = g.stereo ? 0.f : t.wu, wv = g.stereo ? 0.f : t.wv;   // pose terms off for stereo pairs
+      int l = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+#pragma unroll
+        for (int b = 0; b <= a; ++b) { hj[l] += wu * t.Jju[a] * t.Jju[b] + wv * t.Jjv[a] * t.Jjv[b]; ++l; }
+        vj[a] += wu * t.ru * t.Jju[a] + wv * t.rv * t.Jjv[a];
+      }
+      if (!MOTION_ONLY) {
+        float ej[6], ei6[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) ej[a] = wu * t.Jzu * t.Jju[a] + wv * t.Jzv * t.Jjv[a];
+        adjT(g.T, ej, ei6);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          Eacc[q][a] -= ei6[a];
+          if (ok[q]) Ej[((long)e * 6 + a) * HW + p] = ej[a];
+        }
+      }
+    }
+    // block reduction of the 27 per-edge sums: wave shuffles, then 4 waves through LDS
+#pragma unroll
+    for (int l = 0; l < 21; ++l) hj[l] = wave_sum(hj[l]);
+#pragma unroll
+    for (int n = 0; n < 6; ++n) vj[n] = wave_sum(vj[n]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+      for (int l = 0; l < 21; ++l) s_red[wave][l] = hj[l];
+#pragma unroll
+      for (int n = 0; n < 6; ++n) s_red[wave][21 + n] = vj[n];
+    }
+    __syncthreads();
+    if (tid < 27)
+      Hpart[((long)e * NS + strip) * HP_STRIDE + tid] = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
+  }
+
+  if (!MOTION_ONLY) {
+    const int krow = k < n_eta_rows ? k : (n_eta_rows > 0 ? n_eta_rows - 1 : 0);
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+      if (!ok[q]) continue;
+      const int p = px[q];
+      const float ds = disps_sens[(long)f * HW + p];
+      const bool m = ds > 0.f;
+      const float C = Cs[q] + (m ? ALPHA_PRIOR : (n_eta_rows > 0 ? eta[(long)krow * HW + p] : 0.f));
+      const float w = Ws[q] - (m ? ALPHA_PRIOR * (h[q] - ds) : 0.f);
+      Q[(long)k * HW + p] = 1.f / C;
+      W[(long)k * HW + p] = w;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) Ei[((long)k * 6 + a) * HW + p] = Eacc[q][a];
+    }
+  }
+}
+
+// ---- per-edge pose Hessian blocks from the reduced Hjj / vj via the adjoint ---------------------
+__global__ __launch_bounds__(64) void ba_pose_blocks_kernel(
+    const float* __restrict__ poses, const int64_t* __restrict__ ii, const int64_t* __restrict__ jj,
+    const float* __restrict__ Hpart, int E, int NS, int t0, int P, double* __restrict__ H, int ld, int brow) {
+  const int e = blockIdx.x;
+  const int tid = threadIdx.x;
+  __shared__ double s_h[6][6], s_v[6], s_A[6][6], s_AH[6][6];
+  const int i = (int)ii[e], j = (int)jj[e];
+  if (i == j) return;                                    // stereo pair: no pose terms
+  const int pi = i - t0, pj = j - t0;
+  const bool vi_ok = pi >= 0 && pi < P, vj_ok = pj >= 0 && pj < P;
+  if (!vi_ok && !vj_ok) return;
+  if (tid < 27) {
+    double s = 0;
+    for (int st = 0; st < NS; ++st) s += (double)Hpart[((long)e * NS + st) * HP_STRIDE + tid];
+    if (tid < 21) {
+      int a = 0, rem = tid;
+      while (rem > a) { rem -= a + 1; ++a; }
+      s_h[a][rem] = s; s_h[rem][a] = s;
+    } else {
+      s_v[tid - 21] = s;
+    }
+  }
+  if (tid >= 32 && tid < 38) {                           // column c of A = -Adj(Tij)^T
+    const int c = tid - 32;
+    EdgeGeom g = edge_geom(poses, i, j);
+    float ec[6] = {0, 0, 0, 0, 0, 0}, col[6];
+    ec[c] = 1.f;
+    adjT(g.T, ec, col);
+    for (int r = 0; r < 6; ++r) s_A[r][c] = -(double)col[r];
+  }
+  __syncthreads();
+  if (tid < 36) {
+    const int r = tid / 6, c = tid % 6;
+    double s = 0;
+    for (int m = 0; m < 6; ++m) s += s_A[r][m] * s_h[m][c];
+    s_AH[r][c] = s;                                      // Hij = A Hjj
+  }
+  __syncthreads();
+  if (tid < 36) {
+    const int r = tid / 6, c = tid % 6;
+    if (vj_ok) atomicAdd(&H[(long)(6 * pj + r) * ld + 6 * pj + c], s_h[r][c]);
+    if (vi_ok && vj_ok) {
+      atomicAdd(&H[(long)(6 * pi + r) * ld + 6 * pj + c], s_AH[r][c]);     // Hij
+      atomicAdd(&H[(long)(6 * pj + r) * ld + 6 * pi + c], s_AH[c][r]);     // Hji = Hij^T
+    }
+    if (vi_ok) {
+      double s = 0;
+      for (int m = 0; m < 6; ++m) s += s_AH[r][m] * s_A[c][m];              // Hii = A Hjj A^T
+      atomicAdd(&H[(long)(6 * pi + r) * ld + 6 * pi + c], s);
+    }
+  } else if (tid < 42) {
+    const int r = tid - 36;
+    if (vj_ok) atomicAdd(&H[(long)brow * ld + 6 * pj + r], s_v[r]);
+    if (vi_ok) {
+      double s = 0;
+      for (int m = 0; m < 6; ++m) s += s_A[r][m] * s_v[m];
+      atomicAdd(&H[(long)brow * ld + 6 * pi + r], s);
+    }
+  }
+}
+
+// ---- Schur complement blocks of one depth block: Gram matrix on the fp32 MFMA -------------------
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__global__ __launch_bounds__(256) void ba_gram_kernel(
+    const float* __restrict__ Q, const float* __restrict__ W, const float* __restrict__ Ei,
+    const float* __restrict__ Ej, const int64_t* __restrict__ jj, const int* __restrict__ kx,
+    const int* __restrict__ eoff, const int* __restrict__ eidx, const int* __restrict__ meta,
+    int HW, int NSG, int t0, int P, double* __restrict__ H, int ld, int brow) {
+  const int k = blockIdx.x;
+  if (k >= meta[0]) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int f = kx[k];
+  const int e0 = eoff[k];
+  const int nslots = 1 + (eoff[k + 1] - e0);
+  const int nchunks = (nslots + GS - 1) / GS;
+  // pixel range of this block
+  const int per = ((HW + NSG - 1) / NSG + 63) / 64 * 64;
+  const int p_begin = blockIdx.y * per, p_end = min(HW, p_begin + per);
+  if (p_begin >= p_end) return;
+
+  __shared__ float s_M[2][64 * GLD];          // [chunk a / chunk b][px][col]
+  __shared__ float s_out[GCOLS * GCOLS];      // cross-wave reduction
+  __shared__ int s_pose[2][GS];
+
+  for (int ca = 0; ca < nchunks; ++ca) {
+    for (int cb = ca; cb < nchunks; ++cb) {
+      // pose index (relative) of every slot of both chunks; -1 = inactive
+      if (tid < 2 * GS) {
+        const int which = tid / GS, s = (which ? cb : ca) * GS + tid % GS;
+        int pose = -1;
+        if (s < nslots) {
+          const int fr = (s == 0) ? f : (int)jj[eidx[e0 + s - 1]];
+          const int r = fr - t0;
+          if (r >= 0 && r < P) pose = r;
+        }
+        s_pose[which][tid % GS] = pose;
+      }
+      f32x4 acc[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+      for (int pb = p_begin; pb < p_end; pb += 64) {
+        __syncthreads();
+        // stage M tiles: thread -> (pixel = tid&63, column group = tid>>6)
+        {
+          const int pl = tid & 63, p = pb + pl;
+          const bool pok = p < p_end;
+          const float sq = pok ? sqrtf(Q[(long)k * HW + p]) : 0.f;
+          for (int which = 0; which < (ca == cb ? 1 : 2); ++which) {
+            const int c = which ? cb : ca;
+            for (int col = tid >> 6; col < GCOLS; col += 4) {
+              float v = 0.f;
+              if (pok) {
+                if (col < 6 * GS) {
+                  const int s = c * GS + col / 6, a = col % 6;
+                  if (s < nslots) {
+                    v = (s == 0) ? Ei[((long)k * 6 + a) * HW + p]
+                                 : Ej[((long)eidx[e0 + s - 1] * 6 + a) * HW + p];
+                  }
+                } else if (col == 6 * GS) {
+                  v = W[(long)k * HW + p];
+                }
+              }
+              s_M[which][pl * GLD + col] = v * sq;
+            }
+          }
+        }
+        __syncthreads();
+        // each wave contracts 16 of the 64 pixels (K = 4 per MFMA)
+        const float* MA = s_M[0];
+        const float* MB = s_M[ca == cb ? 0 : 1];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int prow = wave * 16 + kk * 4 + (lane >> 4);
+          float a[4], b[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            a[t] = MA[prow * GLD + t * 16 + (lane & 15)];
+            b[t] = MB[prow * GLD + t * 16 + (lane & 15)];
+          }
+#pragma unroll
+          for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj)
+              acc[ti * 4 + tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ti], b[tj], acc[ti * 4 + tj], 0, 0, 0);
+        }
+      }
+      // reduce the 4 waves' partial Grams in LDS (fixed order), then add into the fp64 system
+      for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+          for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int row = ti * 16 + (lane >> 4) * 4 + r, col = tj * 16 + (lane & 15);
+                if (w == 0) s_out[row * GCOLS + col] = acc[ti * 4 + tj][r];
+                else s_out[row * GCOLS + col] += acc[ti * 4 + tj][r];
+              }
+        }
+      }
+      __syncthreads();
+      // G[row=(slot a, r)][col=(slot b, c)]  -> S block (pose_a, pose_b);  column 6*GS of chunk b = E Q w
+      for (int o = tid; o < 6 * GS * 6 * GS; o += 256) {
+        const int row = o / (6 * GS), col = o % (6 * GS);
+        const int sa = row / 6, sb = col / 6;
+        const int pa = s_pose[0][sa], pbq = s_pose[ca == cb ? 0 : 1][sb];
+        if (pa < 0 || pbq < 0) continue;
+        const double v = (double)s_out[row * GCOLS + col];
+        atomicAdd(&H[(long)(6 * pa + row % 6) * ld + 6 * pbq + col % 6], -v);
+        if (ca != cb) atomicAdd(&H[(long)(6 * pbq + col % 6) * ld + 6 * pa + row % 6], -v);
+      }
+      // rhs: bS[pose_a] += sum_px E_a Q w   (w column lives in chunk tile `b`; take it once per chunk a)
+      if (cb == ca) {
+        for (int o = tid; o < 6 * GS; o += 256) {
+          const int pa = s_pose[0][o / 6];
+          if (pa >= 0) atomicAdd(&H[(long)brow * ld + 6 * pa + o % 6], -(double)s_out[o * GCOLS + 6 * GS]);
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ solve
+__global__ void ba_damp_kernel(double* __restrict__ H, int ld, int n, int npad, double lm, double ep) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npad) return;
+  if (i < n) { const double d = H[(long)i * ld + i]; H[(long)i * ld + i] = d + ep + lm * d; }
+  else H[(long)i * ld + i] = 1.0;
+}
+
+// factor the diagonal block j (every workgroup redundantly, in LDS), then solve this workgroup's row block
+__global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ H, int ld, int j,
+                                                          double* __restrict__ Linv, int* __restrict__ meta) {
+  __shared__ double sL[NB * NBP];
+  __shared__ double sI[NB * NBP];
+  __shared__ double sX[NB * NBP];
+  const int tid = threadIdx.x;
+  const int r = j + blockIdx.x;
+  const long d0 = (long)j * NB;
+  for (int o = tid; o < NB * NB; o += 256) {
+    const int a = o / NB, b = o % NB;
+    sL[a * NBP + b] = (b <= a) ? H[(d0 + a) * ld + d0 + b] : 0.0;
+  }
+  __syncthreads();
+  for (int c = 0; c < NB; ++c) {
+    if (tid == 0) {
+      double d = sL[c * NBP + c];
+      if (!(d > 0.0) || !(d < 1e300)) { meta[1] = 1; d = 1.0; }
+      sL[c * NBP + c] = sqrt(d);
+    }
+    __syncthreads();
+    const double inv = 1.0 / sL[c * NBP + c];
+    if (tid > c && tid < NB) sL[tid * NBP + c] *= inv;
+    __syncthreads();
+    const int m = NB - 1 - c;                       // trailing size
+    for (int o = tid; o < m * m; o += 256) {
+      const int a = c + 1 + o / m, b = c + 1 + o % m;
+      if (b <= a) sL[a * NBP + b] -= sL[a * NBP + c] * sL[b * NBP + c];
+    }
+    __syncthreads();
+  }
+  // inverse of the lower-triangular factor, one column per thread
+  if (tid < NB) {
+    const int c = tid;
+    for (int a = 0; a < NB; ++a) sI[a * NBP + c] = 0.0;
+    sI[c * NBP + c] = 1.0 / sL[c * NBP + c];
+    for (int a = c + 1; a < NB; ++a) {
+      double s = 0;
+      for (int m = c; m < a; ++m) s += sL[a * NBP + m] * sI[m * NBP + c];
+      sI[a * NBP + c] = -s / sL[a * NBP + a];
+    }
+  }
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    for (int o = tid; o < NB * NB; o += 256) {
+      const int a = o / NB, b = o % NB;
+      H[(d0 + a) * ld + d0 + b] = sL[a * NBP + b];
+      Linv[(long)j * NB * NB + o] = sI[a * NBP + b];
+    }
+    return;
+  }
+  const long r0 = (long)r * NB;
+  for (int o = tid; o < NB * NB; o += 256) sX[(o / NB) * NBP + o % NB] = H[(r0 + o / NB) * ld + d0 + o % NB];
+  __syncthreads();
+  // Y = X * Linv^T  (Linv lower triangular)
+  for (int o = tid; o < NB * NB; o += 256) {
+    const int a = o / NB, c = o % NB;
+    double s = 0;
+    for (int m = 0; m <= c; ++m) s += sX[a * NBP + m] * sI[c * NBP + m];
+    H[(r0 + a) * ld + d0 + c] = s;
+  }
+}
+
+// trailing update A_rc -= L_rj L_cj^T for j < c <= r
+__global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ H, int ld, int j, int nbk) {
+  const int r = j + 1 + blockIdx.y, c = j + 1 + blockIdx.x;
+  if (c > r || c >= nbk) return;
+  __shared__ double sA[NB * NBP];
+  __shared__ double sB[NB * NBP];
+  const int tid = threadIdx.x;
+  const long r0 = (long)r * NB, c0 = (long)c * NB, d0 = (long)j * NB;
+  for (int o = tid; o < NB * NB; o += 256) {
+    const int a = o / NB, b = o % NB;
+    sA[a * NBP + b] = H[(r0 + a) * ld + d0 + b];
+    sB[a * NBP + b] = H[(c0 + a) * ld + d0 + b];
+  }
+  __syncthreads();
+  const int ty = tid >> 4, tx = tid & 15;               // 16x16 threads, 3x3 outputs each
+  double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  for (int m = 0; m < NB; ++m) {
+    double a[3], b[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) { a[u] = sA[(ty + 16 * u) * NBP + m]; b[u] = sB[(tx + 16 * u) * NBP + m]; }
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+      for (int v = 0; v < 3; ++v) acc[u][v] += a[u] * b[v];
+  }
+#pragma unroll
+  for (int u = 0; u < 3; ++u)
+#pragma unroll
+    for (int v = 0; v < 3; ++v) H[(r0 + ty + 16 * u) * ld + c0 + tx + 16 * v] -= acc[u][v];
+}
+
+// back substitution step j of L^T x = y (y lives in row `brow` of H): x_j = Linv_j^T y_j, then
+// y_r -= L_{j,r}^T x_j for this workgroup's r < j
+__global__ __launch_bounds__(64) void chol_backsub_kernel(double* __restrict__ H, int ld, int j, int brow,
+                                                           const double* __restrict__ Linv, double* __restrict__ x) {
+  __shared__ double sx[NB];
+  const int tid = threadIdx.x;
+  const long d0 = (long)j * NB;
+  if (tid < NB) {
+    double s = 0;
+    const double* I = Linv + (long)j * NB * NB;
+    for (int m = tid; m < NB; ++m) s += I[m * NB + tid] * H[(long)brow * ld + d0 + m];
+    sx[tid] = s;
+    if (blockIdx.x == 0) x[d0 + tid] = s;
+  }
+  __syncthreads();
+  const int r = (int)blockIdx.x - 1;
+  if (r < 0 || r >= j) return;
+  if (tid < NB) {
+    double s = 0;
+    for (int a = 0; a < NB; ++a) s += H[(d0 + a) * ld + (long)r * NB + tid] * sx[a];
+    H[(long)brow * ld + (long)r * NB + tid] -= s;
+  }
+}
+
+__global__ void ba_dx_kernel(const double* __restrict__ x, const int* __restrict__ meta, int n,
+                             float* __restrict__ dx_ws, float* __restrict__ dx_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = meta[1] ? 0.f : (float)x[i];
+  dx_ws[i] = v;
+  if (dx_out) dx_out[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------ update
+__global__ __launch_bounds__(256) void ba_backsub_kernel(
+    float* __restrict__ disps, const float* __restrict__ Q, const float* __restrict__ W,
+    const float* __restrict__ Ei, const float* __restrict__ Ej, const float* __restrict__ dx,
+    const int64_t* __restrict__ jj, const int* __restrict__ kx, const int* __restrict__ eoff,
+    const int* __restrict__ eidx, const int* __restrict__ meta, int HW, int t0, int P,
+    float* __restrict__ dz_out, int n_dz_rows) {
+  const int k = blockIdx.x;
+  const int p = blockIdx.y * 256 + threadIdx.x;
+  if (p >= HW) return;
+  if (k >= meta[0]) { if (dz_out && k < n_dz_rows) dz_out[(long)k * HW + p] = 0.f; return; }
+  const int f = kx[k];
+  float s = 0.f;
+  {
+    const int r = f - t0;
+    if (r > 0 && r < P) {                                   // rows with relative pose index <= 0 are skipped
+#pragma unroll
+      for (int a = 0; a < 6; ++a) s += Ei[((long)k * 6 + a) * HW + p] * dx[6 * r + a];
+    }
+  }
+  const int e0 = eoff[k], e1 = eoff[k + 1];
+  for (int ei = e0; ei < e1; ++ei) {
+    const int e = eidx[ei];
+    const int r = (int)jj[e] - t0;
+    if (r > 0 && r < P) {
+#pragma unroll
+      for (int a = 0; a < 6; ++a) s += Ej[((long)e * 6 + a) * HW + p] * dx[6 * r + a];
+    }
+  }
+  const float dz = Q[(long)k * HW + p] * (W[(long)k * HW + p] - s);
+  disps[(long)f * HW + p] += dz;
+  if (dz_out && k < n_dz_rows) dz_out[(long)k * HW + p] = dz;
+}
+
+__global__ void ba_pose_retr_kernel(float* __restrict__ poses, const float* __restrict__ dx, int t0, int P) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  float xi[6];
+#pragma unroll
+  for (int a = 0; a < 6; ++a) xi[a] = dx[6 * i + a];
+  SE3f T = load_pose(poses + 7 * (long)(t0 + i));
+  store_pose(poses + 7 * (long)(t0 + i), retr(xi, T));
+}
+
+// ------------------------------------------------------------------------------------------ host
+int check_args(int F, int E, int ht, int wd, int t0, int t1) {
+  if (F <= 0 || E < 0 || ht <= 0 || wd <= 0) return DH_ERR_ARG;
+  if (t0 < 0 || t1 < t0 || t1 > F) return DH_ERR_ARG;
+  return DH_OK;
+}
+
+int run_prep(const BaLayout& L, char* ws, const int64_t* ii, int E, int F, int t0, int t1, hipStream_t st) {
+  hipLaunchKernelGGL(ba_prep_kernel, dim3(1), dim3(1024), 0, st, ii, E, F, t0, t1,
+                     (int*)(ws + L.kmap), (int*)(ws + L.kx), (int*)(ws + L.eoff), (int*)(ws + L.cursor),
+                     (int*)(ws + L.eidx), (int*)(ws + L.meta));
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
+int run_build(const BaLayout& L, char* ws, const float* poses, const float* disps, const float* intr,
+              const float* disps_sens, const float* targets, const float* weights, const float* eta,
+              int n_eta_rows, const int64_t* ii, const int64_t* jj, int F, int E, int HW, int wd,
+              int t0, int motion_only, hipStream_t st) {
+  double* H = (double*)(ws + L.H);
+  if (hipMemsetAsync(H, 0, sizeof(double) * (size_t)(L.npad + NB) * L.ld, st) != hipSuccess) return DH_ERR_LAUNCH;
+  const int* kx = (const int*)(ws + L.kx); const int* eoff = (const int*)(ws + L.eoff);
+  const int* eidx = (const int*)(ws + L.eidx); const int* meta = (const int*)(ws + L.meta);
+  dim3 grid(F, L.NS);
+  if (motion_only)
+    hipLaunchKernelGGL(ba_build_kernel<true>, grid, dim3(256), 0, st, poses, disps, intr, disps_sens, targets,
+                       weights, eta, n_eta_rows, jj, kx, eoff, eidx, meta, HW, wd, L.NS,
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)(ws + L.Hpart));
+  else
+    hipLaunchKernelGGL(ba_build_kernel<false>, grid, dim3(256), 0, st, poses, disps, intr, disps_sens, targets,
+                       weights, eta, n_eta_rows, jj, kx, eoff, eidx, meta, HW, wd, L.NS,
+                       (float*)(ws + L.Q), (float*)(ws + L.W), (float*)(ws + L.Ei), (float*)(ws + L.Ej),
+                       (float*)(ws + L.Hpart));
+  DH_LAUNCH_CHECK();
+  if (E > 0 && L.P > 0) {
+    hipLaunchKernelGGL(ba_pose_blocks_kernel, dim3(E), dim3(64), 0, st, poses, ii, jj,
+                       (const float*)(ws + L.Hpart), E, L.NS, t0, L.P, H, L.ld, L.npad);
+    DH_LAUNCH_CHECK();
+  }
+  if (!motion_only && L.P > 0) {
+    const int NSG = HW >= 1536 ? 2 : 1;
+    hipLaunchKernelGGL(ba_gram_kernel, dim3(F, NSG), dim3(256), 0, st, (const float*)(ws + L.Q),
+                       (const float*)(ws + L.W), (const float*)(ws + L.Ei), (const float*)(ws + L.Ej), jj, kx,
+                       eoff, eidx, meta, HW, NSG, t0, L.P, H, L.ld, L.npad);
+    DH_LAUNCH_CHECK();
+  }
+  return DH_OK;
+}
+
+int run_finish(const BaLayout& L, char* ws, float* poses, float* disps, const int64_t* jj, int F, int HW,
+               int t0, float lm, float ep, int motion_only, float* dx_out, float* dz_out, int n_dz_rows,
+               hipStream_t st) {
+  double* H = (double*)(ws + L.H);
+  double* x = (double*)(ws + L.x);
+  double* Linv = (double*)(ws + L.Linv);
+  int* meta = (int*)(ws + L.meta);
+  float* dxw = (float*)(ws + L.dx);
+  if (L.P > 0) {
+    hipLaunchKernelGGL(ba_damp_kernel, dim3((L.npad + 255) / 256), dim3(256), 0, st, H, L.ld, L.n, L.npad,
+                       (double)lm, (double)ep);
+    const int nbrows = L.nbk + 1;                        // + rhs block row
+    for (int j = 0; j < L.nbk; ++j) {
+      hipLaunchKernelGGL(chol_panel_kernel, dim3(nbrows - j), dim3(256), 0, st, H, L.ld, j, Linv, meta);
+      const int m = nbrows - j - 1;
+      if (m > 0) hipLaunchKernelGGL(chol_update_kernel, dim3(m, m), dim3(256), 0, st, H, L.ld, j, L.nbk);
+    }
+    for (int j = L.nbk - 1; j >= 0; --j)
+      hipLaunchKernelGGL(chol_backsub_kernel, dim3(j + 1), dim3(64), 0, st, H, L.ld, j, L.npad, Linv, x);
+    hipLaunchKernelGGL(ba_dx_kernel, dim3((L.n + 255) / 256), dim3(256), 0, st, x, meta, L.n, dxw, dx_out);
+    DH_LAUNCH_CHECK();
+  }
+  if (!motion_only) {
+    hipLaunchKernelGGL(ba_backsub_kernel, dim3(F, (HW + 255) / 256), dim3(256), 0, st, disps,
+                       (const float*)(ws + L.Q), (const float*)(ws + L.W), (const float*)(ws + L.Ei),
+                       (const float*)(ws + L.Ej), dxw, jj, (const int*)(ws + L.kx), (const int*)(ws + L.eoff),
+                       (const int*)(ws + L.eidx), meta, HW, t0, L.P, dz_out, n_dz_rows);
+    DH_LAUNCH_CHECK();
+  }
+  if (L.P > 0) {
+    hipLaunchKernelGGL(ba_pose_retr_kernel, dim3((L.P + 63) / 64), dim3(64), 0, st, poses, dxw, t0, L.P);
+    DH_LAUNCH_CHECK();
+  }
+  return DH_OK;
+}
+
+}  // namespace
+
+extern "C" size_t dh_ba_workspace_bytes(int num_frames, int n_edges, int ht, int wd, int t0, int t1, int motion_only) {
+  if (check_args(num_frames, n_edges, ht, wd, t0, t1) != DH_OK) return 0;
+  return make_layout(num_frames, n_edges, ht * wd, t0, t1, motion_only).total;
+}
+
+extern "C" int dh_ba_build(const float* poses, const float* disps, const float* intrinsics, const float* disps_sens,
+                           const float* targets, const float* weights, const float* eta,
+                           const int64_t* ii, const int64_t* jj,
+                           int num_frames, int n_edges, int n_eta_rows, int ht, int wd,
+                           int t0, int t1, int motion_only,
+                           double** Hsys_out, double** bsys_out, void* workspace, size_t workspace_bytes,
+                           dh_stream_t stream) {
+  int rc = check_args(num_frames, n_edges, ht, wd, t0, t1);
+  if (rc != DH_OK) return rc;
+  if (!poses || !disps || !intrinsics || !workspace) return DH_ERR_ARG;
+  if (n_edges > 0 && (!targets || !weights || !ii || !jj)) return DH_ERR_ARG;
+  if (!motion_only && (!disps_sens || (n_eta_rows > 0 && !eta))) return DH_ERR_ARG;
+  const BaLayout L = make_layout(num_frames, n_edges, ht * wd, t0, t1, motion_only);
+  if (workspace_bytes < L.total) return DH_ERR_WORKSPACE;
+  char* ws = (char*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  rc = run_prep(L, ws, ii, n_edges, num_frames, t0, t1, st);
+  if (rc != DH_OK) return rc;
+  rc = run_build(L, ws, poses, disps, intrinsics, disps_sens, targets, weights, eta, n_eta_rows, ii, jj,
+                 num_frames, n_edges, ht * wd, wd, t0, motion_only, st);
+  if (Hsys_out) *Hsys_out = (double*)(ws + L.H);
+  if (bsys_out) *bsys_out = (double*)(ws + L.H) + (size_t)L.npad * L.ld;
+  return rc;
+}
+
+extern "C" int dh_ba_finish(float* poses, float* disps, const int64_t* jj,
+                            int num_frames, int n_edges, int ht, int wd, int t0, int t1,
+                            float lm, float ep, int motion_only, float* dx_out, float* dz_out,
+                            void* workspace, size_t workspace_bytes, dh_stream_t stream) {
+  int rc = check_args(num_frames, n_edges, ht, wd, t0, t1);
+  if (rc != DH_OK) return rc;
+  if (!poses || !disps || !workspace) return DH_ERR_ARG;
+  const BaLayout L = make_layout(num_frames, n_edges, ht * wd, t0, t1, motion_only);
+  if (workspace_bytes < L.total) return DH_ERR_WORKSPACE;
+  if (n_edges > 0 && !jj) return DH_ERR_ARG;
+  return run_finish(L, (char*)workspace, poses, disps, jj, num_frames, ht * wd, t0, lm, ep, motion_only,
+                    dx_out, dz_out, num_frames, (hipStream_t)stream);
+}
+
+extern "C" int dh_ba(float* poses, float* disps, const float* intrinsics, const float* disps_sens,
+                     const float* targets, const float* weights, const float* eta,
+                     const int64_t* ii, const int64_t* jj,
+                     int num_frames, int n_edges, int n_eta_rows, int ht, int wd,
+                     int t0, int t1, int iterations, float lm, float ep, int motion_only,
+                     float* dx_out, float* dz_out, void* workspace, size_t workspace_bytes, dh_stream_t stream) {
+  int rc = check_args(num_frames, n_edges, ht, wd, t0, t1);
+  if (rc != DH_OK) return rc;
+  if (iterations < 0) return DH_ERR_ARG;
+  if (!poses || !disps || !intrinsics || !workspace) return DH_ERR_ARG;
+  if (n_edges > 0 && (!targets || !weights || !ii || !jj)) return DH_ERR_ARG;
+  if (!motion_only && (!disps_sens || (n_eta_rows > 0 && !eta))) return DH_ERR_ARG;
+  const int HW = ht * wd;
+  const BaLayout L = make_layout(num_frames, n_edges, HW, t0, t1, motion_only);
+  if (workspace_bytes < L.total) return DH_ERR_WORKSPACE;
+  char* ws = (char*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  rc = run_prep(L, ws, ii, n_edges, num_frames, t0, t1, st);
+  if (rc != DH_OK) return rc;
+  for (int it = 0; it < iterations; ++it) {
+    rc = run_build(L, ws, poses, disps, intrinsics, disps_sens, targets, weights, eta, n_eta_rows, ii, jj,
+                   num_frames, n_edges, HW, wd, t0, motion_only, st);
+    if (rc != DH_OK) return rc;
+    const bool last = it == iterations - 1;
+    rc = run_finish(L, ws, poses, disps, jj, num_frames, HW, t0, lm, ep, motion_only,
+                    last ? dx_out : nullptr, last ? dz_out : nullptr, n_eta_rows, st);
+    if (rc != DH_OK) return rc;
+  }
+  return DH_OK;
+}

@@ -1,0 +1,148 @@
+// Shared device helpers for libdroid_hip (gfx950 / CDNA4, wave64).
+// SE(3) helpers follow the semantics of the reference's device functions
+// (reference src/droid_kernels.cu:67-184, 886-904); written for this library, f32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include "../../include/droid_hip.h"
+
+#define DH_WAVE 64
+#define DH_MIN_DEPTH 0.25f        // kernels' depth threshold (src/droid_kernels.cu:35)
+#define DH_MIN_DEPTH_PY 0.2f      // Python reprojection threshold (geom/projective_ops.py:6)
+
+#define DH_LAUNCH_CHECK()                                  \
+  do {                                                     \
+    if (hipGetLastError() != hipSuccess) return DH_ERR_LAUNCH; \
+  } while (0)
+
+namespace dh {
+
+struct Vec3 { float x, y, z; };
+struct Quat { float x, y, z, w; };
+struct SE3f { Vec3 t; Quat q; };
+
+__device__ __forceinline__ Vec3 cross(const Vec3& a, const Vec3& b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+
+// rotate X by unit quaternion q
+__device__ __forceinline__ Vec3 rot(const Quat& q, const Vec3& X) {
+  Vec3 qv{q.x, q.y, q.z};
+  Vec3 uv = cross(qv, X);
+  uv.x *= 2.f; uv.y *= 2.f; uv.z *= 2.f;
+  Vec3 c = cross(qv, uv);
+  return {X.x + q.w * uv.x + c.x, X.y + q.w * uv.y + c.y, X.z + q.w * uv.z + c.z};
+}
+
+__device__ __forceinline__ Quat qconj(const Quat& q) { return {-q.x, -q.y, -q.z, q.w}; }
+
+__device__ __forceinline__ Quat qmul(const Quat& a, const Quat& b) {
+  return {a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+          a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z,
+          a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x,
+          a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z};
+}
+
+__device__ __forceinline__ SE3f load_pose(const float* p) {
+  return {{p[0], p[1], p[2]}, {p[3], p[4], p[5], p[6]}};
+}
+__device__ __forceinline__ void store_pose(float* p, const SE3f& T) {
+  p[0] = T.t.x; p[1] = T.t.y; p[2] = T.t.z; p[3] = T.q.x; p[4] = T.q.y; p[5] = T.q.z; p[6] = T.q.w;
+}
+
+// Tij = Tj * Ti^-1
+__device__ __forceinline__ SE3f rel(const SE3f& Ti, const SE3f& Tj) {
+  SE3f r;
+  r.q = qmul(Tj.q, qconj(Ti.q));
+  Vec3 rt = rot(r.q, Ti.t);
+  r.t = {Tj.t.x - rt.x, Tj.t.y - rt.y, Tj.t.z - rt.z};
+  return r;
+}
+
+__device__ __forceinline__ SE3f inv(const SE3f& T) {
+  SE3f r;
+  r.q = qconj(T.q);
+  Vec3 rt = rot(r.q, T.t);
+  r.t = {-rt.x, -rt.y, -rt.z};
+  return r;
+}
+
+__device__ __forceinline__ SE3f mul(const SE3f& A, const SE3f& B) {
+  SE3f r;
+  r.q = qmul(A.q, B.q);
+  Vec3 rt = rot(A.q, B.t);
+  r.t = {A.t.x + rt.x, A.t.y + rt.y, A.t.z + rt.z};
+  return r;
+}
+
+// stereo pair: fixed right-camera offset (src/droid_kernels.cu:228-238)
+__device__ __forceinline__ SE3f stereo_rel() { return {{-0.1f, 0.f, 0.f}, {0.f, 0.f, 0.f, 1.f}}; }
+
+// Y = Adj(T)^T X on 6-vectors (tau,phi)
+__device__ __forceinline__ void adjT(const SE3f& T, const float* X, float* Y) {
+  Quat qi = qconj(T.q);
+  Vec3 a = rot(qi, {X[0], X[1], X[2]});
+  Vec3 b = rot(qi, {X[3], X[4], X[5]});
+  Vec3 u = cross({X[0], X[1], X[2]}, T.t);
+  Vec3 v = rot(qi, u);
+  Y[0] = a.x; Y[1] = a.y; Y[2] = a.z;
+  Y[3] = b.x + v.x; Y[4] = b.y + v.y; Y[5] = b.z + v.z;
+}
+
+__device__ __forceinline__ Quat so3_exp(const Vec3& phi) {
+  float th2 = phi.x * phi.x + phi.y * phi.y + phi.z * phi.z;
+  float th4 = th2 * th2;
+  float th = sqrtf(th2);
+  float imag, real;
+  if (th2 < 1e-8f) {
+    imag = 0.5f - (1.0f / 48.0f) * th2 + (1.0f / 3840.0f) * th4;
+    real = 1.0f - (1.0f / 8.0f) * th2 + (1.0f / 384.0f) * th4;
+  } else {
+    imag = sinf(0.5f * th) / th;
+    real = cosf(0.5f * th);
+  }
+  return {imag * phi.x, imag * phi.y, imag * phi.z, real};
+}
+
+__device__ __forceinline__ SE3f se3_exp(const float* xi) {
+  Vec3 tau{xi[0], xi[1], xi[2]}, phi{xi[3], xi[4], xi[5]};
+  SE3f r;
+  r.q = so3_exp(phi);
+  float th2 = phi.x * phi.x + phi.y * phi.y + phi.z * phi.z;
+  float th = sqrtf(th2);
+  r.t = tau;
+  if (th > 1e-4f) {
+    float a = (1.f - cosf(th)) / th2;
+    float b = (th - sinf(th)) / (th * th2);
+    Vec3 c1 = cross(phi, tau);
+    Vec3 c2 = cross(phi, c1);
+    r.t.x += a * c1.x + b * c2.x;
+    r.t.y += a * c1.y + b * c2.y;
+    r.t.z += a * c1.z + b * c2.z;
+  }
+  return r;
+}
+
+// exp(xi) * T
+__device__ __forceinline__ SE3f retr(const float* xi, const SE3f& T) { return mul(se3_exp(xi), T); }
+
+// ---- wave64 reductions (DPP-backed shuffles) -------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ float to_float(__half h) { return __half2float(h); }
+__device__ __forceinline__ float to_float(float f) { return f; }
+template <typename T> __device__ __forceinline__ T from_float(float f);
+template <> __device__ __forceinline__ float from_float<float>(float f) { return f; }
+template <> __device__ __forceinline__ __half from_float<__half>(float f) { return __float2half(f); }
+
+}  // namespace dh

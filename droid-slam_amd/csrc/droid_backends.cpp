@@ -1,0 +1,299 @@
+// Python module `droid_backends` on top of the C ABI of libdroid_hip.so.
+//
+// Same nine functions, positional signatures, in-place semantics and error convention as the
+// reference's pybind module (reference src/droid.cpp:93-259), so droid_slam/depth_video.py:196-222 and
+// droid_slam/modules/corr.py:12,19,79,86 call it unchanged.  This file only does what a torch binding
+// has to do: contiguity checks (TORCH_CHECK -> RuntimeError, as droid.cpp:89-90), output allocation on
+// the inputs' device, workspace allocation through torch's caching allocator, and handing the current
+// HIP stream to the C ABI.  No arithmetic happens here, and there is no CPU fallback: CPU tensors are
+// rejected.
+#include <torch/extension.h>
+#include <c10/hip/HIPStream.h>
+#include <vector>
+#include "../../include/droid_hip.h"
+
+namespace {
+
+#define CHECK_CONTIGUOUS(x) TORCH_CHECK(x.is_contiguous(), #x " must be contiguous")
+#define CHECK_DEVICE(x) TORCH_CHECK(x.is_cuda(), #x " must be a ROCm device tensor (droid_backends has no CPU path)")
+#define CHECK_INPUT(x) \
+  CHECK_DEVICE(x);     \
+  CHECK_CONTIGUOUS(x)
+#define CHECK_F32(x) TORCH_CHECK(x.scalar_type() == torch::kFloat32, #x " must be float32")
+#define CHECK_I64(x) TORCH_CHECK(x.scalar_type() == torch::kInt64, #x " must be int64")
+
+dh_stream_t cur_stream() { return (dh_stream_t)c10::hip::getCurrentHIPStream().stream(); }
+
+void check_status(int rc, const char* what) {
+  TORCH_CHECK(rc == DH_OK, what, ": ", dh_status_string(rc));
+}
+
+int dtype_code(const torch::Tensor& t, const char* name) {
+  if (t.scalar_type() == torch::kFloat16) return DH_F16;
+  if (t.scalar_type() == torch::kFloat32) return DH_F32;
+  TORCH_CHECK(false, name, " must be float16 or float32");
+  return -1;
+}
+
+// ---- ba (droid.cpp:93-122) --------------------------------------------------------------------
+std::vector<torch::Tensor> ba(torch::Tensor poses, torch::Tensor disps, torch::Tensor intrinsics,
+                              torch::Tensor disps_sens, torch::Tensor targets, torch::Tensor weights,
+                              torch::Tensor eta, torch::Tensor ii, torch::Tensor jj, const int t0, const int t1,
+                              const int iterations, const float lm, const float ep, const bool motion_only) {
+  CHECK_INPUT(targets); CHECK_INPUT(weights); CHECK_INPUT(poses); CHECK_INPUT(disps);
+  CHECK_INPUT(intrinsics); CHECK_INPUT(disps_sens); CHECK_INPUT(ii); CHECK_INPUT(jj);
+  CHECK_DEVICE(eta);
+  CHECK_F32(poses); CHECK_F32(disps); CHECK_F32(intrinsics); CHECK_F32(disps_sens);
+  CHECK_F32(targets); CHECK_F32(weights); CHECK_F32(eta); CHECK_I64(ii); CHECK_I64(jj);
+  eta = eta.contiguous();                           // the reference does not check eta (droid.cpp:110-117)
+  const int F = (int)disps.size(0), ht = (int)disps.size(1), wd = (int)disps.size(2);
+  const int E = (int)ii.size(0);
+  TORCH_CHECK(poses.size(0) >= F && disps_sens.size(0) >= F, "poses / disps_sens shorter than disps");
+  TORCH_CHECK(jj.size(0) == E && targets.size(0) == E && weights.size(0) == E, "edge count mismatch");
+  const int HW = ht * wd;
+  const int K = HW > 0 ? (int)(eta.numel() / HW) : 0;
+  const int P = t1 - t0;
+  auto fopts = poses.options();
+  torch::Tensor dx = torch::zeros({P > 0 ? P : 0, 6}, fopts);
+  torch::Tensor dz = torch::zeros({K, HW}, fopts);
+  const size_t wsb = dh_ba_workspace_bytes(F, E, ht, wd, t0, t1, motion_only ? 1 : 0);
+  TORCH_CHECK(wsb > 0, "ba: invalid arguments (t0/t1/buffer sizes)");
+  torch::Tensor ws = torch::empty({(int64_t)wsb}, poses.options().dtype(torch::kUInt8));
+  const int rc = dh_ba(poses.data_ptr<float>(), disps.data_ptr<float>(), intrinsics.data_ptr<float>(),
+                       disps_sens.data_ptr<float>(), targets.data_ptr<float>(), weights.data_ptr<float>(),
+                       eta.data_ptr<float>(), ii.data_ptr<int64_t>(), jj.data_ptr<int64_t>(),
+                       F, E, K, ht, wd, t0, t1, iterations, lm, ep, motion_only ? 1 : 0,
+                       dx.data_ptr<float>(), motion_only ? nullptr : dz.data_ptr<float>(),
+                       ws.data_ptr(), wsb, cur_stream());
+  check_status(rc, "ba");
+  return {dx, dz};
+}
+
+
+// ---- split BA for the edge-sharded multi-GPU solver: build -> (all-reduce of `system`) -> finish ------
+// returns {workspace (opaque, keeps everything alive), system [(npad+48), npad] f64 view into it}: rows
+// 0..npad-1 = reduced camera matrix (6P x 6P in the top-left corner), row npad = right-hand side.
+std::vector<torch::Tensor> ba_build(torch::Tensor poses, torch::Tensor disps, torch::Tensor intrinsics,
+                                    torch::Tensor disps_sens, torch::Tensor targets, torch::Tensor weights,
+                                    torch::Tensor eta, torch::Tensor ii, torch::Tensor jj, const int t0, const int t1,
+                                    const bool motion_only) {
+  CHECK_INPUT(targets); CHECK_INPUT(weights); CHECK_INPUT(poses); CHECK_INPUT(disps);
+  CHECK_INPUT(intrinsics); CHECK_INPUT(disps_sens); CHECK_INPUT(ii); CHECK_INPUT(jj); CHECK_INPUT(eta);
+  CHECK_F32(poses); CHECK_F32(disps); CHECK_F32(intrinsics); CHECK_F32(disps_sens);
+  CHECK_F32(targets); CHECK_F32(weights); CHECK_F32(eta); CHECK_I64(ii); CHECK_I64(jj);
+  const int F = (int)disps.size(0), ht = (int)disps.size(1), wd = (int)disps.size(2);
+  const int E = (int)ii.size(0), HW = ht * wd;
+  const int K = HW > 0 ? (int)(eta.numel() / HW) : 0;
+  const size_t wsb = dh_ba_workspace_bytes(F, E, ht, wd, t0, t1, motion_only ? 1 : 0);
+  TORCH_CHECK(wsb > 0, "ba_build: invalid arguments");
+  torch::Tensor ws = torch::empty({(int64_t)wsb}, poses.options().dtype(torch::kUInt8));
+  double* H = nullptr; double* b = nullptr;
+  check_status(dh_ba_build(poses.data_ptr<float>(), disps.data_ptr<float>(), intrinsics.data_ptr<float>(),
+                           disps_sens.data_ptr<float>(), targets.data_ptr<float>(), weights.data_ptr<float>(),
+                           eta.data_ptr<float>(), ii.data_ptr<int64_t>(), jj.data_ptr<int64_t>(), F, E, K, ht, wd,
+                           t0, t1, motion_only ? 1 : 0, &H, &b, ws.data_ptr(), wsb, cur_stream()),
+               "ba_build");
+  const int64_t n = 6 * (int64_t)(t1 - t0), npad = (n + 47) / 48 * 48;
+  torch::Tensor sys = torch::from_blob(H, {npad + 48, npad}, poses.options().dtype(torch::kFloat64));
+  return {ws, sys};
+}
+
+std::vector<torch::Tensor> ba_finish(torch::Tensor poses, torch::Tensor disps, torch::Tensor jj, torch::Tensor ws,
+                                     const int n_eta_rows, const int t0, const int t1, const float lm, const float ep,
+                                     const bool motion_only) {
+  CHECK_INPUT(poses); CHECK_INPUT(disps); CHECK_INPUT(jj); CHECK_INPUT(ws); CHECK_F32(poses); CHECK_F32(disps);
+  CHECK_I64(jj);
+  const int F = (int)disps.size(0), ht = (int)disps.size(1), wd = (int)disps.size(2), E = (int)jj.size(0);
+  const int P = t1 - t0;
+  torch::Tensor dx = torch::zeros({P > 0 ? P : 0, 6}, poses.options());
+  torch::Tensor dz = torch::zeros({F, ht * wd}, poses.options());
+  check_status(dh_ba_finish(poses.data_ptr<float>(), disps.data_ptr<float>(), jj.data_ptr<int64_t>(), F, E, ht, wd,
+                            t0, t1, lm, ep, motion_only ? 1 : 0, dx.data_ptr<float>(),
+                            motion_only ? nullptr : dz.data_ptr<float>(), ws.data_ptr(), (size_t)ws.numel(),
+                            cur_stream()),
+               "ba_finish");
+  return {dx, dz.narrow(0, 0, std::min(n_eta_rows, F))};
+}
+
+// ---- geometry (droid.cpp:125-171, 228-242) ------------------------------------------------------
+torch::Tensor frame_distance(torch::Tensor poses, torch::Tensor disps, torch::Tensor intrinsics,
+                             torch::Tensor ii, torch::Tensor jj, const float beta) {
+  CHECK_INPUT(poses); CHECK_INPUT(disps); CHECK_INPUT(intrinsics); CHECK_INPUT(ii); CHECK_INPUT(jj);
+  CHECK_F32(poses); CHECK_F32(disps); CHECK_F32(intrinsics); CHECK_I64(ii); CHECK_I64(jj);
+  const int M = (int)ii.size(0);
+  torch::Tensor dist = torch::zeros({M}, poses.options());
+  check_status(dh_frame_distance(poses.data_ptr<float>(), disps.data_ptr<float>(), intrinsics.data_ptr<float>(),
+                                 ii.data_ptr<int64_t>(), jj.data_ptr<int64_t>(), dist.data_ptr<float>(), M,
+                                 (int)disps.size(1), (int)disps.size(2), beta, cur_stream()),
+               "frame_distance");
+  return dist;
+}
+
+std::vector<torch::Tensor> projmap(torch::Tensor poses, torch::Tensor disps, torch::Tensor intrinsics,
+                                   torch::Tensor ii, torch::Tensor jj) {
+  CHECK_INPUT(poses); CHECK_INPUT(disps); CHECK_INPUT(intrinsics); CHECK_INPUT(ii); CHECK_INPUT(jj);
+  CHECK_F32(poses); CHECK_F32(disps); CHECK_F32(intrinsics); CHECK_I64(ii); CHECK_I64(jj);
+  const int M = (int)ii.size(0), ht = (int)disps.size(1), wd = (int)disps.size(2);
+  torch::Tensor coords = torch::empty({M, ht, wd, 3}, poses.options());
+  torch::Tensor valid = torch::empty({M, ht, wd, 1}, poses.options());
+  check_status(dh_projmap(poses.data_ptr<float>(), disps.data_ptr<float>(), intrinsics.data_ptr<float>(),
+                          ii.data_ptr<int64_t>(), jj.data_ptr<int64_t>(), coords.data_ptr<float>(),
+                          valid.data_ptr<float>(), M, ht, wd, cur_stream()),
+               "projmap");
+  return {coords, valid};
+}
+
+torch::Tensor iproj(torch::Tensor poses, torch::Tensor disps, torch::Tensor intrinsics) {
+  CHECK_INPUT(poses); CHECK_INPUT(disps); CHECK_INPUT(intrinsics);
+  CHECK_F32(poses); CHECK_F32(disps); CHECK_F32(intrinsics);
+  const int N = (int)disps.size(0), ht = (int)disps.size(1), wd = (int)disps.size(2);
+  torch::Tensor points = torch::empty({N, ht, wd, 3}, disps.options());
+  check_status(dh_iproj(poses.data_ptr<float>(), disps.data_ptr<float>(), intrinsics.data_ptr<float>(),
+                        points.data_ptr<float>(), N, ht, wd, cur_stream()),
+               "iproj");
+  return points;
+}
+
+torch::Tensor depth_filter(torch::Tensor poses, torch::Tensor disps, torch::Tensor intrinsics,
+                           torch::Tensor ix, torch::Tensor thresh) {
+  CHECK_INPUT(poses); CHECK_INPUT(disps); CHECK_INPUT(intrinsics); CHECK_INPUT(ix); CHECK_INPUT(thresh);
+  CHECK_F32(poses); CHECK_F32(disps); CHECK_F32(intrinsics); CHECK_I64(ix); CHECK_F32(thresh);
+  const int M = (int)ix.size(0), N = (int)disps.size(0), ht = (int)disps.size(1), wd = (int)disps.size(2);
+  torch::Tensor counter = torch::empty({M, ht, wd}, disps.options());
+  check_status(dh_depth_filter(poses.data_ptr<float>(), disps.data_ptr<float>(), intrinsics.data_ptr<float>(),
+                               ix.data_ptr<int64_t>(), thresh.data_ptr<float>(), counter.data_ptr<float>(), M, N,
+                               ht, wd, cur_stream()),
+               "depth_filter");
+  return counter;
+}
+
+// ---- correlation (droid.cpp:175-226) -------------------------------------------------------------
+std::vector<torch::Tensor> corr_index_forward(torch::Tensor volume, torch::Tensor coords, int radius) {
+  CHECK_INPUT(volume); CHECK_INPUT(coords); CHECK_F32(coords);
+  TORCH_CHECK(volume.dim() == 5 && coords.dim() == 4, "corr_index_forward: volume [N,h1,w1,h2,w2], coords [N,2,h1,w1]");
+  const int N = (int)volume.size(0), h1 = (int)volume.size(1), w1 = (int)volume.size(2);
+  torch::Tensor corr = torch::empty({N, 2 * radius + 1, 2 * radius + 1, h1, w1}, volume.options());
+  check_status(dh_corr_index_fwd(volume.data_ptr(), coords.data_ptr<float>(), corr.data_ptr(),
+                                 dtype_code(volume, "volume"), N, h1, w1, (int)volume.size(3), (int)volume.size(4),
+                                 radius, cur_stream()),
+               "corr_index_forward");
+  return {corr};
+}
+
+std::vector<torch::Tensor> corr_index_backward(torch::Tensor volume, torch::Tensor coords,
+                                               torch::Tensor corr_grad, int radius) {
+  CHECK_INPUT(volume); CHECK_INPUT(coords); CHECK_INPUT(corr_grad); CHECK_F32(coords);
+  TORCH_CHECK(corr_grad.scalar_type() == volume.scalar_type(), "corr_grad dtype must match volume");
+  torch::Tensor volume_grad = torch::empty_like(volume);
+  check_status(dh_corr_index_bwd(coords.data_ptr<float>(), corr_grad.data_ptr(), volume_grad.data_ptr(),
+                                 dtype_code(volume, "volume"), (int)volume.size(0), (int)volume.size(1),
+                                 (int)volume.size(2), (int)volume.size(3), (int)volume.size(4), radius, cur_stream()),
+               "corr_index_backward");
+  return {volume_grad};
+}
+
+std::vector<torch::Tensor> altcorr_forward(torch::Tensor fmap1, torch::Tensor fmap2, torch::Tensor coords,
+                                           torch::Tensor ii, torch::Tensor jj, int radius) {
+  CHECK_INPUT(fmap1); CHECK_INPUT(fmap2); CHECK_INPUT(coords); CHECK_DEVICE(ii); CHECK_DEVICE(jj);
+  CHECK_F32(coords); CHECK_I64(ii); CHECK_I64(jj);
+  TORCH_CHECK(fmap1.scalar_type() == fmap2.scalar_type(), "fmap dtypes differ");
+  ii = ii.contiguous(); jj = jj.contiguous();
+  const int B = (int)coords.size(0), M = (int)coords.size(1), H = (int)coords.size(3), W = (int)coords.size(4);
+  const int rd = 2 * radius + 1;
+  torch::Tensor corr = torch::empty({B, M, rd, rd, H, W}, fmap1.options());
+  check_status(dh_altcorr_fwd(fmap1.data_ptr(), fmap2.data_ptr(), coords.data_ptr<float>(), ii.data_ptr<int64_t>(),
+                              jj.data_ptr<int64_t>(), corr.data_ptr(), dtype_code(fmap1, "fmap1"), B,
+                              (int)fmap1.size(1), (int)fmap2.size(1), (int)fmap1.size(2), H, W, (int)fmap2.size(3),
+                              (int)fmap2.size(4), M, radius, cur_stream()),
+               "altcorr_forward");
+  return {corr};
+}
+
+// argument order follows the definition the reference actually links (droid.cpp:212-226)
+std::vector<torch::Tensor> altcorr_backward(torch::Tensor fmap1, torch::Tensor fmap2, torch::Tensor coords,
+                                            torch::Tensor corr_grad, torch::Tensor ii, torch::Tensor jj, int radius) {
+  CHECK_INPUT(fmap1); CHECK_INPUT(fmap2); CHECK_INPUT(coords); CHECK_INPUT(corr_grad);
+  CHECK_DEVICE(ii); CHECK_DEVICE(jj); CHECK_F32(coords); CHECK_I64(ii); CHECK_I64(jj);
+  ii = ii.contiguous(); jj = jj.contiguous();
+  torch::Tensor g = corr_grad.to(torch::kFloat32).contiguous();
+  torch::Tensor g1 = torch::zeros(fmap1.sizes(), fmap1.options().dtype(torch::kFloat32));
+  torch::Tensor g2 = torch::zeros(fmap2.sizes(), fmap2.options().dtype(torch::kFloat32));
+  const int B = (int)coords.size(0), M = (int)coords.size(1), H = (int)coords.size(3), W = (int)coords.size(4);
+  check_status(dh_altcorr_bwd(fmap1.data_ptr(), fmap2.data_ptr(), coords.data_ptr<float>(), ii.data_ptr<int64_t>(),
+                              jj.data_ptr<int64_t>(), g.data_ptr<float>(), g1.data_ptr<float>(),
+                              g2.data_ptr<float>(), dtype_code(fmap1, "fmap1"), B, (int)fmap1.size(1),
+                              (int)fmap2.size(1), (int)fmap1.size(2), H, W, (int)fmap2.size(3), (int)fmap2.size(4),
+                              M, radius, cur_stream()),
+               "altcorr_backward");
+  return {g1.to(fmap1.scalar_type()), g2.to(fmap2.scalar_type())};
+}
+
+// ---- extensions beyond the reference module (used by droid_amd / lietorch compat) ----------------
+std::vector<torch::Tensor> reproject(torch::Tensor poses, torch::Tensor disps, torch::Tensor intrinsics,
+                                     torch::Tensor ii, torch::Tensor jj) {
+  CHECK_INPUT(poses); CHECK_INPUT(disps); CHECK_INPUT(intrinsics); CHECK_INPUT(ii); CHECK_INPUT(jj);
+  CHECK_F32(poses); CHECK_F32(disps); CHECK_F32(intrinsics); CHECK_I64(ii); CHECK_I64(jj);
+  const int E = (int)ii.size(0), ht = (int)disps.size(1), wd = (int)disps.size(2);
+  torch::Tensor coords = torch::empty({E, ht, wd, 2}, poses.options());
+  torch::Tensor valid = torch::empty({E, ht, wd, 1}, poses.options());
+  check_status(dh_reproject(poses.data_ptr<float>(), disps.data_ptr<float>(), intrinsics.data_ptr<float>(),
+                            ii.data_ptr<int64_t>(), jj.data_ptr<int64_t>(), coords.data_ptr<float>(),
+                            valid.data_ptr<float>(), E, ht, wd, cur_stream()),
+               "reproject");
+  return {coords, valid};
+}
+
+torch::Tensor se3_op(const std::string& op, torch::Tensor a, torch::Tensor b) {
+  CHECK_INPUT(a); CHECK_F32(a);
+  const bool two = (op == "mul" || op == "retr");
+  if (two) { CHECK_INPUT(b); CHECK_F32(b); }
+  const int64_t n = (op == "exp" || op == "retr") ? a.numel() / 6 : a.numel() / 7;
+  auto shape = a.sizes().vec();
+  shape.back() = 7;
+  torch::Tensor out = torch::empty(shape, a.options());
+  int rc;
+  if (op == "inv") rc = dh_se3_inv(a.data_ptr<float>(), out.data_ptr<float>(), (int)n, cur_stream());
+  else if (op == "mul") rc = dh_se3_mul(a.data_ptr<float>(), b.data_ptr<float>(), out.data_ptr<float>(), (int)n, cur_stream());
+  else if (op == "exp") rc = dh_se3_exp(a.data_ptr<float>(), out.data_ptr<float>(), (int)n, cur_stream());
+  else if (op == "retr") rc = dh_se3_retr(a.data_ptr<float>(), b.data_ptr<float>(), out.data_ptr<float>(), (int)n, cur_stream());
+  else { TORCH_CHECK(false, "se3_op: unknown op ", op); rc = DH_ERR_ARG; }
+  check_status(rc, "se3_op");
+  return out;
+}
+
+// a [n,7], X [n,npts,D] with D = 4 (act) or 6 (adjT)
+torch::Tensor se3_map(const std::string& op, torch::Tensor a, torch::Tensor X) {
+  CHECK_INPUT(a); CHECK_INPUT(X); CHECK_F32(a); CHECK_F32(X);
+  const int n = (int)(a.numel() / 7);
+  const int D = (op == "act4") ? 4 : 6;
+  TORCH_CHECK(X.size(-1) == D, "se3_map: last dim must be ", D);
+  const int npts = n > 0 ? (int)(X.numel() / D / n) : 0;
+  torch::Tensor Y = torch::empty_like(X);
+  int rc = (op == "act4") ? dh_se3_act4(a.data_ptr<float>(), X.data_ptr<float>(), Y.data_ptr<float>(), n, npts, cur_stream())
+                          : dh_se3_adjT(a.data_ptr<float>(), X.data_ptr<float>(), Y.data_ptr<float>(), n, npts, cur_stream());
+  check_status(rc, "se3_map");
+  return Y;
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  // bundle adjustment kernels (names and order as reference src/droid.cpp:246-259)
+  m.def("ba", &ba, "bundle adjustment");
+  m.def("frame_distance", &frame_distance, "frame_distance");
+  m.def("projmap", &projmap, "projmap");
+  m.def("depth_filter", &depth_filter, "depth_filter");
+  m.def("iproj", &iproj, "back projection");
+  // correlation volume kernels
+  m.def("altcorr_forward", &altcorr_forward, "ALTCORR forward");
+  m.def("altcorr_backward", &altcorr_backward, "ALTCORR backward");
+  m.def("corr_index_forward", &corr_index_forward, "INDEX forward");
+  m.def("corr_index_backward", &corr_index_backward, "INDEX backward");
+  // MI355X extensions (not in the reference module)
+  m.def("ba_build", &ba_build, "per-rank reduced camera system (split BA)");
+  m.def("ba_finish", &ba_finish, "damp + solve + back-substitute + retract (split BA)");
+  m.def("reproject", &reproject, "fused reprojection (Python thresholds)");
+  m.def("se3_op", &se3_op, "SE3 inv/mul/exp/retr");
+  m.def("se3_map", &se3_map, "SE3 act4/adjT");
+  m.def("version", []() { return std::string(dh_version()); });
+}

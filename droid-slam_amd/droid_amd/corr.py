@@ -1,0 +1,80 @@
+"""Host-side mirrors of the reference's correlation blocks on top of droid_backends.
+
+Same constructor / call interface as ``CorrBlock`` and ``AltCorrBlock`` of the reference
+(droid_slam/modules/corr.py:23-60, 89-117) so that factor-graph code written against them runs as is.
+Inference only (no autograd): the hot path runs under ``torch.no_grad()`` in the reference as well
+(droid_slam/droid.py:62, droid_backend.py:24).
+
+``CorrBlock``     materialised 4-level pyramid in the reference layout
+                  ``[E, h1, w1, h2/2^l, w2/2^l]``; lookup = droid_backends.corr_index_forward per level.
+``AltCorrBlock``  on-the-fly correlation from pooled feature pyramids; lookup =
+                  droid_backends.altcorr_forward per level.
+"""
+import torch
+import torch.nn.functional as F
+
+import droid_backends
+
+
+class CorrBlock:
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=3, chunk=64):
+        self.num_levels = num_levels
+        self.radius = radius
+        batch, num, dim, ht, wd = fmap1.shape
+        assert batch == 1, "CorrBlock mirrors the inference path (batch == 1)"
+        self.corr_pyramid = [
+            torch.empty(num, ht, wd, ht // 2 ** l, wd // 2 ** l, dtype=fmap1.dtype, device=fmap1.device)
+            for l in range(num_levels)]
+        f1 = fmap1[0].reshape(num, dim, ht * wd) / 4.0
+        f2 = fmap2[0].reshape(num, dim, ht * wd) / 4.0
+        for s in range(0, num, chunk):                      # bounded temporaries, volumes written in place
+            e = min(num, s + chunk)
+            corr = torch.matmul(f1[s:e].transpose(1, 2), f2[s:e]).reshape((e - s) * ht * wd, 1, ht, wd)
+            for l in range(num_levels):
+                self.corr_pyramid[l][s:e] = corr.view(e - s, ht, wd, ht // 2 ** l, wd // 2 ** l)
+                if l + 1 < num_levels:
+                    corr = F.avg_pool2d(corr, 2, stride=2)
+
+    def __call__(self, coords):
+        batch, num, ht, wd, _ = coords.shape
+        c = coords.permute(0, 1, 4, 2, 3).contiguous().view(batch * num, 2, ht, wd)
+        out = []
+        for l in range(self.num_levels):
+            corr, = droid_backends.corr_index_forward(self.corr_pyramid[l], c / 2 ** l, self.radius)
+            out.append(corr.view(batch, num, -1, ht, wd))
+        return torch.cat(out, dim=2)
+
+    def cat(self, other):
+        for l in range(self.num_levels):
+            self.corr_pyramid[l] = torch.cat([self.corr_pyramid[l], other.corr_pyramid[l]], 0)
+        return self
+
+    def __getitem__(self, index):
+        for l in range(self.num_levels):
+            self.corr_pyramid[l] = self.corr_pyramid[l][index]
+        return self
+
+    def bytes(self):
+        return sum(v.numel() * v.element_size() for v in self.corr_pyramid)
+
+
+class AltCorrBlock:
+    def __init__(self, fmaps, num_levels=4, radius=3):
+        self.num_levels = num_levels
+        self.radius = radius
+        B, N, C, H, W = fmaps.shape
+        f = fmaps.reshape(B * N, C, H, W)
+        self.pyramid = []
+        for l in range(num_levels):
+            self.pyramid.append(f.view(B, N, C, H // 2 ** l, W // 2 ** l))
+            if l + 1 < num_levels:
+                f = F.avg_pool2d(f, 2, stride=2)
+
+    def __call__(self, coords, ii, jj):
+        c = coords.permute(0, 1, 4, 2, 3).contiguous()
+        outs = []
+        for l in range(self.num_levels):
+            corr, = droid_backends.altcorr_forward(self.pyramid[0], self.pyramid[l].contiguous(), c / 2 ** l,
+                                                   ii, jj, self.radius)
+            outs.append(corr.flatten(2, 3))
+        return torch.stack(outs, dim=2).flatten(2, 3)

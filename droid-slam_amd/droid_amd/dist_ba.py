@@ -1,0 +1,99 @@
+"""Edge-sharded dense BA across the GPUs of one node (new design, the reference has no
+collective in its BA path).
+
+Partition: contiguous ranges of SOURCE frames balanced by edge count -- the axis the reference chunks on
+(droid_slam/factor_graph.py:284-287).  Rank r holds the edges whose source frame it owns, their
+targets/weights (and correlation volumes / GRU state) and is the only rank that updates the inverse
+depths of its frames; poses are replicated (28 B per frame).
+
+Per Gauss-Newton iteration:
+    build    every rank reduces ITS edges to a partial reduced camera system  (droid_backends.ba_build)
+    exchange ONE all-reduce (sum, fp64) of [A - S | v - b_S] over RCCL/xGMI   (torch.distributed)
+    finish   every rank damps + solves redundantly (no broadcast), back-substitutes the depths of its own
+             frames and retracts the replicated poses                         (droid_backends.ba_finish)
+At the end the owned depth maps are exchanged with one all-reduce of the depth increments so that every
+rank leaves with the full, identical `disps` buffer (what depth_video.ba's callers expect).
+
+Reduction order differs from the single-GPU run, so results agree to fp32 tolerance, not bitwise.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_edges_by_source_frame(ii, world):
+    """Host-side partition.  ii: int array of source frames.  Returns (edge index arrays per rank,
+    frame-range boundaries [world+1]) with every source frame's edges on exactly one rank."""
+    ii = np.asarray(ii)
+    E = len(ii)
+    order = np.argsort(ii, kind="stable")
+    s = ii[order]
+    cuts = [0]
+    for r in range(1, world):
+        b = (E * r) // world
+        if b <= cuts[-1]:
+            cuts.append(cuts[-1]); continue
+        f = s[min(b, E - 1)]
+        lo = int(np.searchsorted(s, f, side="left"))
+        hi = int(np.searchsorted(s, f, side="right"))
+        cut = lo if (b - lo) <= (hi - b) else hi          # snap to the nearer frame boundary
+        cuts.append(max(cut, cuts[-1]))
+    cuts.append(E)
+    shards = [np.sort(order[cuts[r]:cuts[r + 1]]) for r in range(world)]
+    nf = int(ii.max()) + 1 if E else 0
+    bounds = [0]
+    for r in range(1, world):
+        bounds.append(int(s[cuts[r]]) if cuts[r] < E else nf)
+    bounds.append(1 << 30)
+    for r in range(1, world + 1):
+        bounds[r] = max(bounds[r], bounds[r - 1])
+    return shards, bounds
+
+
+def local_eta_rows(ii_all, ii_local, t0, t1):
+    """Rows of the global eta (ordered by unique(arange(t0,t1) U ii_all)) that belong to the local
+    depth-block list unique(arange(t0,t1) U ii_local)."""
+    kx_g = np.unique(np.concatenate([np.arange(t0, t1), np.asarray(ii_all)]))
+    kx_l = np.unique(np.concatenate([np.arange(t0, t1), np.asarray(ii_local)]))
+    return np.searchsorted(kx_g, kx_l), kx_l
+
+
+class DistBA:
+    """ba() with the droid_backends.ba contract, applied to this rank's edge shard."""
+
+    def __init__(self, world=None, frame_lo=0, frame_hi=1 << 30, group=None, backend=None):
+        self.world = dist.get_world_size(group) if (world is None and dist.is_initialized()) else (world or 1)
+        self.group = group
+        self.frame_lo, self.frame_hi = frame_lo, frame_hi
+        if backend is None:
+            import droid_backends as backend          # HIP path; fails loudly without the extension
+        self.be = backend
+
+    def set_owned_frames(self, lo, hi):
+        self.frame_lo, self.frame_hi = int(lo), int(hi)
+
+    def _allreduce(self, t):
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def ba(self, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1,
+           iterations=2, lm=1e-4, ep=0.1, motion_only=False):
+        F = disps.shape[0]
+        lo, hi = max(0, self.frame_lo), min(F, self.frame_hi)
+        disps_in = disps.clone()
+        dx = dz = None
+        for _ in range(iterations):
+            before = disps.clone() if not motion_only else None
+            ws, system = self.be.ba_build(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj,
+                                          t0, t1, motion_only)
+            self._allreduce(system)
+            dx, dz = self.be.ba_finish(poses, disps, jj, ws, eta.shape[0], t0, t1, lm, ep, motion_only)
+            if not motion_only:
+                # only the owner of a frame updates its depth map
+                disps[:lo] = before[:lo]
+                disps[hi:] = before[hi:]
+        if not motion_only and self.world > 1:
+            delta = disps - disps_in
+            self._allreduce(delta)
+            disps.copy_(disps_in + delta)
+        return dx, dz

@@ -1,0 +1,156 @@
+/*
+ * droid_hip.h -- C ABI of libdroid_hip.so: the MI355X (gfx950) implementation of DROID-SLAM's
+ * dense bundle-adjustment update operator.
+ *
+ * This is the drop-in boundary: plain pointers + sizes + a HIP stream, no torch types.  Each entry
+ * point replaces one function that the reference registers in its `droid_backends` extension
+ * (reference src/droid.cpp:246-259); the torch binding in droid-slam_amd/csrc/droid_backends.cpp
+ * re-creates that Python module on top of these calls.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless the name ends in `_host`;
+ *   - tensors are dense, row-major ("contiguous") in the shapes given below;
+ *   - `stream` is a hipStream_t (passed as void* so that C callers need no HIP headers); all work is
+ *     enqueued on it and the call returns without synchronising;
+ *   - poses are world->camera [tx,ty,tz,qx,qy,qz,qw]; tangent vectors are (tau,phi); updates are
+ *     LEFT multiplications exp(xi)*T (reference src/droid_kernels.cu:886-904);
+ *   - return value: DH_OK (0) or a DH_ERR_* code; dh_status_string() names it.  Argument errors are
+ *     detected before anything is enqueued.  Like the reference, a failed Cholesky factorisation is
+ *     NOT an error: the pose update of that iteration is zero (src/droid_kernels.cu:1211-1219).
+ */
+#ifndef DROID_HIP_H
+#define DROID_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DH_OK 0
+#define DH_ERR_ARG 1
+#define DH_ERR_WORKSPACE 2
+#define DH_ERR_LAUNCH 3
+#define DH_ERR_UNSUPPORTED 4
+
+/* element types of correlation volumes / feature maps */
+#define DH_F16 0
+#define DH_F32 1
+
+typedef void* dh_stream_t;
+
+const char* dh_version(void);
+const char* dh_status_string(int status);
+
+/* ------------------------------------------------------------------------------------------------
+ * Correlation-volume lookup.  Replaces corr_index_forward / corr_index_backward
+ * (reference src/droid.cpp:175-196 -> src/correlation_kernels.cu:127-186).
+ *   volume [N,h1,w1,h2,w2] (dtype), coords [N,2,h1,w1] f32 (x,y) -> corr [N,2r+1,2r+1,h1,w1] (dtype)
+ * corr is fully overwritten (no pre-zeroing needed).  First window index = x offset.
+ */
+int dh_corr_index_fwd(const void* volume, const float* coords, void* corr, int dtype,
+                      int N, int h1, int w1, int h2, int w2, int radius, dh_stream_t stream);
+/* volume_grad [N,h1,w1,h2,w2] (dtype) is fully overwritten with the adjoint of the lookup. */
+int dh_corr_index_bwd(const float* coords, const void* corr_grad, void* volume_grad, int dtype,
+                      int N, int h1, int w1, int h2, int w2, int radius, dh_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * On-the-fly ("alt") correlation.  Replaces altcorr_forward / altcorr_backward
+ * (reference src/droid.cpp:198-226 -> src/altcorr_kernel.cu:132-225).
+ *   fmap1 [B,N1,C,H,W], fmap2 [B,N2,C,H2,W2] (dtype), coords [B,M,2,H,W] f32, ii,jj [M] i64
+ *   -> corr [B,M,2r+1,2r+1,H,W] (dtype), x offset outer (the layout the reference returns as a
+ *   permuted view, altcorr_kernel.cu:171, here written densely).  Features are scaled by 1/4 each.
+ */
+int dh_altcorr_fwd(const void* fmap1, const void* fmap2, const float* coords,
+                   const int64_t* ii, const int64_t* jj, void* corr, int dtype,
+                   int B, int N1, int N2, int C, int H, int W, int H2, int W2, int M, int radius,
+                   dh_stream_t stream);
+/* corr_grad [B,M,2r+1,2r+1,H,W] f32 (x offset outer); fmap1_grad/fmap2_grad f32, ACCUMULATED into
+ * (caller zero-fills), shapes of fmap1/fmap2. */
+int dh_altcorr_bwd(const void* fmap1, const void* fmap2, const float* coords,
+                   const int64_t* ii, const int64_t* jj, const float* corr_grad,
+                   float* fmap1_grad, float* fmap2_grad, int dtype,
+                   int B, int N1, int N2, int C, int H, int W, int H2, int W2, int M, int radius,
+                   dh_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dense bundle adjustment.  Replaces ba (reference src/droid.cpp:93-122 -> ba_cuda,
+ * src/droid_kernels.cu:1323-1443).
+ *   poses [num_frames,7] f32      IN/OUT (poses t0..t1-1 are retracted in place)
+ *   disps [num_frames,ht,wd] f32  IN/OUT (disps of every frame in unique(arange(t0,t1) U ii))
+ *   intrinsics [4] f32 (fx,fy,cx,cy), disps_sens [num_frames,ht,wd] f32
+ *   targets, weights [E,2,ht,wd] f32;  eta [K,ht,wd] f32, K = |unique(arange(t0,t1) U ii)|
+ *   ii, jj [E] i64
+ *   dx_out [t1-t0,6] f32, dz_out [K,ht*wd] f32 (may be NULL): updates of the LAST iteration
+ * Everything (index building, Schur complement, fp64 Cholesky, back-substitution, retraction) runs
+ * on the device with no host round trip.  `workspace` must hold dh_ba_workspace_bytes(...) bytes.
+ */
+size_t dh_ba_workspace_bytes(int num_frames, int n_edges, int ht, int wd, int t0, int t1, int motion_only);
+int dh_ba(float* poses, float* disps, const float* intrinsics, const float* disps_sens,
+          const float* targets, const float* weights, const float* eta,
+          const int64_t* ii, const int64_t* jj,
+          int num_frames, int n_edges, int n_eta_rows, int ht, int wd,
+          int t0, int t1, int iterations, float lm, float ep, int motion_only,
+          float* dx_out, float* dz_out, void* workspace, size_t workspace_bytes, dh_stream_t stream);
+
+/* Split form used by the edge-sharded multi-GPU solver (one RCCL all-reduce between the two calls):
+ * dh_ba_build fills the reduced camera system of THIS rank's edges,
+ *   Hsys [6P,6P] f64 (row-major, lower+upper), bsys [6P] f64, and keeps per-frame depth terms in the
+ *   workspace; dh_ba_finish damps, solves, back-substitutes the depths of the frames this rank owns
+ *   and retracts.  dh_ba() == dh_ba_build + dh_ba_finish per iteration. */
+int dh_ba_build(const float* poses, const float* disps, const float* intrinsics, const float* disps_sens,
+                const float* targets, const float* weights, const float* eta,
+                const int64_t* ii, const int64_t* jj,
+                int num_frames, int n_edges, int n_eta_rows, int ht, int wd,
+                int t0, int t1, int motion_only,
+                double** Hsys_out, double** bsys_out, void* workspace, size_t workspace_bytes, dh_stream_t stream);
+int dh_ba_finish(float* poses, float* disps, const int64_t* jj,
+                 int num_frames, int n_edges, int ht, int wd, int t0, int t1,
+                 float lm, float ep, int motion_only, float* dx_out, float* dz_out,
+                 void* workspace, size_t workspace_bytes, dh_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Geometry kernels of the droid_backends API (reference src/droid.cpp:125-171,228-242).
+ *   frame_distance: dist [M] f32   (src/droid_kernels.cu:527-666, 1447-1469)
+ *   projmap: coords [M,ht,wd,3] f32 (channel 2 = 0), valid [M,ht,wd,1] f32  (:436-525, 1472-1497)
+ *   iproj: points [N,ht,wd,3] f32  (:788-859, 1527-1550)
+ *   depth_filter: counter [M,ht,wd] f32 (:670-784, 1500-1524)
+ */
+int dh_frame_distance(const float* poses, const float* disps, const float* intrinsics,
+                      const int64_t* ii, const int64_t* jj, float* dist,
+                      int M, int ht, int wd, float beta, dh_stream_t stream);
+int dh_projmap(const float* poses, const float* disps, const float* intrinsics,
+               const int64_t* ii, const int64_t* jj, float* coords, float* valid,
+               int M, int ht, int wd, dh_stream_t stream);
+int dh_iproj(const float* poses, const float* disps, const float* intrinsics, float* points,
+             int N, int ht, int wd, dh_stream_t stream);
+int dh_depth_filter(const float* poses, const float* disps, const float* intrinsics,
+                    const int64_t* ix, const float* thresh, float* counter,
+                    int M, int num_frames, int ht, int wd, dh_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * SE(3) group ops and the fused reprojection: the subset of the un-vendored `lietorch` that sits on
+ * the path (reference droid_slam/geom/projective_ops.py:165-198, depth_video.py:171-179).
+ * All arrays f32; poses/elements are 7-vectors, n = number of group elements.
+ *   dh_se3_inv: out[i] = a[i]^-1          dh_se3_mul: out[i] = a[i]*b[i]
+ *   dh_se3_exp: out[i] = exp(xi[i])       dh_se3_retr: out[i] = exp(xi[i])*a[i]
+ *   dh_se3_act4: Y[i,p,:] = a[i] * X[i,p,:]  (homogeneous 4-vectors, npts per element)
+ *   dh_se3_adjT: Y[i,p,:] = Adj(a[i])^T X[i,p,:]  (6-vectors)
+ *   dh_reproject: coords [E,ht,wd,2], valid [E,ht,wd,1] with the Python thresholds
+ *                 (MIN_DEPTH 0.2, Z<0.1 -> 1, stereo override for ii==jj; projective_ops.py:6,52,176-185)
+ */
+int dh_se3_inv(const float* a, float* out, int n, dh_stream_t stream);
+int dh_se3_mul(const float* a, const float* b, float* out, int n, dh_stream_t stream);
+int dh_se3_exp(const float* xi, float* out, int n, dh_stream_t stream);
+int dh_se3_retr(const float* xi, const float* a, float* out, int n, dh_stream_t stream);
+int dh_se3_act4(const float* a, const float* X, float* Y, int n, int npts, dh_stream_t stream);
+int dh_se3_adjT(const float* a, const float* X, float* Y, int n, int npts, dh_stream_t stream);
+int dh_reproject(const float* poses, const float* disps, const float* intrinsics,
+                 const int64_t* ii, const int64_t* jj, float* coords, float* valid,
+                 int E, int ht, int wd, dh_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DROID_HIP_H */

@@ -1,0 +1,367 @@
+"""GPU parity tests: the HIP path (through droid_backends -> C ABI) against the CPU oracle on identical
+seeded inputs, and against the committed reference-Python golden vectors.  Run on the MI355X box:
+
+    python -m pytest tests -m gpu -x -q
+
+Tolerances: corr lookup fp32 <= 1e-5 abs (scaled), fp16 <= 2^-9 * max|corr|;
+BA: dx  ||d||/||dx|| <= 1e-3, dz / disps rel 1e-3, poses |dt| <= 1e-4, rotation <= 1e-4 rad.
+"""
+import ctypes
+import os
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ba as oba, corr as ocorr, geom as ogeom, se3 as ose3
+from droid_amd import synthetic as syn
+
+
+@pytest.fixture(scope="module")
+def db():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    import droid_backends
+    return droid_backends
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda().contiguous()
+
+
+# ------------------------------------------------------------------------------------------ corr lookup
+def _rand_coords(rng, N, h1, w1, h2, w2, spread=4.0):
+    """mostly in-range, some far out of range, some exactly integral"""
+    x = rng.uniform(-spread, w2 - 1 + spread, (N, h1, w1))
+    y = rng.uniform(-spread, h2 - 1 + spread, (N, h1, w1))
+    x[:, 0, 0] = 5.0; y[:, 0, 0] = 2.0
+    x[:, -1, -1] = -50.0
+    y[:, -1, 0] = 1e4
+    return np.stack([x, y], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("shape", [(3, 12, 16, 48, 64), (2, 6, 8, 24, 32), (2, 5, 7, 12, 16), (2, 4, 4, 6, 8),
+                                   (2, 3, 5, 5, 7), (1, 2, 2, 2, 2)])
+def test_corr_index_forward(db, dtype, shape):
+    N, h1, w1, h2, w2 = shape
+    rng = np.random.default_rng(hash(shape) % 1000)
+    vol = rng.standard_normal(shape).astype(np.float32)
+    coords = _rand_coords(rng, N, h1, w1, h2, w2)
+    v = dev(vol, dtype)
+    out, = db.corr_index_forward(v, dev(coords), 3)
+    assert out.shape == (N, 7, 7, h1, w1) and out.dtype == dtype
+    ref = ocorr.corr_index_forward(v.float().cpu().numpy(), coords, 3)
+    tol = 2e-5 if dtype == torch.float32 else 2.0 ** -9 * np.abs(ref).max()
+    assert np.abs(out.float().cpu().numpy() - ref).max() <= tol
+
+
+@pytest.mark.parametrize("radius", [1, 2, 4])
+def test_corr_index_forward_other_radius(db, radius):
+    rng = np.random.default_rng(radius)
+    shape = (2, 6, 8, 12, 16)
+    vol = rng.standard_normal(shape).astype(np.float32)
+    coords = _rand_coords(rng, *shape)
+    out, = db.corr_index_forward(dev(vol), dev(coords), radius)
+    ref = ocorr.corr_index_forward(vol, coords, radius)
+    assert np.abs(out.cpu().numpy() - ref).max() < 2e-5
+
+
+def test_corr_index_empty_and_noncontiguous(db):
+    out, = db.corr_index_forward(torch.zeros(0, 4, 4, 4, 4).cuda(), torch.zeros(0, 2, 4, 4).cuda(), 3)
+    assert out.shape == (0, 7, 7, 4, 4)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        db.corr_index_forward(torch.zeros(2, 4, 4, 4, 8).cuda()[..., ::2], torch.zeros(2, 2, 4, 4).cuda(), 3)
+
+
+def test_corr_index_backward_is_the_adjoint(db):
+    rng = np.random.default_rng(5)
+    shape = (2, 6, 8, 12, 16)
+    coords = _rand_coords(rng, *shape, spread=2.0)
+    g = rng.standard_normal((2, 7, 7, 6, 8)).astype(np.float32)
+    vg, = db.corr_index_backward(torch.zeros(shape).cuda(), dev(coords), dev(g), 3)
+    ref = ocorr.corr_index_backward(shape, coords, g, 3)
+    assert np.abs(vg.cpu().numpy() - ref).max() < 1e-5
+    # <lookup(v), g> == <v, adjoint(g)>
+    vol = rng.standard_normal(shape).astype(np.float32)
+    out, = db.corr_index_forward(dev(vol), dev(coords), 3)
+    lhs = float((out.double().cpu() * torch.as_tensor(g).double()).sum())
+    rhs = float((torch.as_tensor(vol).double() * vg.double().cpu()).sum())
+    assert abs(lhs - rhs) < 1e-3 * max(1.0, abs(lhs))
+
+
+def test_full_size_lookup_properties(db):
+    """BASELINE full size (48x64, one level-0 volume of 16 edges): linearity and the constant-volume identity."""
+    torch.manual_seed(0)
+    N, h, w = 16, 48, 64
+    vol = torch.randn(N, h, w, h, w, device="cuda", dtype=torch.float16)
+    coords = torch.stack([torch.rand(N, h, w, device="cuda") * (w + 6) - 3,
+                          torch.rand(N, h, w, device="cuda") * (h + 6) - 3], 1).contiguous()
+    a, = db.corr_index_forward(vol, coords, 3)
+    b, = db.corr_index_forward(vol * 2, coords, 3)
+    assert (b.float() - 2 * a.float()).abs().max() <= 2.0 ** -8 * a.float().abs().max()
+    ones, = db.corr_index_forward(torch.ones_like(vol), coords, 3)
+    inside = ((coords[:, 0] >= 3) & (coords[:, 0] <= w - 5) & (coords[:, 1] >= 3) & (coords[:, 1] <= h - 5))
+    sel = ones.float().permute(0, 3, 4, 1, 2)[inside]
+    assert (sel - 1).abs().max() < 2e-3
+
+
+# ------------------------------------------------------------------------------------------ alt corr
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_altcorr_forward(db, dtype):
+    rng = np.random.default_rng(8)
+    B, N, C, H, W = 1, 4, 32, 12, 16
+    fm = rng.standard_normal((B, N, C, H, W)).astype(np.float32)
+    ii = np.array([0, 1, 3, 2, 2]); jj = np.array([1, 0, 3, 0, 3])
+    M = len(ii)
+    f1 = dev(fm, dtype)
+    for lvl, (H2, W2) in enumerate([(12, 16), (6, 8)]):
+        f2np = fm if lvl == 0 else ocorr.avg_pool2(fm.astype(np.float64)).astype(np.float32)
+        f2 = dev(f2np, dtype)
+        coords = np.stack([rng.uniform(-3, W2 + 2, (B, M, H, W)), rng.uniform(-3, H2 + 2, (B, M, H, W))], 2).astype(np.float32)
+        out, = db.altcorr_forward(f1, f2, dev(coords), dev(ii), dev(jj), 3)
+        assert out.shape == (B, M, 7, 7, H, W)
+        ref = ocorr.altcorr_forward(f1.float().cpu().numpy(), f2.float().cpu().numpy(), coords, ii, jj, 3)
+        tol = 1e-4 if dtype == torch.float32 else 2.0 ** -8 * np.abs(ref).max()
+        assert np.abs(out.float().cpu().numpy() - ref).max() <= tol
+
+
+def test_altcorr_matches_volume_lookup_at_full_size(db):
+    """alt path == lookup into the materialised volume (48x64, C=128): the size-independent identity."""
+    torch.manual_seed(1)
+    N, C, H, W = 3, 128, 48, 64
+    fm = torch.randn(1, N, C, H, W, device="cuda").half()
+    ii = torch.tensor([0, 1, 2], device="cuda"); jj = torch.tensor([1, 2, 0], device="cuda")
+    coords = torch.stack([torch.rand(1, 3, H, W, device="cuda") * (W + 4) - 2,
+                          torch.rand(1, 3, H, W, device="cuda") * (H + 4) - 2], 2).contiguous()
+    alt, = db.altcorr_forward(fm, fm, coords, ii, jj, 3)
+    f1 = fm[0, ii].float().reshape(3, C, H * W) / 4
+    f2 = fm[0, jj].float().reshape(3, C, H * W) / 4
+    vol = torch.matmul(f1.transpose(1, 2), f2).reshape(3, H, W, H, W).contiguous()
+    ref, = db.corr_index_forward(vol, coords[0].contiguous(), 3)
+    assert (alt[0].float() - ref).abs().max() <= 2.0 ** -8 * ref.abs().max()
+
+
+# ------------------------------------------------------------------------------------------ BA
+def _run_ba(db, g, t0, t1, itrs, lm, ep, motion_only=False, eta=None):
+    poses = dev(g["poses"]); disps = dev(g["disps"])
+    eta_t = dev(g["eta"] if eta is None else eta)
+    dx, dz = db.ba(poses, disps, dev(g["intrinsics"]), dev(g["disps_sens"]), dev(g["targets"]), dev(g["weights"]),
+                   eta_t, dev(g["ii"]), dev(g["jj"]), t0, t1, itrs, lm, ep, motion_only)
+    torch.cuda.synchronize()
+    return poses.cpu().numpy(), disps.cpu().numpy(), dx.cpu().numpy(), dz.cpu().numpy()
+
+
+def _oracle_ba(g, t0, t1, itrs, lm, ep, motion_only=False, eta=None):
+    poses = g["poses"].astype(np.float64).copy(); disps = g["disps"].astype(np.float64).copy()
+    dx, dz = oba.ba(poses, disps, g["intrinsics"], g["disps_sens"], g["targets"], g["weights"],
+                    g["eta"] if eta is None else eta, g["ii"], g["jj"], t0, t1, itrs, lm, ep, motion_only)
+    return poses, disps, dx, dz
+
+
+def _eta_for(g, t0, t1):
+    kx = np.unique(np.concatenate([np.arange(t0, t1), g["ii"]]))
+    rng = np.random.default_rng(99)
+    return (0.2 * rng.uniform(1e-6, 1e-3, (len(kx),) + g["disps"].shape[1:]) + 1e-7).astype(np.float32)
+
+
+def _check_ba(got, ref, motion_only=False, scale=1.0):
+    p, d, dx, dz = got
+    rp, rd, rdx, rdz = ref
+    assert np.linalg.norm(dx - rdx) <= 1e-3 * np.linalg.norm(rdx) + 1e-7
+    assert np.abs(p[:, :3] - rp[:, :3]).max() <= 1e-4 * scale
+    dq = np.abs(np.sum(p[:, 3:] * rp[:, 3:], -1))
+    assert np.all(2 * np.arccos(np.clip(dq, 0, 1)) <= 1e-3)
+    assert np.abs(np.linalg.norm(p[:, 3:], axis=-1) - 1).max() < 1e-4
+    if not motion_only:
+        assert np.abs(dz - rdz).max() <= 1e-3 * np.abs(rdz).max() + 1e-6
+        assert np.abs(d - rd).max() <= 1e-3 * max(1.0, np.abs(rd).max())
+
+
+@pytest.mark.parametrize("case", ["mono", "stereo", "sensor", "t0_3", "many_edges"])
+def test_ba_small_graphs(db, case):
+    kw = dict(n_frames=6, seed=21, ht=12, wd=16)
+    t0 = 1
+    if case == "stereo":
+        kw.update(stereo=True)
+    if case == "sensor":
+        kw.update(sensor_depth=True)
+    if case == "many_edges":
+        kw.update(n_frames=14, radius=13)            # 13 out-edges per frame -> two Gram chunks
+    g = syn.small_graph(**kw)
+    N = g["n_frames"]
+    if case == "t0_3":
+        t0 = 3
+    eta = _eta_for(g, t0, N)
+    for itrs in (1, 2):
+        got = _run_ba(db, g, t0, N, itrs, 1e-4, 0.1, eta=eta)
+        ref = _oracle_ba(g, t0, N, itrs, 1e-4, 0.1, eta=eta)
+        _check_ba(got, ref)
+    # frames outside [t0,t1) keep their pose
+    assert np.array_equal(got[0][:t0], g["poses"][:t0])
+
+
+def test_ba_motion_only(db):
+    g = syn.small_graph(n_frames=6, seed=4, ht=12, wd=16)
+    got = _run_ba(db, g, 1, 6, 2, 1e-4, 0.1, motion_only=True)
+    ref = _oracle_ba(g, 1, 6, 2, 1e-4, 0.1, motion_only=True)
+    _check_ba(got, ref, motion_only=True)
+    assert np.array_equal(got[1], g["disps"])            # depths untouched
+
+
+def test_ba_config_c1(db):
+    """BASELINE configs[0]: 8 keyframes / 32 edges at 48x64."""
+    g = syn.make_graph("C1")
+    got = _run_ba(db, g, 1, 8, 2, g["lm"], g["ep"])
+    ref = _oracle_ba(g, 1, 8, 2, g["lm"], g["ep"])
+    _check_ba(got, ref)
+
+
+def test_ba_config_c2_converges_and_matches(db):
+    """BASELINE configs[1]: 64 keyframes / 512 edges.  One oracle iteration for parity, then the
+    size-independent property: the weighted reprojection cost decreases under repeated BA."""
+    g = syn.make_graph("C2")
+    got = _run_ba(db, g, 1, 64, 1, g["lm"], g["ep"])
+    ref = _oracle_ba(g, 1, 64, 1, g["lm"], g["ep"])
+    _check_ba(got, ref)
+    poses = dev(g["poses"]); disps = dev(g["disps"])
+    args = [dev(g[k]) for k in ("intrinsics", "disps_sens", "targets", "weights", "eta", "ii", "jj")]
+    c0 = oba.reprojection_cost(g["poses"], g["disps"], g["intrinsics"], g["targets"], g["weights"], g["ii"], g["jj"])
+    costs = [c0]
+    for _ in range(4):
+        db.ba(poses, disps, *args, 1, 64, 2, g["lm"], g["ep"], False)
+        disps.clamp_(min=0.001)
+        costs.append(oba.reprojection_cost(poses.cpu().numpy(), disps.cpu().numpy(), g["intrinsics"],
+                                           g["targets"], g["weights"], g["ii"], g["jj"]))
+    assert costs[1] < 0.5 * costs[0]
+    assert costs[-1] <= costs[1] * 1.01
+
+
+def test_ba_cholesky_failure_gives_zero_update(db):
+    """SparseBlock::solve semantics (src/droid_kernels.cu:1211-1219): not SPD -> dx = 0."""
+    g = syn.small_graph(n_frames=5, seed=2, ht=12, wd=16)
+    p, d, dx, dz = _run_ba(db, g, 1, 5, 1, 0.0, -1e9, motion_only=True)
+    assert np.all(dx == 0) and np.array_equal(p, g["poses"])
+
+
+def test_ba_is_run_to_run_stable(db):
+    g = syn.make_graph("C1")
+    a = _run_ba(db, g, 1, 8, 2, g["lm"], g["ep"])
+    b = _run_ba(db, g, 1, 8, 2, g["lm"], g["ep"])
+    assert np.abs(a[0] - b[0]).max() < 1e-6 and np.abs(a[1] - b[1]).max() < 1e-5
+
+
+# ------------------------------------------------------------------------------------------ geometry
+def test_geometry_kernels(db):
+    g = syn.small_graph(n_frames=8, seed=13, ht=12, wd=16)
+    poses, disps, intr = dev(g["poses_gt"]), dev(g["disps_gt"]), dev(g["intrinsics"])
+    ii, jj = g["ii"], g["jj"]
+    d = db.frame_distance(poses, disps, intr, dev(ii), dev(jj), 0.3).cpu().numpy()
+    ref = ogeom.frame_distance(g["poses_gt"], g["disps_gt"], g["intrinsics"], ii, jj, 0.3)
+    assert np.abs(d - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+    c, v = db.projmap(poses, disps, intr, dev(ii), dev(jj))
+    rc, rv = ogeom.projmap(g["poses_gt"], g["disps_gt"], g["intrinsics"], ii, jj)
+    assert np.abs(c.cpu().numpy() - rc).max() < 1e-3 and np.array_equal(v.cpu().numpy(), rv.astype(np.float32))
+    pts = db.iproj(poses, disps, intr).cpu().numpy()
+    rp = ogeom.iproj(g["poses_gt"], g["disps_gt"], g["intrinsics"])
+    assert np.abs(pts - rp).max() <= 1e-4 * np.abs(rp).max()
+    ix = np.arange(8); th = np.full(8, 0.05, dtype=np.float32)
+    cnt = db.depth_filter(poses, disps, intr, dev(ix), dev(th)).cpu().numpy()
+    rcnt = ogeom.depth_filter(g["poses_gt"], g["disps_gt"], g["intrinsics"], ix, th)
+    assert np.mean(cnt != rcnt) < 0.01            # threshold comparisons may flip on fp32 rounding
+    assert cnt.max() <= 6 and cnt.min() >= 0
+
+
+def test_reproject_matches_reference_python_golden(db, golden_dir):
+    g = np.load(os.path.join(golden_dir, "ba_python.npz"))
+    coords, valid = db.reproject(dev(g["poses"], torch.float32), dev(g["disps"], torch.float32),
+                                 dev(g["intrinsics"], torch.float32), dev(g["ii"]), dev(g["jj"]))
+    assert np.abs(coords.cpu().numpy() - g["coords"]).max() < 2e-4
+    assert np.mean(valid.cpu().numpy() != g["valid"]) < 1e-3
+
+
+def test_se3_ops(db):
+    rng = np.random.default_rng(6)
+    n = 100
+    a = ose3.random_se3(rng, n); b = ose3.random_se3(rng, n)
+    xi = rng.normal(0, 0.3, (n, 6)); xi[0] = 0; xi[1, 3:] = 1e-6
+    A, Bt, XI = dev(a, torch.float32), dev(b, torch.float32), dev(xi, torch.float32)
+    t, q = ose3.se3_inv(a[:, :3], a[:, 3:])
+    assert np.abs(db.se3_op("inv", A, A).cpu().numpy() - np.concatenate([t, q], -1)).max() < 1e-5
+    t, q = ose3.se3_mul(a[:, :3], a[:, 3:], b[:, :3], b[:, 3:])
+    assert np.abs(db.se3_op("mul", A, Bt).cpu().numpy() - np.concatenate([t, q], -1)).max() < 1e-5
+    t, q = ose3.se3_exp(xi)
+    assert np.abs(db.se3_op("exp", XI, XI).cpu().numpy() - np.concatenate([t, q], -1)).max() < 1e-5
+    t, q = ose3.se3_retr(xi, a[:, :3], a[:, 3:])
+    assert np.abs(db.se3_op("retr", XI, A).cpu().numpy() - np.concatenate([t, q], -1)).max() < 1e-5
+    X = rng.normal(0, 1, (n, 7, 4)); J = rng.normal(0, 1, (n, 7, 6))
+    Y = db.se3_map("act4", A, dev(X, torch.float32)).cpu().numpy()
+    assert np.abs(Y - ose3.se3_act(a[:, None, :3], a[:, None, 3:], X)).max() < 1e-5
+    Z = db.se3_map("adjT", A, dev(J, torch.float32)).cpu().numpy()
+    assert np.abs(Z - ose3.se3_adjT(a[:, None, :3], a[:, None, 3:], J)).max() < 2e-5
+
+
+# ------------------------------------------------------------------------------------------ raw C ABI
+def test_raw_c_abi_call(db):
+    """Call the C entry point directly (ctypes, raw device pointers, explicit stream)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = ctypes.CDLL(os.path.join(root, "droid-slam_amd", "libdroid_hip.so"))
+    rng = np.random.default_rng(1)
+    shape = (2, 6, 8, 12, 16)
+    vol = rng.standard_normal(shape).astype(np.float32)
+    coords = _rand_coords(rng, *shape)
+    v, c = dev(vol), dev(coords)
+    out = torch.empty(2, 7, 7, 6, 8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    rc = lib.dh_corr_index_fwd(ctypes.c_void_p(v.data_ptr()), ctypes.c_void_p(c.data_ptr()),
+                               ctypes.c_void_p(out.data_ptr()), 1, 2, 6, 8, 12, 16, 3, ctypes.c_void_p(st))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert np.abs(out.cpu().numpy() - ocorr.corr_index_forward(vol, coords, 3)).max() < 2e-5
+
+
+# ------------------------------------------------------------------------------------------ sharded BA
+def test_sharded_ba_equals_single_gpu(db):
+    """Edge-sharded BA emulated on one GPU: per-shard ba_build, summed systems (what the RCCL
+    all-reduce does), per-shard ba_finish with depth ownership == one fused ba call."""
+    from droid_amd.dist_ba import shard_edges_by_source_frame, local_eta_rows
+    g = syn.make_graph("C1")
+    N, t0, t1 = 8, 1, 8
+    ref_p, ref_d, ref_dx, _ = _run_ba(db, g, t0, t1, 1, g["lm"], g["ep"])
+    world = 3
+    shards, bounds = shard_edges_by_source_frame(g["ii"], world)
+    intr, sens = dev(g["intrinsics"]), dev(g["disps_sens"])
+    states = []
+    for r in range(world):
+        e = shards[r]
+        rows, _ = local_eta_rows(g["ii"], g["ii"][e], t0, t1)
+        poses, disps = dev(g["poses"]), dev(g["disps"])
+        jj = dev(g["jj"][e])
+        eta = dev(g["eta"][rows])
+        ws, system = db.ba_build(poses, disps, intr, sens, dev(g["targets"][e]), dev(g["weights"][e]), eta,
+                                 dev(g["ii"][e]), jj, t0, t1, False)
+        states.append((poses, disps, jj, ws, system, eta.shape[0]))
+    total = sum(s[4] for s in states)
+    out_d = torch.as_tensor(g["disps"]).cuda()
+    for r, (poses, disps, jj, ws, system, nrows) in enumerate(states):
+        system.copy_(total)
+        dx, dz = db.ba_finish(poses, disps, jj, ws, nrows, t0, t1, g["lm"], g["ep"], False)
+        lo, hi = bounds[r], min(bounds[r + 1], N)
+        out_d[lo:hi] = disps[lo:hi]
+        assert np.linalg.norm(dx.cpu().numpy() - ref_dx) <= 1e-4 * np.linalg.norm(ref_dx)
+        assert np.abs(poses.cpu().numpy() - ref_p).max() < 1e-5
+    assert np.abs(out_d.cpu().numpy() - ref_d).max() <= 1e-4 * max(1.0, np.abs(ref_d).max())
+
+
+def test_dist_ba_world1_equals_fused(db):
+    from droid_amd.dist_ba import DistBA
+    g = syn.make_graph("C1")
+    ref_p, ref_d, ref_dx, ref_dz = _run_ba(db, g, 1, 8, 2, g["lm"], g["ep"])
+    poses, disps = dev(g["poses"]), dev(g["disps"])
+    dx, dz = DistBA(world=1).ba(poses, disps, dev(g["intrinsics"]), dev(g["disps_sens"]), dev(g["targets"]),
+                                dev(g["weights"]), dev(g["eta"]), dev(g["ii"]), dev(g["jj"]), 1, 8, 2, g["lm"], g["ep"])
+    assert np.abs(poses.cpu().numpy() - ref_p).max() < 1e-6
+    assert np.abs(disps.cpu().numpy() - ref_d).max() < 1e-5
