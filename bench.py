@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--config", default="C3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-update-op", action="store_true", help="skip the ConvGRU block (diagnostics only)")
+    ap.add_argument("--no-lookup", action="store_true", help="skip the correlation pyramid (BA-only diagnostics)")
     ap.add_argument("--edge-chunk", type=int, default=512, help="edges per update-operator chunk")
     return ap.parse_args()
 
@@ -137,7 +138,7 @@ def main():
 
     # ---- correlation pyramid for this rank's edges (setup, untimed) ----
     c = (ii == jj).long() if rig > 1 else torch.zeros_like(ii)
-    corr = CorrBlock(fmaps[ii, 0][None], fmaps[jj, c][None])
+    corr = None if args.no_lookup else CorrBlock(fmaps[ii, 0][None], fmaps[jj, c][None])
     torch.cuda.synchronize()
 
     from droid_amd.dist_ba import DistBA
@@ -151,7 +152,7 @@ def main():
         coords1, _ = db.reproject(poses, disps, intr, ii, jj)
         e0, e1, e2, e3 = ev(), ev(), ev(), ev()
         e0.record()
-        feats = corr(coords1[None])
+        feats = corr(coords1[None]) if corr is not None else None
         e1.record()
         # TODO(update op): ConvGRU block goes here; until it lands the BA consumes the synthetic targets
         e2.record()

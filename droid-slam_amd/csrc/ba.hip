@@ -24,6 +24,7 @@
 // The reduced camera system is accumulated with fp64 atomics (order-dependent only at the 1e-16
 // level); everything else is deterministic.
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -373,62 +374,83 @@ __global__ __launch_bounds__(256) void ba_gram_kernel(
   const int e0 = eoff[k];
   const int nslots = 1 + (eoff[k + 1] - e0);
   const int nchunks = (nslots + GS - 1) / GS;
-  // pixel range of this block
   const int per = ((HW + NSG - 1) / NSG + 63) / 64 * 64;
   const int p_begin = blockIdx.y * per, p_end = min(HW, p_begin + per);
   if (p_begin >= p_end) return;
 
-  __shared__ float s_M[2][64 * GLD];          // [chunk a / chunk b][px][col]
-  __shared__ float s_out[GCOLS * GCOLS];      // cross-wave reduction
+  __shared__ float s_M[2][64 * GLD];            // [chunk a / chunk b][px][col], already scaled by sqrt(Q)
+  __shared__ float s_out[GCOLS * GCOLS];        // cross-wave reduction
   __shared__ int s_pose[2][GS];
+  __shared__ const float* s_col[2][GCOLS];      // per-column source rows (nullptr = zero column)
+
+  const int pl = tid & 63, cg = tid >> 6;       // staging role: pixel within the tile, column group
 
   for (int ca = 0; ca < nchunks; ++ca) {
     for (int cb = ca; cb < nchunks; ++cb) {
-      // pose index (relative) of every slot of both chunks; -1 = inactive
+      const bool same = ca == cb;
+      const int nw = same ? 1 : 2;
+      __syncthreads();
+      if (tid < 2 * GCOLS) {
+        const int which = tid / GCOLS, col = tid % GCOLS, c = which ? cb : ca;
+        const float* ptr = nullptr;
+        if (col < 6 * GS) {
+          const int sl = c * GS + col / 6, a = col % 6;
+          if (sl < nslots)
+            ptr = (sl == 0) ? Ei + ((long)k * 6 + a) * HW : Ej + ((long)eidx[e0 + sl - 1] * 6 + a) * HW;
+        } else if (col == 6 * GS) {
+          ptr = W + (long)k * HW;
+        }
+        s_col[which][col] = ptr;
+      }
       if (tid < 2 * GS) {
-        const int which = tid / GS, s = (which ? cb : ca) * GS + tid % GS;
+        const int which = tid / GS, sl = (which ? cb : ca) * GS + tid % GS;
         int pose = -1;
-        if (s < nslots) {
-          const int fr = (s == 0) ? f : (int)jj[eidx[e0 + s - 1]];
+        if (sl < nslots) {
+          const int fr = (sl == 0) ? f : (int)jj[eidx[e0 + sl - 1]];
           const int r = fr - t0;
           if (r >= 0 && r < P) pose = r;
         }
         s_pose[which][tid % GS] = pose;
       }
+      __syncthreads();
+
       f32x4 acc[16];
 #pragma unroll
       for (int t = 0; t < 16; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-      for (int pb = p_begin; pb < p_end; pb += 64) {
-        __syncthreads();
-        // stage M tiles: thread -> (pixel = tid&63, column group = tid>>6)
-        {
-          const int pl = tid & 63, p = pb + pl;
-          const bool pok = p < p_end;
-          const float sq = pok ? sqrtf(Q[(long)k * HW + p]) : 0.f;
-          for (int which = 0; which < (ca == cb ? 1 : 2); ++which) {
-            const int c = which ? cb : ca;
-            for (int col = tid >> 6; col < GCOLS; col += 4) {
-              float v = 0.f;
-              if (pok) {
-                if (col < 6 * GS) {
-                  const int s = c * GS + col / 6, a = col % 6;
-                  if (s < nslots) {
-                    v = (s == 0) ? Ei[((long)k * 6 + a) * HW + p]
-                                 : Ej[((long)eidx[e0 + s - 1] * 6 + a) * HW + p];
-                  }
-                } else if (col == 6 * GS) {
-                  v = W[(long)k * HW + p];
-                }
-              }
-              s_M[which][pl * GLD + col] = v * sq;
+      // software pipeline: the next tile's 16(+16) values travel from HBM while this tile is on the MFMA
+      float pre[2][16], preq;
+      auto issue = [&](int pb) {
+        const int p = pb + pl;
+        const bool pok = p < p_end;
+        preq = pok ? Q[(long)k * HW + p] : 0.f;
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+          if (which < nw) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const float* ptr = s_col[which][cg + 4 * i];
+              pre[which][i] = (pok && ptr) ? ptr[p] : 0.f;
             }
           }
         }
+      };
+      issue(p_begin);
+      for (int pb = p_begin; pb < p_end; pb += 64) {
         __syncthreads();
-        // each wave contracts 16 of the 64 pixels (K = 4 per MFMA)
+        {
+          const float sq = sqrtf(preq);
+#pragma unroll
+          for (int which = 0; which < 2; ++which)
+            if (which < nw) {
+#pragma unroll
+              for (int i = 0; i < 16; ++i) s_M[which][pl * GLD + cg + 4 * i] = pre[which][i] * sq;
+            }
+        }
+        __syncthreads();
+        if (pb + 64 < p_end) issue(pb + 64);
         const float* MA = s_M[0];
-        const float* MB = s_M[ca == cb ? 0 : 1];
+        const float* MB = s_M[same ? 0 : 1];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
           const int prow = wave * 16 + kk * 4 + (lane >> 4);
@@ -442,7 +464,8 @@ __global__ __launch_bounds__(256) void ba_gram_kernel(
           for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
             for (int tj = 0; tj < 4; ++tj)
-              acc[ti * 4 + tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ti], b[tj], acc[ti * 4 + tj], 0, 0, 0);
+              if (!same || tj >= ti)          // a chunk against itself is symmetric: upper tiles only
+                acc[ti * 4 + tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ti], b[tj], acc[ti * 4 + tj], 0, 0, 0);
         }
       }
       // reduce the 4 waves' partial Grams in LDS (fixed order), then add into the fp64 system
@@ -452,34 +475,34 @@ __global__ __launch_bounds__(256) void ba_gram_kernel(
 #pragma unroll
           for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
-            for (int tj = 0; tj < 4; ++tj)
+            for (int tj = 0; tj < 4; ++tj) {
+              if (same && tj < ti) continue;
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 const int row = ti * 16 + (lane >> 4) * 4 + r, col = tj * 16 + (lane & 15);
                 if (w == 0) s_out[row * GCOLS + col] = acc[ti * 4 + tj][r];
                 else s_out[row * GCOLS + col] += acc[ti * 4 + tj][r];
               }
+            }
         }
       }
       __syncthreads();
-      // G[row=(slot a, r)][col=(slot b, c)]  -> S block (pose_a, pose_b);  column 6*GS of chunk b = E Q w
+      // G[row=(slot a, r)][col=(slot b, c)] -> S block (pose_a, pose_b); column 6*GS = E Q w
       for (int o = tid; o < 6 * GS * 6 * GS; o += 256) {
         const int row = o / (6 * GS), col = o % (6 * GS);
-        const int sa = row / 6, sb = col / 6;
-        const int pa = s_pose[0][sa], pbq = s_pose[ca == cb ? 0 : 1][sb];
+        const int pa = s_pose[0][row / 6], pbq = s_pose[same ? 0 : 1][col / 6];
         if (pa < 0 || pbq < 0) continue;
-        const double v = (double)s_out[row * GCOLS + col];
+        const bool lower = same && (col >> 4) < (row >> 4);
+        const double v = (double)(lower ? s_out[col * GCOLS + row] : s_out[row * GCOLS + col]);
         atomicAdd(&H[(long)(6 * pa + row % 6) * ld + 6 * pbq + col % 6], -v);
-        if (ca != cb) atomicAdd(&H[(long)(6 * pbq + col % 6) * ld + 6 * pa + row % 6], -v);
+        if (!same) atomicAdd(&H[(long)(6 * pbq + col % 6) * ld + 6 * pa + row % 6], -v);
       }
-      // rhs: bS[pose_a] += sum_px E_a Q w   (w column lives in chunk tile `b`; take it once per chunk a)
-      if (cb == ca) {
+      if (same) {
         for (int o = tid; o < 6 * GS; o += 256) {
           const int pa = s_pose[0][o / 6];
           if (pa >= 0) atomicAdd(&H[(long)brow * ld + 6 * pa + o % 6], -(double)s_out[o * GCOLS + 6 * GS]);
         }
       }
-      __syncthreads();
     }
   }
 }
@@ -492,67 +515,96 @@ __global__ void ba_damp_kernel(double* __restrict__ H, int ld, int n, int npad, 
   else H[(long)i * ld + i] = 1.0;
 }
 
-// factor the diagonal block j (every workgroup redundantly, in LDS), then solve this workgroup's row block
-__global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ H, int ld, int j,
-                                                          double* __restrict__ Linv, int* __restrict__ meta) {
-  __shared__ double sL[NB * NBP];
+// ---- diagonal block: ONE wave, the 48x48 block lives in registers (lane r = row r) -----------------
+// Factorisation and the inverse of the factor are chains of ~1128 dependent fp64 FMAs each.  Row r stays
+// in lane r's registers; what every lane needs from the others (column c of L during the factorisation,
+// row a of L during the inversion) is published through LDS and read back as wave-wide broadcasts
+// (same address in all lanes: conflict-free, pipelined) -- no barriers between waves, no scratch.
+__device__ __forceinline__ double lane_bcast(double v, int lane) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// 1/sqrt(a) in fp64: hardware estimate + two Newton steps (no IEEE sqrt/div sequences on the pivot path)
+__device__ __forceinline__ double fast_rsqrt(double a) {
+  double y = __builtin_amdgcn_rsq(a);
+  y = y * (1.5 - 0.5 * a * y * y);
+  y = y * (1.5 - 0.5 * a * y * y);
+  return y;
+}
+
+__global__ __launch_bounds__(64) void chol_diag_kernel(
+    double* __restrict__ H, int ld, int j, double* __restrict__ Linv, int* __restrict__ meta) {
+  const int r = threadIdx.x;                     // row (lanes 48..63 idle)
+  const long d0 = (long)j * NB;
+  const bool act = r < NB;
+  double row[NB];
+#pragma unroll
+  for (int c = 0; c < NB; ++c) row[c] = (act && c <= r) ? H[(d0 + r) * ld + d0 + c] : 0.0;
+  bool fail = false;
+  double dinv[NB];                               // 1 / L[c][c] (wave-uniform)
+  // entries above the diagonal (c2 > r) are never read by anybody: they are allowed to collect garbage,
+  // which removes every per-element predicate from the rank-1 updates
+#pragma unroll
+  for (int c = 0; c < NB; ++c) {
+    double piv = lane_bcast(row[c], c);
+    if (!(piv > 0.0) || !(piv < 1e300)) { fail = true; piv = 1.0; }
+    const double rs = fast_rsqrt(piv);
+    dinv[c] = rs;
+    row[c] = (r == c) ? piv * rs : row[c] * rs;
+#pragma unroll
+    for (int c2 = c + 1; c2 < NB; ++c2) row[c2] -= row[c] * lane_bcast(row[c], c2);   // L[r][c] * L[c2][c]
+  }
+  if (fail && r == 0) meta[1] = 1;
+  if (act) {
+#pragma unroll
+    for (int k = 0; k < NB; ++k) H[(d0 + r) * ld + d0 + k] = (k <= r) ? row[k] : 0.0;
+  }
+  // X = L^-1, lane c holds column c: X[a][c] = ((a==c) - sum_{m<a} L[a][m] X[m][c]) / L[a][a]
+  double x[NB];
+  const int c = r;
+#pragma unroll
+  for (int a2 = 0; a2 < NB; ++a2) {
+    double sacc = (c == a2) ? 1.0 : 0.0;
+#pragma unroll
+    for (int m = 0; m < a2; ++m) sacc -= lane_bcast(row[m], a2) * x[m];
+    x[a2] = (c > a2) ? 0.0 : sacc * dinv[a2];
+  }
+  if (act) {
+#pragma unroll
+    for (int k = 0; k < NB; ++k) Linv[(long)j * NB * NB + (long)k * NB + c] = x[k];
+  }
+}
+
+// ---- panel: Y = A_rj * Linv_j^T for every block row r > j (incl. the rhs row) -------------------------
+__global__ __launch_bounds__(256) void chol_trsm_kernel(double* __restrict__ H, int ld, int j,
+                                                        const double* __restrict__ Linv) {
   __shared__ double sI[NB * NBP];
   __shared__ double sX[NB * NBP];
   const int tid = threadIdx.x;
-  const int r = j + blockIdx.x;
-  const long d0 = (long)j * NB;
+  const int r = j + 1 + blockIdx.x;
+  const long d0 = (long)j * NB, r0 = (long)r * NB;
   for (int o = tid; o < NB * NB; o += 256) {
-    const int a = o / NB, b = o % NB;
-    sL[a * NBP + b] = (b <= a) ? H[(d0 + a) * ld + d0 + b] : 0.0;
+    sI[(o / NB) * NBP + o % NB] = Linv[(long)j * NB * NB + o];
+    sX[(o / NB) * NBP + o % NB] = H[(r0 + o / NB) * ld + d0 + o % NB];
   }
   __syncthreads();
-  for (int c = 0; c < NB; ++c) {
-    if (tid == 0) {
-      double d = sL[c * NBP + c];
-      if (!(d > 0.0) || !(d < 1e300)) { meta[1] = 1; d = 1.0; }
-      sL[c * NBP + c] = sqrt(d);
-    }
-    __syncthreads();
-    const double inv = 1.0 / sL[c * NBP + c];
-    if (tid > c && tid < NB) sL[tid * NBP + c] *= inv;
-    __syncthreads();
-    const int m = NB - 1 - c;                       // trailing size
-    for (int o = tid; o < m * m; o += 256) {
-      const int a = c + 1 + o / m, b = c + 1 + o % m;
-      if (b <= a) sL[a * NBP + b] -= sL[a * NBP + c] * sL[b * NBP + c];
-    }
-    __syncthreads();
+  const int ty = tid >> 4, tx = tid & 15;
+  double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  for (int m = 0; m < NB; ++m) {
+    double a[3], b[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) { a[u] = sX[(ty + 16 * u) * NBP + m]; b[u] = sI[(tx + 16 * u) * NBP + m]; }
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+      for (int v = 0; v < 3; ++v) acc[u][v] += a[u] * b[v];
   }
-  // inverse of the lower-triangular factor, one column per thread
-  if (tid < NB) {
-    const int c = tid;
-    for (int a = 0; a < NB; ++a) sI[a * NBP + c] = 0.0;
-    sI[c * NBP + c] = 1.0 / sL[c * NBP + c];
-    for (int a = c + 1; a < NB; ++a) {
-      double s = 0;
-      for (int m = c; m < a; ++m) s += sL[a * NBP + m] * sI[m * NBP + c];
-      sI[a * NBP + c] = -s / sL[a * NBP + a];
-    }
-  }
-  __syncthreads();
-  if (blockIdx.x == 0) {
-    for (int o = tid; o < NB * NB; o += 256) {
-      const int a = o / NB, b = o % NB;
-      H[(d0 + a) * ld + d0 + b] = sL[a * NBP + b];
-      Linv[(long)j * NB * NB + o] = sI[a * NBP + b];
-    }
-    return;
-  }
-  const long r0 = (long)r * NB;
-  for (int o = tid; o < NB * NB; o += 256) sX[(o / NB) * NBP + o % NB] = H[(r0 + o / NB) * ld + d0 + o % NB];
-  __syncthreads();
-  // Y = X * Linv^T  (Linv lower triangular)
-  for (int o = tid; o < NB * NB; o += 256) {
-    const int a = o / NB, c = o % NB;
-    double s = 0;
-    for (int m = 0; m <= c; ++m) s += sX[a * NBP + m] * sI[c * NBP + m];
-    H[(r0 + a) * ld + d0 + c] = s;
-  }
+#pragma unroll
+  for (int u = 0; u < 3; ++u)
+#pragma unroll
+    for (int v = 0; v < 3; ++v) H[(r0 + ty + 16 * u) * ld + d0 + tx + 16 * v] = acc[u][v];
 }
 
 // trailing update A_rc -= L_rj L_cj^T for j < c <= r
@@ -588,26 +640,35 @@ __global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ H
 
 // back substitution step j of L^T x = y (y lives in row `brow` of H): x_j = Linv_j^T y_j, then
 // y_r -= L_{j,r}^T x_j for this workgroup's r < j
-__global__ __launch_bounds__(64) void chol_backsub_kernel(double* __restrict__ H, int ld, int j, int brow,
+__global__ __launch_bounds__(256) void chol_backsub_kernel(double* __restrict__ H, int ld, int j, int brow,
                                                            const double* __restrict__ Linv, double* __restrict__ x) {
+  __shared__ double sI[NB * NBP];
+  __shared__ double sy[NB];
   __shared__ double sx[NB];
+  __shared__ double sp[4][NB];
   const int tid = threadIdx.x;
   const long d0 = (long)j * NB;
+  for (int o = tid; o < NB * NB; o += 256) sI[(o / NB) * NBP + o % NB] = Linv[(long)j * NB * NB + o];
+  if (tid < NB) sy[tid] = H[(long)brow * ld + d0 + tid];
+  __syncthreads();
   if (tid < NB) {
     double s = 0;
-    const double* I = Linv + (long)j * NB * NB;
-    for (int m = tid; m < NB; ++m) s += I[m * NB + tid] * H[(long)brow * ld + d0 + m];
+    for (int m = tid; m < NB; ++m) s += sI[m * NBP + tid] * sy[m];
     sx[tid] = s;
     if (blockIdx.x == 0) x[d0 + tid] = s;
   }
   __syncthreads();
   const int r = (int)blockIdx.x - 1;
   if (r < 0 || r >= j) return;
-  if (tid < NB) {
+  const int col = tid & 63, part = tid >> 6;
+  if (col < NB) {
     double s = 0;
-    for (int a = 0; a < NB; ++a) s += H[(d0 + a) * ld + (long)r * NB + tid] * sx[a];
-    H[(long)brow * ld + (long)r * NB + tid] -= s;
+#pragma unroll
+    for (int a = part * 12; a < part * 12 + 12; ++a) s += H[(d0 + a) * ld + (long)r * NB + col] * sx[a];
+    sp[part][col] = s;
   }
+  __syncthreads();
+  if (tid < NB) H[(long)brow * ld + (long)r * NB + tid] -= (sp[0][tid] + sp[1][tid]) + (sp[2][tid] + sp[3][tid]);
 }
 
 __global__ void ba_dx_kernel(const double* __restrict__ x, const int* __restrict__ meta, int n,
@@ -703,7 +764,10 @@ int run_build(const BaLayout& L, char* ws, const float* poses, const float* disp
     DH_LAUNCH_CHECK();
   }
   if (!motion_only && L.P > 0) {
-    const int NSG = HW >= 1536 ? 2 : 1;
+    const int kest = std::max(1, std::min(F, L.P + E));
+    // one MFMA pass over a whole 48x64 frame is ~26 us on one CU: split frames into pixel strips only
+    // while there are fewer frames than CUs (every extra strip multiplies the fp64 atomics)
+    const int NSG = std::max(1, std::min((256 + kest - 1) / kest, std::max(1, HW / 256)));
     hipLaunchKernelGGL(ba_gram_kernel, dim3(F, NSG), dim3(256), 0, st, (const float*)(ws + L.Q),
                        (const float*)(ws + L.W), (const float*)(ws + L.Ei), (const float*)(ws + L.Ej), jj, kx,
                        eoff, eidx, meta, HW, NSG, t0, L.P, H, L.ld, L.npad);
@@ -725,12 +789,13 @@ int run_finish(const BaLayout& L, char* ws, float* poses, float* disps, const in
                        (double)lm, (double)ep);
     const int nbrows = L.nbk + 1;                        // + rhs block row
     for (int j = 0; j < L.nbk; ++j) {
-      hipLaunchKernelGGL(chol_panel_kernel, dim3(nbrows - j), dim3(256), 0, st, H, L.ld, j, Linv, meta);
+      hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(64), 0, st, H, L.ld, j, Linv, meta);
       const int m = nbrows - j - 1;
-      if (m > 0) hipLaunchKernelGGL(chol_update_kernel, dim3(m, m), dim3(256), 0, st, H, L.ld, j, L.nbk);
+      hipLaunchKernelGGL(chol_trsm_kernel, dim3(m), dim3(256), 0, st, H, L.ld, j, (const double*)Linv);
+      if (m > 1) hipLaunchKernelGGL(chol_update_kernel, dim3(m, m), dim3(256), 0, st, H, L.ld, j, L.nbk);
     }
     for (int j = L.nbk - 1; j >= 0; --j)
-      hipLaunchKernelGGL(chol_backsub_kernel, dim3(j + 1), dim3(64), 0, st, H, L.ld, j, L.npad, Linv, x);
+      hipLaunchKernelGGL(chol_backsub_kernel, dim3(j + 1), dim3(256), 0, st, H, L.ld, j, L.npad, Linv, x);
     hipLaunchKernelGGL(ba_dx_kernel, dim3((L.n + 255) / 256), dim3(256), 0, st, x, meta, L.n, dxw, dx_out);
     DH_LAUNCH_CHECK();
   }
