@@ -199,10 +199,10 @@ def main():
             "dtype": "f32 (BA; fp64 solve) / f16 (correlation pyramid)", "data": "synthetic",
             "config": {"workload": "%s: %d keyframes, %d edges, %dx%d, ba itrs=%d lm=%g ep=%g" % (
                 cfg.name, N, E_all, ht, wd, g["itrs"], g["lm"], g["ep"]),
-                "stages": "reproject + corr lookup (4 levels, materialised fp16 pyramid) + ba",
+                "stages": "reproject + corr lookup (4 levels, materialised fp16 pyramid, MI355X layout) + ba",
                 "parallelism": "edge-sharded x%d" % world},
             "ms_per_global_ba": ba, "ms_corr_lookup": lk,
-            "roofline": {"kernel": "corr_index_fwd_r3_kernel<half> (4 launches = 1 pyramid lookup)", "bound": "hbm",
+            "roofline": {"kernel": "pyr_lookup_kernel (1 launch = 4-level pyramid lookup of all edges)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch_group": lookup_bytes},

@@ -10,6 +10,7 @@
 #include <torch/extension.h>
 #include <c10/hip/HIPStream.h>
 #include <vector>
+#include <algorithm>
 #include "../../include/droid_hip.h"
 
 namespace {
@@ -228,6 +229,41 @@ std::vector<torch::Tensor> altcorr_backward(torch::Tensor fmap1, torch::Tensor f
   return {g1.to(fmap1.scalar_type()), g2.to(fmap2.scalar_type())};
 }
 
+
+// ---- MI355X-native correlation pyramid (own layout; droid_amd.corr.CorrBlock) ----------------------------
+torch::Tensor corr_pyramid_build(torch::Tensor fmap1, torch::Tensor fmap2) {
+  CHECK_INPUT(fmap1); CHECK_INPUT(fmap2);
+  TORCH_CHECK(fmap1.scalar_type() == torch::kFloat16 && fmap2.scalar_type() == torch::kFloat16, "fmaps must be float16");
+  TORCH_CHECK(fmap1.dim() == 4 && fmap1.sizes() == fmap2.sizes(), "corr_pyramid_build: fmaps [E,C,h,w] of equal shape");
+  const int E = (int)fmap1.size(0), C = (int)fmap1.size(1), h = (int)fmap1.size(2), w = (int)fmap1.size(3);
+  const size_t bytes1 = dh_corr_pyramid_bytes(1, h, w);
+  TORCH_CHECK(bytes1 > 0, "corr_pyramid_build: unsupported image size (need h % 8 == 0 and w in {8,16,32,64})");
+  torch::Tensor pyr = torch::empty({E, (int64_t)(bytes1 / 2)}, fmap1.options());
+  const int chunk = 256;                                  // bounds the channel-last scratch copies
+  const size_t wsb = dh_corr_pyramid_workspace_bytes(std::min(E, chunk), h, w);
+  torch::Tensor ws = torch::empty({(int64_t)wsb}, fmap1.options().dtype(torch::kUInt8));
+  for (int s = 0; s < E; s += chunk) {
+    const int n = std::min(chunk, E - s);
+    check_status(dh_corr_pyramid_build(fmap1[s].data_ptr(), fmap2[s].data_ptr(), pyr[s].data_ptr(), ws.data_ptr(), wsb,
+                                       n, C, h, w, cur_stream()),
+                 "corr_pyramid_build");
+  }
+  return pyr;
+}
+
+torch::Tensor corr_pyramid_lookup(torch::Tensor pyramid, torch::Tensor coords) {
+  CHECK_INPUT(pyramid); CHECK_INPUT(coords); CHECK_F32(coords);
+  TORCH_CHECK(pyramid.scalar_type() == torch::kFloat16, "pyramid must be float16");
+  TORCH_CHECK(coords.dim() == 4 && coords.size(3) == 2, "corr_pyramid_lookup: coords [E,h,w,2]");
+  const int E = (int)coords.size(0), h = (int)coords.size(1), w = (int)coords.size(2);
+  TORCH_CHECK(pyramid.size(0) == E && (size_t)pyramid.size(1) * 2 == dh_corr_pyramid_bytes(1, h, w),
+              "corr_pyramid_lookup: pyramid does not match coords");
+  torch::Tensor out = torch::empty({E, 4 * 49, h, w}, pyramid.options());
+  check_status(dh_corr_pyramid_lookup(pyramid.data_ptr(), coords.data_ptr<float>(), out.data_ptr(), E, h, w, cur_stream()),
+               "corr_pyramid_lookup");
+  return out;
+}
+
 // ---- extensions beyond the reference module (used by droid_amd / lietorch compat) ----------------
 std::vector<torch::Tensor> reproject(torch::Tensor poses, torch::Tensor disps, torch::Tensor intrinsics,
                                      torch::Tensor ii, torch::Tensor jj) {
@@ -292,6 +328,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   // MI355X extensions (not in the reference module)
   m.def("ba_build", &ba_build, "per-rank reduced camera system (split BA)");
   m.def("ba_finish", &ba_finish, "damp + solve + back-substitute + retract (split BA)");
+  m.def("corr_pyramid_build", &corr_pyramid_build, "all-pairs correlation pyramid, MI355X layout");
+  m.def("corr_pyramid_lookup", &corr_pyramid_lookup, "fused 4-level lookup on the MI355X pyramid");
   m.def("reproject", &reproject, "fused reprojection (Python thresholds)");
   m.def("se3_op", &se3_op, "SE3 inv/mul/exp/retr");
   m.def("se3_map", &se3_map, "SE3 act4/adjT");

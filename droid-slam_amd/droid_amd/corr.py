@@ -16,7 +16,9 @@ import torch.nn.functional as F
 import droid_backends
 
 
-class CorrBlock:
+class CorrBlockRef:
+    """Reference-layout pyramid (any image size); lookups through droid_backends.corr_index_forward."""
+
     def __init__(self, fmap1, fmap2, num_levels=4, radius=3, chunk=64):
         self.num_levels = num_levels
         self.radius = radius
@@ -78,3 +80,37 @@ class AltCorrBlock:
                                                    ii, jj, self.radius)
             outs.append(corr.flatten(2, 3))
         return torch.stack(outs, dim=2).flatten(2, 3)
+
+
+class CorrBlock:
+    """MI355X-native pyramid: built on the fp16 MFMA in the displacement-skewed, 8x8-block interleaved
+    layout of csrc/corr_pyramid.hip and looked up by ONE fused kernel over the 4 levels.  Same interface as
+    the reference CorrBlock (corr.py:23-60): CorrBlock(fmap1, fmap2), block(coords), cat, __getitem__."""
+
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=3):
+        assert num_levels == 4 and radius == 3, "the fused pyramid is specialised to 4 levels / radius 3"
+        batch, num, dim, ht, wd = fmap1.shape
+        assert batch == 1
+        self.num_levels, self.radius = num_levels, radius
+        self.ht, self.wd = ht, wd
+        self.pyramid = droid_backends.corr_pyramid_build(fmap1[0].half().contiguous(), fmap2[0].half().contiguous())
+
+    @staticmethod
+    def supported(ht, wd):
+        return ht % 8 == 0 and wd in (8, 16, 32, 64)
+
+    def __call__(self, coords):
+        batch, num, ht, wd, _ = coords.shape
+        out = droid_backends.corr_pyramid_lookup(self.pyramid, coords.reshape(batch * num, ht, wd, 2).contiguous())
+        return out.view(batch, num, -1, ht, wd)
+
+    def cat(self, other):
+        self.pyramid = torch.cat([self.pyramid, other.pyramid], 0)
+        return self
+
+    def __getitem__(self, index):
+        self.pyramid = self.pyramid[index]
+        return self
+
+    def bytes(self):
+        return self.pyramid.numel() * self.pyramid.element_size()

@@ -75,6 +75,26 @@ int dh_altcorr_bwd(const void* fmap1, const void* fmap2, const float* coords,
                    dh_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * MI355X-native correlation pyramid (own layout, built and consumed only by this library).
+ * Replaces CorrBlock.__init__ / CorrBlock.__call__ (reference droid_slam/modules/corr.py:23-50,63-71):
+ * per level the all-pairs contraction (f1/4)^T pool_l(f2/4) on the fp16 MFMA, written in a
+ * displacement-skewed, 8x8-source-block interleaved layout (DESIGN.md "correlation pyramid layout"),
+ * then ONE lookup kernel over all 4 levels.
+ *   fmap1, fmap2 [E,C=128,h,w] f16 -> pyramid (opaque f16, dh_corr_pyramid_bytes(E,h,w) bytes; edge-major,
+ *     so concatenating / indexing edges is a plain copy of dh_corr_pyramid_bytes(1,h,w)-sized records)
+ *   coords [E,h,w,2] f32 (x,y; what CorrBlock.__call__ receives) -> out [E,4*49,h,w] f16,
+ *     channel = level*49 + xoff*7 + yoff (corr.py:46-50).  radius 3, 4 levels, h % 8 == 0, w in {8,16,32,64}
+ *     (otherwise DH_ERR_ARG: use dh_corr_index_fwd on a reference-layout volume).
+ *   build needs dh_corr_pyramid_workspace_bytes(E,h,w) bytes of scratch (channel-last feature copies).
+ */
+size_t dh_corr_pyramid_bytes(int E, int h, int w);
+size_t dh_corr_pyramid_workspace_bytes(int E, int h, int w);
+int dh_corr_pyramid_build(const void* fmap1, const void* fmap2, void* pyramid, void* workspace,
+                          size_t workspace_bytes, int E, int C, int h, int w, dh_stream_t stream);
+int dh_corr_pyramid_lookup(const void* pyramid, const float* coords, void* out,
+                           int E, int h, int w, dh_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Dense bundle adjustment.  Replaces ba (reference src/droid.cpp:93-122 -> ba_cuda,
  * src/droid_kernels.cu:1323-1443).
  *   poses [num_frames,7] f32      IN/OUT (poses t0..t1-1 are retracted in place)

@@ -381,3 +381,67 @@ def test_dist_ba_world1_equals_fused(db):
                                 dev(g["weights"]), dev(g["eta"]), dev(g["ii"]), dev(g["jj"]), 1, 8, 2, g["lm"], g["ep"])
     assert np.abs(poses.cpu().numpy() - ref_p).max() < 1e-6
     assert np.abs(disps.cpu().numpy() - ref_d).max() < 1e-5
+
+
+# ------------------------------------------------------------------------------------------ native pyramid
+def _smooth_coords(rng, E, h, w, amp=6.0):
+    """coherent flow field (what a reprojection produces) + a few outliers / out-of-image pixels"""
+    yy, xx = np.meshgrid(np.arange(h, dtype=np.float64), np.arange(w, dtype=np.float64), indexing="ij")
+    c = np.zeros((E, h, w, 2), dtype=np.float64)
+    for e in range(E):
+        a = rng.uniform(-amp, amp, 6)
+        c[e, ..., 0] = xx + a[0] + a[1] * xx / w + a[2] * yy / h
+        c[e, ..., 1] = yy + a[3] + a[4] * xx / w + a[5] * yy / h
+    c[:, 0, 0] = [-30.0, 5.0]
+    c[:, -1, -1] = [w + 2.5, h - 0.5]
+    return c.astype(np.float32)
+
+
+@pytest.mark.parametrize("shape", [(3, 16, 16), (2, 8, 32), (2, 24, 8), (2, 48, 64)])
+@pytest.mark.parametrize("kind", ["smooth", "random"])
+def test_native_corr_pyramid_vs_oracle(db, shape, kind):
+    from droid_amd.corr import CorrBlock
+    E, h, w = shape
+    rng = np.random.default_rng(E * 1000 + h + w)
+    f1 = rng.standard_normal((E, 128, h, w)).astype(np.float16)
+    f2 = rng.standard_normal((E, 128, h, w)).astype(np.float16)
+    if kind == "smooth":
+        coords = _smooth_coords(rng, E, h, w)
+    else:
+        coords = np.stack([rng.uniform(-4, w + 3, (E, h, w)), rng.uniform(-4, h + 3, (E, h, w))], -1).astype(np.float32)
+    blk = CorrBlock(dev(f1)[None], dev(f2)[None])
+    out = blk(dev(coords)[None])[0].float().cpu().numpy()
+    assert out.shape == (E, 196, h, w)
+    pyr = ocorr.corr_pyramid(f1, f2, 4)
+    ref = ocorr.corr_block_lookup(pyr, coords, 3)
+    assert np.abs(out - ref).max() <= 2.0 ** -8 * np.abs(ref).max()
+
+
+def test_native_pyramid_matches_reference_layout_path_full_size(db):
+    """same features, same coords: fused lookup on the skewed layout == 4 corr_index_forward launches"""
+    from droid_amd.corr import CorrBlock, CorrBlockRef
+    torch.manual_seed(3)
+    E, h, w = 6, 48, 64
+    f1 = torch.randn(1, E, 128, h, w, device="cuda").half()
+    f2 = torch.randn(1, E, 128, h, w, device="cuda").half()
+    rng = np.random.default_rng(0)
+    coords = dev(_smooth_coords(rng, E, h, w))[None]
+    a = CorrBlock(f1, f2)(coords).float()
+    b = CorrBlockRef(f1, f2)(coords).float()
+    assert a.shape == b.shape == (1, E, 196, h, w)
+    assert (a - b).abs().max() <= 2.0 ** -7 * b.abs().max()
+
+
+def test_native_pyramid_cat_and_index(db):
+    from droid_amd.corr import CorrBlock
+    torch.manual_seed(4)
+    h, w = 16, 16
+    f1 = torch.randn(1, 5, 128, h, w, device="cuda").half()
+    f2 = torch.randn(1, 5, 128, h, w, device="cuda").half()
+    coords = dev(_smooth_coords(np.random.default_rng(1), 5, h, w))[None]
+    full = CorrBlock(f1, f2)(coords)
+    a = CorrBlock(f1[:, :2], f2[:, :2]).cat(CorrBlock(f1[:, 2:], f2[:, 2:]))
+    assert torch.equal(a(coords), full)
+    mask = torch.tensor([True, False, True, True, False], device="cuda")
+    sub = a[mask]
+    assert torch.equal(sub(coords[:, mask]), full[:, mask])
