@@ -29,6 +29,7 @@
 // (coords read once), separable bilinear interpolation in fp32 registers, results staged per level in
 // LDS and written as full 128-byte rows of the [E,196,h,w] output.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 using namespace dh;
@@ -211,12 +212,47 @@ __global__ __launch_bounds__(256) void pyr_build_kernel(const __half* __restrict
 }
 
 // ---------------------------------------------------------------------------------------- lookup
-// workgroup = (edge, 8-row strip), wave = 8x8 source block, lane p = yy*8 + xx
-__global__ __launch_bounds__(512) void pyr_lookup_kernel(const __half* __restrict__ pyr, const float* __restrict__ coords,
-                                                          __half* __restrict__ out, PyrDims D) {
-  extern __shared__ __half s_out[];               // [49][8 rows][w]
+// workgroup = (edge, 8-row strip), wave = 8x8 source block, lane p = yy*8 + xx.
+//   * tap loads are UNCONDITIONAL, from clamped in-slice offsets (wave-uniform SGPR base + 32-bit lane
+//     offset); out-of-image taps are zeroed afterwards in registers.  (A predicated load costs a branch +
+//     s_waitcnt vmcnt(0) each and leaves ONE request in flight per wave: measured 1.7 TB/s.)
+//   * rolling prefetch in half-level batches (4 window rows = 32 loads = 32 VGPRs): while one half is
+//     interpolated the other half and/or the next level's first half are in flight, also across the staging
+//     barriers and the output stores.  The loads are inline asm so that they can stay outstanding across the
+//     barriers (hipcc would drain vmcnt at a __syncthreads()) and the waits are explicit counted
+//     s_waitcnt vmcnt(N): vector-memory operations return in order on this ISA family, so "at most N
+//     outstanding" with N younger operations issued means the older batch has landed.  (d16 / d16_hi loads
+//     cannot be used to pack two taps per VGPR: with SRAM-ECC they clear the other half.)
+//   * staging tile in LDS: [49 planes][8 rows][w] fp16, the 16-byte segments of a row XOR-swizzled by the
+//     row so that the per-wave column of segments spreads over the banks; x-neighbour lanes exchange values
+//     (DPP quad_perm) so every lane writes one packed dword per channel pair;
+//   * the strip of one channel is 8 full rows = 1 KB contiguous in [E,196,h,w]: one 16-byte store per lane.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ float dpp_swap_x(float v) {      // value of lane ^ 1
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+
+constexpr int HALF_ROWS = WIN / 2;                 // window rows per batch
+constexpr int MIN_STORES = (NCH_OUT * 8) / 64;     // output-store instructions every wave issues per level (>= 6)
+
+struct LevelGeom {                                  // per-lane addressing / weights of one level
+  const __half* base;                               // wave-uniform
+  int coloff[WIN];                                  // byte offsets (lane included)
+  uint32_t cmask[WIN / 2];                          // 0xffff / 0 per window column, two columns per register
+  int Y0, y1l, h2, w2;
+  float dx, dy;
+};
+struct HalfTaps { uint32_t raw[HALF_ROWS][WIN]; uint32_t rows; };
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__global__ __launch_bounds__(512, 4) void pyr_lookup_kernel(const __half* __restrict__ pyr, const float* __restrict__ coords,
+                                                             __half* __restrict__ out, PyrDims D) {
+  extern __shared__ __half s_out[];               // [49][8 rows][w], swizzled
   const int e = blockIdx.y, by = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, bx = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int bx = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int w = D.w, h = D.h, HW = h * w;
   const int nbx = w / 8, nthreads = nbx * 64;
   const int yy = lane >> 3, xx = lane & 7;
@@ -225,55 +261,120 @@ __global__ __launch_bounds__(512) void pyr_lookup_kernel(const __half* __restric
   const float2 c0 = reinterpret_cast<const float2*>(coords)[(long)e * HW + (long)y1 * w + x1];
   const __half* ebase = pyr + (long)e * D.edge_elems;
 
-#pragma unroll
-  for (int l = 0; l < NLEV; ++l) {
+  auto geom = [&](int l, LevelGeom& G) {
     const int h2 = D.h2[l], w2 = D.w2[l];
     const float inv = 1.0f / (float)(1 << l);
     const float cx = c0.x * inv, cy = c0.y * inv;           // exact: power-of-two scaling, as coords / 2**i
     float fxf = floorf(cx), fyf = floorf(cy);
-    const float dx = cx - fxf, dy = cy - fyf;
+    G.dx = cx - fxf; G.dy = cy - fyf;
     fxf = fminf(fmaxf(fxf, -65536.f), 65536.f);
     fyf = fminf(fmaxf(fyf, -65536.f), 65536.f);
-    const int X0 = (int)fxf - RAD, Y0 = (int)fyf - RAD;
-    const int x1l = x1 >> l, y1l = y1 >> l;
-    const __half* base = ebase + D.lev_off[l] + (long)sb * h2 * w2 * 64 + lane;
-    int coloff[WIN]; bool colok[WIN];
+    const int X0 = (int)fxf - RAD;
+    G.Y0 = (int)fyf - RAD;
+    const int x1l = x1 >> l;
+    G.y1l = y1 >> l; G.h2 = h2; G.w2 = w2;
+    G.base = ebase + D.lev_off[l] + (long)sb * h2 * w2 * 64;
 #pragma unroll
     for (int i = 0; i < WIN; ++i) {
       const int x2 = X0 + i;
-      colok[i] = (unsigned)x2 < (unsigned)w2;
-      coloff[i] = colok[i] ? wrap(x2 - x1l, w2) * 64 : 0;
+      const bool ok = (unsigned)x2 < (unsigned)w2;
+      if ((i & 1) == 0) G.cmask[i >> 1] = ok ? 0xffffu : 0u; else G.cmask[i >> 1] |= ok ? 0xffff0000u : 0u;
+      G.coloff[i] = ((ok ? wrap(x2 - x1l, w2) * 64 : 0) + lane) * 2;
     }
-    float prev[OUTW];
+  };
+  auto request = [&](const LevelGeom& G, int half, HalfTaps& T) {
+    uint32_t rows = 0;
 #pragma unroll
-    for (int j = 0; j < WIN; ++j) {
-      const int y2 = Y0 + j;
-      const bool rowok = (unsigned)y2 < (unsigned)h2;
-      const int rowoff = rowok ? wrap(y2 - y1l, h2) * w2 * 64 : 0;
+    for (int jj = 0; jj < HALF_ROWS; ++jj) {
+      const int y2 = G.Y0 + half * HALF_ROWS + jj;
+      const bool ok = (unsigned)y2 < (unsigned)G.h2;
+      rows |= ok ? (1u << jj) : 0u;
+      const int rowoff = (ok ? wrap(y2 - G.y1l, G.h2) * G.w2 * 64 : 0) * 2;
+#pragma unroll
+      for (int i = 0; i < WIN; ++i)
+        asm volatile("global_load_ushort %0, %1, %2" : "=v"(T.raw[jj][i]) : "v"(rowoff + G.coloff[i]), "s"(G.base));
+    }
+    T.rows = rows;
+  };
+  // ties every tap register to this point so that no use can be scheduled above the preceding wait
+  auto landed = [&](HalfTaps& T) {
+#pragma unroll
+    for (int jj = 0; jj < HALF_ROWS; ++jj)
+      asm volatile("" : "+v"(T.raw[jj][0]), "+v"(T.raw[jj][1]), "+v"(T.raw[jj][2]), "+v"(T.raw[jj][3]),
+                        "+v"(T.raw[jj][4]), "+v"(T.raw[jj][5]), "+v"(T.raw[jj][6]), "+v"(T.raw[jj][7]));
+  };
+
+  const bool odd = xx & 1;
+  const int seg = bx ^ (yy & (nbx - 1));
+  __half* srow = s_out + yy * w + seg * 8 + (xx & ~1);           // + ch * 8 * w
+  float prev[OUTW], stash = 0.f;
+  // interpolate the 4 window rows of one batch; outputs of window row pair (j-1, j) go to LDS
+  auto consume = [&](const LevelGeom& G, const HalfTaps& T, int half) {
+    const float dx = G.dx, dy = G.dy;
+#pragma unroll
+    for (int jj = 0; jj < HALF_ROWS; ++jj) {
+      const int j = half * HALF_ROWS + jj;
+      const bool rowok = (T.rows >> jj) & 1;
       float t[WIN];
 #pragma unroll
-      for (int i = 0; i < WIN; ++i) t[i] = (rowok && colok[i]) ? __half2float(base[rowoff + coloff[i]]) : 0.f;
-      float cur[OUTW];
+      for (int i = 0; i < WIN; ++i)
+        t[i] = (float)__builtin_bit_cast(_Float16, (unsigned short)(T.raw[jj][i] & ((i & 1) ? (G.cmask[i >> 1] >> 16) : G.cmask[i >> 1])));
+      float c[OUTW];
 #pragma unroll
-      for (int a = 0; a < OUTW; ++a) cur[a] = t[a] + dx * (t[a + 1] - t[a]);
+      for (int a = 0; a < OUTW; ++a) { const float v = t[a] + dx * (t[a + 1] - t[a]); c[a] = rowok ? v : 0.f; }
       if (j > 0) {
+        float o[OUTW];
 #pragma unroll
-        for (int a = 0; a < OUTW; ++a)
-          s_out[((a * OUTW + (j - 1)) * 8 + yy) * w + x1] = __float2half(prev[a] + dy * (cur[a] - prev[a]));
+        for (int a = 0; a < OUTW; ++a) o[a] = prev[a] + dy * (c[a] - prev[a]);
+        // channel ch = a*7 + (j-1).  Pair two channels (A for even lanes, B for odd lanes): each lane sends the
+        // partner the value of the partner's channel and writes (x even, x odd) of its own channel as one dword.
+        auto put_pair = [&](float vA, float vB, int chA, int chB) {
+          const float mine = odd ? vB : vA, give = odd ? vA : vB;
+          const float got = dpp_swap_x(give);
+          const __half2 pk = odd ? __floats2half2_rn(got, mine) : __floats2half2_rn(mine, got);
+          *reinterpret_cast<__half2*>(srow + (odd ? chB : chA) * 8 * w) = pk;
+        };
+        put_pair(o[0], o[1], 0 * OUTW + (j - 1), 1 * OUTW + (j - 1));
+        put_pair(o[2], o[3], 2 * OUTW + (j - 1), 3 * OUTW + (j - 1));
+        put_pair(o[4], o[5], 4 * OUTW + (j - 1), 5 * OUTW + (j - 1));
+        if ((j - 1) & 1) put_pair(stash, o[6], 6 * OUTW + (j - 2), 6 * OUTW + (j - 1));
+        else stash = o[6];
+        if (j == WIN - 1) put_pair(o[6], o[6], 6 * OUTW + (j - 1), 6 * OUTW + (j - 1));   // both lanes: same dword
       }
 #pragma unroll
-      for (int a = 0; a < OUTW; ++a) prev[a] = cur[a];
+      for (int a = 0; a < OUTW; ++a) prev[a] = c[a];
     }
-    __syncthreads();
-    // full 128-byte rows of the [E, 196, h, w] output: piece = 8 pixels (16 B)
-    const int pieces_per_row = w / 8, npieces = NCH_OUT * 8 * pieces_per_row;
+  };
+
+  LevelGeom G, Gn;
+  HalfTaps A, B;
+  geom(0, G);
+  request(G, 0, A);
+  request(G, 1, B);
+#pragma unroll
+  for (int l = 0; l < NLEV; ++l) {
+    const bool more = l + 1 < NLEV;
+    // issue order so far: ... A_l(32) B_l(32) [stores of level l-1 (>= MIN_STORES)]
+    if (l == 0) wait_vm<32>(); else wait_vm<32 + MIN_STORES>();
+    landed(A);
+    consume(G, A, 0);
+    if (more) { geom(l + 1, Gn); request(Gn, 0, A); }
+    // younger than B_l: [stores of level l-1] [A_{l+1}(32)]
+    if (l == 0) wait_vm<32>(); else if (more) wait_vm<32 + MIN_STORES>(); else wait_vm<0>();
+    landed(B);
+    consume(G, B, 1);
+    if (more) request(Gn, 1, B);
+    lds_barrier();
+    // one channel strip = 8 full rows = contiguous in the output; piece = 8 pixels (16 B)
+    const int npieces = NCH_OUT * 8 * nbx;
     for (int o = tid; o < npieces; o += nthreads) {
-      const int seg = o % pieces_per_row, row = (o / pieces_per_row) % 8, ch = o / (pieces_per_row * 8);
-      const uint4 val = *reinterpret_cast<const uint4*>(s_out + (ch * 8 + row) * w + seg * 8);
-      __half* dst = out + (((long)e * (NLEV * NCH_OUT) + l * NCH_OUT + ch) * h + by * 8 + row) * w + seg * 8;
+      const int sg = o % nbx, row = (o / nbx) % 8, ch = o / (nbx * 8);
+      const uint4 val = *reinterpret_cast<const uint4*>(s_out + (ch * 8 + row) * w + (sg ^ (row & (nbx - 1))) * 8);
+      __half* dst = out + (((long)e * (NLEV * NCH_OUT) + l * NCH_OUT + ch) * h + by * 8 + row) * w + sg * 8;
       *reinterpret_cast<uint4*>(dst) = val;
     }
-    __syncthreads();
+    lds_barrier();
+    if (more) G = Gn;
   }
 }
 

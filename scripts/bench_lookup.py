@@ -1,0 +1,52 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the fused pyramid lookup (and optionally the build) on one MI355X.
+usage: python scripts/bench_lookup.py [--edges 1024] [--reps 5] [--flow smooth|reproj|random] [--build-reps 0]"""
+import argparse, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "droid-slam_amd")]
+import numpy as np, torch
+import droid_backends as db
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--edges", type=int, default=1024)
+ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--flow", default="reproj")
+ap.add_argument("--build-reps", type=int, default=0)
+a = ap.parse_args()
+E, h, w = a.edges, 48, 64
+torch.manual_seed(0)
+f = torch.randn(64, 128, h, w, device="cuda").half()
+idx1 = torch.randint(0, 64, (E,), device="cuda"); idx2 = torch.randint(0, 64, (E,), device="cuda")
+f1, f2 = f[idx1].contiguous(), f[idx2].contiguous()
+pyr = db.corr_pyramid_build(f1, f2)
+torch.cuda.synchronize()
+if a.build_reps:
+    t = []
+    for _ in range(a.build_reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); p2 = db.corr_pyramid_build(f1[:256], f2[:256]); e1.record(); torch.cuda.synchronize(); t.append(e0.elapsed_time(e1))
+    ms = min(t); fl = 256 * 2.0 * 128 * 3072 * (3072 + 768 + 192 + 48)
+    print("build 256 edges: %.3f ms  %.1f TFLOP/s  write %.1f GB/s" % (ms, fl / ms / 1e9, 256 * 25067520 / ms / 1e6))
+rng = np.random.default_rng(0)
+yy, xx = np.meshgrid(np.arange(h, dtype=np.float32), np.arange(w, dtype=np.float32), indexing="ij")
+if a.flow == "random":
+    c = np.stack([rng.uniform(0, w, (E, h, w)), rng.uniform(0, h, (E, h, w))], -1).astype(np.float32)
+elif a.flow == "smooth":
+    am = rng.uniform(-6, 6, (E, 6, 1, 1)).astype(np.float32)
+    c = np.stack([xx + am[:, 0] + am[:, 1] * xx / w + am[:, 2] * yy / h, yy + am[:, 3] + am[:, 4] * xx / w + am[:, 5] * yy / h], -1)
+else:
+    from droid_amd import synthetic as syn
+    g = syn.make_graph(syn.CONFIGS["C3"])
+    d = lambda x: torch.as_tensor(np.ascontiguousarray(x)).cuda()
+    ii, jj = d(g["ii"][:E]), d(g["jj"][:E])
+    c, _ = db.reproject(d(g["poses"]), d(g["disps"]), d(g["intrinsics"]), ii, jj)
+    c = c.cpu().numpy()
+coords = torch.as_tensor(np.ascontiguousarray(c)).cuda()
+out = db.corr_pyramid_lookup(pyr, coords); torch.cuda.synchronize()
+t = []
+for _ in range(a.reps):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); out = db.corr_pyramid_lookup(pyr, coords); e1.record(); torch.cuda.synchronize(); t.append(e0.elapsed_time(e1))
+ms = float(np.median(t)); nbytes = 880.0 * E * h * w
+print("lookup %s E=%d: median %.3f ms min %.3f  -> %.1f GB/s algorithmic (%.1f%% of 8 TB/s)" % (
+    a.flow, E, ms, min(t), nbytes / ms / 1e6, nbytes / ms / 1e6 / 80.0))
