@@ -9,14 +9,20 @@
 // per-level kernel moves ~4.3 TB/s of cache lines for ~0.55 TB/s of useful taps).  Here the volume of
 // level l is stored as
 //
-//     V'[e][level][sb = 8x8 source block][v][u][p]      (fp16, p = 6-bit index inside the source block)
+//     V'[e][level][sb = 8x8 source block][v][u/2][p][u&1]   (fp16, p = 6-bit index inside the source block)
 //     v = (y2 - (y1 >> l)) mod h2_l ,  u = (x2 - (x1 >> l)) mod w2_l        ("displacement" coordinates)
+//     plus one all-zero row v = h2_l per source block (where out-of-image window rows are pointed)
 //
-// i.e. one 128-byte line holds, for ONE displacement (v,u), the 64 pixels of an 8x8 source block.  A
-// wave = one source block; when the flow is spatially coherent (it is: it comes from a reprojection)
-// all 64 lanes want the same displacement cells, so every tap load of the wave is one fully used line
-// and the window rows of a wave are 8 consecutive lines.  Zero padding outside the image is applied from
-// the un-wrapped (x2,y2) in registers.  Same size as the reference pyramid (no padding).
+// i.e. 256 contiguous bytes hold, for ONE pair of x-adjacent displacements, the 64 pixels of an 8x8 source
+// block, and every lane finds two of its own window taps in one aligned dword.  A wave = one source block;
+// when the flow is spatially coherent (it is: it comes from a reprojection) all 64 lanes want the same
+// displacement cells, so a tap load of the wave is one fully used 256-byte run and the window rows of a wave
+// are consecutive runs.  Why pairs: the texture-address path of a CU retires a wave-wide load in ~6-8 cycles
+// per 128-byte line it touches whatever the width per lane (measured, scripts/ubench/ta_rate.hip), and at the
+// coarser levels neighbouring lanes alternate between two adjacent cells, so 2-byte-per-lane loads (one cell
+// per 128-byte line) cost ~14 cycles each and 64 of them per level made the lookup TA-bound at 3.3 TB/s; with
+// pairs a window row is 5 dword loads instead of 8 ushort loads.  Out-of-image columns are zeroed in
+// registers from the un-wrapped x2.  Size: reference pyramid + 1/h2_l per level (zero rows), 25.6 MB/edge.
 //
 // Build: per level a true contraction over the 128 feature channels on the fp16 MFMA
 // (v_mfma_f32_16x16x32_f16), V_l = f1^T * pool_l(f2) / 16 (pooling commutes with the contraction; the
@@ -44,6 +50,7 @@ constexpr int NCH_OUT = OUTW * OUTW;   // 49
 struct PyrDims {
   int h, w, nblk;                // source image, number of 8x8 source blocks
   int h2[NLEV], w2[NLEV];
+  long blk_elems[NLEV];          // elements of one source block of a level: (h2 + 1 zero row) * w2 * 64
   long lev_off[NLEV];            // element offset of each level inside one edge
   long edge_elems;
   int tgt_off[NLEV + 1];         // target-pixel offset of each level in the pooled f2 pyramid
@@ -55,13 +62,19 @@ __host__ __device__ inline PyrDims make_dims(int h, int w) {
   long off = 0; int t = 0;
   for (int l = 0; l < NLEV; ++l) {
     d.h2[l] = h >> l; d.w2[l] = w >> l;
+    d.blk_elems[l] = (long)(d.h2[l] + 1) * d.w2[l] * 64;
     d.lev_off[l] = off; d.tgt_off[l] = t;
-    off += (long)h * w * d.h2[l] * d.w2[l];
+    off += (long)d.nblk * d.blk_elems[l];
     t += d.h2[l] * d.w2[l];
   }
   d.tgt_off[NLEV] = t;
   d.edge_elems = off;
   return d;
+}
+
+// element offset of cell (v,u), pixel p inside a source block of a level with row length w2 (even)
+__host__ __device__ inline long cell_off(int v, int u, int p, int w2) {
+  return (((long)v * (w2 >> 1) + (u >> 1)) * 64 + p) * 2 + (u & 1);
 }
 
 // ---------------------------------------------------------------------------------------- prep
@@ -169,10 +182,8 @@ __global__ __launch_bounds__(256) void pyr_build_kernel(const __half* __restrict
       }
     }
     // D[row = p (source), col = q (target)]: lane holds col = lane&15, rows (lane>>4)*4 + r of each tile.
-    // stage[(cell_local) * 64 + p]: cell_local = (target row inside chunk)*w2 + u  -- but rows of the chunk
-    // are addressed by (q - q0) with u replacing x2: idx = (q_local - x2 + u) = q_local + (u - x2)
-    const int sx = bx * 8 >> l, sy = by * 8 >> l;      // block origin at this level (for the wrap arithmetic)
-    (void)sy;
+    // Staging tile [pair of cells][p][2]: a target keeps its row inside the chunk and swaps x2 for u, so
+    // cell_local = q_local - x2 + u; cells (2k, 2k+1) of a row are interleaved per pixel like in HBM.
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       const int ql = nt * 16 + (lane & 15);
@@ -185,128 +196,143 @@ __global__ __launch_bounds__(256) void pyr_build_kernel(const __half* __restrict
           const int p = t * 16 + (lane >> 4) * 4 + r;
           const int x1l = (bx * 8 + (p & 7)) >> l;
           const int u = wrap(x2 - x1l, w2);
-          // position inside the chunk keeps the target row, swaps x2 for u
-          stage[(ql - x2 + u) * 64 + p] = __float2half(acc[t][nt][r] * 0.0625f);
+          const int cl = ql - x2 + u;
+          stage[((cl >> 1) * 64 + p) * 2 + (cl & 1)] = __float2half(acc[t][nt][r] * 0.0625f);
         }
     }
-    (void)sx;
     __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0): wave-private tile complete
     __builtin_amdgcn_wave_barrier();
-    // read back 16-byte pieces: piece = (cell_local, yy) = 8 source pixels of one source row
+    // read back 16-byte pieces: piece = (pair of cells, source row yy, half row) = 4 source pixels x 2 cells
     // global cell: v = wrap(y2 - (y1 >> l)), same u
+    __half* lbase = obase + D.lev_off[l] + (long)sb * D.blk_elems[l];
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int piece = it * 64 + lane;
-      const int cl = piece >> 3, yy = piece & 7;
+      const int pr = piece >> 4, yy = (piece >> 1) & 7, xh = piece & 1;
+      const int cl = pr * 2;
       if (cl < nq) {
         const int q = q0 + cl;
         const int y2 = q / w2, u = q - y2 * w2;
         const int v = wrap(y2 - ((by * 8 + yy) >> l), h2);
-        const uint4 val = *reinterpret_cast<const uint4*>(stage + cl * 64 + yy * 8);
-        __half* dst = obase + D.lev_off[l] + ((long)sb * T + (long)v * w2 + u) * 64 + yy * 8;
-        *reinterpret_cast<uint4*>(dst) = val;
+        const int p = yy * 8 + xh * 4;
+        const uint4 val = *reinterpret_cast<const uint4*>(stage + (pr * 64 + p) * 2);
+        *reinterpret_cast<uint4*>(lbase + cell_off(v, u, p, w2)) = val;
       }
     }
     __builtin_amdgcn_wave_barrier();
+  }
+  // the all-zero row v = h2 of every level of this source block
+#pragma unroll
+  for (int l = 0; l < NLEV; ++l) {
+    uint4* z = reinterpret_cast<uint4*>(obase + D.lev_off[l] + (long)sb * D.blk_elems[l] + (long)D.h2[l] * D.w2[l] * 64);
+    const int n16 = D.w2[l] * 64 / 8;
+    for (int o = tid; o < n16; o += 256) z[o] = uint4{0u, 0u, 0u, 0u};
   }
 }
 
 // ---------------------------------------------------------------------------------------- lookup
 // workgroup = (edge, 8-row strip), wave = 8x8 source block, lane p = yy*8 + xx.
-//   * tap loads are UNCONDITIONAL, from clamped in-slice offsets (wave-uniform SGPR base + 32-bit lane
-//     offset); out-of-image taps are zeroed afterwards in registers.  (A predicated load costs a branch +
-//     s_waitcnt vmcnt(0) each and leaves ONE request in flight per wave: measured 1.7 TB/s.)
-//   * rolling prefetch in half-level batches (4 window rows = 32 loads = 32 VGPRs): while one half is
+//   * a window row (8 taps from displacement cell u0) is FIVE aligned dword loads (cell pairs floor(u0/2)..+4,
+//     modulo the row); the 8 taps are extracted with v_alignbit by the lane's parity of u0.  Loads are
+//     UNCONDITIONAL (wave-uniform SGPR base + 32-bit lane offset): out-of-image window rows point at the
+//     block's all-zero row, out-of-image columns are zeroed afterwards by AND-ing the packed pairs.
+//     (A predicated load costs a branch + s_waitcnt vmcnt(0) each and leaves ONE request in flight per wave:
+//     that version ran at 1.7 TB/s.)
+//   * rolling prefetch in half-level batches (4 window rows = 20 loads = 20 VGPRs): while one half is
 //     interpolated the other half and/or the next level's first half are in flight, also across the staging
 //     barriers and the output stores.  The loads are inline asm so that they can stay outstanding across the
 //     barriers (hipcc would drain vmcnt at a __syncthreads()) and the waits are explicit counted
 //     s_waitcnt vmcnt(N): vector-memory operations return in order on this ISA family, so "at most N
-//     outstanding" with N younger operations issued means the older batch has landed.  (d16 / d16_hi loads
-//     cannot be used to pack two taps per VGPR: with SRAM-ECC they clear the other half.)
+//     outstanding" with N younger operations issued means the older batch has landed.
 //   * staging tile in LDS: [49 planes][8 rows][w] fp16, the 16-byte segments of a row XOR-swizzled by the
-//     row so that the per-wave column of segments spreads over the banks; x-neighbour lanes exchange values
-//     (DPP quad_perm) so every lane writes one packed dword per channel pair;
-//   * the strip of one channel is 8 full rows = 1 KB contiguous in [E,196,h,w]: one 16-byte store per lane.
+//     row so that the per-wave column of segments spreads over the banks; x-neighbour lanes exchange packed
+//     channel pairs (DPP quad_perm + v_perm) so every lane writes one dword per channel pair;
+//   * the strip of one channel is 8 full rows = 1 KB contiguous in [E,196,h,w]: one 16-byte store per lane,
+//     wave k of the workgroup stores channels k, k+8, ...
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-__device__ __forceinline__ float dpp_swap_x(float v) {      // value of lane ^ 1
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+__device__ __forceinline__ uint32_t dpp_swap_x(uint32_t v) {      // value of lane ^ 1
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
 }
 
 constexpr int HALF_ROWS = WIN / 2;                 // window rows per batch
+constexpr int NPAIR = WIN / 2 + 1;                 // dword loads per window row
+constexpr int BATCH = HALF_ROWS * NPAIR;           // loads per batch (20)
 constexpr int MIN_STORES = (NCH_OUT * 8) / 64;     // output-store instructions every wave issues per level (>= 6)
 
 struct LevelGeom {                                  // per-lane addressing / weights of one level
-  const __half* base;                               // wave-uniform
-  int coloff[WIN];                                  // byte offsets (lane included)
-  uint32_t cmask[WIN / 2];                          // 0xffff / 0 per window column, two columns per register
-  int Y0, y1l, h2, w2;
+  const __half* base;                               // wave-uniform: this source block of this level
+  int coloff[NPAIR];                                // byte offsets of the 5 cell pairs (lane included)
+  uint32_t cmask[WIN / 2];                          // column validity of the aligned tap pairs (0xffff per tap)
+  int Y0, y1l, par16;                               // first window row, own row at this level, 16 * (u0 & 1)
   float dx, dy;
 };
-struct HalfTaps { uint32_t raw[HALF_ROWS][WIN]; uint32_t rows; };
+struct HalfTaps { uint32_t raw[HALF_ROWS][NPAIR]; };
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-__global__ __launch_bounds__(512, 4) void pyr_lookup_kernel(const __half* __restrict__ pyr, const float* __restrict__ coords,
-                                                             __half* __restrict__ out, PyrDims D) {
-  extern __shared__ __half s_out[];               // [49][8 rows][w], swizzled
+template <int W>
+__global__ __launch_bounds__(W * 8, 4) void pyr_lookup_kernel(const __half* __restrict__ pyr, const float* __restrict__ coords,
+                                                               __half* __restrict__ out, PyrDims D) {
+  extern __shared__ __half s_out[];               // [49][8 rows][W], swizzled
+  constexpr int NBX = W / 8, NTHREADS = W * 8;
   const int e = blockIdx.y, by = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
   const int bx = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int w = D.w, h = D.h, HW = h * w;
-  const int nbx = w / 8, nthreads = nbx * 64;
+  const int h = D.h, HW = h * W;
   const int yy = lane >> 3, xx = lane & 7;
   const int y1 = by * 8 + yy, x1 = bx * 8 + xx;
-  const int sb = by * nbx + bx;
-  const float2 c0 = reinterpret_cast<const float2*>(coords)[(long)e * HW + (long)y1 * w + x1];
+  const int sb = by * NBX + bx;
+  const float2 c0 = reinterpret_cast<const float2*>(coords)[(long)e * HW + (long)y1 * W + x1];
   const __half* ebase = pyr + (long)e * D.edge_elems;
 
   auto geom = [&](int l, LevelGeom& G) {
-    const int h2 = D.h2[l], w2 = D.w2[l];
+    const int w2 = W >> l;                                   // power of two
     const float inv = 1.0f / (float)(1 << l);
-    const float cx = c0.x * inv, cy = c0.y * inv;           // exact: power-of-two scaling, as coords / 2**i
+    const float cx = c0.x * inv, cy = c0.y * inv;            // exact: power-of-two scaling, as coords / 2**i
     float fxf = floorf(cx), fyf = floorf(cy);
     G.dx = cx - fxf; G.dy = cy - fyf;
     fxf = fminf(fmaxf(fxf, -65536.f), 65536.f);
     fyf = fminf(fmaxf(fyf, -65536.f), 65536.f);
     const int X0 = (int)fxf - RAD;
     G.Y0 = (int)fyf - RAD;
-    const int x1l = x1 >> l;
-    G.y1l = y1 >> l; G.h2 = h2; G.w2 = w2;
-    G.base = ebase + D.lev_off[l] + (long)sb * h2 * w2 * 64;
+    G.y1l = y1 >> l;
+    G.base = ebase + D.lev_off[l] + (long)sb * D.blk_elems[l];
+    const int u0 = (X0 - (x1 >> l)) & (w2 - 1);              // two's complement: correct for any X0
+    G.par16 = (u0 & 1) * 16;
+    const int k0 = u0 >> 1;
 #pragma unroll
-    for (int i = 0; i < WIN; ++i) {
-      const int x2 = X0 + i;
-      const bool ok = (unsigned)x2 < (unsigned)w2;
-      if ((i & 1) == 0) G.cmask[i >> 1] = ok ? 0xffffu : 0u; else G.cmask[i >> 1] |= ok ? 0xffff0000u : 0u;
-      G.coloff[i] = ((ok ? wrap(x2 - x1l, w2) * 64 : 0) + lane) * 2;
+    for (int m = 0; m < NPAIR; ++m) G.coloff[m] = (((k0 + m) & (w2 / 2 - 1)) * 64 + lane) * 4;
+#pragma unroll
+    for (int n = 0; n < WIN / 2; ++n) {
+      const uint32_t lo = (unsigned)(X0 + 2 * n) < (unsigned)w2 ? 0xffffu : 0u;
+      const uint32_t hi = (unsigned)(X0 + 2 * n + 1) < (unsigned)w2 ? 0xffff0000u : 0u;
+      G.cmask[n] = lo | hi;
     }
   };
-  auto request = [&](const LevelGeom& G, int half, HalfTaps& T) {
-    uint32_t rows = 0;
+  auto request = [&](int l, const LevelGeom& G, int half, HalfTaps& T) {
+    const int w2 = W >> l, h2 = D.h2[l];
 #pragma unroll
     for (int jj = 0; jj < HALF_ROWS; ++jj) {
       const int y2 = G.Y0 + half * HALF_ROWS + jj;
-      const bool ok = (unsigned)y2 < (unsigned)G.h2;
-      rows |= ok ? (1u << jj) : 0u;
-      const int rowoff = (ok ? wrap(y2 - G.y1l, G.h2) * G.w2 * 64 : 0) * 2;
+      const int v = (unsigned)y2 < (unsigned)h2 ? wrap(y2 - G.y1l, h2) : h2;      // h2 = the all-zero row
+      const int rowoff = v * (w2 * 128);
 #pragma unroll
-      for (int i = 0; i < WIN; ++i)
-        asm volatile("global_load_ushort %0, %1, %2" : "=v"(T.raw[jj][i]) : "v"(rowoff + G.coloff[i]), "s"(G.base));
+      for (int m = 0; m < NPAIR; ++m)
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(T.raw[jj][m]) : "v"(rowoff + G.coloff[m]), "s"(G.base));
     }
-    T.rows = rows;
   };
   // ties every tap register to this point so that no use can be scheduled above the preceding wait
   auto landed = [&](HalfTaps& T) {
 #pragma unroll
     for (int jj = 0; jj < HALF_ROWS; ++jj)
-      asm volatile("" : "+v"(T.raw[jj][0]), "+v"(T.raw[jj][1]), "+v"(T.raw[jj][2]), "+v"(T.raw[jj][3]),
-                        "+v"(T.raw[jj][4]), "+v"(T.raw[jj][5]), "+v"(T.raw[jj][6]), "+v"(T.raw[jj][7]));
+      asm volatile("" : "+v"(T.raw[jj][0]), "+v"(T.raw[jj][1]), "+v"(T.raw[jj][2]), "+v"(T.raw[jj][3]), "+v"(T.raw[jj][4]));
   };
 
   const bool odd = xx & 1;
-  const int seg = bx ^ (yy & (nbx - 1));
-  __half* srow = s_out + yy * w + seg * 8 + (xx & ~1);           // + ch * 8 * w
+  const uint32_t psel = odd ? 0x03020706u : 0x05040100u;        // v_perm_b32(P, W, psel): see put_pair
+  const int seg = bx ^ (yy & (NBX - 1));
+  __half* srow = s_out + yy * W + seg * 8 + (xx & ~1);           // + ch * 8 * W
   float prev[OUTW], stash = 0.f;
   // interpolate the 4 window rows of one batch; outputs of window row pair (j-1, j) go to LDS
   auto consume = [&](const LevelGeom& G, const HalfTaps& T, int half) {
@@ -314,32 +340,39 @@ __global__ __launch_bounds__(512, 4) void pyr_lookup_kernel(const __half* __rest
 #pragma unroll
     for (int jj = 0; jj < HALF_ROWS; ++jj) {
       const int j = half * HALF_ROWS + jj;
-      const bool rowok = (T.rows >> jj) & 1;
       float t[WIN];
 #pragma unroll
-      for (int i = 0; i < WIN; ++i)
-        t[i] = (float)__builtin_bit_cast(_Float16, (unsigned short)(T.raw[jj][i] & ((i & 1) ? (G.cmask[i >> 1] >> 16) : G.cmask[i >> 1])));
+      for (int n = 0; n < WIN / 2; ++n) {
+        const uint32_t pr = __builtin_amdgcn_alignbit(T.raw[jj][n + 1], T.raw[jj][n], G.par16) & G.cmask[n];
+        t[2 * n] = (float)__builtin_bit_cast(_Float16, (unsigned short)(pr & 0xffffu));
+        t[2 * n + 1] = (float)__builtin_bit_cast(_Float16, (unsigned short)(pr >> 16));
+      }
       float c[OUTW];
 #pragma unroll
-      for (int a = 0; a < OUTW; ++a) { const float v = t[a] + dx * (t[a + 1] - t[a]); c[a] = rowok ? v : 0.f; }
+      for (int a = 0; a < OUTW; ++a) c[a] = t[a] + dx * (t[a + 1] - t[a]);
       if (j > 0) {
         float o[OUTW];
 #pragma unroll
         for (int a = 0; a < OUTW; ++a) o[a] = prev[a] + dy * (c[a] - prev[a]);
-        // channel ch = a*7 + (j-1).  Pair two channels (A for even lanes, B for odd lanes): each lane sends the
-        // partner the value of the partner's channel and writes (x even, x odd) of its own channel as one dword.
+        // channel ch = a*7 + (j-1).  Two channels per step (A stored by even lanes, B by odd lanes):
+        // Wd = [A_self, B_self] (fp16 pair), Pd = the x-neighbour's Wd; even lane stores [A_self, A_nb] = bytes
+        // (Wd.lo, Pd.lo), odd lane [B_nb, B_self] = (Pd.hi, Wd.hi): one v_perm_b32 with a per-lane selector.
         auto put_pair = [&](float vA, float vB, int chA, int chB) {
-          const float mine = odd ? vB : vA, give = odd ? vA : vB;
-          const float got = dpp_swap_x(give);
-          const __half2 pk = odd ? __floats2half2_rn(got, mine) : __floats2half2_rn(mine, got);
-          *reinterpret_cast<__half2*>(srow + (odd ? chB : chA) * 8 * w) = pk;
+          const uint32_t Wd = __builtin_bit_cast(uint32_t, __floats2half2_rn(vA, vB));
+          const uint32_t Pd = dpp_swap_x(Wd);
+          const uint32_t pk = __builtin_amdgcn_perm(Pd, Wd, psel);
+          *reinterpret_cast<uint32_t*>(srow + (odd ? chB : chA) * 8 * W) = pk;
         };
         put_pair(o[0], o[1], 0 * OUTW + (j - 1), 1 * OUTW + (j - 1));
         put_pair(o[2], o[3], 2 * OUTW + (j - 1), 3 * OUTW + (j - 1));
         put_pair(o[4], o[5], 4 * OUTW + (j - 1), 5 * OUTW + (j - 1));
         if ((j - 1) & 1) put_pair(stash, o[6], 6 * OUTW + (j - 2), 6 * OUTW + (j - 1));
         else stash = o[6];
-        if (j == WIN - 1) put_pair(o[6], o[6], 6 * OUTW + (j - 1), 6 * OUTW + (j - 1));   // both lanes: same dword
+        if (j == WIN - 1) {                                  // last channel: both lanes of a pair write the same dword
+          const uint32_t Wd = __builtin_bit_cast(uint32_t, __floats2half2_rn(o[6], o[6]));
+          const uint32_t Pd = dpp_swap_x(Wd);
+          *reinterpret_cast<uint32_t*>(srow + (6 * OUTW + 6) * 8 * W) = odd ? ((Pd & 0xffffu) | (Wd & 0xffff0000u)) : ((Wd & 0xffffu) | (Pd & 0xffff0000u));
+        }
       }
 #pragma unroll
       for (int a = 0; a < OUTW; ++a) prev[a] = c[a];
@@ -349,37 +382,43 @@ __global__ __launch_bounds__(512, 4) void pyr_lookup_kernel(const __half* __rest
   LevelGeom G, Gn;
   HalfTaps A, B;
   geom(0, G);
-  request(G, 0, A);
-  request(G, 1, B);
+  request(0, G, 0, A);
+  request(0, G, 1, B);
 #pragma unroll
   for (int l = 0; l < NLEV; ++l) {
     const bool more = l + 1 < NLEV;
-    // issue order so far: ... A_l(32) B_l(32) [stores of level l-1 (>= MIN_STORES)]
-    if (l == 0) wait_vm<32>(); else wait_vm<32 + MIN_STORES>();
+    // issue order so far: ... A_l(BATCH) B_l(BATCH) [stores of level l-1 (>= MIN_STORES)]
+    if (l == 0) wait_vm<BATCH>(); else wait_vm<BATCH + MIN_STORES>();
     landed(A);
     consume(G, A, 0);
-    if (more) { geom(l + 1, Gn); request(Gn, 0, A); }
-    // younger than B_l: [stores of level l-1] [A_{l+1}(32)]
-    if (l == 0) wait_vm<32>(); else if (more) wait_vm<32 + MIN_STORES>(); else wait_vm<0>();
+    if (more) { geom(l + 1, Gn); request(l + 1, Gn, 0, A); }
+    // younger than B_l: [stores of level l-1] [A_{l+1}(BATCH)]
+    if (l == 0) wait_vm<BATCH>(); else if (more) wait_vm<BATCH + MIN_STORES>(); else wait_vm<0>();
     landed(B);
     consume(G, B, 1);
-    if (more) request(Gn, 1, B);
+    if (more) request(l + 1, Gn, 1, B);
     lds_barrier();
-    // one channel strip = 8 full rows = contiguous in the output; piece = 8 pixels (16 B)
-    const int npieces = NCH_OUT * 8 * nbx;
-    for (int o = tid; o < npieces; o += nthreads) {
-      const int sg = o % nbx, row = (o / nbx) % 8, ch = o / (nbx * 8);
-      const uint4 val = *reinterpret_cast<const uint4*>(s_out + (ch * 8 + row) * w + (sg ^ (row & (nbx - 1))) * 8);
-      __half* dst = out + (((long)e * (NLEV * NCH_OUT) + l * NCH_OUT + ch) * h + by * 8 + row) * w + sg * 8;
-      *reinterpret_cast<uint4*>(dst) = val;
+    // one channel strip = 8 full rows = contiguous in the output; piece = 8 pixels (16 B).
+    // piece o -> sg = o % NBX, row = (o / NBX) % 8, ch = o / (NBX * 8): all shifts (NBX is a power of two)
+    constexpr int NPIECES = NCH_OUT * 8 * NBX;
+    __half* obase = out + ((long)e * (NLEV * NCH_OUT) + l * NCH_OUT) * HW + (long)by * 8 * W;
+#pragma unroll
+    for (int it = 0; it < (NPIECES + NTHREADS - 1) / NTHREADS; ++it) {
+      const int o = tid + it * NTHREADS;
+      if (it * NTHREADS + NTHREADS <= NPIECES || o < NPIECES) {
+        const int sg = o % NBX, row = (o / NBX) % 8, ch = o / (NBX * 8);
+        const uint4 val = *reinterpret_cast<const uint4*>(s_out + (ch * 8 + row) * W + (sg ^ (row & (NBX - 1))) * 8);
+        *reinterpret_cast<uint4*>(obase + (long)ch * HW + row * W + sg * 8) = val;
+      }
     }
     lds_barrier();
     if (more) G = Gn;
   }
 }
 
-// the skewed chunks of the build kernel need 64 % w2_l == 0 on every level: w in {8,16,32,64}; h multiple of 8
-bool dims_ok(int h, int w) { return h >= 8 && h % 8 == 0 && (w == 8 || w == 16 || w == 32 || w == 64); }
+// the skewed chunks of the build kernel need 64 % w2_l == 0 and cell pairs need w2_l even on every level:
+// w in {16,32,64}; h multiple of 8
+bool dims_ok(int h, int w) { return h >= 8 && h % 8 == 0 && (w == 16 || w == 32 || w == 64); }
 
 }  // namespace
 
@@ -424,8 +463,14 @@ extern "C" int dh_corr_pyramid_lookup(const void* pyramid, const float* coords, 
   if (!pyramid || !coords || !out) return DH_ERR_ARG;
   const PyrDims D = make_dims(h, w);
   const size_t lds = (size_t)NCH_OUT * 8 * w * sizeof(__half);
-  hipLaunchKernelGGL(pyr_lookup_kernel, dim3(h / 8, E), dim3((w / 8) * 64), lds, (hipStream_t)stream,
-                     (const __half*)pyramid, coords, (__half*)out, D);
+  const dim3 grid(h / 8, E);
+  hipStream_t st = (hipStream_t)stream;
+  if (w == 64)
+    hipLaunchKernelGGL(pyr_lookup_kernel<64>, grid, dim3(512), lds, st, (const __half*)pyramid, coords, (__half*)out, D);
+  else if (w == 32)
+    hipLaunchKernelGGL(pyr_lookup_kernel<32>, grid, dim3(256), lds, st, (const __half*)pyramid, coords, (__half*)out, D);
+  else
+    hipLaunchKernelGGL(pyr_lookup_kernel<16>, grid, dim3(128), lds, st, (const __half*)pyramid, coords, (__half*)out, D);
   DH_LAUNCH_CHECK();
   return DH_OK;
 }

@@ -237,7 +237,7 @@ torch::Tensor corr_pyramid_build(torch::Tensor fmap1, torch::Tensor fmap2) {
   TORCH_CHECK(fmap1.dim() == 4 && fmap1.sizes() == fmap2.sizes(), "corr_pyramid_build: fmaps [E,C,h,w] of equal shape");
   const int E = (int)fmap1.size(0), C = (int)fmap1.size(1), h = (int)fmap1.size(2), w = (int)fmap1.size(3);
   const size_t bytes1 = dh_corr_pyramid_bytes(1, h, w);
-  TORCH_CHECK(bytes1 > 0, "corr_pyramid_build: unsupported image size (need h % 8 == 0 and w in {8,16,32,64})");
+  TORCH_CHECK(bytes1 > 0, "corr_pyramid_build: unsupported image size (need h % 8 == 0 and w in {16,32,64})");
   torch::Tensor pyr = torch::empty({E, (int64_t)(bytes1 / 2)}, fmap1.options());
   const int chunk = 256;                                  // bounds the channel-last scratch copies
   const size_t wsb = dh_corr_pyramid_workspace_bytes(std::min(E, chunk), h, w);

@@ -97,7 +97,7 @@ class CorrBlock:
 
     @staticmethod
     def supported(ht, wd):
-        return ht % 8 == 0 and wd in (8, 16, 32, 64)
+        return ht % 8 == 0 and wd in (16, 32, 64)
 
     def __call__(self, coords):
         batch, num, ht, wd, _ = coords.shape

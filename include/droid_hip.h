@@ -83,7 +83,7 @@ int dh_altcorr_bwd(const void* fmap1, const void* fmap2, const float* coords,
  *   fmap1, fmap2 [E,C=128,h,w] f16 -> pyramid (opaque f16, dh_corr_pyramid_bytes(E,h,w) bytes; edge-major,
  *     so concatenating / indexing edges is a plain copy of dh_corr_pyramid_bytes(1,h,w)-sized records)
  *   coords [E,h,w,2] f32 (x,y; what CorrBlock.__call__ receives) -> out [E,4*49,h,w] f16,
- *     channel = level*49 + xoff*7 + yoff (corr.py:46-50).  radius 3, 4 levels, h % 8 == 0, w in {8,16,32,64}
+ *     channel = level*49 + xoff*7 + yoff (corr.py:46-50).  radius 3, 4 levels, h % 8 == 0, w in {16,32,64}
  *     (otherwise DH_ERR_ARG: use dh_corr_index_fwd on a reference-layout volume).
  *   build needs dh_corr_pyramid_workspace_bytes(E,h,w) bytes of scratch (channel-last feature copies).
  */
