@@ -302,7 +302,12 @@ __global__ __launch_bounds__(W * 8, 4) void pyr_lookup_kernel(const __half* __re
     G.par16 = (u0 & 1) * 16;
     const int k0 = u0 >> 1;
 #pragma unroll
-    for (int m = 0; m < NPAIR; ++m) G.coloff[m] = (((k0 + m) & (w2 / 2 - 1)) * 64 + lane) * 4;
+    for (int m = 0; m < NPAIR; ++m) {
+      // even u0: the window is exactly pairs k0..k0+3; the 5th load re-reads pair k0+3 instead of fetching a
+      // line nobody needs (coherent waves share the parity, so this is a real saving in HBM lines)
+      const int mm = (m == NPAIR - 1) ? NPAIR - 2 + (u0 & 1) : m;
+      G.coloff[m] = (((k0 + mm) & (w2 / 2 - 1)) * 64 + lane) * 4;
+    }
 #pragma unroll
     for (int n = 0; n < WIN / 2; ++n) {
       const uint32_t lo = (unsigned)(X0 + 2 * n) < (unsigned)w2 ? 0xffffu : 0u;
