@@ -30,8 +30,7 @@ namespace {
 
 using namespace dh;
 
-constexpr int NB = 48;            // Cholesky block (8 poses)
-constexpr int NBP = NB + 1;       // padded LDS leading dimension (doubles)
+constexpr int NB = 64;            // Cholesky block
 constexpr int PPT = 3;            // pixels per thread in build/backsub strips
 constexpr int STRIP = 256 * PPT;  // pixels per strip
 constexpr int HP_STRIDE = 28;     // per (edge, strip) partial: 21 Hjj + 6 vj (+1 pad)
@@ -515,11 +514,20 @@ __global__ void ba_damp_kernel(double* __restrict__ H, int ld, int n, int npad, 
   else H[(long)i * ld + i] = 1.0;
 }
 
-// ---- diagonal block: ONE wave, the 48x48 block lives in registers (lane r = row r) -----------------
-// Factorisation and the inverse of the factor are chains of ~1128 dependent fp64 FMAs each.  Row r stays
-// in lane r's registers; what every lane needs from the others (column c of L during the factorisation,
-// row a of L during the inversion) is published through LDS and read back as wave-wide broadcasts
-// (same address in all lanes: conflict-free, pipelined) -- no barriers between waves, no scratch.
+// ---- blocked Cholesky, NB = 64, two launches per block column -----------------------------------------
+// step j:  chol_panel_kernel  one workgroup per block row r > j (incl. the rhs row): EVERY workgroup factors the
+//                             diagonal block A_jj itself in LDS (redundant work is free, a separate launch and
+//                             its ~2 us dependency gap are not), inverts the factor (W = L_jj^-1) and forms
+//                             L_rj = A_rj W^T on the fp64 MFMA; workgroup 0 also keeps W_j for the back solve;
+//          chol_update_kernel A_rc -= L_rj L_cj^T for j < c <= r on the fp64 MFMA (v_mfma_f64_16x16x4_f64).
+// Inside a 64x64 block the factorisation is blocked again by 16: the 16x16 diagonal sub-block is factorised
+// by ONE wave with row r in the registers of lane r (cross-lane traffic = v_readlane broadcasts, no barriers),
+// the panel below it by row-wise substitution, the trailing update by all 4 waves.
+constexpr int SB = 16;            // sub-block
+constexpr int LDB = NB + 2;       // LDS leading dimension (doubles): 16 rows x {k, k+1} hit 32 distinct bank pairs
+
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+
 __device__ __forceinline__ double lane_bcast(double v, int lane) {
   int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
   int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
@@ -534,141 +542,247 @@ __device__ __forceinline__ double fast_rsqrt(double a) {
   return y;
 }
 
-__global__ __launch_bounds__(64) void chol_diag_kernel(
-    double* __restrict__ H, int ld, int j, double* __restrict__ Linv, int* __restrict__ meta) {
-  const int r = threadIdx.x;                     // row (lanes 48..63 idle)
-  const long d0 = (long)j * NB;
-  const bool act = r < NB;
-  double row[NB];
+// In-place Cholesky of the SPD block S (lower triangle used, LDS, leading dimension LDB) by 256 threads;
+// on return the lower triangle holds L, `dinv[i]` = 1 / L[i][i].  Returns false if a pivot is not positive
+// and finite (the factor is then meaningless but finite work is still done: SparseBlock::solve semantics
+// are applied by the caller through meta[1]).
+__device__ bool chol64_lds(double* __restrict__ S, double* __restrict__ dinv, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  bool ok = true;
+#pragma unroll 1
+  for (int k = 0; k < NB / SB; ++k) {
+    const int o = k * SB;
+    if (wave == 0) {
+      // 16x16 diagonal sub-block, lane r = row r (lanes >= 16 compute on zeros)
+      const int r = lane & 15;
+      const bool act = lane < SB;
+      double row[SB];
 #pragma unroll
-  for (int c = 0; c < NB; ++c) row[c] = (act && c <= r) ? H[(d0 + r) * ld + d0 + c] : 0.0;
-  bool fail = false;
-  double dinv[NB];                               // 1 / L[c][c] (wave-uniform)
-  // entries above the diagonal (c2 > r) are never read by anybody: they are allowed to collect garbage,
-  // which removes every per-element predicate from the rank-1 updates
+      for (int c = 0; c < SB; ++c) row[c] = (act && c <= r) ? S[(o + r) * LDB + o + c] : 0.0;
 #pragma unroll
-  for (int c = 0; c < NB; ++c) {
-    double piv = lane_bcast(row[c], c);
-    if (!(piv > 0.0) || !(piv < 1e300)) { fail = true; piv = 1.0; }
-    const double rs = fast_rsqrt(piv);
-    dinv[c] = rs;
-    row[c] = (r == c) ? piv * rs : row[c] * rs;
+      for (int c = 0; c < SB; ++c) {
+        double piv = lane_bcast(row[c], c);
+        if (!(piv > 0.0) || !(piv < 1e300)) { ok = false; piv = 1.0; }
+        const double rs = fast_rsqrt(piv);
+        if (lane == c) dinv[o + c] = rs;
+        row[c] = (r == c) ? piv * rs : row[c] * rs;
 #pragma unroll
-    for (int c2 = c + 1; c2 < NB; ++c2) row[c2] -= row[c] * lane_bcast(row[c], c2);   // L[r][c] * L[c2][c]
+        for (int c2 = c + 1; c2 < SB; ++c2) row[c2] -= row[c] * lane_bcast(row[c], c2);   // L[r][c] * L[c2][c]
+      }
+      if (act) {
+#pragma unroll
+        for (int c = 0; c < SB; ++c) S[(o + r) * LDB + o + c] = (c <= r) ? row[c] : 0.0;
+      }
+    }
+    __syncthreads();
+    const int nrem = NB - o - SB;                       // rows below the sub-block
+    if (nrem > 0) {
+      // panel: X[i][:] = A[i][:] L_kk^-T, one thread per row (the factor is read as LDS broadcasts)
+      if (tid < nrem) {
+        double* prow = S + (o + SB + tid) * LDB + o;
+        double x[SB];
+#pragma unroll
+        for (int c = 0; c < SB; ++c) {
+          double v = prow[c];
+#pragma unroll
+          for (int m = 0; m < c; ++m) v -= x[m] * S[(o + c) * LDB + o + m];
+          x[c] = v * dinv[o + c];
+        }
+#pragma unroll
+        for (int c = 0; c < SB; ++c) prow[c] = x[c];
+      }
+      __syncthreads();
+      // trailing update of the lower triangle: S[i][j] -= sum_m X[i][m] X[j][m]
+      for (int idx = tid; idx < nrem * nrem; idx += 256) {
+        const int i = idx / nrem, j = idx - i * nrem;
+        if (j > i) continue;
+        const double* xi = S + (o + SB + i) * LDB + o;
+        const double* xj = S + (o + SB + j) * LDB + o;
+        double acc = 0.0;
+#pragma unroll
+        for (int m = 0; m < SB; ++m) acc += xi[m] * xj[m];
+        S[(o + SB + i) * LDB + o + SB + j] -= acc;
+      }
+      __syncthreads();
+    }
   }
-  if (fail && r == 0) meta[1] = 1;
-  if (act) {
+  return __syncthreads_and(ok ? 1 : 0) != 0;
+}
+
+// W = L^-1 (lower triangular, zero above the diagonal) from the factor in S; T = 3 x 16x16 scratch blocks
+__device__ void tri_inverse64_lds(const double* __restrict__ S, const double* __restrict__ dinv, double* __restrict__ Wm,
+                                  double* __restrict__ T, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int idx = tid; idx < NB * NB; idx += 256) Wm[(idx >> 6) * LDB + (idx & 63)] = 0.0;
+  __syncthreads();
+  {
+    // diagonal 16x16 blocks: wave k inverts block k, lane c = column c
+    const int o = wave * SB, c = lane;
+    if (c < SB) {
+      double x[SB];
 #pragma unroll
-    for (int k = 0; k < NB; ++k) H[(d0 + r) * ld + d0 + k] = (k <= r) ? row[k] : 0.0;
+      for (int a = 0; a < SB; ++a) {
+        double v = (a == c) ? 1.0 : 0.0;
+#pragma unroll
+        for (int m = 0; m < a; ++m) v -= S[(o + a) * LDB + o + m] * x[m];
+        x[a] = (a < c) ? 0.0 : v * dinv[o + a];
+      }
+#pragma unroll
+      for (int a = 0; a < SB; ++a) Wm[(o + a) * LDB + o + c] = x[a];
+    }
   }
-  // X = L^-1, lane c holds column c: X[a][c] = ((a==c) - sum_{m<a} L[a][m] X[m][c]) / L[a][a]
-  double x[NB];
-  const int c = r;
+  __syncthreads();
+  const int ti = tid >> 4, tj = tid & 15;                // one output element of a 16x16 block per thread
+#pragma unroll 1
+  for (int d = 1; d < NB / SB; ++d) {
+    const int nblk = NB / SB - d;                        // blocks (k + d, k), k = 0 .. nblk-1
+    for (int k = 0; k < nblk; ++k) {                     // T_k = sum_{m=k}^{k+d-1} L[k+d][m] W[m][k]
+      const int i = k + d;
+      double acc = 0.0;
+      for (int m = k; m < i; ++m)
 #pragma unroll
-  for (int a2 = 0; a2 < NB; ++a2) {
-    double sacc = (c == a2) ? 1.0 : 0.0;
+        for (int q = 0; q < SB; ++q) acc += S[(i * SB + ti) * LDB + m * SB + q] * Wm[(m * SB + q) * LDB + k * SB + tj];
+      T[(k * SB + ti) * (SB + 1) + tj] = acc;
+    }
+    __syncthreads();
+    for (int k = 0; k < nblk; ++k) {                     // W[k+d][k] = -W[k+d][k+d] T_k
+      const int i = k + d;
+      double acc = 0.0;
 #pragma unroll
-    for (int m = 0; m < a2; ++m) sacc -= lane_bcast(row[m], a2) * x[m];
-    x[a2] = (c > a2) ? 0.0 : sacc * dinv[a2];
-  }
-  if (act) {
-#pragma unroll
-    for (int k = 0; k < NB; ++k) Linv[(long)j * NB * NB + (long)k * NB + c] = x[k];
+      for (int q = 0; q < SB; ++q) acc += Wm[(i * SB + ti) * LDB + i * SB + q] * T[(k * SB + q) * (SB + 1) + tj];
+      Wm[(i * SB + ti) * LDB + k * SB + tj] = -acc;
+    }
+    __syncthreads();
   }
 }
 
-// ---- panel: Y = A_rj * Linv_j^T for every block row r > j (incl. the rhs row) -------------------------
-__global__ __launch_bounds__(256) void chol_trsm_kernel(double* __restrict__ H, int ld, int j,
-                                                        const double* __restrict__ Linv) {
-  __shared__ double sI[NB * NBP];
-  __shared__ double sX[NB * NBP];
-  const int tid = threadIdx.x;
+// D (64x64) = A B^T with A, B in LDS (leading dimension LDB); wave w owns rows 16w..16w+15.
+// kmax4[nt] = number of 4-wide k steps for column tile nt (lets a triangular B skip its zero part).
+// v_mfma_f64_16x16x4_f64: A operand lane l -> A[i = l&15][k = l>>4], B operand -> B^T[k][j] = B[j = l&15][k = l>>4],
+// result reg q of lane l -> D[row = (l>>4) + 4q][col = l&15].
+template <bool TRI>
+__device__ __forceinline__ void mfma_abt_64(const double* __restrict__ A, const double* __restrict__ B, int wave, int lane,
+                                            f64x4 (&acc)[4]) {
+  const int i = wave * 16 + (lane & 15), kq = lane >> 4;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) acc[nt] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < NB / 4; ++kk) {
+    const double a = A[i * LDB + kk * 4 + kq];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      if (TRI && kk >= 4 * (nt + 1)) continue;           // B[n][k] = 0 for k > n
+      const double b = B[(nt * 16 + (lane & 15)) * LDB + kk * 4 + kq];
+      acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[nt], 0, 0, 0);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ H, int ld, int j, double* __restrict__ Linv,
+                                                         int* __restrict__ meta) {
+  extern __shared__ double s_chol[];
+  double* S = s_chol;                     // A_jj -> L_jj
+  double* Wm = S + NB * LDB;              // L_jj^-1
+  double* At = Wm + NB * LDB;             // A_rj
+  double* T = At + NB * LDB;              // 3 x 16 x 17
+  double* dinv = T + 3 * SB * (SB + 1);   // 64
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = j + 1 + blockIdx.x;
   const long d0 = (long)j * NB, r0 = (long)r * NB;
   for (int o = tid; o < NB * NB; o += 256) {
-    sI[(o / NB) * NBP + o % NB] = Linv[(long)j * NB * NB + o];
-    sX[(o / NB) * NBP + o % NB] = H[(r0 + o / NB) * ld + d0 + o % NB];
+    const int a = o >> 6, b = o & 63;
+    S[a * LDB + b] = H[(d0 + a) * ld + d0 + b];
+    At[a * LDB + b] = H[(r0 + a) * ld + d0 + b];
   }
   __syncthreads();
-  const int ty = tid >> 4, tx = tid & 15;
-  double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-  for (int m = 0; m < NB; ++m) {
-    double a[3], b[3];
+  const bool ok = chol64_lds(S, dinv, tid);
+  if (!ok && tid == 0) meta[1] = 1;
+  tri_inverse64_lds(S, dinv, Wm, T, tid);
+  if (blockIdx.x == 0)
+    for (int o = tid; o < NB * NB; o += 256) Linv[(long)j * NB * NB + o] = Wm[(o >> 6) * LDB + (o & 63)];
+  f64x4 acc[4];
+  mfma_abt_64<true>(At, Wm, wave, lane, acc);
 #pragma unroll
-    for (int u = 0; u < 3; ++u) { a[u] = sX[(ty + 16 * u) * NBP + m]; b[u] = sI[(tx + 16 * u) * NBP + m]; }
+  for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-    for (int u = 0; u < 3; ++u)
-#pragma unroll
-      for (int v = 0; v < 3; ++v) acc[u][v] += a[u] * b[v];
-  }
-#pragma unroll
-  for (int u = 0; u < 3; ++u)
-#pragma unroll
-    for (int v = 0; v < 3; ++v) H[(r0 + ty + 16 * u) * ld + d0 + tx + 16 * v] = acc[u][v];
+    for (int q = 0; q < 4; ++q)
+      H[(r0 + wave * 16 + (lane >> 4) + 4 * q) * ld + d0 + nt * 16 + (lane & 15)] = acc[nt][q];
 }
 
-// trailing update A_rc -= L_rj L_cj^T for j < c <= r
+// trailing update A_rc -= L_rj L_cj^T for j < c <= r (r runs over the rhs block row too)
 __global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ H, int ld, int j, int nbk) {
   const int r = j + 1 + blockIdx.y, c = j + 1 + blockIdx.x;
   if (c > r || c >= nbk) return;
-  __shared__ double sA[NB * NBP];
-  __shared__ double sB[NB * NBP];
-  const int tid = threadIdx.x;
+  extern __shared__ double s_chol[];
+  double* sA = s_chol;
+  double* sB = sA + NB * LDB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long r0 = (long)r * NB, c0 = (long)c * NB, d0 = (long)j * NB;
   for (int o = tid; o < NB * NB; o += 256) {
-    const int a = o / NB, b = o % NB;
-    sA[a * NBP + b] = H[(r0 + a) * ld + d0 + b];
-    sB[a * NBP + b] = H[(c0 + a) * ld + d0 + b];
+    const int a = o >> 6, b = o & 63;
+    sA[a * LDB + b] = H[(r0 + a) * ld + d0 + b];
+    sB[a * LDB + b] = H[(c0 + a) * ld + d0 + b];
   }
   __syncthreads();
-  const int ty = tid >> 4, tx = tid & 15;               // 16x16 threads, 3x3 outputs each
-  double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-  for (int m = 0; m < NB; ++m) {
-    double a[3], b[3];
+  f64x4 acc[4];
+  mfma_abt_64<false>(sA, sB, wave, lane, acc);
 #pragma unroll
-    for (int u = 0; u < 3; ++u) { a[u] = sA[(ty + 16 * u) * NBP + m]; b[u] = sB[(tx + 16 * u) * NBP + m]; }
+  for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-    for (int u = 0; u < 3; ++u)
-#pragma unroll
-      for (int v = 0; v < 3; ++v) acc[u][v] += a[u] * b[v];
-  }
-#pragma unroll
-  for (int u = 0; u < 3; ++u)
-#pragma unroll
-    for (int v = 0; v < 3; ++v) H[(r0 + ty + 16 * u) * ld + c0 + tx + 16 * v] -= acc[u][v];
+    for (int q = 0; q < 4; ++q)
+      H[(r0 + wave * 16 + (lane >> 4) + 4 * q) * ld + c0 + nt * 16 + (lane & 15)] -= acc[nt][q];
 }
 
-// back substitution step j of L^T x = y (y lives in row `brow` of H): x_j = Linv_j^T y_j, then
-// y_r -= L_{j,r}^T x_j for this workgroup's r < j
-__global__ __launch_bounds__(256) void chol_backsub_kernel(double* __restrict__ H, int ld, int j, int brow,
+// back substitution of L^T x = y (y = row `brow` of H) in groups of BG block rows per launch:
+// every workgroup solves the group's triangular system itself (x_g = W_g^T (y_g - sum_{g' > g in group} L_g'g^T x_g')),
+// workgroup 0 publishes x, workgroup 1 + q applies the group's contribution to y_q for its own q < group start.
+constexpr int BG = 4;
+__global__ __launch_bounds__(256) void chol_backsub_kernel(double* __restrict__ H, int ld, int jhi, int brow,
                                                            const double* __restrict__ Linv, double* __restrict__ x) {
-  __shared__ double sI[NB * NBP];
-  __shared__ double sy[NB];
-  __shared__ double sx[NB];
+  __shared__ double sx[BG * NB];
+  __shared__ double sy[BG * NB];
   __shared__ double sp[4][NB];
   const int tid = threadIdx.x;
-  const long d0 = (long)j * NB;
-  for (int o = tid; o < NB * NB; o += 256) sI[(o / NB) * NBP + o % NB] = Linv[(long)j * NB * NB + o];
-  if (tid < NB) sy[tid] = H[(long)brow * ld + d0 + tid];
+  const int jlo = max(0, jhi - BG + 1), ng = jhi - jlo + 1;
+  for (int o = tid; o < ng * NB; o += 256) sy[o] = H[(long)brow * ld + (long)jlo * NB + o];
   __syncthreads();
-  if (tid < NB) {
-    double s = 0;
-    for (int m = tid; m < NB; ++m) s += sI[m * NBP + tid] * sy[m];
-    sx[tid] = s;
-    if (blockIdx.x == 0) x[d0 + tid] = s;
-  }
-  __syncthreads();
-  const int r = (int)blockIdx.x - 1;
-  if (r < 0 || r >= j) return;
   const int col = tid & 63, part = tid >> 6;
-  if (col < NB) {
-    double s = 0;
-#pragma unroll
-    for (int a = part * 12; a < part * 12 + 12; ++a) s += H[(d0 + a) * ld + (long)r * NB + col] * sx[a];
-    sp[part][col] = s;
+  for (int g = ng - 1; g >= 0; --g) {
+    const int jb = jlo + g;
+    // x_g = W_g^T y_g : x[c] = sum_{m >= c} W[m][c] y[m]; 4 partial sums over m
+    {
+      double sacc = 0.0;
+      const double* Wg = Linv + (long)jb * NB * NB;
+      for (int m = part * 16; m < part * 16 + 16; ++m) sacc += Wg[m * NB + col] * sy[g * NB + m];
+      sp[part][col] = sacc;
+    }
+    __syncthreads();
+    if (tid < NB) {
+      const double v = (sp[0][tid] + sp[1][tid]) + (sp[2][tid] + sp[3][tid]);
+      sx[g * NB + tid] = v;
+      if (blockIdx.x == 0) x[(long)jb * NB + tid] = v;
+    }
+    __syncthreads();
+    // y_g' -= L[jb][g']^T x_g for the earlier blocks of the group
+    for (int gp = 0; gp < g; ++gp) {
+      double sacc = 0.0;
+      for (int a = part * 16; a < part * 16 + 16; ++a)
+        sacc += H[((long)jb * NB + a) * ld + (long)(jlo + gp) * NB + col] * sx[g * NB + a];
+      sp[part][col] = sacc;
+      __syncthreads();
+      if (tid < NB) sy[gp * NB + tid] -= (sp[0][tid] + sp[1][tid]) + (sp[2][tid] + sp[3][tid]);
+      __syncthreads();
+    }
   }
+  const int q = (int)blockIdx.x - 1;                    // earlier block row updated by this workgroup
+  if (q < 0 || q >= jlo) return;
+  double sacc = 0.0;
+  for (int g = 0; g < ng; ++g)
+    for (int a = part * 16; a < part * 16 + 16; ++a)
+      sacc += H[((long)(jlo + g) * NB + a) * ld + (long)q * NB + col] * sx[g * NB + a];
+  sp[part][col] = sacc;
   __syncthreads();
-  if (tid < NB) H[(long)brow * ld + (long)r * NB + tid] -= (sp[0][tid] + sp[1][tid]) + (sp[2][tid] + sp[3][tid]);
+  if (tid < NB) H[(long)brow * ld + (long)q * NB + tid] -= (sp[0][tid] + sp[1][tid]) + (sp[2][tid] + sp[3][tid]);
 }
 
 __global__ void ba_dx_kernel(const double* __restrict__ x, const int* __restrict__ meta, int n,
@@ -788,14 +902,29 @@ int run_finish(const BaLayout& L, char* ws, float* poses, float* disps, const in
     hipLaunchKernelGGL(ba_damp_kernel, dim3((L.npad + 255) / 256), dim3(256), 0, st, H, L.ld, L.n, L.npad,
                        (double)lm, (double)ep);
     const int nbrows = L.nbk + 1;                        // + rhs block row
-    for (int j = 0; j < L.nbk; ++j) {
-      hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(64), 0, st, H, L.ld, j, Linv, meta);
-      const int m = nbrows - j - 1;
-      hipLaunchKernelGGL(chol_trsm_kernel, dim3(m), dim3(256), 0, st, H, L.ld, j, (const double*)Linv);
-      if (m > 1) hipLaunchKernelGGL(chol_update_kernel, dim3(m, m), dim3(256), 0, st, H, L.ld, j, L.nbk);
+    static const hipError_t lds_err = [] {               // > 64 KB of dynamic LDS must be opted into
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_panel_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_update_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+      return e;
+    }();
+    if (lds_err != hipSuccess) {
+      if (getenv("DH_DEBUG")) fprintf(stderr, "libdroid_hip: hipFuncSetAttribute: %s\n", hipGetErrorString(lds_err));
+      return DH_ERR_LAUNCH;
     }
-    for (int j = L.nbk - 1; j >= 0; --j)
-      hipLaunchKernelGGL(chol_backsub_kernel, dim3(j + 1), dim3(256), 0, st, H, L.ld, j, L.npad, Linv, x);
+    const size_t lds_panel = sizeof(double) * (3 * NB * LDB + 3 * SB * (SB + 1) + NB);
+    const size_t lds_upd = sizeof(double) * 2 * NB * LDB;
+    for (int j = 0; j < L.nbk; ++j) {
+      const int m = nbrows - j - 1;
+      hipLaunchKernelGGL(chol_panel_kernel, dim3(m), dim3(256), lds_panel, st, H, L.ld, j, Linv, meta);
+      DH_LAUNCH_CHECK();
+      if (m > 1) hipLaunchKernelGGL(chol_update_kernel, dim3(m - 1, m), dim3(256), lds_upd, st, H, L.ld, j, L.nbk);
+      DH_LAUNCH_CHECK();
+    }
+    for (int jhi = L.nbk - 1; jhi >= 0; jhi -= BG)
+      hipLaunchKernelGGL(chol_backsub_kernel, dim3(std::max(1, jhi - BG + 2)), dim3(256), 0, st, H, L.ld, jhi, L.npad, Linv, x);
     hipLaunchKernelGGL(ba_dx_kernel, dim3((L.n + 255) / 256), dim3(256), 0, st, x, meta, L.n, dxw, dx_out);
     DH_LAUNCH_CHECK();
   }
@@ -818,6 +947,13 @@ int run_finish(const BaLayout& L, char* ws, float* poses, float* disps, const in
 extern "C" size_t dh_ba_workspace_bytes(int num_frames, int n_edges, int ht, int wd, int t0, int t1, int motion_only) {
   if (check_args(num_frames, n_edges, ht, wd, t0, t1) != DH_OK) return 0;
   return make_layout(num_frames, n_edges, ht * wd, t0, t1, motion_only).total;
+}
+
+extern "C" int dh_ba_system_shape(int t0, int t1, int* rows, int* cols) {
+  if (t0 < 0 || t1 < t0 || !rows || !cols) return DH_ERR_ARG;
+  const int n = 6 * (t1 - t0), npad = (n + NB - 1) / NB * NB;
+  *rows = npad + NB; *cols = npad;
+  return DH_OK;
 }
 
 extern "C" int dh_ba_build(const float* poses, const float* disps, const float* intrinsics, const float* disps_sens,

@@ -5,15 +5,21 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include "../../include/droid_hip.h"
 
 #define DH_WAVE 64
 #define DH_MIN_DEPTH 0.25f        // kernels' depth threshold (src/droid_kernels.cu:35)
 #define DH_MIN_DEPTH_PY 0.2f      // Python reprojection threshold (geom/projective_ops.py:6)
 
-#define DH_LAUNCH_CHECK()                                  \
-  do {                                                     \
-    if (hipGetLastError() != hipSuccess) return DH_ERR_LAUNCH; \
+#define DH_LAUNCH_CHECK()                                                                  \
+  do {                                                                                     \
+    const hipError_t dh_e_ = hipGetLastError();                                            \
+    if (dh_e_ != hipSuccess) {                                                             \
+      if (getenv("DH_DEBUG")) fprintf(stderr, "libdroid_hip: %s at %s:%d\n", hipGetErrorString(dh_e_), __FILE__, __LINE__); \
+      return DH_ERR_LAUNCH;                                                                \
+    }                                                                                      \
   } while (0)
 
 namespace dh {

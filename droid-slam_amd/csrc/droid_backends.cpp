@@ -94,8 +94,9 @@ std::vector<torch::Tensor> ba_build(torch::Tensor poses, torch::Tensor disps, to
                            eta.data_ptr<float>(), ii.data_ptr<int64_t>(), jj.data_ptr<int64_t>(), F, E, K, ht, wd,
                            t0, t1, motion_only ? 1 : 0, &H, &b, ws.data_ptr(), wsb, cur_stream()),
                "ba_build");
-  const int64_t n = 6 * (int64_t)(t1 - t0), npad = (n + 47) / 48 * 48;
-  torch::Tensor sys = torch::from_blob(H, {npad + 48, npad}, poses.options().dtype(torch::kFloat64));
+  int rows = 0, cols = 0;
+  check_status(dh_ba_system_shape(t0, t1, &rows, &cols), "ba_system_shape");
+  torch::Tensor sys = torch::from_blob(H, {rows, cols}, poses.options().dtype(torch::kFloat64));
   return {ws, sys};
 }
 

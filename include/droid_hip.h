@@ -119,6 +119,9 @@ int dh_ba(float* poses, float* disps, const float* intrinsics, const float* disp
  *   Hsys [6P,6P] f64 (row-major, lower+upper), bsys [6P] f64, and keeps per-frame depth terms in the
  *   workspace; dh_ba_finish damps, solves, back-substitutes the depths of the frames this rank owns
  *   and retracts.  dh_ba() == dh_ba_build + dh_ba_finish per iteration. */
+/* shape of the system buffer behind Hsys_out: [rows, cols] f64, row-major; rows [0, 6P) x cols [0, 6P) = Hsys,
+ * row `cols` = bsys (the right-hand side travels as an extra block row), everything else padding. */
+int dh_ba_system_shape(int t0, int t1, int* rows, int* cols);
 int dh_ba_build(const float* poses, const float* disps, const float* intrinsics, const float* disps_sens,
                 const float* targets, const float* weights, const float* eta,
                 const int64_t* ii, const int64_t* jj,
