@@ -1,0 +1,269 @@
+// Implicit-GEMM 2-D convolution (stride 1, "same" padding) on the fp16 MFMA with fused epilogues: the
+// building block of the ConvGRU update operator (reference droid_slam/droid_net.py:78-143 UpdateModule,
+// droid_slam/modules/gru.py:5-33 ConvGRU, droid_net.py:44-75 GraphAgg; cuDNN/cuBLAS under autocast there).
+//
+// GEMM view:  D[pixel][cout] = sum_{tap, c} X[pixel + tap][c] * Wt[cout][tap * Ctot + c]
+//   M = N*H*W pixels (activations NHWC fp16, up to 4 channel segments that are concatenated on the fly:
+//       the 448-channel GRU input cat(net, inp, corr, flow) is never materialised),
+//   N = Cout, K = KH*KW*Ctot (weights pre-packed [CoutPad][Kpad], K contiguous, zero padded).
+// Workgroup = 8 waves, tile 256 pixels x BN couts, K chunks of 64; v_mfma_f32_32x32x16_f16, fp32 accumulate.
+//   * operands go global -> registers (issued before the MFMAs of the current chunk) -> LDS, one LDS stage:
+//     2 workgroups per CU hide each other's staging;
+//   * LDS rows are 64 + 8 halves (144 B): the 16-byte fragment reads of 16 consecutive rows fall in 16
+//     disjoint bank quads, so ds_read_b128 is conflict-free (row stride 36 dwords, 36*m mod 64 distinct);
+//   * epilogues fuse bias, activation and the GRU algebra, so z, r*net and the new hidden state are written
+//     once and never re-read by an elementwise kernel:
+//       ZR   cout <  128: z = sigmoid(acc + b + g)          cout >= 128: r*net = sigmoid(acc + b + g) * net
+//       Q    net' = (1 - z) * net + z * tanh(acc + b + g)   (in place on net)
+//       GLO  sum over pixels of sigmoid(acc + b) * net  -> per-image fp32 accumulators (global context)
+//   where g[image][cout] is the 1x1 "global context" term of the ConvGRU.
+#include "common.h"
+
+namespace {
+using namespace dh;
+
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BM = 256;            // pixels per workgroup
+constexpr int BK = 64;             // K chunk
+constexpr int LDT = BK + 8;        // LDS row stride (halves)
+constexpr int MAXSEG = 4;
+
+enum Epi { EPI_LINEAR = 0, EPI_RELU = 1, EPI_SIGMOID = 2, EPI_GRU_ZR = 3, EPI_GRU_Q = 4, EPI_GLO = 5,
+           EPI_SOFTPLUS_001 = 6, EPI_HEADS = 7 };
+
+struct ConvParams {
+  const __half* in[MAXSEG]; int segC[MAXSEG]; int segS[MAXSEG]; int nseg; int Ctot;   // segS = pixel stride (elements)
+  const __half* wt; const float* bias;
+  int N, H, W, KH, KW, Cout, CoutPad, Kreal, Kpad, epi;
+  void* out; int out_f32; int out_stride;
+  const float* gterm; const __half* aux0; int aux0_stride; const __half* aux1; int aux1_stride; float* red;
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { const float e = __expf(-2.f * fabsf(x)); const float t = (1.f - e) / (1.f + e); return x < 0 ? -t : t; }
+__device__ __forceinline__ float round_h(float v) { return __half2float(__float2half(v)); }
+
+// WM x WN = per-wave output tile, waves arranged (BM / WM) x (BN / WN)
+template <int WM, int WN, int BN, int EPI>
+__global__ __launch_bounds__(512, 2) void conv_igemm_kernel(ConvParams P) {
+  constexpr int WAVES_M = BM / WM, TM = WM / 32, TN = WN / 32;
+  static_assert(WAVES_M * (BN / WN) == 8, "8 waves");
+  extern __shared__ __half s_conv[];
+  __half* sA = s_conv;                     // [BM][LDT]
+  __half* sB = s_conv + BM * LDT;          // [BN][LDT]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave % WAVES_M) * WM, wn0 = (wave / WAVES_M) * WN;
+  const long M = (long)P.N * P.H * P.W;
+  const long m0 = (long)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int HW = P.H * P.W;
+  const int padh = P.KH / 2, padw = P.KW / 2;
+
+  // ---- loader roles: A pieces (16 B = 8 channels of one pixel), 4 per thread; B pieces, BN*8/512 per thread
+  constexpr int A_PIECES = BM * 8 / 512, B_PIECES = (BN * 8 + 511) / 512;
+  int a_y[A_PIECES], a_x[A_PIECES], a_row0[A_PIECES];       // a_row0 = image * H (row index of the image's first row)
+#pragma unroll
+  for (int i = 0; i < A_PIECES; ++i) {
+    const int id = tid + 512 * i;
+    const long pix = m0 + (id >> 3);
+    const bool ok = pix < M;
+    const long pc = ok ? pix : 0;
+    const int n = (int)(pc / HW), r = (int)(pc - (long)n * HW);
+    a_row0[i] = n * P.H; a_y[i] = ok ? r / P.W : -(1 << 20); a_x[i] = r - (r / P.W) * P.W;
+  }
+  const int kc = tid & 7;                  // 8-half piece inside the chunk (same for all of a thread's pieces)
+  // running decomposition of k = chunk*64 + kc*8 into (tap -> dy, dx) and channel c
+  int cur_c = kc * 8, cur_dy = 0, cur_dx = 0;
+  while (cur_c >= P.Ctot) { cur_c -= P.Ctot; if (++cur_dx == P.KW) { cur_dx = 0; ++cur_dy; } }
+
+  uint4 ra[A_PIECES], rb[B_PIECES];
+  const int nchunks = P.Kpad / BK;
+  auto fetch = [&](int chunk) {
+    // segment of channel cur_c
+    int s = 0, cs = cur_c;
+#pragma unroll
+    for (int q = 0; q < MAXSEG - 1; ++q) if (s == q && q + 1 < P.nseg && cs >= P.segC[q]) { cs -= P.segC[q]; s = q + 1; }
+    const __half* base = P.in[0]; int segc = P.segS[0];
+#pragma unroll
+    for (int q = 1; q < MAXSEG; ++q) if (s == q) { base = P.in[q]; segc = P.segS[q]; }
+    const bool kvalid = cur_dy < P.KH;     // beyond the last tap: zero padding of K
+#pragma unroll
+    for (int i = 0; i < A_PIECES; ++i) {
+      const int yy = a_y[i] + cur_dy - padh, xx = a_x[i] + cur_dx - padw;
+      const bool ok = kvalid && (unsigned)yy < (unsigned)P.H && (unsigned)xx < (unsigned)P.W;
+      const __half* src = base + ((long)(a_row0[i] + (ok ? yy : 0)) * P.W + (ok ? xx : 0)) * segc + cs;
+      ra[i] = ok ? *reinterpret_cast<const uint4*>(src) : uint4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int i = 0; i < B_PIECES; ++i) {
+      const int id = tid + 512 * i;
+      const int row = id >> 3;
+      const bool ok = row < BN && n0 + row < P.CoutPad;
+      rb[i] = ok ? *reinterpret_cast<const uint4*>(P.wt + (long)(n0 + row) * P.Kpad + (long)chunk * BK + kc * 8) : uint4{0u, 0u, 0u, 0u};
+    }
+    // advance k by one chunk
+    cur_c += BK;
+    while (cur_c >= P.Ctot) { cur_c -= P.Ctot; if (++cur_dx == P.KW) { cur_dx = 0; ++cur_dy; } }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_PIECES; ++i) {
+      const int id = tid + 512 * i;
+      *reinterpret_cast<uint4*>(sA + (id >> 3) * LDT + kc * 8) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_PIECES; ++i) {
+      const int id = tid + 512 * i;
+      if ((id >> 3) < BN) *reinterpret_cast<uint4*>(sB + (id >> 3) * LDT + kc * 8) = rb[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+
+  fetch(0);
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    __syncthreads();                       // previous chunk's fragments have been read
+    stage();
+    __syncthreads();
+    if (chunk + 1 < nchunks) fetch(chunk + 1);
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      half8 af[TM], bf[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+        af[a] = *reinterpret_cast<const half8*>(sA + (wm0 + a * 32 + (lane & 31)) * LDT + ks * 16 + (lane >> 5) * 8);
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+        bf[b] = *reinterpret_cast<const half8*>(sB + (wn0 + b * 32 + (lane & 31)) * LDT + ks * 16 + (lane >> 5) * 8);
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: lane holds cout = n0 + wn0 + b*32 + (lane&31), pixels wm0 + a*32 + (q&3) + 8*(q>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const int co = n0 + wn0 + b * 32 + (lane & 31);
+    const bool co_ok = co < P.Cout;
+    const float bias = co < P.CoutPad ? P.bias[co] : 0.f;
+    float glo_sum = 0.f; long glo_img = -1;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const long pix = m0 + wm0 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        if (pix >= M || !co_ok) continue;
+        const int img = (int)(pix / HW);
+        float v = acc[a][b][q] + bias;
+        if (P.gterm) v += P.gterm[(long)img * P.CoutPad + co];
+        switch (EPI) {
+          case EPI_RELU: v = fmaxf(v, 0.f); break;
+          case EPI_SIGMOID: v = sigmoidf_(v); break;
+          case EPI_GRU_ZR: {
+            v = sigmoidf_(v);
+            if (co >= 128) v = round_h(v) * __half2float(P.aux0[pix * P.aux0_stride + co - 128]);   // r * net
+          } break;
+          case EPI_GRU_Q: {
+            const float qv = round_h(tanhf_(v));
+            const float z = __half2float(P.aux1[pix * P.aux1_stride + co]);
+            const float h = __half2float(P.aux0[pix * P.aux0_stride + co]);
+            v = (1.f - z) * h + z * qv;
+          } break;
+          case EPI_GLO: {
+            v = round_h(sigmoidf_(v)) * __half2float(P.aux0[pix * P.aux0_stride + co]);
+            v = round_h(v);
+            if (glo_img >= 0 && glo_img != img) { atomicAdd(&P.red[glo_img * P.Cout + co], glo_sum); glo_sum = 0.f; }
+            glo_img = img; glo_sum += v;
+          } break;
+          case EPI_SOFTPLUS_001: { const float hv = round_h(v); v = 0.01f * round_h(hv > 20.f ? hv : log1pf(__expf(hv))); } break;
+          case EPI_HEADS: if (co >= 2) v = sigmoidf_(round_h(v)); break;          // (delta_x, delta_y, w_x, w_y)
+          default: break;
+        }
+        if (EPI == EPI_GLO) continue;
+        if (P.out_f32) reinterpret_cast<float*>(P.out)[pix * P.out_stride + co] = round_h(v);
+        else reinterpret_cast<__half*>(P.out)[pix * P.out_stride + co] = __float2half(v);
+      }
+    if (EPI == EPI_GLO && glo_img >= 0) {
+      // lanes l and l+32 hold the same cout: combine, one atomic per (wave, cout)
+      const float other = __shfl_xor(glo_sum, 32, 64);
+      const long oimg = ((long)__shfl_xor((int)glo_img, 32, 64));
+      if (oimg == glo_img) { if (lane < 32) atomicAdd(&P.red[glo_img * P.Cout + co], glo_sum + other); }
+      else atomicAdd(&P.red[glo_img * P.Cout + co], glo_sum);
+    }
+  }
+}
+
+template <int WM, int WN, int BN, int EPI>
+int launch_epi(const ConvParams& P, hipStream_t st) {
+  const long M = (long)P.N * P.H * P.W;
+  const dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((P.CoutPad + BN - 1) / BN));
+  const size_t lds = (size_t)(BM + BN) * LDT * sizeof(__half);
+  hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, BN, EPI>), grid, dim3(512), lds, st, P);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
+template <int WM, int WN, int BN>
+int launch(const ConvParams& P, hipStream_t st) {
+  switch (P.epi) {
+    case EPI_LINEAR: return launch_epi<WM, WN, BN, EPI_LINEAR>(P, st);
+    case EPI_RELU: return launch_epi<WM, WN, BN, EPI_RELU>(P, st);
+    case EPI_SIGMOID: return launch_epi<WM, WN, BN, EPI_SIGMOID>(P, st);
+    case EPI_GRU_ZR: return launch_epi<WM, WN, BN, EPI_GRU_ZR>(P, st);
+    case EPI_GRU_Q: return launch_epi<WM, WN, BN, EPI_GRU_Q>(P, st);
+    case EPI_GLO: return launch_epi<WM, WN, BN, EPI_GLO>(P, st);
+    case EPI_SOFTPLUS_001: return launch_epi<WM, WN, BN, EPI_SOFTPLUS_001>(P, st);
+    case EPI_HEADS: return launch_epi<WM, WN, BN, EPI_HEADS>(P, st);
+  }
+  return DH_ERR_ARG;
+}
+
+}  // namespace
+
+extern "C" int dh_conv2d_nhwc_f16(const void* const* inputs, const int* in_channels, const int* in_strides, int n_inputs,
+                                  const void* weights, const float* bias,
+                                  int N, int H, int W, int KH, int KW, int Cout, int CoutPad, int Kpad, int epilogue,
+                                  void* out, int out_is_f32, int out_stride,
+                                  const float* gterm, const void* aux0, int aux0_stride, const void* aux1, int aux1_stride,
+                                  float* red, dh_stream_t stream) {
+  if (n_inputs < 1 || n_inputs > MAXSEG || !inputs || !in_channels || !weights || !bias) return DH_ERR_ARG;
+  if (N < 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0 || !(KH & 1) || !(KW & 1)) return DH_ERR_ARG;
+  if (Cout <= 0 || CoutPad < Cout || CoutPad % 32 || Kpad <= 0 || Kpad % BK) return DH_ERR_ARG;
+  if (epilogue < 0 || epilogue > EPI_HEADS) return DH_ERR_ARG;
+  ConvParams P{};
+  int ctot = 0;
+  for (int i = 0; i < n_inputs; ++i) {
+    if (!inputs[i] || in_channels[i] <= 0 || in_channels[i] % 8) return DH_ERR_ARG;
+    P.in[i] = (const __half*)inputs[i]; P.segC[i] = in_channels[i]; ctot += in_channels[i];
+    P.segS[i] = in_strides ? in_strides[i] : in_channels[i];
+    if (P.segS[i] < in_channels[i] || P.segS[i] % 8 || ((uintptr_t)inputs[i]) % 16) return DH_ERR_ARG;
+  }
+  for (int i = n_inputs; i < MAXSEG; ++i) { P.in[i] = P.in[0]; P.segC[i] = 1 << 30; P.segS[i] = P.segS[0]; }
+  P.nseg = n_inputs; P.Ctot = ctot;
+  P.Kreal = KH * KW * ctot;
+  if (Kpad < P.Kreal) return DH_ERR_ARG;
+  if (epilogue == EPI_GLO && (!red || !aux0)) return DH_ERR_ARG;
+  if (epilogue == EPI_GRU_ZR && !aux0) return DH_ERR_ARG;
+  if (epilogue == EPI_GRU_Q && (!aux0 || !aux1)) return DH_ERR_ARG;
+  if (epilogue != EPI_GLO && !out) return DH_ERR_ARG;
+  if (N == 0) return DH_OK;
+  P.wt = (const __half*)weights; P.bias = bias;
+  P.N = N; P.H = H; P.W = W; P.KH = KH; P.KW = KW; P.Cout = Cout; P.CoutPad = CoutPad; P.Kpad = Kpad; P.epi = epilogue;
+  P.out = out; P.out_f32 = out_is_f32; P.out_stride = out_stride;
+  P.gterm = gterm; P.aux0 = (const __half*)aux0; P.aux0_stride = aux0_stride;
+  P.aux1 = (const __half*)aux1; P.aux1_stride = aux1_stride; P.red = red;
+  hipStream_t st = (hipStream_t)stream;
+  if (CoutPad >= 128) return launch<64, 64, 128>(P, st);
+  if (CoutPad >= 64) return launch<64, 32, 64>(P, st);
+  return launch<32, 32, 32>(P, st);
+}

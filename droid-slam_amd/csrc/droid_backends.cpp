@@ -265,6 +265,38 @@ torch::Tensor corr_pyramid_lookup(torch::Tensor pyramid, torch::Tensor coords) {
   return out;
 }
 
+// ---- implicit-GEMM convolution with fused epilogues (droid_amd.update.UpdateModule) ----------------------
+void conv2d_nhwc(std::vector<torch::Tensor> inputs, torch::Tensor weight, torch::Tensor bias, int64_t KH, int64_t KW,
+                 int64_t Cout, int64_t epilogue, c10::optional<torch::Tensor> out, int64_t out_stride,
+                 c10::optional<torch::Tensor> gterm, c10::optional<torch::Tensor> aux0, c10::optional<torch::Tensor> aux1,
+                 c10::optional<torch::Tensor> red) {
+  TORCH_CHECK(!inputs.empty() && inputs.size() <= 4, "conv2d_nhwc: 1..4 inputs");
+  const void* ptrs[4]; int chans[4], strides[4];
+  const int64_t N = inputs[0].size(0), H = inputs[0].size(1), W = inputs[0].size(2);
+  for (size_t i = 0; i < inputs.size(); ++i) {
+    const torch::Tensor& t = inputs[i];
+    TORCH_CHECK(t.is_cuda() && t.scalar_type() == torch::kFloat16 && t.dim() == 4, "conv2d_nhwc: inputs [N,H,W,C] float16 device tensors");
+    TORCH_CHECK(t.size(0) == N && t.size(1) == H && t.size(2) == W, "conv2d_nhwc: input shapes differ");
+    // dense NHWC or a channel slice of one: stride(3) == 1, pixels equally spaced
+    TORCH_CHECK(t.stride(3) == 1 && t.stride(1) == t.stride(2) * W && t.stride(0) == t.stride(1) * H, "conv2d_nhwc: input must be NHWC (channel slices allowed)");
+    ptrs[i] = t.data_ptr(); chans[i] = (int)t.size(3); strides[i] = (int)t.stride(2);
+  }
+  CHECK_INPUT(weight); CHECK_INPUT(bias); CHECK_F32(bias);
+  TORCH_CHECK(weight.scalar_type() == torch::kFloat16 && weight.dim() == 2, "conv2d_nhwc: packed weight [CoutPad,Kpad] float16");
+  auto opt_ptr = [](const c10::optional<torch::Tensor>& t) -> void* { return t.has_value() ? t->data_ptr() : nullptr; };
+  auto last = [](const c10::optional<torch::Tensor>& t) -> int { return t.has_value() ? (int)t->stride(2) : 0; };   // pixel stride
+  const bool out_f32 = out.has_value() && out->scalar_type() == torch::kFloat32;
+  if (gterm.has_value()) { const torch::Tensor& gt = *gterm; CHECK_INPUT(gt); CHECK_F32(gt); }
+  if (red.has_value()) { const torch::Tensor& rt = *red; CHECK_INPUT(rt); CHECK_F32(rt); }
+  check_status(dh_conv2d_nhwc_f16(ptrs, chans, strides, (int)inputs.size(), weight.data_ptr(), bias.data_ptr<float>(),
+                                  (int)N, (int)H, (int)W, (int)KH, (int)KW, (int)Cout, (int)weight.size(0), (int)weight.size(1),
+                                  (int)epilogue, opt_ptr(out), out_f32 ? 1 : 0, (int)out_stride,
+                                  gterm.has_value() ? gterm->data_ptr<float>() : nullptr,
+                                  opt_ptr(aux0), last(aux0), opt_ptr(aux1), last(aux1),
+                                  red.has_value() ? red->data_ptr<float>() : nullptr, cur_stream()),
+               "conv2d_nhwc");
+}
+
 // ---- extensions beyond the reference module (used by droid_amd / lietorch compat) ----------------
 std::vector<torch::Tensor> reproject(torch::Tensor poses, torch::Tensor disps, torch::Tensor intrinsics,
                                      torch::Tensor ii, torch::Tensor jj) {
@@ -331,6 +363,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("ba_finish", &ba_finish, "damp + solve + back-substitute + retract (split BA)");
   m.def("corr_pyramid_build", &corr_pyramid_build, "all-pairs correlation pyramid, MI355X layout");
   m.def("corr_pyramid_lookup", &corr_pyramid_lookup, "fused 4-level lookup on the MI355X pyramid");
+  m.def("conv2d_nhwc", &conv2d_nhwc, "implicit-GEMM NHWC convolution on the fp16 MFMA with fused epilogues");
   m.def("reproject", &reproject, "fused reprojection (Python thresholds)");
   m.def("se3_op", &se3_op, "SE3 inv/mul/exp/retr");
   m.def("se3_map", &se3_map, "SE3 act4/adjT");

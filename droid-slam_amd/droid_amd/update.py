@@ -1,0 +1,168 @@
+"""ConvGRU update operator on MI355X: host-side mirror of the reference's UpdateModule
+(droid_slam/droid_net.py:78-143), ConvGRU (droid_slam/modules/gru.py:5-33) and GraphAgg (droid_net.py:44-75).
+
+Same constructor-free interface as the reference module object: ``UpdateModule.forward(net, inp, corr, flow, ii, jj)``
+with the reference's tensor shapes, and ``load_state_dict`` accepts the reference's parameter names
+(``update.*`` of a droid.pth checkpoint), so ``factor_graph.py`` can call it unchanged.
+
+All convolutions and the GRU algebra run in the hand-written implicit-GEMM kernel of csrc/conv.hip
+(droid_backends.conv2d_nhwc: fp16 MFMA, fp32 accumulate, fused bias/activation/gate epilogues); activations are
+kept NHWC fp16 between layers, the 448-channel GRU input is never concatenated, z|r and the two head stems are
+single launches.  torch is used only for allocation, the per-edge 128-vector "global context" GEMVs and the
+scatter-mean over source frames (index_add_), i.e. plumbing.  There is no CPU path.
+"""
+import torch
+import torch.nn.functional as F
+
+import droid_backends
+
+EPI_LINEAR, EPI_RELU, EPI_SIGMOID, EPI_GRU_ZR, EPI_GRU_Q, EPI_GLO, EPI_SOFTPLUS_001, EPI_HEADS = range(8)
+COR_PLANES = 4 * 49
+COR_PAD = 200            # 196 correlation channels padded to a multiple of 8 (16-byte pieces in NHWC)
+
+# reference parameter shapes (Cout, Cin, k); droid_net.py:83-108, gru.py:8-17, droid_net.py:47-57
+PARAM_SHAPES = {
+    "corr_encoder.0": (128, COR_PLANES, 1), "corr_encoder.2": (128, 128, 3),
+    "flow_encoder.0": (128, 4, 7), "flow_encoder.2": (64, 128, 3),
+    "weight.0": (128, 128, 3), "weight.2": (2, 128, 3),
+    "delta.0": (128, 128, 3), "delta.2": (2, 128, 3),
+    "gru.convz": (128, 448, 3), "gru.convr": (128, 448, 3), "gru.convq": (128, 448, 3),
+    "gru.w": (128, 128, 1),
+    "gru.convz_glo": (128, 128, 1), "gru.convr_glo": (128, 128, 1), "gru.convq_glo": (128, 128, 1),
+    "agg.conv1": (128, 128, 3), "agg.conv2": (128, 128, 3),
+    "agg.eta.0": (1, 128, 3), "agg.upmask.0": (576, 128, 1),
+}
+
+
+def _round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+def pack_conv(weight, bias, cin_pad=None):
+    """[Cout,Cin,KH,KW] -> ([CoutPad, Kpad] f16 with k = (dy*KW+dx)*CinPad + c, bias [CoutPad] f32)."""
+    cout, cin, kh, kw = weight.shape
+    cin_pad = cin if cin_pad is None else cin_pad
+    w = weight.float()
+    if cin_pad != cin:
+        w = F.pad(w, (0, 0, 0, 0, 0, cin_pad - cin))
+    w = w.permute(0, 2, 3, 1).reshape(cout, kh * kw * cin_pad)
+    cout_pad, kpad = _round_up(cout, 32), _round_up(w.shape[1], 64)
+    wp = torch.zeros(cout_pad, kpad, dtype=torch.float16, device=weight.device)
+    wp[:cout, :w.shape[1]] = w.half()
+    bp = torch.zeros(cout_pad, dtype=torch.float32, device=weight.device)
+    bp[:cout] = bias.float()
+    return wp.contiguous(), bp.contiguous()
+
+
+class _Conv:
+    def __init__(self, wp, bp, k, cout):
+        self.w, self.b, self.k, self.cout = wp, bp, k, cout
+
+    def __call__(self, inputs, epi, out=None, out_stride=None, gterm=None, aux0=None, aux1=None, red=None):
+        x0 = inputs[0]
+        if out is None and epi != EPI_GLO:
+            out = torch.empty(x0.shape[0], x0.shape[1], x0.shape[2], self.cout, dtype=torch.float16, device=x0.device)
+        stride = 0 if out is None else (out.shape[-1] if out_stride is None else out_stride)
+        droid_backends.conv2d_nhwc(list(inputs), self.w, self.b, self.k, self.k, self.cout, epi, out, stride,
+                                   gterm, aux0, aux1, red)
+        return out
+
+
+class UpdateModule:
+    """Weight-compatible, inference-only replacement of droid_net.UpdateModule."""
+
+    def __init__(self, device="cuda"):
+        self.device = torch.device(device)
+        self.params = None
+
+    # ---- parameters ----------------------------------------------------------------------------
+    def load_state_dict(self, sd, prefix=""):
+        """sd: reference names ('gru.convz.weight', ...), optionally prefixed (e.g. 'update.')."""
+        g = lambda n: sd[prefix + n].to(self.device)
+        P = {}
+        conv = lambda name, cin_pad=None: _Conv(*pack_conv(g(name + ".weight"), g(name + ".bias"), cin_pad),
+                                                PARAM_SHAPES[name][2], PARAM_SHAPES[name][0])
+        P["corr0"] = conv("corr_encoder.0", COR_PAD)
+        P["corr2"] = conv("corr_encoder.2")
+        P["flow0"] = conv("flow_encoder.0", 8)
+        P["flow2"] = conv("flow_encoder.2")
+        P["gru_w"] = conv("gru.w")
+        # z | r as one convolution with 256 outputs
+        wz, wr = g("gru.convz.weight"), g("gru.convr.weight")
+        P["zr"] = _Conv(*pack_conv(torch.cat([wz, wr], 0), torch.cat([g("gru.convz.bias"), g("gru.convr.bias")], 0)), 3, 256)
+        P["q"] = conv("gru.convq")
+        for n in ("z", "r", "q"):
+            P["glo_" + n] = (g("gru.conv%s_glo.weight" % n).float().reshape(128, 128), g("gru.conv%s_glo.bias" % n).float())
+        # the two head stems (delta.0 | weight.0) share their input: one convolution with 256 outputs;
+        # the two 2-channel heads become one block-diagonal convolution on those 256 channels
+        P["heads0"] = _Conv(*pack_conv(torch.cat([g("delta.0.weight"), g("weight.0.weight")], 0),
+                                       torch.cat([g("delta.0.bias"), g("weight.0.bias")], 0)), 3, 256)
+        w2 = torch.zeros(4, 256, 3, 3, device=self.device)
+        w2[0:2, 0:128] = g("delta.2.weight").float()
+        w2[2:4, 128:256] = g("weight.2.weight").float()
+        P["heads2"] = _Conv(*pack_conv(w2, torch.cat([g("delta.2.bias"), g("weight.2.bias")], 0)), 3, 4)
+        P["agg1"] = conv("agg.conv1")
+        P["agg2"] = conv("agg.conv2")
+        P["eta"] = conv("agg.eta.0")
+        P["upmask"] = conv("agg.upmask.0")
+        self.params = P
+        return self
+
+    # ---- layout helpers (module boundary only) -----------------------------------------------------
+    @staticmethod
+    def to_nhwc(x, cpad=None):
+        """[E,C,h,w] -> [E,h,w,Cpad] f16 contiguous."""
+        x = x.permute(0, 2, 3, 1)
+        if cpad is not None and cpad != x.shape[-1]:
+            x = F.pad(x, (0, cpad - x.shape[-1]))
+        return x.to(torch.float16).contiguous()
+
+    # ---- the operator ----------------------------------------------------------------------------
+    def forward_nhwc(self, net, inp, corr, flow, ii):
+        """net, inp [E,h,w,128] f16 (net is updated IN PLACE), corr [E,h,w,200] f16 (196 + zero pad),
+        flow [E,h,w,8] f16 (4 + zero pad), ii [E] int64 ->
+        (net, delta [E,h,w,2] f32, weight [E,h,w,2] f32, eta [K,h,w] f32, upmask [K,h,w,576] f16)."""
+        P = self.params
+        E, h, w, _ = net.shape
+        c = P["corr2"]([P["corr0"]([corr], EPI_RELU)], EPI_RELU)
+        f = P["flow2"]([P["flow0"]([flow], EPI_RELU)], EPI_RELU)
+        # global context: mean over pixels of sigmoid(w(net)) * net, then three 128x128 GEMVs per edge
+        red = torch.zeros(E, 128, dtype=torch.float32, device=net.device)
+        P["gru_w"]([net], EPI_GLO, aux0=net, red=red)
+        glo = (red / float(h * w)).half().float()
+        gz, gr, gq = (torch.addmm(P["glo_" + n][1], glo, P["glo_" + n][0].t()).half().float() for n in ("z", "r", "q"))
+        gzr = torch.cat([gz, gr], 1).contiguous()
+        zr = P["zr"]([net, inp, c, f], EPI_GRU_ZR, gterm=gzr, aux0=net)             # [E,h,w,256] = z | r*net
+        P["q"]([zr[..., 128:], inp, c, f], EPI_GRU_Q, out=net, gterm=gq.contiguous(), aux0=net, aux1=zr)
+        hd = P["heads0"]([net], EPI_RELU)
+        dw = torch.empty(E, h, w, 4, dtype=torch.float32, device=net.device)
+        P["heads2"]([hd], EPI_HEADS, out=dw)
+        # GraphAgg: conv -> mean over the edges of each source frame -> conv -> eta / upmask
+        x = P["agg1"]([net], EPI_RELU)
+        _, ix = torch.unique(ii, return_inverse=True)
+        K = int(ix.max().item()) + 1 if E > 0 else 0
+        acc = torch.zeros(K, h, w, 128, dtype=torch.float32, device=net.device).index_add_(0, ix, x.float())
+        cnt = torch.zeros(K, dtype=torch.float32, device=net.device).index_add_(0, ix, torch.ones(E, device=net.device))
+        xm = (acc / cnt.view(-1, 1, 1, 1)).half().contiguous()
+        x2 = P["agg2"]([xm], EPI_RELU)
+        eta = torch.empty(K, h, w, 1, dtype=torch.float32, device=net.device)
+        P["eta"]([x2], EPI_SOFTPLUS_001, out=eta)
+        upmask = P["upmask"]([x2], EPI_LINEAR)
+        return net, dw[..., :2], dw[..., 2:], eta[..., 0], upmask
+
+    def forward(self, net, inp, corr, flow=None, ii=None, jj=None):
+        """Reference interface (droid_net.py:111-143): net, inp [1,E,128,h,w], corr [1,E,196,h,w],
+        flow [1,E,4,h,w] -> net [1,E,128,h,w], delta, weight [1,E,h,w,2], eta [1,K,h,w], upmask [1,K,576,h,w]."""
+        batch, num, ch, ht, wd = net.shape
+        assert batch == 1
+        if flow is None:
+            flow = torch.zeros(batch, num, 4, ht, wd, device=net.device)
+        if ii is None:
+            ii = torch.arange(num, device=net.device)
+        n = self.to_nhwc(net[0]); i = self.to_nhwc(inp[0])
+        c = self.to_nhwc(corr[0], COR_PAD); f = self.to_nhwc(flow[0], 8)
+        n, delta, weight, eta, upmask = self.forward_nhwc(n, i, c, f, ii.to(net.device))
+        net_out = n.permute(0, 3, 1, 2)[None].to(net.dtype)
+        return net_out, delta[None], weight[None], eta[None], upmask.permute(0, 3, 1, 2)[None]
+
+    __call__ = forward

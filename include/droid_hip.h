@@ -134,6 +134,29 @@ int dh_ba_finish(float* poses, float* disps, const int64_t* jj,
                  void* workspace, size_t workspace_bytes, dh_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * ConvGRU update operator building block.  Replaces the cuDNN convolutions + elementwise GRU algebra of
+ * UpdateModule / ConvGRU / GraphAgg (reference droid_slam/droid_net.py:78-143,44-75, modules/gru.py:5-33).
+ * Implicit-GEMM convolution, stride 1, "same" padding, fp16 MFMA with fp32 accumulation, NHWC activations.
+ *   inputs[i] [N,H,W,in_channels[i]] f16 (1..4 tensors, concatenated along channels on the fly; channels % 8 == 0;
+ *   in_strides[i] = elements between consecutive pixels, NULL = dense: lets a segment be a channel slice of a wider tensor)
+ *   weights [CoutPad, Kpad] f16 with k = (dy*KW + dx) * sum(in_channels) + c, zero padded (Kpad % 64 == 0,
+ *   CoutPad % 32 == 0);  bias [CoutPad] f32
+ *   out [N,H,W,out_stride] (f16, or f32 holding fp16-rounded values when out_is_f32), channels [0,Cout) written
+ *   epilogue: 0 linear, 1 relu, 2 sigmoid,
+ *     3 GRU z|r  (Cout = 256: z = sigmoid(.+g) for cout < 128, r*net for cout >= 128; aux0 = net [.,128]),
+ *     4 GRU q    (out = (1-z)*net + z*tanh(.+g); aux0 = net, aux1 = z|r tensor; out may alias aux0),
+ *     5 global-context reduction (red[N,Cout] f32 += sum_pixels sigmoid(.)*aux0; nothing else is written),
+ *     6 0.01*softplus, 7 (delta_x, delta_y, sigmoid w_x, sigmoid w_y)
+ *   gterm [N,CoutPad] f32 or NULL: per-image additive term (the ConvGRU's 1x1 global-context convolutions).
+ */
+int dh_conv2d_nhwc_f16(const void* const* inputs, const int* in_channels, const int* in_strides, int n_inputs,
+                       const void* weights, const float* bias,
+                       int N, int H, int W, int KH, int KW, int Cout, int CoutPad, int Kpad, int epilogue,
+                       void* out, int out_is_f32, int out_stride,
+                       const float* gterm, const void* aux0, int aux0_stride, const void* aux1, int aux1_stride,
+                       float* red, dh_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Geometry kernels of the droid_backends API (reference src/droid.cpp:125-171,228-242).
  *   frame_distance: dist [M] f32   (src/droid_kernels.cu:527-666, 1447-1469)
  *   projmap: coords [M,ht,wd,3] f32 (channel 2 = 0), valid [M,ht,wd,1] f32  (:436-525, 1472-1497)

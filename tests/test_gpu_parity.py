@@ -445,3 +445,66 @@ def test_native_pyramid_cat_and_index(db):
     mask = torch.tensor([True, False, True, True, False], device="cuda")
     sub = a[mask]
     assert torch.equal(sub(coords[:, mask]), full[:, mask])
+
+
+# ------------------------------------------------------------------------------------------ ConvGRU update operator
+class _SD:
+    def __init__(self, sd):
+        self._sd = sd
+
+    def state_dict(self):
+        return self._sd
+
+
+def _update_inputs(E, h, w, seed):
+    g = torch.Generator().manual_seed(seed)
+    net = torch.tanh(torch.randn(E, 128, h, w, generator=g))
+    inp = torch.relu(torch.randn(E, 128, h, w, generator=g))
+    corr = torch.randn(E, 196, h, w, generator=g) * 2.0
+    flow = (torch.randn(E, 4, h, w, generator=g) * 4.0).clamp(-64, 64)
+    return net.half().float(), inp.half().float(), corr.half().float(), flow.half().float()
+
+
+@pytest.mark.parametrize("shape", [(6, 16, 16), (5, 12, 16), (3, 48, 64)])
+def test_update_operator_vs_oracle(db, shape):
+    """UpdateModule (implicit-GEMM MFMA convolutions + fused GRU epilogues) vs the fp32 oracle restatement of
+    droid_net.py:111-143 on identical weights and fp16-representable inputs.  The HIP path rounds every layer
+    output to fp16 like the reference under autocast; tolerances are for that rounding chain."""
+    from oracle import update as oupd
+    from droid_amd.update import UpdateModule
+    from droid_amd.weights import deterministic_state_dict
+    E, h, w = shape
+    sd = deterministic_state_dict(_SD(oupd.empty_state_dict()), seed=7)
+    net, inp, corr, flow = _update_inputs(E, h, w, seed=E + h)
+    ii = torch.tensor(([0, 0, 1, 2, 2, 2] * 3)[:E], dtype=torch.int64)
+    rn, rd, rw, re, ru = oupd.update_forward(sd, net, inp, corr, flow, ii)
+    mod = UpdateModule().load_state_dict(sd)
+    n, d, wt, eta, up = mod(net[None].cuda().half(), inp[None].cuda().half(), corr[None].cuda().half(),
+                            flow[None].cuda(), ii.cuda(), None)
+    torch.cuda.synchronize()
+    assert n.shape == (1, E, 128, h, w) and d.shape == (1, E, h, w, 2) and wt.shape == (1, E, h, w, 2)
+    K = len(torch.unique(ii))
+    assert eta.shape == (1, K, h, w) and up.shape == (1, K, 576, h, w)
+    cmp = lambda a, b: (a.float().cpu() - b).abs().max().item()
+    assert cmp(n[0], rn) <= 2e-2
+    assert cmp(d[0], rd) <= 3e-2 * max(1.0, rd.abs().max().item())
+    assert cmp(wt[0], rw) <= 2e-2
+    assert cmp(eta[0], re) <= 2e-2 * re.abs().max().item() + 1e-5
+    assert cmp(up[0], ru) <= 3e-2 * max(1.0, ru.abs().max().item())
+
+
+def test_conv2d_nhwc_matches_torch_conv(db):
+    """the raw convolution entry point against torch's fp32 conv2d: 1x1 / 3x3 / 7x7, multi-segment input, all tile configs"""
+    from droid_amd.update import pack_conv, EPI_LINEAR, EPI_RELU
+    torch.manual_seed(0)
+    N, H, W = 3, 12, 16
+    for (cins, cout, k) in [((128, 64, 8), 128, 3), ((200,), 64, 1), ((8,), 32, 7), ((128,), 576, 1), ((64, 64), 4, 3)]:
+        xs = [torch.randn(N, H, W, c, device="cuda").half() for c in cins]
+        wgt = torch.randn(cout, sum(cins), k, k, device="cuda") / (sum(cins) * k * k) ** 0.5
+        bias = torch.randn(cout, device="cuda")
+        wp, bp = pack_conv(wgt, bias)
+        out = torch.empty(N, H, W, cout, device="cuda", dtype=torch.float16)
+        db.conv2d_nhwc(xs, wp, bp, k, k, cout, EPI_LINEAR, out, cout, None, None, None, None)
+        x = torch.cat(xs, -1).float().permute(0, 3, 1, 2)
+        ref = torch.nn.functional.conv2d(x, wgt.half().float(), bias, padding=k // 2).permute(0, 2, 3, 1)
+        assert (out.float() - ref).abs().max() <= 1e-2 * max(1.0, ref.abs().max().item())
