@@ -136,34 +136,61 @@ def main():
     rig = g["fmaps"].shape[1]
     fmaps = d(g["fmaps"])
 
-    # ---- correlation pyramid for this rank's edges (setup, untimed) ----
+    # ---- correlation pyramid for this rank's edges (setup, untimed: built once per edge lifetime) ----
     c = (ii == jj).long() if rig > 1 else torch.zeros_like(ii)
     corr = None if args.no_lookup else CorrBlock(fmaps[ii, 0][None], fmaps[jj, c][None])
+    # ---- ConvGRU update operator: random-init weights of the reference architecture (no droid.pth here) ----
+    upd = None
+    if not args.no_update_op:
+        from droid_amd.update import UpdateModule, empty_state_dict
+        from droid_amd.weights import deterministic_state_dict
+
+        class _SD:
+            def state_dict(self):
+                return empty_state_dict()
+        upd = UpdateModule(dev).load_state_dict(deterministic_state_dict(_SD(), seed=1234))
+        net = d(g["nets"])[ii].permute(0, 2, 3, 1).contiguous()        # hidden state per edge, NHWC fp16
+        inp = d(g["inps"])[ii].permute(0, 2, 3, 1).contiguous()
+    yy, xx = torch.meshgrid(torch.arange(ht, device=dev, dtype=torch.float32),
+                            torch.arange(wd, device=dev, dtype=torch.float32), indexing="ij")
+    coords0 = torch.stack([xx, yy], -1)[None]                             # [1,h,w,2]
+    target_prev = targets.permute(0, 2, 3, 1).contiguous()                # [E,h,w,2]
     torch.cuda.synchronize()
 
     from droid_amd.dist_ba import DistBA
     solver = DistBA(world) if world > 1 else None
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
-    lk_ms, ba_ms = [], []
+    lk_ms, up_ms, ba_ms = [], [], []
 
     def step(timed):
+        """one FactorGraph.update iteration (reference factor_graph.py:214-263)"""
         poses.copy_(poses0); disps.copy_(disps0)
-        coords1, _ = db.reproject(poses, disps, intr, ii, jj)
+        coords1, _ = db.reproject(poses, disps, intr, ii, jj)              # [E,h,w,2]
         e0, e1, e2, e3 = ev(), ev(), ev(), ev()
         e0.record()
-        feats = corr(coords1[None]) if corr is not None else None
+        fused = upd is not None and corr is not None
+        # channel-last features straight into the update operator; the reference-layout [E,196,h,w] otherwise
+        feats = (corr.lookup_nhwc(coords1[None]) if fused else corr(coords1[None])[0]) if corr is not None else None
         e1.record()
-        # TODO(update op): ConvGRU block goes here; until it lands the BA consumes the synthetic targets
+        if upd is not None and feats is not None:
+            motn = torch.cat([coords1 - coords0, target_prev - coords1], -1).clamp(-64.0, 64.0)
+            flow = torch.nn.functional.pad(motn, (0, 4)).half()
+            _, delta, weight, damping, upmask = upd.forward_nhwc(net, inp, feats, flow, ii)
+            tgt = (coords1 + delta).permute(0, 3, 1, 2).contiguous()
+            wgt = weight.permute(0, 3, 1, 2).contiguous()
+            eta_ba = (0.2 * damping + 1e-7).contiguous()
+        else:
+            tgt, wgt, eta_ba = targets, weights, eta
         e2.record()
         if solver is None:
-            db.ba(poses, disps, intr, sens, targets, weights, eta, ii, jj, 1, N, g["itrs"], g["lm"], g["ep"], False)
+            db.ba(poses, disps, intr, sens, tgt, wgt, eta_ba, ii, jj, 1, N, g["itrs"], g["lm"], g["ep"], False)
         else:
-            solver.ba(poses, disps, intr, sens, targets, weights, eta, ii, jj, 1, N, g["itrs"], g["lm"], g["ep"])
+            solver.ba(poses, disps, intr, sens, tgt, wgt, eta_ba, ii, jj, 1, N, g["itrs"], g["lm"], g["ep"])
         disps.clamp_(min=0.001)
         e3.record()
         if timed:
-            lk_ms.append((e0, e1)); ba_ms.append((e2, e3))
+            lk_ms.append((e0, e1)); up_ms.append((e1, e2)); ba_ms.append((e2, e3))
         return feats
 
     def barrier():
@@ -184,11 +211,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     lk = float(np.mean([a.elapsed_time(b) for a, b in lk_ms])) if lk_ms else 0.0
+    up = float(np.mean([a.elapsed_time(b) for a, b in up_ms])) if up_ms else 0.0
     ba = float(np.mean([a.elapsed_time(b) for a, b in ba_ms])) if ba_ms else 0.0
 
     if rank == 0:
         ms = 1000.0 * elapsed / max(1, args.steps)
         ep_total = E_all * HW
+        # (the channel-last variant also writes 7 zero channels per level: 936 B/ep physical; only the 880 B count)
         lookup_bytes = LOOKUP_BYTES_PER_EP_F16 * E * HW
         achieved = lookup_bytes / (lk * 1e-3) / 1e9 if lk > 0 else 0.0
         out = {
@@ -199,10 +228,12 @@ def main():
             "dtype": "f32 (BA; fp64 solve) / f16 (correlation pyramid)", "data": "synthetic",
             "config": {"workload": "%s: %d keyframes, %d edges, %dx%d, ba itrs=%d lm=%g ep=%g" % (
                 cfg.name, N, E_all, ht, wd, g["itrs"], g["lm"], g["ep"]),
-                "stages": "reproject + corr lookup (4 levels, materialised fp16 pyramid, MI355X layout) + ba",
+                "stages": "reproject + corr lookup (4 levels, materialised fp16 pyramid, MI355X layout) + %sba" % (
+                    "ConvGRU update operator (random-init weights) + " if upd is not None else ""),
                 "parallelism": "edge-sharded x%d" % world},
-            "ms_per_global_ba": ba, "ms_corr_lookup": lk,
-            "roofline": {"kernel": "pyr_lookup_kernel (1 launch = 4-level pyramid lookup of all edges)", "bound": "hbm",
+            "ms_per_global_ba": ba, "ms_corr_lookup": lk, "ms_update_operator": up,
+            "roofline": {"kernel": "pyr_lookup_kernel<64, %s> (1 launch = 4-level pyramid lookup of all edges)" % (
+                "channel-last" if upd is not None and corr is not None else "reference layout"), "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch_group": lookup_bytes},

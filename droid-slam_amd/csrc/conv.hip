@@ -47,7 +47,7 @@ __device__ __forceinline__ float round_h(float v) { return __half2float(__float2
 
 // WM x WN = per-wave output tile, waves arranged (BM / WM) x (BN / WN)
 template <int WM, int WN, int BN, int EPI>
-__global__ __launch_bounds__(512, 2) void conv_igemm_kernel(ConvParams P) {
+__global__ __launch_bounds__(512, 4) void conv_igemm_kernel(ConvParams P) {
   constexpr int WAVES_M = BM / WM, TM = WM / 32, TN = WN / 32;
   static_assert(WAVES_M * (BN / WN) == 8, "8 waves");
   extern __shared__ __half s_conv[];
@@ -203,6 +203,31 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(ConvParams P) {
   }
 }
 
+// mean over the rows of each segment (GraphAgg's scatter_mean over the edges of a source frame, reference
+// droid_net.py:67): out[k] = mean_{e in order[seg_off[k] .. seg_off[k+1])} x[e]; one thread = 8 channels (16 B),
+// fp32 accumulation in a fixed order, one rounding to fp16.
+__global__ __launch_bounds__(256) void segment_mean_kernel(const __half* __restrict__ x, const int64_t* __restrict__ order,
+                                                           const int64_t* __restrict__ seg_off, __half* __restrict__ out,
+                                                           long row8) {
+  const int k = blockIdx.y;
+  const long o = (long)blockIdx.x * 256 + threadIdx.x;
+  if (o >= row8) return;
+  const long a = seg_off[k], b = seg_off[k + 1];
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (long i = a; i < b; ++i) {
+    const uint4 v = reinterpret_cast<const uint4*>(x)[order[i] * row8 + o];
+    const __half2* h2 = reinterpret_cast<const __half2*>(&v);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const float2 f = __half22float2(h2[q]); acc[2 * q] += f.x; acc[2 * q + 1] += f.y; }
+  }
+  const float inv = b > a ? 1.f / (float)(b - a) : 0.f;
+  uint4 r;
+  __half2* rh = reinterpret_cast<__half2*>(&r);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) rh[q] = __floats2half2_rn(acc[2 * q] * inv, acc[2 * q + 1] * inv);
+  reinterpret_cast<uint4*>(out)[(long)k * row8 + o] = r;
+}
+
 template <int WM, int WN, int BN, int EPI>
 int launch_epi(const ConvParams& P, hipStream_t st) {
   const long M = (long)P.N * P.H * P.W;
@@ -266,4 +291,16 @@ extern "C" int dh_conv2d_nhwc_f16(const void* const* inputs, const int* in_chann
   if (CoutPad >= 128) return launch<64, 64, 128>(P, st);
   if (CoutPad >= 64) return launch<64, 32, 64>(P, st);
   return launch<32, 32, 32>(P, st);
+}
+
+extern "C" int dh_segment_mean_f16(const void* x, const int64_t* order, const int64_t* seg_off, void* out,
+                                   int K, long row_elems, dh_stream_t stream) {
+  if (K < 0 || row_elems <= 0 || row_elems % 8) return DH_ERR_ARG;
+  if (K == 0) return DH_OK;
+  if (!x || !order || !seg_off || !out) return DH_ERR_ARG;
+  const long row8 = row_elems / 8;
+  hipLaunchKernelGGL(segment_mean_kernel, dim3((unsigned)((row8 + 255) / 256), K), dim3(256), 0, (hipStream_t)stream,
+                     (const __half*)x, order, seg_off, (__half*)out, row8);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
 }

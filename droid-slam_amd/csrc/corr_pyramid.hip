@@ -271,7 +271,12 @@ struct HalfTaps { uint32_t raw[HALF_ROWS][NPAIR]; };
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int W>
+// NHWC = false: out [E,196,h,w] (the reference's tensor, channel = level*49 + xoff*7 + yoff), staged through LDS.
+// NHWC = true : out [E,h,w,224] for the update operator of this library (csrc/conv.hip): per level 56 channels,
+//               channel = level*56 + yoff*7 + xoff, channels 49..55 of a level zero.  A lane owns all channels
+//               of its pixel, so they are packed in registers and stored as 7 x 16 bytes per level: no LDS,
+//               no workgroup barrier at all.
+template <int W, bool NHWC>
 __global__ __launch_bounds__(W * 8, 4) void pyr_lookup_kernel(const __half* __restrict__ pyr, const float* __restrict__ coords,
                                                                __half* __restrict__ out, PyrDims D) {
   extern __shared__ __half s_out[];               // [49][8 rows][W], swizzled
@@ -339,7 +344,9 @@ __global__ __launch_bounds__(W * 8, 4) void pyr_lookup_kernel(const __half* __re
   const int seg = bx ^ (yy & (NBX - 1));
   __half* srow = s_out + yy * W + seg * 8 + (xx & ~1);           // + ch * 8 * W
   float prev[OUTW], stash = 0.f;
-  // interpolate the 4 window rows of one batch; outputs of window row pair (j-1, j) go to LDS
+  constexpr int NHWC_LEVEL_CH = 56, NHWC_CH = NLEV * NHWC_LEVEL_CH;   // 49 + 7 zero channels per level
+  uint32_t packed[NHWC_LEVEL_CH / 2];                                 // NHWC mode: this pixel's channels of the level
+  // interpolate the 4 window rows of one batch; outputs of window row pair (j-1, j) go to LDS / the packed run
   auto consume = [&](const LevelGeom& G, const HalfTaps& T, int half) {
     const float dx = G.dx, dy = G.dy;
 #pragma unroll
@@ -359,6 +366,15 @@ __global__ __launch_bounds__(W * 8, 4) void pyr_lookup_kernel(const __half* __re
         float o[OUTW];
 #pragma unroll
         for (int a = 0; a < OUTW; ++a) o[a] = prev[a] + dy * (c[a] - prev[a]);
+        if (NHWC) {
+          // channels (j-1)*7 + a, a = 0..6, of this level: append to the lane's packed fp16 run
+#pragma unroll
+          for (int a = 0; a < OUTW; ++a) {
+            const int ch = (j - 1) * OUTW + a;
+            const uint32_t hv = (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)o[a]);
+            if (ch & 1) packed[ch >> 1] |= hv << 16; else packed[ch >> 1] = hv;
+          }
+        } else {
         // channel ch = a*7 + (j-1).  Two channels per step (A stored by even lanes, B by odd lanes):
         // Wd = [A_self, B_self] (fp16 pair), Pd = the x-neighbour's Wd; even lane stores [A_self, A_nb] = bytes
         // (Wd.lo, Pd.lo), odd lane [B_nb, B_self] = (Pd.hi, Wd.hi): one v_perm_b32 with a per-lane selector.
@@ -377,6 +393,7 @@ __global__ __launch_bounds__(W * 8, 4) void pyr_lookup_kernel(const __half* __re
           const uint32_t Wd = __builtin_bit_cast(uint32_t, __floats2half2_rn(o[6], o[6]));
           const uint32_t Pd = dpp_swap_x(Wd);
           *reinterpret_cast<uint32_t*>(srow + (6 * OUTW + 6) * 8 * W) = odd ? ((Pd & 0xffffu) | (Wd & 0xffff0000u)) : ((Wd & 0xffffu) | (Pd & 0xffff0000u));
+        }
         }
       }
 #pragma unroll
@@ -402,21 +419,33 @@ __global__ __launch_bounds__(W * 8, 4) void pyr_lookup_kernel(const __half* __re
     landed(B);
     consume(G, B, 1);
     if (more) request(l + 1, Gn, 1, B);
-    lds_barrier();
-    // one channel strip = 8 full rows = contiguous in the output; piece = 8 pixels (16 B).
-    // piece o -> sg = o % NBX, row = (o / NBX) % 8, ch = o / (NBX * 8): all shifts (NBX is a power of two)
-    constexpr int NPIECES = NCH_OUT * 8 * NBX;
-    __half* obase = out + ((long)e * (NLEV * NCH_OUT) + l * NCH_OUT) * HW + (long)by * 8 * W;
+    if (NHWC) {
+      asm volatile("" ::: "memory");       // the stores below stay younger than the B_{l+1} requests (wait counts)
 #pragma unroll
-    for (int it = 0; it < (NPIECES + NTHREADS - 1) / NTHREADS; ++it) {
-      const int o = tid + it * NTHREADS;
-      if (it * NTHREADS + NTHREADS <= NPIECES || o < NPIECES) {
-        const int sg = o % NBX, row = (o / NBX) % 8, ch = o / (NBX * 8);
-        const uint4 val = *reinterpret_cast<const uint4*>(s_out + (ch * 8 + row) * W + (sg ^ (row & (NBX - 1))) * 8);
-        *reinterpret_cast<uint4*>(obase + (long)ch * HW + row * W + sg * 8) = val;
-      }
-    }
+      for (int q = NCH_OUT / 2 + 1; q < NHWC_LEVEL_CH / 2; ++q) packed[q] = 0u;
+      packed[NCH_OUT / 2] &= 0xffffu;      // channel 49 (upper half of the dword of channel 48) is padding
+      uint4* dst = reinterpret_cast<uint4*>(out + (((long)e * h + y1) * W + x1) * NHWC_CH + l * NHWC_LEVEL_CH);
+#pragma unroll
+      for (int q = 0; q < NHWC_LEVEL_CH / 8; ++q)
+        dst[q] = uint4{packed[4 * q], packed[4 * q + 1], packed[4 * q + 2], packed[4 * q + 3]};
+      asm volatile("" ::: "memory");
+    } else {
     lds_barrier();
+      // one channel strip = 8 full rows = contiguous in the output; piece = 8 pixels (16 B).
+      // piece o -> sg = o % NBX, row = (o / NBX) % 8, ch = o / (NBX * 8): all shifts (NBX is a power of two)
+      constexpr int NPIECES = NCH_OUT * 8 * NBX;
+      __half* obase = out + ((long)e * (NLEV * NCH_OUT) + l * NCH_OUT) * HW + (long)by * 8 * W;
+  #pragma unroll
+      for (int it = 0; it < (NPIECES + NTHREADS - 1) / NTHREADS; ++it) {
+        const int o = tid + it * NTHREADS;
+        if (it * NTHREADS + NTHREADS <= NPIECES || o < NPIECES) {
+          const int sg = o % NBX, row = (o / NBX) % 8, ch = o / (NBX * 8);
+          const uint4 val = *reinterpret_cast<const uint4*>(s_out + (ch * 8 + row) * W + (sg ^ (row & (NBX - 1))) * 8);
+          *reinterpret_cast<uint4*>(obase + (long)ch * HW + row * W + sg * 8) = val;
+        }
+      }
+      lds_barrier();
+    }
     if (more) G = Gn;
   }
 }
@@ -461,21 +490,35 @@ extern "C" int dh_corr_pyramid_build(const void* fmap1, const void* fmap2, void*
   return DH_OK;
 }
 
+namespace {
+template <bool NHWC>
+int launch_lookup(const void* pyramid, const float* coords, void* out, int E, int h, int w, hipStream_t st) {
+  const PyrDims D = make_dims(h, w);
+  const size_t lds = NHWC ? 0 : (size_t)NCH_OUT * 8 * w * sizeof(__half);
+  const dim3 grid(h / 8, E);
+  if (w == 64)
+    hipLaunchKernelGGL((pyr_lookup_kernel<64, NHWC>), grid, dim3(512), lds, st, (const __half*)pyramid, coords, (__half*)out, D);
+  else if (w == 32)
+    hipLaunchKernelGGL((pyr_lookup_kernel<32, NHWC>), grid, dim3(256), lds, st, (const __half*)pyramid, coords, (__half*)out, D);
+  else
+    hipLaunchKernelGGL((pyr_lookup_kernel<16, NHWC>), grid, dim3(128), lds, st, (const __half*)pyramid, coords, (__half*)out, D);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+}  // namespace
+
 extern "C" int dh_corr_pyramid_lookup(const void* pyramid, const float* coords, void* out,
                                       int E, int h, int w, dh_stream_t stream) {
   if (E < 0 || !dims_ok(h, w)) return DH_ERR_ARG;
   if (E == 0) return DH_OK;
   if (!pyramid || !coords || !out) return DH_ERR_ARG;
-  const PyrDims D = make_dims(h, w);
-  const size_t lds = (size_t)NCH_OUT * 8 * w * sizeof(__half);
-  const dim3 grid(h / 8, E);
-  hipStream_t st = (hipStream_t)stream;
-  if (w == 64)
-    hipLaunchKernelGGL(pyr_lookup_kernel<64>, grid, dim3(512), lds, st, (const __half*)pyramid, coords, (__half*)out, D);
-  else if (w == 32)
-    hipLaunchKernelGGL(pyr_lookup_kernel<32>, grid, dim3(256), lds, st, (const __half*)pyramid, coords, (__half*)out, D);
-  else
-    hipLaunchKernelGGL(pyr_lookup_kernel<16>, grid, dim3(128), lds, st, (const __half*)pyramid, coords, (__half*)out, D);
-  DH_LAUNCH_CHECK();
-  return DH_OK;
+  return launch_lookup<false>(pyramid, coords, out, E, h, w, (hipStream_t)stream);
+}
+
+extern "C" int dh_corr_pyramid_lookup_nhwc(const void* pyramid, const float* coords, void* out,
+                                           int E, int h, int w, dh_stream_t stream) {
+  if (E < 0 || !dims_ok(h, w)) return DH_ERR_ARG;
+  if (E == 0) return DH_OK;
+  if (!pyramid || !coords || !out) return DH_ERR_ARG;
+  return launch_lookup<true>(pyramid, coords, out, E, h, w, (hipStream_t)stream);
 }

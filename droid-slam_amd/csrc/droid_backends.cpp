@@ -265,6 +265,32 @@ torch::Tensor corr_pyramid_lookup(torch::Tensor pyramid, torch::Tensor coords) {
   return out;
 }
 
+torch::Tensor corr_pyramid_lookup_nhwc(torch::Tensor pyramid, torch::Tensor coords) {
+  CHECK_INPUT(pyramid); CHECK_INPUT(coords); CHECK_F32(coords);
+  TORCH_CHECK(pyramid.scalar_type() == torch::kFloat16, "pyramid must be float16");
+  TORCH_CHECK(coords.dim() == 4 && coords.size(3) == 2, "corr_pyramid_lookup_nhwc: coords [E,h,w,2]");
+  const int E = (int)coords.size(0), h = (int)coords.size(1), w = (int)coords.size(2);
+  TORCH_CHECK(pyramid.size(0) == E && (size_t)pyramid.size(1) * 2 == dh_corr_pyramid_bytes(1, h, w),
+              "corr_pyramid_lookup_nhwc: pyramid does not match coords");
+  torch::Tensor out = torch::empty({E, h, w, 224}, pyramid.options());
+  check_status(dh_corr_pyramid_lookup_nhwc(pyramid.data_ptr(), coords.data_ptr<float>(), out.data_ptr(), E, h, w, cur_stream()),
+               "corr_pyramid_lookup_nhwc");
+  return out;
+}
+
+torch::Tensor segment_mean(torch::Tensor x, torch::Tensor order, torch::Tensor seg_off) {
+  CHECK_INPUT(x); CHECK_INPUT(order); CHECK_INPUT(seg_off); CHECK_I64(order); CHECK_I64(seg_off);
+  TORCH_CHECK(x.scalar_type() == torch::kFloat16 && x.dim() >= 2, "segment_mean: x [E,...] float16");
+  const int64_t E = x.size(0), K = seg_off.numel() - 1;
+  TORCH_CHECK(order.numel() == E && K >= 0, "segment_mean: order [E], seg_off [K+1]");
+  const int64_t row = E > 0 ? x.numel() / E : 0;
+  auto sizes = x.sizes().vec(); sizes[0] = K;
+  torch::Tensor out = torch::empty(sizes, x.options());
+  if (E > 0) check_status(dh_segment_mean_f16(x.data_ptr(), order.data_ptr<int64_t>(), seg_off.data_ptr<int64_t>(), out.data_ptr(),
+                                              (int)K, (long)row, cur_stream()), "segment_mean");
+  return out;
+}
+
 // ---- implicit-GEMM convolution with fused epilogues (droid_amd.update.UpdateModule) ----------------------
 void conv2d_nhwc(std::vector<torch::Tensor> inputs, torch::Tensor weight, torch::Tensor bias, int64_t KH, int64_t KW,
                  int64_t Cout, int64_t epilogue, c10::optional<torch::Tensor> out, int64_t out_stride,
@@ -363,6 +389,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("ba_finish", &ba_finish, "damp + solve + back-substitute + retract (split BA)");
   m.def("corr_pyramid_build", &corr_pyramid_build, "all-pairs correlation pyramid, MI355X layout");
   m.def("corr_pyramid_lookup", &corr_pyramid_lookup, "fused 4-level lookup on the MI355X pyramid");
+  m.def("corr_pyramid_lookup_nhwc", &corr_pyramid_lookup_nhwc, "fused 4-level lookup, channel-last output for the update operator");
+  m.def("segment_mean", &segment_mean, "mean over row segments (GraphAgg scatter_mean)");
   m.def("conv2d_nhwc", &conv2d_nhwc, "implicit-GEMM NHWC convolution on the fp16 MFMA with fused epilogues");
   m.def("reproject", &reproject, "fused reprojection (Python thresholds)");
   m.def("se3_op", &se3_op, "SE3 inv/mul/exp/retr");

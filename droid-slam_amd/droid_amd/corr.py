@@ -104,6 +104,11 @@ class CorrBlock:
         out = droid_backends.corr_pyramid_lookup(self.pyramid, coords.reshape(batch * num, ht, wd, 2).contiguous())
         return out.view(batch, num, -1, ht, wd)
 
+    def lookup_nhwc(self, coords):
+        """[1,E,h,w,2] -> [E,h,w,224] channel-last features for droid_amd.update.UpdateModule.forward_nhwc"""
+        batch, num, ht, wd, _ = coords.shape
+        return droid_backends.corr_pyramid_lookup_nhwc(self.pyramid, coords.reshape(batch * num, ht, wd, 2).contiguous())
+
     def cat(self, other):
         self.pyramid = torch.cat([self.pyramid, other.pyramid], 0)
         return self

@@ -18,7 +18,18 @@ import droid_backends
 
 EPI_LINEAR, EPI_RELU, EPI_SIGMOID, EPI_GRU_ZR, EPI_GRU_Q, EPI_GLO, EPI_SOFTPLUS_001, EPI_HEADS = range(8)
 COR_PLANES = 4 * 49
-COR_PAD = 200            # 196 correlation channels padded to a multiple of 8 (16-byte pieces in NHWC)
+COR_NHWC = 224           # channel-last correlation features: 4 levels x (49 + 7 zero channels)
+
+
+def corr_channel_map():
+    """index [224] into the reference's 196 correlation channels (level*49 + xoff*7 + yoff) for the channel-last
+    layout written by droid_backends.corr_pyramid_lookup_nhwc (level*56 + yoff*7 + xoff); -1 = zero padding."""
+    m = torch.full((COR_NHWC,), -1, dtype=torch.long)
+    for l in range(4):
+        for a in range(7):
+            for b in range(7):
+                m[l * 56 + b * 7 + a] = l * 49 + a * 7 + b
+    return m
 
 # reference parameter shapes (Cout, Cin, k); droid_net.py:83-108, gru.py:8-17, droid_net.py:47-57
 PARAM_SHAPES = {
@@ -32,6 +43,15 @@ PARAM_SHAPES = {
     "agg.conv1": (128, 128, 3), "agg.conv2": (128, 128, 3),
     "agg.eta.0": (1, 128, 3), "agg.upmask.0": (576, 128, 1),
 }
+
+
+def empty_state_dict(dtype=torch.float32):
+    """zero tensors under the reference's parameter names (shape template for random-init / checkpoint loading)"""
+    sd = {}
+    for k, (co, ci, ks) in PARAM_SHAPES.items():
+        sd[k + ".weight"] = torch.zeros(co, ci, ks, ks, dtype=dtype)
+        sd[k + ".bias"] = torch.zeros(co, dtype=dtype)
+    return sd
 
 
 def _round_up(v, m):
@@ -82,7 +102,12 @@ class UpdateModule:
         P = {}
         conv = lambda name, cin_pad=None: _Conv(*pack_conv(g(name + ".weight"), g(name + ".bias"), cin_pad),
                                                 PARAM_SHAPES[name][2], PARAM_SHAPES[name][0])
-        P["corr0"] = conv("corr_encoder.0", COR_PAD)
+        cmap = corr_channel_map().to(self.device)
+        w0 = g("corr_encoder.0.weight").float()
+        w0p = torch.zeros(128, COR_NHWC, 1, 1, device=self.device)
+        w0p[:, cmap >= 0] = w0[:, cmap[cmap >= 0]]
+        P["corr0"] = _Conv(*pack_conv(w0p, g("corr_encoder.0.bias")), 1, 128)
+        self.cmap = cmap
         P["corr2"] = conv("corr_encoder.2")
         P["flow0"] = conv("flow_encoder.0", 8)
         P["flow2"] = conv("flow_encoder.2")
@@ -119,8 +144,8 @@ class UpdateModule:
 
     # ---- the operator ----------------------------------------------------------------------------
     def forward_nhwc(self, net, inp, corr, flow, ii):
-        """net, inp [E,h,w,128] f16 (net is updated IN PLACE), corr [E,h,w,200] f16 (196 + zero pad),
-        flow [E,h,w,8] f16 (4 + zero pad), ii [E] int64 ->
+        """net, inp [E,h,w,128] f16 (net is updated IN PLACE), corr [E,h,w,224] f16 in the channel-last order of
+        droid_backends.corr_pyramid_lookup_nhwc (see corr_channel_map), flow [E,h,w,8] f16 (4 + zero pad), ii [E] int64 ->
         (net, delta [E,h,w,2] f32, weight [E,h,w,2] f32, eta [K,h,w] f32, upmask [K,h,w,576] f16)."""
         P = self.params
         E, h, w, _ = net.shape
@@ -139,12 +164,13 @@ class UpdateModule:
         P["heads2"]([hd], EPI_HEADS, out=dw)
         # GraphAgg: conv -> mean over the edges of each source frame -> conv -> eta / upmask
         x = P["agg1"]([net], EPI_RELU)
-        _, ix = torch.unique(ii, return_inverse=True)
-        K = int(ix.max().item()) + 1 if E > 0 else 0
-        acc = torch.zeros(K, h, w, 128, dtype=torch.float32, device=net.device).index_add_(0, ix, x.float())
-        cnt = torch.zeros(K, dtype=torch.float32, device=net.device).index_add_(0, ix, torch.ones(E, device=net.device))
-        xm = (acc / cnt.view(-1, 1, 1, 1)).half().contiguous()
+        _, ix, cnt = torch.unique(ii, return_inverse=True, return_counts=True)
+        order = torch.argsort(ix, stable=True)
+        seg_off = torch.zeros(cnt.numel() + 1, dtype=torch.int64, device=net.device)
+        seg_off[1:] = torch.cumsum(cnt, 0)
+        xm = droid_backends.segment_mean(x, order, seg_off)
         x2 = P["agg2"]([xm], EPI_RELU)
+        K = xm.shape[0]
         eta = torch.empty(K, h, w, 1, dtype=torch.float32, device=net.device)
         P["eta"]([x2], EPI_SOFTPLUS_001, out=eta)
         upmask = P["upmask"]([x2], EPI_LINEAR)
@@ -160,7 +186,9 @@ class UpdateModule:
         if ii is None:
             ii = torch.arange(num, device=net.device)
         n = self.to_nhwc(net[0]); i = self.to_nhwc(inp[0])
-        c = self.to_nhwc(corr[0], COR_PAD); f = self.to_nhwc(flow[0], 8)
+        cpad = torch.cat([corr[0], torch.zeros_like(corr[0][:, :1])], 1)          # channel 196 = zeros for the pads
+        c = self.to_nhwc(cpad[:, torch.where(self.cmap >= 0, self.cmap, torch.full_like(self.cmap, COR_PLANES))])
+        f = self.to_nhwc(flow[0], 8)
         n, delta, weight, eta, upmask = self.forward_nhwc(n, i, c, f, ii.to(net.device))
         net_out = n.permute(0, 3, 1, 2)[None].to(net.dtype)
         return net_out, delta[None], weight[None], eta[None], upmask.permute(0, 3, 1, 2)[None]

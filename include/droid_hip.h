@@ -93,6 +93,10 @@ int dh_corr_pyramid_build(const void* fmap1, const void* fmap2, void* pyramid, v
                           size_t workspace_bytes, int E, int C, int h, int w, dh_stream_t stream);
 int dh_corr_pyramid_lookup(const void* pyramid, const float* coords, void* out,
                            int E, int h, int w, dh_stream_t stream);
+/* same lookup written channel-last for the update operator of this library (dh_conv2d_nhwc_f16):
+ *   out [E,h,w,224] f16, channel = level*56 + yoff*7 + xoff, channels 49..55 of every level are zero. */
+int dh_corr_pyramid_lookup_nhwc(const void* pyramid, const float* coords, void* out,
+                                int E, int h, int w, dh_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Dense bundle adjustment.  Replaces ba (reference src/droid.cpp:93-122 -> ba_cuda,
@@ -155,6 +159,11 @@ int dh_conv2d_nhwc_f16(const void* const* inputs, const int* in_channels, const 
                        void* out, int out_is_f32, int out_stride,
                        const float* gterm, const void* aux0, int aux0_stride, const void* aux1, int aux1_stride,
                        float* red, dh_stream_t stream);
+
+/* GraphAgg's scatter_mean (reference droid_net.py:67, torch_scatter): out[k,:] = mean of the rows x[order[i],:],
+ * i in [seg_off[k], seg_off[k+1]); x [E,row_elems] f16, out [K,row_elems] f16, row_elems % 8 == 0. */
+int dh_segment_mean_f16(const void* x, const int64_t* order, const int64_t* seg_off, void* out,
+                        int K, long row_elems, dh_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Geometry kernels of the droid_backends API (reference src/droid.cpp:125-171,228-242).

@@ -1,0 +1,29 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the implicit-GEMM convolution shapes of the update operator (one MI355X)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "droid-slam_amd")]
+import torch
+import droid_backends as db
+from droid_amd.update import pack_conv, EPI_RELU, EPI_LINEAR
+E = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+h, w = 48, 64
+torch.manual_seed(0)
+shapes = [("gru z|r 3x3 448->256", (128, 128, 128, 64), 256, 3), ("gru q 3x3 448->128", (128, 128, 128, 64), 128, 3),
+          ("3x3 128->128", (128,), 128, 3), ("heads0 3x3 128->256", (128,), 256, 3), ("heads2 3x3 256->4", (256,), 4, 3),
+          ("corr0 1x1 200->128", (200,), 128, 1), ("flow0 7x7 8->128", (8,), 128, 7), ("flow2 3x3 128->64", (128,), 64, 3),
+          ("upmask 1x1 128->576 (K=512 frames)", (128,), 576, 1)]
+for name, cins, cout, k in shapes:
+    n = E // 8 if "upmask" in name else E
+    xs = [torch.randn(n, h, w, c, device="cuda").half() for c in cins]
+    wgt = torch.randn(cout, sum(cins), k, k, device="cuda") / (sum(cins) * k * k) ** 0.5
+    wp, bp = pack_conv(wgt, torch.zeros(cout, device="cuda"))
+    out = torch.empty(n, h, w, cout, device="cuda", dtype=torch.float16)
+    run = lambda: db.conv2d_nhwc(xs, wp, bp, k, k, cout, EPI_RELU, out, cout, None, None, None, None)
+    run(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(3):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); run(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
+    ms = min(ts); fl = 2.0 * n * h * w * sum(cins) * k * k * cout
+    print("%-38s %8.3f ms  %7.1f TFLOP/s (useful)  %6.1f%% of 2.5 PF" % (name, ms, fl / ms / 1e9, fl / ms / 1e9 / 25.0))

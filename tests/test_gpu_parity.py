@@ -508,3 +508,20 @@ def test_conv2d_nhwc_matches_torch_conv(db):
         x = torch.cat(xs, -1).float().permute(0, 3, 1, 2)
         ref = torch.nn.functional.conv2d(x, wgt.half().float(), bias, padding=k // 2).permute(0, 2, 3, 1)
         assert (out.float() - ref).abs().max() <= 1e-2 * max(1.0, ref.abs().max().item())
+
+
+def test_native_pyramid_channel_last_lookup_equals_reference_layout(db):
+    """corr_pyramid_lookup_nhwc == corr_pyramid_lookup up to the documented channel permutation (bit-exact)"""
+    from droid_amd.corr import CorrBlock
+    from droid_amd.update import corr_channel_map
+    torch.manual_seed(5)
+    for (E, h, w) in [(3, 16, 16), (2, 48, 64)]:
+        f1 = torch.randn(1, E, 128, h, w, device="cuda").half()
+        f2 = torch.randn(1, E, 128, h, w, device="cuda").half()
+        coords = dev(_smooth_coords(np.random.default_rng(2), E, h, w))[None]
+        blk = CorrBlock(f1, f2)
+        a = blk(coords)[0]                        # [E,196,h,w]
+        b = blk.lookup_nhwc(coords)               # [E,h,w,224]
+        m = corr_channel_map().cuda()
+        assert torch.equal(b[..., m >= 0], a.permute(0, 2, 3, 1)[..., m[m >= 0]])
+        assert torch.count_nonzero(b[..., m < 0]) == 0
