@@ -72,6 +72,22 @@ def build_lib(force=False, verbose=False):
     return LIB
 
 
+def audit_asm_loads(force=False, verbose=False):
+    """corr_pyramid.hip issues tap loads from inline asm with explicit vmcnt waits: verify on the generated ISA
+    that the compiler never spills/copies a register whose load is still in flight (scripts/audit_asm_loads.py)."""
+    src = os.path.join(CSRC, "corr_pyramid.hip")
+    stamp = os.path.join(OBJ, "corr_pyramid.audit_ok")
+    if not force and os.path.exists(stamp) and os.path.getmtime(stamp) >= max(os.path.getmtime(src), *map(os.path.getmtime, headers())):
+        return
+    asm = os.path.join(OBJ, "corr_pyramid.s")
+    _run([HIPCC] + HIP_FLAGS + ["-S", "--cuda-device-only", src, "-o", asm], verbose)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "audit_asm_loads.py"), asm, "pyr_lookup_kernel"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("in-flight register hazard in corr_pyramid.hip:\n" + r.stdout)
+    open(stamp, "w").write(r.stdout)
+
+
 def build_ext(force=False, verbose=False):
     import torch
     from torch.utils import cpp_extension as ce
@@ -98,6 +114,7 @@ def build_ext(force=False, verbose=False):
 
 def build_all(force=False, verbose=False):
     build_lib(force, verbose)
+    audit_asm_loads(force, verbose)
     build_ext(force, verbose)
     return LIB, EXT
 

@@ -272,18 +272,21 @@ struct HalfTaps { uint32_t raw[HALF_ROWS][NPAIR]; };
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // NHWC = false: out [E,196,h,w] (the reference's tensor, channel = level*49 + xoff*7 + yoff), staged through LDS.
-// NHWC = true : out [E,h,w,224] for the update operator of this library (csrc/conv.hip): per level 56 channels,
-//               channel = level*56 + yoff*7 + xoff, channels 49..55 of a level zero.  A lane owns all channels
-//               of its pixel, so they are packed in registers and stored as 7 x 16 bytes per level: no LDS,
-//               no workgroup barrier at all.
+// NHWC = true : out [4,E,h,w,56] for the update operator of this library (csrc/conv.hip takes the 4 levels as 4
+//               channel segments): channel = yoff*7 + xoff, channels 49..55 zero.  A lane owns all channels of
+//               its pixel, so they are packed in registers, transposed through a wave-private LDS tile and
+//               stored as 1 KB runs: no workgroup barrier at all.
+// NHWC workgroups are single waves (nothing is shared between the waves of a strip in that mode), which lets the
+// register allocator use 168 VGPRs at 3 waves/SIMD: the inline-asm tap loads must never be spilled or copied
+// while they are in flight (scripts/audit_asm_loads.py checks the generated ISA for exactly that at build time).
 template <int W, bool NHWC>
-__global__ __launch_bounds__(W * 8, 4) void pyr_lookup_kernel(const __half* __restrict__ pyr, const float* __restrict__ coords,
+__global__ __launch_bounds__(NHWC ? 64 : W * 8, NHWC ? 3 : 4) void pyr_lookup_kernel(const __half* __restrict__ pyr, const float* __restrict__ coords,
                                                                __half* __restrict__ out, PyrDims D) {
   extern __shared__ __half s_out[];               // [49][8 rows][W], swizzled
   constexpr int NBX = W / 8, NTHREADS = W * 8;
-  const int e = blockIdx.y, by = blockIdx.x;
+  const int e = blockIdx.y, by = NHWC ? blockIdx.x / NBX : blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int bx = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bx = NHWC ? blockIdx.x % NBX : __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = D.h, HW = h * W;
   const int yy = lane >> 3, xx = lane & 7;
   const int y1 = by * 8 + yy, x1 = bx * 8 + xx;
@@ -424,10 +427,26 @@ __global__ __launch_bounds__(W * 8, 4) void pyr_lookup_kernel(const __half* __re
 #pragma unroll
       for (int q = NCH_OUT / 2 + 1; q < NHWC_LEVEL_CH / 2; ++q) packed[q] = 0u;
       packed[NCH_OUT / 2] &= 0xffffu;      // channel 49 (upper half of the dword of channel 48) is padding
-      uint4* dst = reinterpret_cast<uint4*>(out + (((long)e * h + y1) * W + x1) * NHWC_CH + l * NHWC_LEVEL_CH);
+      // wave-private LDS image of the block's 8 pixel rows (8 px x 112 B = 896 B each): lane p writes its 112 B
+      // at p*112 (conflict-free: 8-lane groups, stride 28 dwords), then the wave reads 16-byte pieces in memory
+      // order, so one store instruction covers 1 KB of (at most two) contiguous runs instead of 64 lines.
+      uint4* wtile = reinterpret_cast<uint4*>(s_out);
 #pragma unroll
       for (int q = 0; q < NHWC_LEVEL_CH / 8; ++q)
-        dst[q] = uint4{packed[4 * q], packed[4 * q + 1], packed[4 * q + 2], packed[4 * q + 3]};
+        wtile[lane * (NHWC_LEVEL_CH / 8) + q] = uint4{packed[4 * q], packed[4 * q + 1], packed[4 * q + 2], packed[4 * q + 3]};
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+      __half* lbase = out + (((long)l * gridDim.y + e) * h + by * 8) * (long)W * NHWC_LEVEL_CH + bx * 8 * NHWC_LEVEL_CH;
+      constexpr int PPR = 8 * NHWC_LEVEL_CH / 8;                 // 16-byte pieces per block row (56)
+#pragma unroll
+      for (int it = 0; it < NHWC_LEVEL_CH / 8; ++it) {
+        const int p = it * 64 + lane;
+        const int row = p / PPR, off = p - row * PPR;
+        const uint4 v = wtile[p];
+        *reinterpret_cast<uint4*>(lbase + (long)row * W * NHWC_LEVEL_CH + off * 8) = v;
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);                        // the tile is reused by the next level
+      __builtin_amdgcn_wave_barrier();
       asm volatile("" ::: "memory");
     } else {
     lds_barrier();
@@ -494,14 +513,15 @@ namespace {
 template <bool NHWC>
 int launch_lookup(const void* pyramid, const float* coords, void* out, int E, int h, int w, hipStream_t st) {
   const PyrDims D = make_dims(h, w);
-  const size_t lds = NHWC ? 0 : (size_t)NCH_OUT * 8 * w * sizeof(__half);
-  const dim3 grid(h / 8, E);
+  const size_t lds = NHWC ? (size_t)64 * 56 * sizeof(__half) : (size_t)NCH_OUT * 8 * w * sizeof(__half);
+  const dim3 grid(NHWC ? (h / 8) * (w / 8) : h / 8, E);
+  const dim3 block(NHWC ? 64 : w * 8);
   if (w == 64)
-    hipLaunchKernelGGL((pyr_lookup_kernel<64, NHWC>), grid, dim3(512), lds, st, (const __half*)pyramid, coords, (__half*)out, D);
+    hipLaunchKernelGGL((pyr_lookup_kernel<64, NHWC>), grid, block, lds, st, (const __half*)pyramid, coords, (__half*)out, D);
   else if (w == 32)
-    hipLaunchKernelGGL((pyr_lookup_kernel<32, NHWC>), grid, dim3(256), lds, st, (const __half*)pyramid, coords, (__half*)out, D);
+    hipLaunchKernelGGL((pyr_lookup_kernel<32, NHWC>), grid, block, lds, st, (const __half*)pyramid, coords, (__half*)out, D);
   else
-    hipLaunchKernelGGL((pyr_lookup_kernel<16, NHWC>), grid, dim3(128), lds, st, (const __half*)pyramid, coords, (__half*)out, D);
+    hipLaunchKernelGGL((pyr_lookup_kernel<16, NHWC>), grid, block, lds, st, (const __half*)pyramid, coords, (__half*)out, D);
   DH_LAUNCH_CHECK();
   return DH_OK;
 }

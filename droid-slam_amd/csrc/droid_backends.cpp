@@ -272,7 +272,7 @@ torch::Tensor corr_pyramid_lookup_nhwc(torch::Tensor pyramid, torch::Tensor coor
   const int E = (int)coords.size(0), h = (int)coords.size(1), w = (int)coords.size(2);
   TORCH_CHECK(pyramid.size(0) == E && (size_t)pyramid.size(1) * 2 == dh_corr_pyramid_bytes(1, h, w),
               "corr_pyramid_lookup_nhwc: pyramid does not match coords");
-  torch::Tensor out = torch::empty({E, h, w, 224}, pyramid.options());
+  torch::Tensor out = torch::empty({4, E, h, w, 56}, pyramid.options());
   check_status(dh_corr_pyramid_lookup_nhwc(pyramid.data_ptr(), coords.data_ptr<float>(), out.data_ptr(), E, h, w, cur_stream()),
                "corr_pyramid_lookup_nhwc");
   return out;

@@ -105,7 +105,7 @@ class CorrBlock:
         return out.view(batch, num, -1, ht, wd)
 
     def lookup_nhwc(self, coords):
-        """[1,E,h,w,2] -> [E,h,w,224] channel-last features for droid_amd.update.UpdateModule.forward_nhwc"""
+        """[1,E,h,w,2] -> [4,E,h,w,56] level-planar channel-last features for droid_amd.update.UpdateModule.forward_nhwc"""
         batch, num, ht, wd, _ = coords.shape
         return droid_backends.corr_pyramid_lookup_nhwc(self.pyramid, coords.reshape(batch * num, ht, wd, 2).contiguous())
 

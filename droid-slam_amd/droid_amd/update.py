@@ -23,7 +23,8 @@ COR_NHWC = 224           # channel-last correlation features: 4 levels x (49 + 7
 
 def corr_channel_map():
     """index [224] into the reference's 196 correlation channels (level*49 + xoff*7 + yoff) for the channel-last
-    layout written by droid_backends.corr_pyramid_lookup_nhwc (level*56 + yoff*7 + xoff); -1 = zero padding."""
+    layout written by droid_backends.corr_pyramid_lookup_nhwc ([level][...][yoff*7 + xoff], 56 per level);
+    -1 = zero padding."""
     m = torch.full((COR_NHWC,), -1, dtype=torch.long)
     for l in range(4):
         for a in range(7):
@@ -144,12 +145,12 @@ class UpdateModule:
 
     # ---- the operator ----------------------------------------------------------------------------
     def forward_nhwc(self, net, inp, corr, flow, ii):
-        """net, inp [E,h,w,128] f16 (net is updated IN PLACE), corr [E,h,w,224] f16 in the channel-last order of
-        droid_backends.corr_pyramid_lookup_nhwc (see corr_channel_map), flow [E,h,w,8] f16 (4 + zero pad), ii [E] int64 ->
+        """net, inp [E,h,w,128] f16 (net is updated IN PLACE), corr [4,E,h,w,56] f16 = the level-planar channel-last
+        output of droid_backends.corr_pyramid_lookup_nhwc (channel order: corr_channel_map), flow [E,h,w,8] f16 (4 + zero pad), ii [E] int64 ->
         (net, delta [E,h,w,2] f32, weight [E,h,w,2] f32, eta [K,h,w] f32, upmask [K,h,w,576] f16)."""
         P = self.params
         E, h, w, _ = net.shape
-        c = P["corr2"]([P["corr0"]([corr], EPI_RELU)], EPI_RELU)
+        c = P["corr2"]([P["corr0"]([corr[0], corr[1], corr[2], corr[3]], EPI_RELU)], EPI_RELU)
         f = P["flow2"]([P["flow0"]([flow], EPI_RELU)], EPI_RELU)
         # global context: mean over pixels of sigmoid(w(net)) * net, then three 128x128 GEMVs per edge
         red = torch.zeros(E, 128, dtype=torch.float32, device=net.device)
@@ -188,6 +189,7 @@ class UpdateModule:
         n = self.to_nhwc(net[0]); i = self.to_nhwc(inp[0])
         cpad = torch.cat([corr[0], torch.zeros_like(corr[0][:, :1])], 1)          # channel 196 = zeros for the pads
         c = self.to_nhwc(cpad[:, torch.where(self.cmap >= 0, self.cmap, torch.full_like(self.cmap, COR_PLANES))])
+        c = c.view(c.shape[0], ht, wd, 4, 56).permute(3, 0, 1, 2, 4).contiguous()
         f = self.to_nhwc(flow[0], 8)
         n, delta, weight, eta, upmask = self.forward_nhwc(n, i, c, f, ii.to(net.device))
         net_out = n.permute(0, 3, 1, 2)[None].to(net.dtype)

@@ -94,7 +94,7 @@ int dh_corr_pyramid_build(const void* fmap1, const void* fmap2, void* pyramid, v
 int dh_corr_pyramid_lookup(const void* pyramid, const float* coords, void* out,
                            int E, int h, int w, dh_stream_t stream);
 /* same lookup written channel-last for the update operator of this library (dh_conv2d_nhwc_f16):
- *   out [E,h,w,224] f16, channel = level*56 + yoff*7 + xoff, channels 49..55 of every level are zero. */
+ *   out [4,E,h,w,56] f16 (level-planar), channel = yoff*7 + xoff, channels 49..55 are zero. */
 int dh_corr_pyramid_lookup_nhwc(const void* pyramid, const float* coords, void* out,
                                 int E, int h, int w, dh_stream_t stream);
 

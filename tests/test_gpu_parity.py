@@ -521,7 +521,8 @@ def test_native_pyramid_channel_last_lookup_equals_reference_layout(db):
         coords = dev(_smooth_coords(np.random.default_rng(2), E, h, w))[None]
         blk = CorrBlock(f1, f2)
         a = blk(coords)[0]                        # [E,196,h,w]
-        b = blk.lookup_nhwc(coords)               # [E,h,w,224]
+        b = blk.lookup_nhwc(coords)               # [4,E,h,w,56]
+        b = b.permute(1, 2, 3, 0, 4).reshape(E, h, w, 224)
         m = corr_channel_map().cuda()
         assert torch.equal(b[..., m >= 0], a.permute(0, 2, 3, 1)[..., m[m >= 0]])
         assert torch.count_nonzero(b[..., m < 0]) == 0
