@@ -113,25 +113,19 @@ def main():
     E_all = len(ii_all)
 
     # ---- edge sharding by source frame (contiguous frame ranges balanced by edge count) ----
-    if world > 1:
-        order = np.argsort(ii_all, kind="stable")
-        bounds = np.linspace(0, E_all, world + 1).astype(int)
-        # snap shard boundaries to source-frame boundaries
-        cuts = [0]
-        for b in bounds[1:-1]:
-            f = ii_all[order[b]]
-            cuts.append(int(np.searchsorted(ii_all[order], f, side="left")))
-        cuts.append(E_all)
-        mine = np.sort(order[cuts[rank]:cuts[rank + 1]])
-    else:
-        mine = np.arange(E_all)
+    from droid_amd.dist_ba import DistBA, shard_edges_by_source_frame, local_eta_rows
+    shards, bounds = shard_edges_by_source_frame(ii_all, world)
+    mine = shards[rank]
+    eta_rows, kx_local = local_eta_rows(ii_all, ii_all[mine], 1, N)      # depth blocks of this rank's BA
     d = lambda a, **kw: torch.as_tensor(np.ascontiguousarray(a), **kw).to(dev)
     ii, jj = d(ii_all[mine]), d(jj_all[mine])
     E = len(mine)
 
     poses0, disps0 = d(g["poses"]), d(g["disps"])
     poses, disps = poses0.clone(), disps0.clone()
-    intr, sens, eta = d(g["intrinsics"]), d(g["disps_sens"]), d(g["eta"])
+    intr, sens, eta = d(g["intrinsics"]), d(g["disps_sens"]), d(g["eta"][eta_rows])
+    kx_t = d(kx_local)
+    damping_buf = torch.full((N, ht, wd), 1e-6, device=dev, dtype=torch.float32)     # factor_graph.py:56
     targets, weights = d(g["targets"][mine]), d(g["weights"][mine])
     rig = g["fmaps"].shape[1]
     fmaps = d(g["fmaps"])
@@ -157,8 +151,10 @@ def main():
     target_prev = targets.permute(0, 2, 3, 1).contiguous()                # [E,h,w,2]
     torch.cuda.synchronize()
 
-    from droid_amd.dist_ba import DistBA
     solver = DistBA(world) if world > 1 else None
+    if solver is not None:
+        solver.set_owned_frames(bounds[rank], bounds[rank + 1])
+    uniq_ii = torch.unique(ii)
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
     lk_ms, up_ms, ba_ms = [], [], []
@@ -179,7 +175,8 @@ def main():
             _, delta, weight, damping, upmask = upd.forward_nhwc(net, inp, feats, flow, ii)
             tgt = (coords1 + delta).permute(0, 3, 1, 2).contiguous()
             wgt = weight.permute(0, 3, 1, 2).contiguous()
-            eta_ba = (0.2 * damping + 1e-7).contiguous()
+            damping_buf[uniq_ii] = damping                                   # factor_graph.py:238
+            eta_ba = (0.2 * damping_buf[kx_t] + 1e-7).contiguous()            # factor_graph.py:251 (rows = depth blocks)
         else:
             tgt, wgt, eta_ba = targets, weights, eta
         e2.record()
@@ -220,6 +217,15 @@ def main():
         # (the channel-last variant also writes 7 zero channels per level: 936 B/ep physical; only the 880 B count)
         lookup_bytes = LOOKUP_BYTES_PER_EP_F16 * E * HW
         achieved = lookup_bytes / (lk * 1e-3) / 1e9 if lk > 0 else 0.0
+        # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc, separate passes, gfx950
+        # FETCH_SIZE correction; scripts/pmc_bench_lookup.sh), scaled to this rank's edge-pixels; None if not measured
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_lookup_pmc.json")))
+            variant = "nhwc" if (upd is not None and corr is not None) else "nchw"
+            traffic = pmc[variant]["hbm_bytes_per_edge_pixel"] * E * HW
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "BA update iterations/sec (edges*pixels/s), 512-KF graph",
             "value": ep_total / (ms * 1e-3), "unit": "edge-pixels/s",
@@ -235,7 +241,7 @@ def main():
             "roofline": {"kernel": "pyr_lookup_kernel<64, %s> (1 launch = 4-level pyramid lookup of all edges)" % (
                 "channel-last" if upd is not None and corr is not None else "reference layout"), "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch_group": lookup_bytes},
         }
         if not args.no_cpu_baseline:

@@ -227,7 +227,7 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj,
         dflat = disps.reshape(disps.shape[0], HW)
         dflat[kx] = (dflat[kx].astype(dtype) + dz).astype(disps.dtype)
         info = dict(ok=ok, H=Hsys, b=bsys, C=C, w=w, kx=kx, A=A, S=S, bA=bA, bS=bS,
-                    Hs=Hs, vs=vs) if return_system else dict(ok=ok)
+                    Hs=Hs, vs=vs, Erow=Erow, Q=Q, ii_exp=ii_exp, jj_exp=jj_exp, kk_exp=kk_exp) if return_system else dict(ok=ok)
     if return_system:
         return dx, dz, info
     return dx, dz

@@ -12,6 +12,7 @@ ap.add_argument("--edges", type=int, default=1024)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--flow", default="reproj")
 ap.add_argument("--build-reps", type=int, default=0)
+ap.add_argument("--nhwc", action="store_true", help="channel-last variant (feeds the update operator)")
 a = ap.parse_args()
 E, h, w = a.edges, 48, 64
 torch.manual_seed(0)
@@ -42,11 +43,12 @@ else:
     c, _ = db.reproject(d(g["poses"]), d(g["disps"]), d(g["intrinsics"]), ii, jj)
     c = c.cpu().numpy()
 coords = torch.as_tensor(np.ascontiguousarray(c)).cuda()
-out = db.corr_pyramid_lookup(pyr, coords); torch.cuda.synchronize()
+look = db.corr_pyramid_lookup_nhwc if a.nhwc else db.corr_pyramid_lookup
+out = look(pyr, coords); torch.cuda.synchronize()
 t = []
 for _ in range(a.reps):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(); out = db.corr_pyramid_lookup(pyr, coords); e1.record(); torch.cuda.synchronize(); t.append(e0.elapsed_time(e1))
+    e0.record(); out = look(pyr, coords); e1.record(); torch.cuda.synchronize(); t.append(e0.elapsed_time(e1))
 ms = float(np.median(t)); nbytes = 880.0 * E * h * w
-print("lookup %s E=%d: median %.3f ms min %.3f  -> %.1f GB/s algorithmic (%.1f%% of 8 TB/s)" % (
-    a.flow, E, ms, min(t), nbytes / ms / 1e6, nbytes / ms / 1e6 / 80.0))
+print("lookup%s %s E=%d: median %.3f ms min %.3f  -> %.1f GB/s algorithmic (%.1f%% of 8 TB/s)" % (
+    " channel-last" if a.nhwc else "", a.flow, E, ms, min(t), nbytes / ms / 1e6, nbytes / ms / 1e6 / 80.0))

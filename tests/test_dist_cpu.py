@@ -1,0 +1,111 @@
+"""world_size-2 gloo test of the edge-sharded BA host logic (droid_amd/dist_ba.py) on CPU.
+
+The per-rank numerics (dh_ba_build / dh_ba_finish) need a GPU; here they are replaced by an injected backend that
+computes the same two halves with the oracle, so what is exercised is exactly what runs between the kernels on
+a multi-GPU node: the partition by source frame, the eta row mapping, the all-reduce of the reduced camera system,
+owner-only depth updates and the final exchange of depth increments.  Sharded result == unsharded oracle.
+"""
+import os
+import sys
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "droid-slam_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+class OracleBackend:
+    """ba_build / ba_finish with the contract of droid_backends (CPU tensors, oracle arithmetic, fp64)."""
+
+    def ba_build(self, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1, motion_only):
+        from oracle import ba as oba
+        assert not motion_only
+        p = poses.numpy().astype(np.float64).copy(); d = disps.numpy().astype(np.float64).copy()
+        _, _, info = oba.ba(p, d, intrinsics.numpy(), disps_sens.numpy(), targets.numpy(), weights.numpy(), eta.numpy(),
+                            ii.numpy(), jj.numpy(), t0, t1, 1, 0.0, 1e30, False, return_system=True)
+        n = 6 * (t1 - t0)
+        system = torch.zeros(n + 1, n, dtype=torch.float64)
+        system[:n] = torch.from_numpy(info["H"]); system[n] = torch.from_numpy(info["b"])
+        return dict(info=info, system=system, t0=t0, t1=t1), system
+
+    def ba_finish(self, poses, disps, jj, ws, n_eta_rows, t0, t1, lm, ep, motion_only):
+        from oracle import ba as oba
+        info, system = ws["info"], ws["system"]
+        n = 6 * (t1 - t0)
+        x, ok = oba.solve_damped(system[:n].numpy().copy(), system[n].numpy().copy(), lm, ep)
+        P = t1 - t0
+        dx = x.reshape(P, 6).astype(np.float32).astype(np.float64)
+        prel = info["jj_exp"] - t0
+        use = (prel > 0) & (prel < P)
+        HW = info["Q"].shape[1]
+        dw = np.zeros((len(prel), HW))
+        dw[use] = np.einsum("nip,ni->np", info["Erow"][use], dx[prel[use]])
+        dz = info["Q"] * (info["w"] - oba._segsum(dw, info["ii_exp"], info["kx"]))
+        pn = poses.numpy().astype(np.float64)
+        oba._retract_poses(pn, dx, t0, t1, np.float64)
+        poses.copy_(torch.from_numpy(pn).to(poses.dtype))
+        dflat = disps.view(disps.shape[0], -1)
+        dflat[torch.from_numpy(info["kx"])] += torch.from_numpy(dz).to(disps.dtype)
+        return torch.from_numpy(dx), torch.from_numpy(dz)
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from droid_amd import synthetic as syn
+        from droid_amd.dist_ba import DistBA, shard_edges_by_source_frame, local_eta_rows
+        g = syn.small_graph(n_frames=7, seed=11, ht=8, wd=12, radius=3)
+        N, t0, t1 = g["n_frames"], 1, g["n_frames"]
+        shards, bounds = shard_edges_by_source_frame(g["ii"], world)
+        mine = shards[rank]
+        rows, _ = local_eta_rows(g["ii"], g["ii"][mine], t0, t1)
+        T = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a)).to(dt)
+        poses, disps = T(g["poses"]), T(g["disps"])
+        solver = DistBA(world, backend=OracleBackend())
+        solver.set_owned_frames(bounds[rank], bounds[rank + 1])
+        solver.ba(poses, disps, T(g["intrinsics"]), T(g["disps_sens"]), T(g["targets"][mine]), T(g["weights"][mine]),
+                  T(g["eta"][rows]), T(g["ii"][mine], torch.int64), T(g["jj"][mine], torch.int64), t0, t1, 2, 1e-4, 0.1)
+        if rank == 0:
+            np.savez(out, poses=poses.numpy(), disps=disps.numpy())
+        # every rank ends with the same state
+        chk = torch.cat([poses.flatten(), disps.flatten()])
+        ref = chk.clone(); dist.broadcast(ref, 0)
+        assert torch.allclose(chk, ref, atol=1e-12)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_ba_two_ranks_gloo(tmp_path):
+    from droid_amd import synthetic as syn
+    from oracle import ba as oba
+    out = str(tmp_path / "rank0.npz")
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    g = syn.small_graph(n_frames=7, seed=11, ht=8, wd=12, radius=3)
+    p = g["poses"].astype(np.float64).copy(); d = g["disps"].astype(np.float64).copy()
+    oba.ba(p, d, g["intrinsics"], g["disps_sens"], g["targets"], g["weights"], g["eta"], g["ii"], g["jj"],
+           1, g["n_frames"], 2, 1e-4, 0.1, False)
+    assert np.abs(got["poses"] - p).max() < 1e-6          # dx is rounded to fp32 in both, summation order differs
+    assert np.abs(got["disps"] - d).max() < 1e-5 * max(1.0, np.abs(d).max())
+
+
+def test_partition_covers_every_edge_once_and_keeps_source_frames_together():
+    from droid_amd.dist_ba import shard_edges_by_source_frame
+    rng = np.random.default_rng(0)
+    ii = rng.integers(0, 50, 400)
+    for world in (1, 2, 3, 8):
+        shards, bounds = shard_edges_by_source_frame(ii, world)
+        allidx = np.sort(np.concatenate(shards))
+        assert np.array_equal(allidx, np.arange(len(ii)))
+        owners = {}
+        for r, s in enumerate(shards):
+            for f in np.unique(ii[s]):
+                assert owners.setdefault(int(f), r) == r
+                assert bounds[r] <= f < bounds[r + 1]
