@@ -49,44 +49,70 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(g, n_frames_sample=24, n_lookup_edges=8):
-    """Oracle (numpy restatement of the reference kernels) on a bounded sample of the same graph."""
-    from oracle import ba as oba, corr as ocorr
-    ii, jj = g["ii"], g["jj"]
-    keep = (ii < n_frames_sample) & (jj < n_frames_sample)
-    sub = dict(g)
-    for k in ("ii", "jj", "targets", "weights"):
-        sub[k] = g[k][keep]
-    N = n_frames_sample
-    kx_full = np.unique(np.concatenate([np.arange(1, g["n_frames"]), ii]))
-    kx = np.unique(np.concatenate([np.arange(1, N), sub["ii"]]))
-    eta = g["eta"][np.searchsorted(kx_full, kx)]
-    poses = g["poses"][:N].astype(np.float32).copy(); disps = g["disps"][:N].astype(np.float32).copy()
-    t0 = time.perf_counter()
-    oba.ba(poses, disps, g["intrinsics"], g["disps_sens"][:N], sub["targets"], sub["weights"], eta,
-           sub["ii"], sub["jj"], 1, N, g["itrs"], g["lm"], g["ep"], False, dtype=np.float32)
-    t_ba = time.perf_counter() - t0
-    ep_ba = int(keep.sum()) * g["ht"] * g["wd"]
-    # lookup on a few edges (volume built on the host just for this)
+def cpu_baseline(g, n_frames_sample=96, n_lookup_edges=8, n_update_edges=8):
+    """Oracle (numpy / torch-CPU restatement of the reference kernels, kind "port") on a bounded sample of the same
+    workload, single-threaded (threadpoolctl + torch.set_num_threads(1)): one update iteration = lookup + update
+    operator + ba(itrs) per edge-pixel, each leg timed on its own sample and summed per edge-pixel."""
+    from oracle import ba as oba, corr as ocorr, update as oupd
+    from droid_amd.weights import deterministic_state_dict
+    import threadpoolctl
+    # untimed setup (host pyramid for the lookup sample) with all host threads
     rng = np.random.default_rng(0)
     ht, wd = g["ht"], g["wd"]
     f1 = rng.standard_normal((n_lookup_edges, 128, ht, wd)).astype(np.float32)
     f2 = rng.standard_normal((n_lookup_edges, 128, ht, wd)).astype(np.float32)
-    pyr = [p.astype(np.float32) for p in ocorr.corr_pyramid(f1, f2, 4)]
+    a_ = torch.from_numpy(f1).reshape(n_lookup_edges, 128, ht * wd) / 4.0
+    b_ = torch.from_numpy(f2).reshape(n_lookup_edges, 128, ht * wd) / 4.0
+    vol = torch.matmul(a_.transpose(1, 2), b_).reshape(n_lookup_edges * ht * wd, 1, ht, wd)
+    pyr = []
+    for _ in range(4):
+        pyr.append(vol.reshape(n_lookup_edges, ht, wd, vol.shape[-2], vol.shape[-1]).numpy())
+        vol = torch.nn.functional.avg_pool2d(vol, 2, stride=2)
     coords = np.stack([rng.uniform(0, wd, (n_lookup_edges, ht, wd)), rng.uniform(0, ht, (n_lookup_edges, ht, wd))], -1)
-    t0 = time.perf_counter()
-    ocorr.corr_block_lookup(pyr, coords.astype(np.float32), 3)
-    t_lk = time.perf_counter() - t0
-    ep_lk = n_lookup_edges * ht * wd
-    per_ep = t_ba / ep_ba + t_lk / ep_lk
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count()
-    return {"value": 1.0 / per_ep, "unit": "edge-pixels/s", "cores": cores, "kind": "port",
-            "sample": "numpy oracle (fp32): ba itrs=%d on the %d-frame / %d-edge sub-graph (%.2fs) + 4-level lookup of "
-                      "%d edges (%.2fs); ConvGRU not included" % (g["itrs"], N, int(keep.sum()), t_ba, n_lookup_edges, t_lk),
-            "ba_s": t_ba, "lookup_s": t_lk}
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    with threadpoolctl.threadpool_limits(limits=1):
+        ii, jj = g["ii"], g["jj"]
+        keep = (ii < n_frames_sample) & (jj < n_frames_sample)
+        sub = dict(g)
+        for k in ("ii", "jj", "targets", "weights"):
+            sub[k] = g[k][keep]
+        N = n_frames_sample
+        kx_full = np.unique(np.concatenate([np.arange(1, g["n_frames"]), ii]))
+        kx = np.unique(np.concatenate([np.arange(1, N), sub["ii"]]))
+        eta = g["eta"][np.searchsorted(kx_full, kx)]
+        poses = g["poses"][:N].astype(np.float32).copy(); disps = g["disps"][:N].astype(np.float32).copy()
+        t0 = time.perf_counter()
+        oba.ba(poses, disps, g["intrinsics"], g["disps_sens"][:N], sub["targets"], sub["weights"], eta,
+               sub["ii"], sub["jj"], 1, N, g["itrs"], g["lm"], g["ep"], False, dtype=np.float32)
+        t_ba = time.perf_counter() - t0
+        ep_ba = int(keep.sum()) * g["ht"] * g["wd"]
+        t0 = time.perf_counter()
+        ocorr.corr_block_lookup(pyr, coords.astype(np.float32), 3)
+        t_lk = time.perf_counter() - t0
+        ep_lk = n_lookup_edges * ht * wd
+        # update operator (fp32 torch-CPU restatement of droid_net.py:111-143)
+
+        class _SD:
+            def state_dict(self):
+                return oupd.empty_state_dict()
+        sd = deterministic_state_dict(_SD(), seed=1234)
+        tg = torch.Generator().manual_seed(0)
+        E1 = n_update_edges
+        args = (torch.randn(E1, 128, ht, wd, generator=tg), torch.randn(E1, 128, ht, wd, generator=tg),
+                torch.randn(E1, 196, ht, wd, generator=tg), torch.randn(E1, 4, ht, wd, generator=tg), torch.zeros(E1, dtype=torch.int64))
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            oupd.update_forward(sd, *args)
+        t_up = time.perf_counter() - t0
+        ep_up = E1 * ht * wd
+    torch.set_num_threads(nthreads)
+    per_ep = t_ba / ep_ba + t_lk / ep_lk + t_up / ep_up
+    return {"value": 1.0 / per_ep, "unit": "edge-pixels/s", "cores": 1, "kind": "port",
+            "sample": "single-threaded numpy/torch-CPU oracle (fp32): ba itrs=%d on the %d-frame / %d-edge sub-graph (%.2fs) + "
+                      "4-level lookup of %d edges (%.2fs) + update operator on %d edge(s) (%.2fs); host has %d cores" % (
+                          g["itrs"], N, int(keep.sum()), t_ba, n_lookup_edges, t_lk, E1, t_up, os.cpu_count()),
+            "ba_s": t_ba, "lookup_s": t_lk, "update_s": t_up}
 
 
 def main():
