@@ -534,79 +534,111 @@ __device__ __forceinline__ double lane_bcast(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
-// 1/sqrt(a) in fp64: hardware estimate + two Newton steps (no IEEE sqrt/div sequences on the pivot path)
+// 1/sqrt(a) in fp64: hardware estimate + two coupled Goldschmidt steps (g -> sqrt(a), h -> 1/(2 sqrt(a))): the
+// dependent chain is rsq + 5 fma-class ops instead of rsq + 8 for the textbook Newton form
 __device__ __forceinline__ double fast_rsqrt(double a) {
-  double y = __builtin_amdgcn_rsq(a);
-  y = y * (1.5 - 0.5 * a * y * y);
-  y = y * (1.5 - 0.5 * a * y * y);
-  return y;
+  const double y = __builtin_amdgcn_rsq(a);
+  double g = a * y, h = 0.5 * y;
+  double r = __builtin_fma(-g, h, 0.5);
+  g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+  r = __builtin_fma(-g, h, 0.5);
+  h = __builtin_fma(h, r, h);
+  return 2.0 * h;
 }
 
-// In-place Cholesky of the SPD block S (lower triangle used, LDS, leading dimension LDB) by 256 threads;
-// on return the lower triangle holds L, `dinv[i]` = 1 / L[i][i].  Returns false if a pivot is not positive
-// and finite (the factor is then meaningless but finite work is still done: SparseBlock::solve semantics
-// are applied by the caller through meta[1]).
-__device__ bool chol64_lds(double* __restrict__ S, double* __restrict__ dinv, int tid) {
+// 64x64 block of the system matrix <-> LDS tile (leading dimension LDB), all 16-byte loads in flight at once
+__device__ __forceinline__ void load_block64(double* __restrict__ dst, const double* __restrict__ src, int ld, int tid) {
+  double2 v[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { const int o = tid + 256 * q; v[q] = *reinterpret_cast<const double2*>(src + (long)(o >> 5) * ld + (o & 31) * 2); }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { const int o = tid + 256 * q; *reinterpret_cast<double2*>(dst + (o >> 5) * LDB + (o & 31) * 2) = v[q]; }
+}
+
+// Blocked Cholesky of the stacked panel P = [A_jj ; A_rj] (128 x 64, LDS, leading dimension LDB) by 256 threads:
+// on return rows 0..63 hold L_jj (lower triangle, zeros above) and rows 64..127 hold L_rj = A_rj L_jj^-T, i.e. the
+// triangular solve of the block row comes out of the same elimination and no inverse is needed here.
+// Per 16-column step: EVERY thread factorises the 16x16 diagonal sub-block redundantly in its own registers (pure
+// register code with compile-time indices: no cross-lane traffic, no barrier before the next phase), one thread
+// per row below substitutes against it (factor taken from registers), and the trailing columns are updated on
+// the fp64 MFMA.  Returns false if a pivot is not positive and finite.
+__device__ bool chol_panel128_lds(double* __restrict__ P, int tid) {
   const int lane = tid & 63, wave = tid >> 6;
   bool ok = true;
 #pragma unroll 1
   for (int k = 0; k < NB / SB; ++k) {
     const int o = k * SB;
-    if (wave == 0) {
-      // 16x16 diagonal sub-block, lane r = row r (lanes >= 16 compute on zeros)
-      const int r = lane & 15;
-      const bool act = lane < SB;
-      double row[SB];
+    double L[SB][SB];                                  // lower triangle used
+    double dinv[SB];
 #pragma unroll
-      for (int c = 0; c < SB; ++c) row[c] = (act && c <= r) ? S[(o + r) * LDB + o + c] : 0.0;
+    for (int r = 0; r < SB; ++r)
+#pragma unroll
+      for (int c = 0; c <= r; ++c) L[r][c] = P[(o + r) * LDB + o + c];       // same address in every lane: broadcast
+#pragma unroll
+    for (int c = 0; c < SB; ++c) {
+      double piv = L[c][c];
+      if (!(piv > 0.0) || !(piv < 1e300)) { ok = false; piv = 1.0; }
+      const double rs = fast_rsqrt(piv);
+      dinv[c] = rs;
+      L[c][c] = piv * rs;
+#pragma unroll
+      for (int r = c + 1; r < SB; ++r) L[r][c] *= rs;
+#pragma unroll
+      for (int c2 = c + 1; c2 < SB; ++c2)
+#pragma unroll
+        for (int r = c2; r < SB; ++r) L[r][c2] -= L[r][c] * L[c2][c];
+    }
+    __syncthreads();                                   // everybody has read the sub-block
+    if (tid < SB) {                                    // publish L_kk (thread r writes row r)
+#pragma unroll
+      for (int r = 0; r < SB; ++r)
+        if (tid == r) {
+#pragma unroll
+          for (int c = 0; c < SB; ++c) P[(o + r) * LDB + o + c] = (c <= r) ? L[r][c] : 0.0;
+        }
+    }
+    // rows below the sub-block (rest of A_jj and all of A_rj): X[i][:] = A[i][:] L_kk^-T, one thread per row
+    const int nbelow = 2 * NB - o - SB;
+    if (tid < nbelow) {
+      double* prow = P + (o + SB + tid) * LDB + o;
+      double x[SB];
+#pragma unroll
+      for (int c = 0; c < SB; ++c) x[c] = prow[c];
 #pragma unroll
       for (int c = 0; c < SB; ++c) {
-        double piv = lane_bcast(row[c], c);
-        if (!(piv > 0.0) || !(piv < 1e300)) { ok = false; piv = 1.0; }
-        const double rs = fast_rsqrt(piv);
-        if (lane == c) dinv[o + c] = rs;
-        row[c] = (r == c) ? piv * rs : row[c] * rs;
+        double v = x[c];
 #pragma unroll
-        for (int c2 = c + 1; c2 < SB; ++c2) row[c2] -= row[c] * lane_bcast(row[c], c2);   // L[r][c] * L[c2][c]
+        for (int m = 0; m < c; ++m) v -= x[m] * L[c][m];
+        x[c] = v * dinv[c];
       }
-      if (act) {
 #pragma unroll
-        for (int c = 0; c < SB; ++c) S[(o + r) * LDB + o + c] = (c <= r) ? row[c] : 0.0;
-      }
+      for (int c = 0; c < SB; ++c) prow[c] = x[c];
     }
     __syncthreads();
-    const int nrem = NB - o - SB;                       // rows below the sub-block
-    if (nrem > 0) {
-      // panel: X[i][:] = A[i][:] L_kk^-T, one thread per row (the factor is read as LDS broadcasts)
-      if (tid < nrem) {
-        double* prow = S + (o + SB + tid) * LDB + o;
-        double x[SB];
+    // trailing update on the fp64 MFMA: P[i][j] -= sum_m X[i][m] X[j][m] for column tiles tj < nC and row tiles
+    // ti >= tj (rows and columns both counted from o + 16; the A_rj rows are row tiles nC .. nR-1)
+    const int nC = (NB - o - SB) / SB, nR = nbelow / SB;
+    const int ntiles = nC * nR - nC * (nC - 1) / 2;
+    for (int t = wave; t < ntiles; t += 4) {
+      int tj = 0, rem = t;
+      while (rem >= nR - tj) { rem -= nR - tj; ++tj; }
+      const int ti = tj + rem;
+      const int r0 = o + SB + ti * SB, c0 = o + SB + tj * SB;
+      f64x4 acc;
 #pragma unroll
-        for (int c = 0; c < SB; ++c) {
-          double v = prow[c];
+      for (int q = 0; q < 4; ++q) acc[q] = P[(r0 + (lane >> 4) + 4 * q) * LDB + c0 + (lane & 15)];
 #pragma unroll
-          for (int m = 0; m < c; ++m) v -= x[m] * S[(o + c) * LDB + o + m];
-          x[c] = v * dinv[o + c];
-        }
-#pragma unroll
-        for (int c = 0; c < SB; ++c) prow[c] = x[c];
+      for (int kk = 0; kk < SB / 4; ++kk) {
+        const double av = -P[(r0 + (lane & 15)) * LDB + o + kk * 4 + (lane >> 4)];
+        const double bv = P[(c0 + (lane & 15)) * LDB + o + kk * 4 + (lane >> 4)];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
       }
-      __syncthreads();
-      // trailing update of the lower triangle: S[i][j] -= sum_m X[i][m] X[j][m]
-      for (int idx = tid; idx < nrem * nrem; idx += 256) {
-        const int i = idx / nrem, j = idx - i * nrem;
-        if (j > i) continue;
-        const double* xi = S + (o + SB + i) * LDB + o;
-        const double* xj = S + (o + SB + j) * LDB + o;
-        double acc = 0.0;
 #pragma unroll
-        for (int m = 0; m < SB; ++m) acc += xi[m] * xj[m];
-        S[(o + SB + i) * LDB + o + SB + j] -= acc;
-      }
-      __syncthreads();
+      for (int q = 0; q < 4; ++q) P[(r0 + (lane >> 4) + 4 * q) * LDB + c0 + (lane & 15)] = acc[q];
     }
+    __syncthreads();
   }
-  return __syncthreads_and(ok ? 1 : 0) != 0;
+  return ok;
 }
 
 // W = L^-1 (lower triangular, zero above the diagonal) from the factor in S; T = 3 x 16x16 scratch blocks
@@ -678,35 +710,48 @@ __device__ __forceinline__ void mfma_abt_64(const double* __restrict__ A, const 
   }
 }
 
-__global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ H, int ld, int j, double* __restrict__ Linv,
-                                                         int* __restrict__ meta) {
+__global__ __launch_bounds__(256, 1) void chol_panel_kernel(double* __restrict__ H, int ld, int j, int* __restrict__ meta) {
   extern __shared__ double s_chol[];
-  double* S = s_chol;                     // A_jj -> L_jj
-  double* Wm = S + NB * LDB;              // L_jj^-1
-  double* At = Wm + NB * LDB;             // A_rj
-  double* T = At + NB * LDB;              // 3 x 16 x 17
-  double* dinv = T + 3 * SB * (SB + 1);   // 64
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double* P = s_chol;                     // [128][LDB]: A_jj over A_rj
+  const int tid = threadIdx.x;
   const int r = j + 1 + blockIdx.x;
   const long d0 = (long)j * NB, r0 = (long)r * NB;
-  for (int o = tid; o < NB * NB; o += 256) {
-    const int a = o >> 6, b = o & 63;
-    S[a * LDB + b] = H[(d0 + a) * ld + d0 + b];
-    At[a * LDB + b] = H[(r0 + a) * ld + d0 + b];
-  }
+  load_block64(P, H + d0 * ld + d0, ld, tid);
+  load_block64(P + NB * LDB, H + r0 * ld + d0, ld, tid);
   __syncthreads();
-  const bool ok = chol64_lds(S, dinv, tid);
+  const bool ok = chol_panel128_lds(P, tid);
   if (!ok && tid == 0) meta[1] = 1;
+  // L_rj back to the matrix; workgroup 0 also stores L_jj (chol_inverse_kernel and nobody else reads it)
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int o = tid + 256 * q;
+    *reinterpret_cast<double2*>(H + (r0 + (o >> 5)) * ld + d0 + (o & 31) * 2) = *reinterpret_cast<const double2*>(P + (NB + (o >> 5)) * LDB + (o & 31) * 2);
+  }
+  if (blockIdx.x == 0) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int o = tid + 256 * q;
+      *reinterpret_cast<double2*>(H + (d0 + (o >> 5)) * ld + d0 + (o & 31) * 2) = *reinterpret_cast<const double2*>(P + (o >> 5) * LDB + (o & 31) * 2);
+    }
+  }
+}
+
+// W_j = L_jj^-1 for every diagonal block (needed by the back substitution only): one workgroup per block, after
+// the factorisation, off its critical path
+__global__ __launch_bounds__(256) void chol_inverse_kernel(const double* __restrict__ H, int ld, double* __restrict__ Linv) {
+  extern __shared__ double s_chol[];
+  double* S = s_chol;
+  double* Wm = S + NB * LDB;
+  double* T = Wm + NB * LDB;
+  double* dinv = T + 3 * SB * (SB + 1);
+  const int tid = threadIdx.x, j = blockIdx.x;
+  const long d0 = (long)j * NB;
+  load_block64(S, H + d0 * ld + d0, ld, tid);
+  __syncthreads();
+  if (tid < NB) dinv[tid] = 1.0 / S[tid * LDB + tid];
+  __syncthreads();
   tri_inverse64_lds(S, dinv, Wm, T, tid);
-  if (blockIdx.x == 0)
-    for (int o = tid; o < NB * NB; o += 256) Linv[(long)j * NB * NB + o] = Wm[(o >> 6) * LDB + (o & 63)];
-  f64x4 acc[4];
-  mfma_abt_64<true>(At, Wm, wave, lane, acc);
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      H[(r0 + wave * 16 + (lane >> 4) + 4 * q) * ld + d0 + nt * 16 + (lane & 15)] = acc[nt][q];
+  for (int o = tid; o < NB * NB; o += 256) Linv[(long)j * NB * NB + o] = Wm[(o >> 6) * LDB + (o & 63)];
 }
 
 // trailing update A_rc -= L_rj L_cj^T for j < c <= r (r runs over the rhs block row too)
@@ -718,11 +763,14 @@ __global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ H
   double* sB = sA + NB * LDB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long r0 = (long)r * NB, c0 = (long)c * NB, d0 = (long)j * NB;
-  for (int o = tid; o < NB * NB; o += 256) {
-    const int a = o >> 6, b = o & 63;
-    sA[a * LDB + b] = H[(r0 + a) * ld + d0 + b];
-    sB[a * LDB + b] = H[(c0 + a) * ld + d0 + b];
-  }
+  load_block64(sA, H + r0 * ld + d0, ld, tid);
+  load_block64(sB, H + c0 * ld + d0, ld, tid);
+  // the block to be updated travels while the MFMAs run
+  double cur[4][4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cur[nt][q] = H[(r0 + wave * 16 + (lane >> 4) + 4 * q) * ld + c0 + nt * 16 + (lane & 15)];
   __syncthreads();
   f64x4 acc[4];
   mfma_abt_64<false>(sA, sB, wave, lane, acc);
@@ -730,56 +778,70 @@ __global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ H
   for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      H[(r0 + wave * 16 + (lane >> 4) + 4 * q) * ld + c0 + nt * 16 + (lane & 15)] -= acc[nt][q];
+      H[(r0 + wave * 16 + (lane >> 4) + 4 * q) * ld + c0 + nt * 16 + (lane & 15)] = cur[nt][q] - acc[nt][q];
 }
 
 // back substitution of L^T x = y (y = row `brow` of H) in groups of BG block rows per launch:
 // every workgroup solves the group's triangular system itself (x_g = W_g^T (y_g - sum_{g' > g in group} L_g'g^T x_g')),
 // workgroup 0 publishes x, workgroup 1 + q applies the group's contribution to y_q for its own q < group start.
-constexpr int BG = 4;
+// Everything a workgroup needs (the W blocks, the in-group L block, its own L blocks for the final update) is
+// requested in one burst up front, so the dependent phases run out of LDS / registers.
+constexpr int BG = 2;
 __global__ __launch_bounds__(256) void chol_backsub_kernel(double* __restrict__ H, int ld, int jhi, int brow,
                                                            const double* __restrict__ Linv, double* __restrict__ x) {
+  extern __shared__ double s_chol[];
+  double* sW = s_chol;                    // [BG][NB][LDB]
+  double* sL = sW + BG * NB * LDB;        // block (jhi, jlo) of L when the group has two block rows
   __shared__ double sx[BG * NB];
   __shared__ double sy[BG * NB];
   __shared__ double sp[4][NB];
   const int tid = threadIdx.x;
   const int jlo = max(0, jhi - BG + 1), ng = jhi - jlo + 1;
+  const int col = tid & 63, part = tid >> 6;
+  for (int g = 0; g < ng; ++g) load_block64(sW + g * NB * LDB, Linv + (long)(jlo + g) * NB * NB, NB, tid);
+  if (ng == 2) load_block64(sL, H + (long)jhi * NB * ld + (long)jlo * NB, ld, tid);
+  const int q = (int)blockIdx.x - 1;                    // earlier block row updated by this workgroup
+  const bool upd = q >= 0 && q < jlo;
+  double lq[BG][16];
+#pragma unroll
+  for (int g = 0; g < BG; ++g)
+#pragma unroll
+    for (int a = 0; a < 16; ++a)
+      lq[g][a] = (upd && g < ng) ? H[((long)(jlo + g) * NB + part * 16 + a) * ld + (long)q * NB + col] : 0.0;
   for (int o = tid; o < ng * NB; o += 256) sy[o] = H[(long)brow * ld + (long)jlo * NB + o];
   __syncthreads();
-  const int col = tid & 63, part = tid >> 6;
   for (int g = ng - 1; g >= 0; --g) {
-    const int jb = jlo + g;
     // x_g = W_g^T y_g : x[c] = sum_{m >= c} W[m][c] y[m]; 4 partial sums over m
     {
       double sacc = 0.0;
-      const double* Wg = Linv + (long)jb * NB * NB;
-      for (int m = part * 16; m < part * 16 + 16; ++m) sacc += Wg[m * NB + col] * sy[g * NB + m];
+      const double* Wg = sW + g * NB * LDB;
+#pragma unroll
+      for (int m = part * 16; m < part * 16 + 16; ++m) sacc += Wg[m * LDB + col] * sy[g * NB + m];
       sp[part][col] = sacc;
     }
     __syncthreads();
     if (tid < NB) {
       const double v = (sp[0][tid] + sp[1][tid]) + (sp[2][tid] + sp[3][tid]);
       sx[g * NB + tid] = v;
-      if (blockIdx.x == 0) x[(long)jb * NB + tid] = v;
+      if (blockIdx.x == 0) x[(long)(jlo + g) * NB + tid] = v;
     }
     __syncthreads();
-    // y_g' -= L[jb][g']^T x_g for the earlier blocks of the group
-    for (int gp = 0; gp < g; ++gp) {
+    if (g == 1) {                                       // y_0 -= L[jhi][jlo]^T x_1
       double sacc = 0.0;
-      for (int a = part * 16; a < part * 16 + 16; ++a)
-        sacc += H[((long)jb * NB + a) * ld + (long)(jlo + gp) * NB + col] * sx[g * NB + a];
+#pragma unroll
+      for (int a = part * 16; a < part * 16 + 16; ++a) sacc += sL[a * LDB + col] * sx[NB + a];
       sp[part][col] = sacc;
       __syncthreads();
-      if (tid < NB) sy[gp * NB + tid] -= (sp[0][tid] + sp[1][tid]) + (sp[2][tid] + sp[3][tid]);
+      if (tid < NB) sy[tid] -= (sp[0][tid] + sp[1][tid]) + (sp[2][tid] + sp[3][tid]);
       __syncthreads();
     }
   }
-  const int q = (int)blockIdx.x - 1;                    // earlier block row updated by this workgroup
-  if (q < 0 || q >= jlo) return;
+  if (!upd) return;
   double sacc = 0.0;
-  for (int g = 0; g < ng; ++g)
-    for (int a = part * 16; a < part * 16 + 16; ++a)
-      sacc += H[((long)(jlo + g) * NB + a) * ld + (long)q * NB + col] * sx[g * NB + a];
+#pragma unroll
+  for (int g = 0; g < BG; ++g)
+#pragma unroll
+    for (int a = 0; a < 16; ++a) sacc += lq[g][a] * (g < ng ? sx[g * NB + part * 16 + a] : 0.0);
   sp[part][col] = sacc;
   __syncthreads();
   if (tid < NB) H[(long)brow * ld + (long)q * NB + tid] -= (sp[0][tid] + sp[1][tid]) + (sp[2][tid] + sp[3][tid]);
@@ -904,27 +966,37 @@ int run_finish(const BaLayout& L, char* ws, float* poses, float* disps, const in
     const int nbrows = L.nbk + 1;                        // + rhs block row
     static const hipError_t lds_err = [] {               // > 64 KB of dynamic LDS must be opted into
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_panel_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_inverse_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
       if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_update_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_backsub_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
       return e;
     }();
     if (lds_err != hipSuccess) {
       if (getenv("DH_DEBUG")) fprintf(stderr, "libdroid_hip: hipFuncSetAttribute: %s\n", hipGetErrorString(lds_err));
       return DH_ERR_LAUNCH;
     }
-    const size_t lds_panel = sizeof(double) * (3 * NB * LDB + 3 * SB * (SB + 1) + NB);
+    const size_t lds_panel = sizeof(double) * 2 * NB * LDB;
+    const size_t lds_inv = sizeof(double) * (2 * NB * LDB + 3 * SB * (SB + 1) + NB);
     const size_t lds_upd = sizeof(double) * 2 * NB * LDB;
     for (int j = 0; j < L.nbk; ++j) {
       const int m = nbrows - j - 1;
-      hipLaunchKernelGGL(chol_panel_kernel, dim3(m), dim3(256), lds_panel, st, H, L.ld, j, Linv, meta);
+      hipLaunchKernelGGL(chol_panel_kernel, dim3(m), dim3(256), lds_panel, st, H, L.ld, j, meta);
       DH_LAUNCH_CHECK();
       if (m > 1) hipLaunchKernelGGL(chol_update_kernel, dim3(m - 1, m), dim3(256), lds_upd, st, H, L.ld, j, L.nbk);
       DH_LAUNCH_CHECK();
     }
+    hipLaunchKernelGGL(chol_inverse_kernel, dim3(L.nbk), dim3(256), lds_inv, st, (const double*)H, L.ld, Linv);
+    DH_LAUNCH_CHECK();
     for (int jhi = L.nbk - 1; jhi >= 0; jhi -= BG)
-      hipLaunchKernelGGL(chol_backsub_kernel, dim3(std::max(1, jhi - BG + 2)), dim3(256), 0, st, H, L.ld, jhi, L.npad, Linv, x);
+      hipLaunchKernelGGL(chol_backsub_kernel, dim3(std::max(1, jhi - BG + 2)), dim3(256),
+                         sizeof(double) * (BG + 1) * NB * LDB, st, H, L.ld, jhi, L.npad, Linv, x);
     hipLaunchKernelGGL(ba_dx_kernel, dim3((L.n + 255) / 256), dim3(256), 0, st, x, meta, L.n, dxw, dx_out);
     DH_LAUNCH_CHECK();
   }
