@@ -292,7 +292,8 @@ torch::Tensor segment_mean(torch::Tensor x, torch::Tensor order, torch::Tensor s
 }
 
 // ---- implicit-GEMM convolution with fused epilogues (droid_amd.update.UpdateModule) ----------------------
-void conv2d_nhwc(std::vector<torch::Tensor> inputs, torch::Tensor weight, torch::Tensor bias, int64_t KH, int64_t KW,
+void conv2d_nhwc(std::vector<torch::Tensor> inputs, torch::Tensor weight, c10::optional<torch::Tensor> weight_halo,
+                 torch::Tensor bias, int64_t KH, int64_t KW,
                  int64_t Cout, int64_t epilogue, c10::optional<torch::Tensor> out, int64_t out_stride,
                  c10::optional<torch::Tensor> gterm, c10::optional<torch::Tensor> aux0, c10::optional<torch::Tensor> aux1,
                  c10::optional<torch::Tensor> red) {
@@ -314,7 +315,7 @@ void conv2d_nhwc(std::vector<torch::Tensor> inputs, torch::Tensor weight, torch:
   const bool out_f32 = out.has_value() && out->scalar_type() == torch::kFloat32;
   if (gterm.has_value()) { const torch::Tensor& gt = *gterm; CHECK_INPUT(gt); CHECK_F32(gt); }
   if (red.has_value()) { const torch::Tensor& rt = *red; CHECK_INPUT(rt); CHECK_F32(rt); }
-  check_status(dh_conv2d_nhwc_f16(ptrs, chans, strides, (int)inputs.size(), weight.data_ptr(), bias.data_ptr<float>(),
+  check_status(dh_conv2d_nhwc_f16(ptrs, chans, strides, (int)inputs.size(), weight.data_ptr(), opt_ptr(weight_halo), bias.data_ptr<float>(),
                                   (int)N, (int)H, (int)W, (int)KH, (int)KW, (int)Cout, (int)weight.size(0), (int)weight.size(1),
                                   (int)epilogue, opt_ptr(out), out_f32 ? 1 : 0, (int)out_stride,
                                   gterm.has_value() ? gterm->data_ptr<float>() : nullptr,

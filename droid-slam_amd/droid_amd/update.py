@@ -75,16 +75,31 @@ def pack_conv(weight, bias, cin_pad=None):
     return wp.contiguous(), bp.contiguous()
 
 
+def pack_conv_halo(weight):
+    """[Cout,Ctot,3,3] -> [CoutPad/128, Ctot/32, 9, 128, 32] f16 for the halo-tile 3x3 kernel (csrc/conv.hip), or None
+    if the shape is not eligible (Ctot % 32, kernel size)."""
+    cout, ctot, kh, kw = weight.shape
+    if kh != 3 or kw != 3 or ctot % 32:
+        return None
+    cp = _round_up(cout, 32)
+    if cp % 128:
+        return None
+    w = torch.zeros(cp, ctot, 9, dtype=torch.float32, device=weight.device)
+    w[:cout] = weight.float().reshape(cout, ctot, 9)
+    w = w.reshape(cp // 128, 128, ctot // 32, 32, 9).permute(0, 2, 4, 1, 3)
+    return w.half().contiguous()
+
+
 class _Conv:
-    def __init__(self, wp, bp, k, cout):
-        self.w, self.b, self.k, self.cout = wp, bp, k, cout
+    def __init__(self, wp, bp, k, cout, wh=None):
+        self.w, self.b, self.k, self.cout, self.wh = wp, bp, k, cout, wh
 
     def __call__(self, inputs, epi, out=None, out_stride=None, gterm=None, aux0=None, aux1=None, red=None):
         x0 = inputs[0]
         if out is None and epi != EPI_GLO:
             out = torch.empty(x0.shape[0], x0.shape[1], x0.shape[2], self.cout, dtype=torch.float16, device=x0.device)
         stride = 0 if out is None else (out.shape[-1] if out_stride is None else out_stride)
-        droid_backends.conv2d_nhwc(list(inputs), self.w, self.b, self.k, self.k, self.cout, epi, out, stride,
+        droid_backends.conv2d_nhwc(list(inputs), self.w, self.wh, self.b, self.k, self.k, self.cout, epi, out, stride,
                                    gterm, aux0, aux1, red)
         return out
 
@@ -102,7 +117,8 @@ class UpdateModule:
         g = lambda n: sd[prefix + n].to(self.device)
         P = {}
         conv = lambda name, cin_pad=None: _Conv(*pack_conv(g(name + ".weight"), g(name + ".bias"), cin_pad),
-                                                PARAM_SHAPES[name][2], PARAM_SHAPES[name][0])
+                                                PARAM_SHAPES[name][2], PARAM_SHAPES[name][0],
+                                                pack_conv_halo(g(name + ".weight")) if cin_pad is None else None)
         cmap = corr_channel_map().to(self.device)
         w0 = g("corr_encoder.0.weight").float()
         w0p = torch.zeros(128, COR_NHWC, 1, 1, device=self.device)
@@ -115,14 +131,15 @@ class UpdateModule:
         P["gru_w"] = conv("gru.w")
         # z | r as one convolution with 256 outputs
         wz, wr = g("gru.convz.weight"), g("gru.convr.weight")
-        P["zr"] = _Conv(*pack_conv(torch.cat([wz, wr], 0), torch.cat([g("gru.convz.bias"), g("gru.convr.bias")], 0)), 3, 256)
+        P["zr"] = _Conv(*pack_conv(torch.cat([wz, wr], 0), torch.cat([g("gru.convz.bias"), g("gru.convr.bias")], 0)), 3, 256,
+                        pack_conv_halo(torch.cat([wz, wr], 0)))
         P["q"] = conv("gru.convq")
         for n in ("z", "r", "q"):
             P["glo_" + n] = (g("gru.conv%s_glo.weight" % n).float().reshape(128, 128), g("gru.conv%s_glo.bias" % n).float())
         # the two head stems (delta.0 | weight.0) share their input: one convolution with 256 outputs;
         # the two 2-channel heads become one block-diagonal convolution on those 256 channels
-        P["heads0"] = _Conv(*pack_conv(torch.cat([g("delta.0.weight"), g("weight.0.weight")], 0),
-                                       torch.cat([g("delta.0.bias"), g("weight.0.bias")], 0)), 3, 256)
+        wh0 = torch.cat([g("delta.0.weight"), g("weight.0.weight")], 0)
+        P["heads0"] = _Conv(*pack_conv(wh0, torch.cat([g("delta.0.bias"), g("weight.0.bias")], 0)), 3, 256, pack_conv_halo(wh0))
         w2 = torch.zeros(4, 256, 3, 3, device=self.device)
         w2[0:2, 0:128] = g("delta.2.weight").float()
         w2[2:4, 128:256] = g("weight.2.weight").float()

@@ -145,6 +145,8 @@ int dh_ba_finish(float* poses, float* disps, const int64_t* jj,
  *   in_strides[i] = elements between consecutive pixels, NULL = dense: lets a segment be a channel slice of a wider tensor)
  *   weights [CoutPad, Kpad] f16 with k = (dy*KW + dx) * sum(in_channels) + c, zero padded (Kpad % 64 == 0,
  *   CoutPad % 32 == 0);  bias [CoutPad] f32
+ *   weights_halo (optional, NULL = none): second copy for the 3x3 halo-tile fast path (W == 64, H % 4 == 0, every
+ *   in_channels[i] % 32 == 0, CoutPad % 128 == 0), laid out [CoutPad/128][Ctot/32][9 taps][128][32] f16
  *   out [N,H,W,out_stride] (f16, or f32 holding fp16-rounded values when out_is_f32), channels [0,Cout) written
  *   epilogue: 0 linear, 1 relu, 2 sigmoid,
  *     3 GRU z|r  (Cout = 256: z = sigmoid(.+g) for cout < 128, r*net for cout >= 128; aux0 = net [.,128]),
@@ -154,7 +156,7 @@ int dh_ba_finish(float* poses, float* disps, const int64_t* jj,
  *   gterm [N,CoutPad] f32 or NULL: per-image additive term (the ConvGRU's 1x1 global-context convolutions).
  */
 int dh_conv2d_nhwc_f16(const void* const* inputs, const int* in_channels, const int* in_strides, int n_inputs,
-                       const void* weights, const float* bias,
+                       const void* weights, const void* weights_halo, const float* bias,
                        int N, int H, int W, int KH, int KW, int Cout, int CoutPad, int Kpad, int epilogue,
                        void* out, int out_is_f32, int out_stride,
                        const float* gterm, const void* aux0, int aux0_stride, const void* aux1, int aux1_stride,

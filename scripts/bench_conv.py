@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "droid-slam_amd")]
 import torch
 import droid_backends as db
-from droid_amd.update import pack_conv, EPI_RELU, EPI_LINEAR
+from droid_amd.update import pack_conv, pack_conv_halo, EPI_RELU, EPI_LINEAR
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 h, w = 48, 64
 torch.manual_seed(0)
@@ -18,8 +18,9 @@ for name, cins, cout, k in shapes:
     xs = [torch.randn(n, h, w, c, device="cuda").half() for c in cins]
     wgt = torch.randn(cout, sum(cins), k, k, device="cuda") / (sum(cins) * k * k) ** 0.5
     wp, bp = pack_conv(wgt, torch.zeros(cout, device="cuda"))
+    wh = pack_conv_halo(wgt) if not os.environ.get("DH_CONV_NO_HALO") else None
     out = torch.empty(n, h, w, cout, device="cuda", dtype=torch.float16)
-    run = lambda: db.conv2d_nhwc(xs, wp, bp, k, k, cout, EPI_RELU, out, cout, None, None, None, None)
+    run = lambda: db.conv2d_nhwc(xs, wp, wh, bp, k, k, cout, EPI_RELU, out, cout, None, None, None, None)
     run(); torch.cuda.synchronize()
     ts = []
     for _ in range(3):

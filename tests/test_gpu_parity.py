@@ -493,18 +493,26 @@ def test_update_operator_vs_oracle(db, shape):
     assert cmp(up[0], ru) <= 3e-2 * max(1.0, ru.abs().max().item())
 
 
-def test_conv2d_nhwc_matches_torch_conv(db):
+@pytest.fixture
+def halo_enabled(monkeypatch):
+    monkeypatch.setenv("DH_CONV_HALO", "1")
+
+
+def test_conv2d_nhwc_matches_torch_conv(db, halo_enabled):
     """the raw convolution entry point against torch's fp32 conv2d: 1x1 / 3x3 / 7x7, multi-segment input, all tile configs"""
-    from droid_amd.update import pack_conv, EPI_LINEAR, EPI_RELU
+    from droid_amd.update import pack_conv, pack_conv_halo, EPI_LINEAR, EPI_RELU
     torch.manual_seed(0)
-    N, H, W = 3, 12, 16
-    for (cins, cout, k) in [((128, 64, 8), 128, 3), ((200,), 64, 1), ((8,), 32, 7), ((128,), 576, 1), ((64, 64), 4, 3)]:
+    cases = [(3, 12, 16, c) for c in [((128, 64, 8), 128, 3), ((200,), 64, 1), ((8,), 32, 7), ((128,), 576, 1), ((64, 64), 4, 3)]]
+    # W == 64, H % 4 == 0, channel segments % 32 == 0, >= 256 input channels: the halo-tile 3x3 fast path
+    # (image borders, 2 cout tiles); the last case stays on the generic loop
+    cases += [(2, 8, 64, c) for c in [((128, 64, 64), 128, 3), ((256,), 256, 3), ((64,), 256, 3)]]
+    for (N, H, W, (cins, cout, k)) in cases:
         xs = [torch.randn(N, H, W, c, device="cuda").half() for c in cins]
         wgt = torch.randn(cout, sum(cins), k, k, device="cuda") / (sum(cins) * k * k) ** 0.5
         bias = torch.randn(cout, device="cuda")
         wp, bp = pack_conv(wgt, bias)
         out = torch.empty(N, H, W, cout, device="cuda", dtype=torch.float16)
-        db.conv2d_nhwc(xs, wp, bp, k, k, cout, EPI_LINEAR, out, cout, None, None, None, None)
+        db.conv2d_nhwc(xs, wp, pack_conv_halo(wgt), bp, k, k, cout, EPI_LINEAR, out, cout, None, None, None, None)
         x = torch.cat(xs, -1).float().permute(0, 3, 1, 2)
         ref = torch.nn.functional.conv2d(x, wgt.half().float(), bias, padding=k // 2).permute(0, 2, 3, 1)
         assert (out.float() - ref).abs().max() <= 1e-2 * max(1.0, ref.abs().max().item())
