@@ -534,3 +534,44 @@ def test_native_pyramid_channel_last_lookup_equals_reference_layout(db):
         m = corr_channel_map().cuda()
         assert torch.equal(b[..., m >= 0], a.permute(0, 2, 3, 1)[..., m[m >= 0]])
         assert torch.count_nonzero(b[..., m < 0]) == 0
+
+
+# ------------------------------------------------------------------------------------------ lietorch / torch_scatter drop-ins
+def test_lietorch_dropin_matches_oracle_and_reference_call_pattern(db):
+    """the SE3 surface the reference's projective_ops.py:165-198 uses, through the `lietorch` package of this repo"""
+    import lietorch
+    from lietorch import SE3
+    rng = np.random.default_rng(3)
+    xi = rng.normal(0, 0.3, (1, 9, 6)).astype(np.float32)
+    G = SE3.exp(dev(xi))                                               # [1,9]
+    t, q = ose3.se3_exp(xi.astype(np.float64))
+    assert np.abs(G.data.cpu().numpy() - ose3.pose_join(t, q)).max() < 1e-5
+    ii = torch.tensor([0, 1, 2, 5, 8], device="cuda"); jj = torch.tensor([1, 0, 4, 5, 2], device="cuda")
+    Gij = G[:, jj] * G[:, ii].inv()                                    # projective_ops.py:174
+    ti, qi = t[0][ii.cpu().numpy()], q[0][ii.cpu().numpy()]
+    tj, qj = t[0][jj.cpu().numpy()], q[0][jj.cpu().numpy()]
+    tinv, qinv = ose3.se3_inv(ti, qi)
+    tr, qr = ose3.se3_mul(tj, qj, tinv, qinv)
+    assert np.abs(Gij.data[0].cpu().numpy() - ose3.pose_join(tr, qr)).max() < 1e-5
+    X = dev(rng.normal(0, 1, (1, 5, 6, 7, 4)).astype(np.float32))
+    Y = Gij[:, :, None, None] * X                                      # projective_ops.py:87 (broadcast over pixels)
+    ref = ose3.se3_act(tr[:, None, None], qr[:, None, None], X[0].cpu().numpy().astype(np.float64))
+    assert np.abs(Y[0].cpu().numpy() - ref).max() < 1e-5
+    J = dev(rng.normal(0, 1, (1, 5, 6, 7, 2, 6)).astype(np.float32))
+    A = Gij[:, :, None, None, None].adjT(J)                            # projective_ops.py:191
+    refA = ose3.se3_adjT(tr[:, None, None, None], qr[:, None, None, None], J[0].cpu().numpy().astype(np.float64))
+    assert np.abs(A[0].cpu().numpy() - refA).max() < 1e-4
+    dxi = dev(rng.normal(0, 0.05, (1, 9, 6)).astype(np.float32))
+    R = G.retr(dxi)                                                    # geom/ba.py:26-28
+    t2, q2 = ose3.se3_retr(dxi.cpu().numpy().astype(np.float64), t, q)
+    assert np.abs(R.data.cpu().numpy() - ose3.pose_join(t2, q2)).max() < 1e-5
+    assert lietorch.cat([G, R], 1).shape == (1, 18) and SE3.IdentityLike(G).data[..., 6].min() == 1
+
+
+def test_torch_scatter_dropin(db):
+    import torch_scatter
+    x = torch.randn(7, 5, device="cuda"); ix = torch.tensor([0, 2, 2, 1, 0, 2, 3], device="cuda")
+    s = torch_scatter.scatter_sum(x, ix, dim=0); m = torch_scatter.scatter_mean(x, ix, dim=0)
+    for k in range(4):
+        assert torch.allclose(s[k], x[ix == k].sum(0), atol=1e-6)
+        assert torch.allclose(m[k], x[ix == k].mean(0), atol=1e-6)
