@@ -227,24 +227,28 @@ constexpr int HCK = 32;                  // channels per chunk
 constexpr int HLD = HCK + 8;             // LDS row stride (halves): 80 B, 16 consecutive rows hit 16 disjoint bank quads
 constexpr int HROWS = 6, HCOLS = 66, HPIX = HROWS * HCOLS;
 constexpr int HPC = HCK / 8;             // 16-byte pieces per pixel / cout row
-constexpr int HBN = 128;
-constexpr int HSLAB = 9 * HBN * HCK;     // halves of one (cout tile, chunk) weight slab
 
-template <int EPI>
+// BN = 128: waves = 4 image rows x 2 cout halves, 64 px x 64 cout per wave (the long-K GRU convolutions, opt-in).
+// BN = 32 : waves = 4 image rows x 2 half rows, 32 px x 32 cout per wave: the 2-/1-channel heads (Cout padded to 32),
+//           where the generic loop is bound by re-reading the activations 9 times from L2 (58 GB at 4096 edges).
+template <int EPI, int BN>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(ConvParams P) {
-  constexpr int BN = HBN, WM = 64, WN = 64, TM = 2, TN = 2;
+  constexpr int WM = BN == 128 ? 64 : 32, WN = BN == 128 ? 64 : 32, TM = WM / 32, TN = WN / 32;
+  constexpr int HSLAB = 9 * BN * HCK;     // halves of one (cout tile, chunk) weight slab
   extern __shared__ __half s_conv[];
   __half* sA = s_conv;                    // [HPIX][HLD]
   __half* sB = s_conv + HPIX * HLD;       // [9][BN][HLD]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wrow = wave & 3, wn0 = (wave >> 2) * WN, wm0 = wrow * WM;
+  const int wrow = wave & 3;
+  const int wx0 = BN == 128 ? 0 : (wave >> 2) * 32;                 // first image column of the wave's pixels
+  const int wn0 = BN == 128 ? (wave >> 2) * WN : 0, wm0 = wrow * 64 + wx0;
   const long M = (long)P.N * P.H * P.W;
   const long m0 = (long)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
   const int HW = P.H * P.W;
   const int img = (int)(m0 / HW), y0 = (int)((m0 - (long)img * HW) / 64);
 
-  constexpr int A_PIECES = (HPIX * HPC + 511) / 512, B_PIECES = 9 * BN * HPC / 512;     // 4, 9
+  constexpr int A_PIECES = (HPIX * HPC + 511) / 512, B_PIECES = (9 * BN * HPC + 511) / 512;     // 4; 9 or 3
   int a_off[A_PIECES]; bool a_ok[A_PIECES];
 #pragma unroll
   for (int i = 0; i < A_PIECES; ++i) {
@@ -273,7 +277,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(ConvParams P) {
     }                                                                                                                \
     _Pragma("unroll") for (int i = 0; i < B_PIECES; ++i)                                                             \
     {                                                                                                                \
-      const uint4 v = *reinterpret_cast<const uint4*>(bslab + (long)(chunk_) * HSLAB + i * 4096);                    \
+      const bool inb = tid + 512 * i < 9 * BN * HPC;                                                                 \
+      const uint4 v = *reinterpret_cast<const uint4*>(bslab + (long)(chunk_) * HSLAB + (inb ? i * 4096 : 0));        \
       rb[i] = uint4{v.x, v.y, v.z, v.w};                                                                             \
     }                                                                                                                \
   }
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(ConvParams P) {
     }                                                                                                                \
     _Pragma("unroll") for (int i = 0; i < B_PIECES; ++i) {                                                           \
       const int id = tid + 512 * i;                                                                                  \
-      *reinterpret_cast<uint4*>(sB + (id / HPC) * HLD + c8) = rb[i];                                                 \
+      if (id < 9 * BN * HPC) *reinterpret_cast<uint4*>(sB + (id / HPC) * HLD + c8) = rb[i];                          \
     }                                                                                                                \
   }
 
@@ -311,7 +316,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(ConvParams P) {
         half8 af[TM], bf[TN];
 #pragma unroll
         for (int a = 0; a < TM; ++a)
-          af[a] = *reinterpret_cast<const half8*>(sA + ((wrow + dy) * HCOLS + a * 32 + (lane & 31) + dx) * HLD + ks * 16 + (lane >> 5) * 8);
+          af[a] = *reinterpret_cast<const half8*>(sA + ((wrow + dy) * HCOLS + wx0 + a * 32 + (lane & 31) + dx) * HLD + ks * 16 + (lane >> 5) * 8);
 #pragma unroll
         for (int b = 0; b < TN; ++b)
           bf[b] = *reinterpret_cast<const half8*>(sB + (t * BN + wn0 + b * 32 + (lane & 31)) * HLD + ks * 16 + (lane >> 5) * 8);
@@ -362,17 +367,24 @@ int launch_epi(const ConvParams& P, hipStream_t st) {
   return DH_OK;
 }
 
-template <int EPI>
+template <int EPI, int BN>
 int launch_halo(const ConvParams& P, hipStream_t st) {
   const long M = (long)P.N * P.H * P.W;
-  const dim3 grid((unsigned)(M / BM), (unsigned)(P.CoutPad / HBN));
-  const size_t lds = (size_t)(HPIX + 9 * HBN) * HLD * sizeof(__half);
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<EPI>),
+  const dim3 grid((unsigned)(M / BM), (unsigned)(P.CoutPad / BN));
+  const size_t lds = (size_t)(HPIX + 9 * BN) * HLD * sizeof(__half);
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<EPI, BN>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
   if (attr != hipSuccess) return DH_ERR_LAUNCH;
-  hipLaunchKernelGGL((conv3x3_halo_kernel<EPI>), grid, dim3(512), lds, st, P);
+  hipLaunchKernelGGL((conv3x3_halo_kernel<EPI, BN>), grid, dim3(512), lds, st, P);
   DH_LAUNCH_CHECK();
   return DH_OK;
+}
+
+// small-Cout heads (CoutPad == 32): always on when the shape allows it
+bool halo32_ok(const ConvParams& P) {
+  if (!P.wt_halo || P.KH != 3 || P.KW != 3 || P.W != 64 || P.H % 4 || P.CoutPad != 32) return false;
+  for (int i = 0; i < P.nseg; ++i) if (P.segC[i] % HCK) return false;
+  return true;
 }
 
 bool halo_ok(const ConvParams& P) {
@@ -382,7 +394,7 @@ bool halo_ok(const ConvParams& P) {
   // (40.5 vs 38.6 ms, 24.6 vs 20.8 ms), so the production path stays on the generic loop until that is understood.
   const char* env = getenv("DH_CONV_HALO");
   if (!env || atoi(env) == 0) return false;
-  if (!P.wt_halo || P.KH != 3 || P.KW != 3 || P.W != 64 || P.H % 4 || P.CoutPad % HBN || P.Ctot < 256) return false;
+  if (!P.wt_halo || P.KH != 3 || P.KW != 3 || P.W != 64 || P.H % 4 || P.CoutPad % 128 || P.Ctot < 256) return false;
   for (int i = 0; i < P.nseg; ++i) if (P.segC[i] % HCK) return false;
   return true;
 }
@@ -439,11 +451,19 @@ extern "C" int dh_conv2d_nhwc_f16(const void* const* inputs, const int* in_chann
   hipStream_t st = (hipStream_t)stream;
   if (halo_ok(P)) {
     switch (P.epi) {
-      case EPI_LINEAR: return launch_halo<EPI_LINEAR>(P, st);
-      case EPI_RELU: return launch_halo<EPI_RELU>(P, st);
-      case EPI_SIGMOID: return launch_halo<EPI_SIGMOID>(P, st);
-      case EPI_GRU_ZR: return launch_halo<EPI_GRU_ZR>(P, st);
-      case EPI_GRU_Q: return launch_halo<EPI_GRU_Q>(P, st);
+      case EPI_LINEAR: return launch_halo<EPI_LINEAR, 128>(P, st);
+      case EPI_RELU: return launch_halo<EPI_RELU, 128>(P, st);
+      case EPI_SIGMOID: return launch_halo<EPI_SIGMOID, 128>(P, st);
+      case EPI_GRU_ZR: return launch_halo<EPI_GRU_ZR, 128>(P, st);
+      case EPI_GRU_Q: return launch_halo<EPI_GRU_Q, 128>(P, st);
+      default: break;
+    }
+  }
+  if (halo32_ok(P)) {
+    switch (P.epi) {
+      case EPI_LINEAR: return launch_halo<EPI_LINEAR, 32>(P, st);
+      case EPI_HEADS: return launch_halo<EPI_HEADS, 32>(P, st);
+      case EPI_SOFTPLUS_001: return launch_halo<EPI_SOFTPLUS_001, 32>(P, st);
       default: break;
     }
   }

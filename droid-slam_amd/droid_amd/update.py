@@ -76,17 +76,18 @@ def pack_conv(weight, bias, cin_pad=None):
 
 
 def pack_conv_halo(weight):
-    """[Cout,Ctot,3,3] -> [CoutPad/128, Ctot/32, 9, 128, 32] f16 for the halo-tile 3x3 kernel (csrc/conv.hip), or None
-    if the shape is not eligible (Ctot % 32, kernel size)."""
+    """[Cout,Ctot,3,3] -> [CoutPad/BN, Ctot/32, 9, BN, 32] f16 for the halo-tile 3x3 kernels (csrc/conv.hip; BN = 32 for
+    the small heads, 128 otherwise), or None if the shape is not eligible (Ctot % 32, kernel size)."""
     cout, ctot, kh, kw = weight.shape
     if kh != 3 or kw != 3 or ctot % 32:
         return None
     cp = _round_up(cout, 32)
-    if cp % 128:
+    bn = 32 if cp == 32 else 128            # cout tile of the kernel variant that will take this convolution
+    if cp % bn:
         return None
     w = torch.zeros(cp, ctot, 9, dtype=torch.float32, device=weight.device)
     w[:cout] = weight.float().reshape(cout, ctot, 9)
-    w = w.reshape(cp // 128, 128, ctot // 32, 32, 9).permute(0, 2, 4, 1, 3)
+    w = w.reshape(cp // bn, bn, ctot // 32, 32, 9).permute(0, 2, 4, 1, 3)
     return w.half().contiguous()
 
 
@@ -143,7 +144,7 @@ class UpdateModule:
         w2 = torch.zeros(4, 256, 3, 3, device=self.device)
         w2[0:2, 0:128] = g("delta.2.weight").float()
         w2[2:4, 128:256] = g("weight.2.weight").float()
-        P["heads2"] = _Conv(*pack_conv(w2, torch.cat([g("delta.2.bias"), g("weight.2.bias")], 0)), 3, 4)
+        P["heads2"] = _Conv(*pack_conv(w2, torch.cat([g("delta.2.bias"), g("weight.2.bias")], 0)), 3, 4, pack_conv_halo(w2))
         P["agg1"] = conv("agg.conv1")
         P["agg2"] = conv("agg.conv2")
         P["eta"] = conv("agg.eta.0")

@@ -20,7 +20,8 @@ for name, cins, cout, k in shapes:
     wp, bp = pack_conv(wgt, torch.zeros(cout, device="cuda"))
     wh = pack_conv_halo(wgt) if not os.environ.get("DH_CONV_NO_HALO") else None
     out = torch.empty(n, h, w, cout, device="cuda", dtype=torch.float16)
-    run = lambda: db.conv2d_nhwc(xs, wp, wh, bp, k, k, cout, EPI_RELU, out, cout, None, None, None, None)
+    epi = EPI_LINEAR if cout <= 4 else EPI_RELU
+    run = lambda: db.conv2d_nhwc(xs, wp, wh, bp, k, k, cout, epi, out, cout, None, None, None, None)
     run(); torch.cuda.synchronize()
     ts = []
     for _ in range(3):
