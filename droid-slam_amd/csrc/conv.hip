@@ -216,23 +216,24 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_kernel(ConvParams P) {
 }
 
 // ---- 3x3 fast path: halo tile -----------------------------------------------------------------------------------
-// For W == 64 the 256 consecutive pixels of a workgroup are 4 full image rows.  Per 32-channel chunk the 6 x 66 pixel
+// For W == 64 the 256 consecutive pixels of a workgroup are 4 full image rows.  Per 16-channel chunk the 6 x 66 pixel
 // halo of the tile is staged ONCE and all 9 taps read their A fragments from it at shifted pixel addresses, next to
-// the 9 x 128 x 32 weight slab of the chunk: 9x less activation traffic, staging and address arithmetic per MFMA
-// than the generic loop and two barriers per 72 MFMAs instead of per 16.  Measured on MI355X the generic loop is
+// the 9 x 128 x 16 weight slab of the chunk (74 KB of LDS: two workgroups per CU): 9x less activation traffic from L2,
+// staging and address arithmetic per MFMA than the generic loop and two barriers per 36 MFMAs instead of per 16.  Measured on MI355X the generic loop is
 // bound by the texture-address cost of its gathers (removing the fetch alone: 0.73 -> 1.17 PFLOP/s), so the weight
-// slab is read from a second, pre-packed copy [cout tile][chunk][tap][128][32] in which a chunk's slab is one
-// contiguous 72 KB run (fully coalesced 1 KB wave loads) and the halo is read as 64-byte runs per pixel.
-constexpr int HCK = 32;                  // channels per chunk
+// slab is read from a second, pre-packed copy [cout tile][chunk][tap][128][16] in which a chunk's slab is one
+// contiguous 36 KB run (fully coalesced 1 KB wave loads) and the halo is read as 32-byte runs per pixel.  The generic
+// loop moves ~9x the activations through the L2->L1 path (measured 8.5 TB/s on a 128->128 convolution: at its limit).
+constexpr int HCK = 16;                  // channels per chunk
 constexpr int HLD = HCK + 8;             // LDS row stride (halves): 80 B, 16 consecutive rows hit 16 disjoint bank quads
 constexpr int HROWS = 6, HCOLS = 66, HPIX = HROWS * HCOLS;
 constexpr int HPC = HCK / 8;             // 16-byte pieces per pixel / cout row
 
-// BN = 128: waves = 4 image rows x 2 cout halves, 64 px x 64 cout per wave (the long-K GRU convolutions, opt-in).
+// BN = 128: waves = 4 image rows x 2 cout halves, 64 px x 64 cout per wave (every 3x3 convolution with >= 128 couts).
 // BN = 32 : waves = 4 image rows x 2 half rows, 32 px x 32 cout per wave: the 2-/1-channel heads (Cout padded to 32),
 //           where the generic loop is bound by re-reading the activations 9 times from L2 (58 GB at 4096 edges).
 template <int EPI, int BN>
-__global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(ConvParams P) {
+__global__ __launch_bounds__(512, 4) void conv3x3_halo_kernel(ConvParams P) {
   constexpr int WM = BN == 128 ? 64 : 32, WN = BN == 128 ? 64 : 32, TM = WM / 32, TN = WN / 32;
   constexpr int HSLAB = 9 * BN * HCK;     // halves of one (cout tile, chunk) weight slab
   extern __shared__ __half s_conv[];
@@ -388,13 +389,25 @@ bool halo32_ok(const ConvParams& P) {
 }
 
 bool halo_ok(const ConvParams& P) {
+  // On by default (DH_CONV_HALO=0 falls back to the generic loop).  Measured on MI355X at 4096 edges inside the full
+  // update iteration: 91.9 vs 104.1 ms for the update operator (step 100.8 vs 113.1 ms); in isolation at 1024 edges
+  // 448->256: 7.3 vs 8.7 ms, 448->128: 3.7 vs 4.3 ms, 128->128: 1.37 vs 1.45 ms.  (A first version with 32-channel
+  // chunks -- one workgroup per CU -- and strided weight reads was slower than the generic loop inside the iteration.)
+  const char* env = getenv("DH_CONV_HALO");
+  if (env && atoi(env) == 0) return false;
+  if (!P.wt_halo || P.KH != 3 || P.KW != 3 || P.W != 64 || P.H % 4 || P.CoutPad != 32) return false;
+  for (int i = 0; i < P.nseg; ++i) if (P.segC[i] % HCK) return false;
+  return true;
+}
+
+bool halo_ok(const ConvParams& P) {
   // Opt-in (DH_CONV_HALO=1).  Measured on MI355X: in isolation (1024 edges, relu epilogue) the halo loop beats the
   // generic one for long K (448 -> 256: 7.7 vs 8.7 ms) and loses for K = 1152 (prologue/epilogue bound at one
   // workgroup per CU); inside the full update iteration at 4096 edges with the GRU epilogues it was 5-18% SLOWER
   // (40.5 vs 38.6 ms, 24.6 vs 20.8 ms), so the production path stays on the generic loop until that is understood.
   const char* env = getenv("DH_CONV_HALO");
   if (!env || atoi(env) == 0) return false;
-  if (!P.wt_halo || P.KH != 3 || P.KW != 3 || P.W != 64 || P.H % 4 || P.CoutPad % 128 || P.Ctot < 256) return false;
+  if (!P.wt_halo || P.KH != 3 || P.KW != 3 || P.W != 64 || P.H % 4 || P.CoutPad % 128 || P.Ctot < 128) return false;
   for (int i = 0; i < P.nseg; ++i) if (P.segC[i] % HCK) return false;
   return true;
 }

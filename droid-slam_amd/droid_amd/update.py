@@ -76,9 +76,10 @@ def pack_conv(weight, bias, cin_pad=None):
 
 
 def pack_conv_halo(weight):
-    """[Cout,Ctot,3,3] -> [CoutPad/BN, Ctot/32, 9, BN, 32] f16 for the halo-tile 3x3 kernels (csrc/conv.hip; BN = 32 for
+    """[Cout,Ctot,3,3] -> [CoutPad/BN, Ctot/16, 9, BN, 16] f16 for the halo-tile 3x3 kernels (csrc/conv.hip; BN = 32 for
     the small heads, 128 otherwise), or None if the shape is not eligible (Ctot % 32, kernel size)."""
     cout, ctot, kh, kw = weight.shape
+    ck = 16                                 # HCK of csrc/conv.hip
     if kh != 3 or kw != 3 or ctot % 32:
         return None
     cp = _round_up(cout, 32)
@@ -87,7 +88,7 @@ def pack_conv_halo(weight):
         return None
     w = torch.zeros(cp, ctot, 9, dtype=torch.float32, device=weight.device)
     w[:cout] = weight.float().reshape(cout, ctot, 9)
-    w = w.reshape(cp // bn, bn, ctot // 32, 32, 9).permute(0, 2, 4, 1, 3)
+    w = w.reshape(cp // bn, bn, ctot // ck, ck, 9).permute(0, 2, 4, 1, 3)
     return w.half().contiguous()
 
 

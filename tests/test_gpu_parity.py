@@ -493,18 +493,15 @@ def test_update_operator_vs_oracle(db, shape):
     assert cmp(up[0], ru) <= 3e-2 * max(1.0, ru.abs().max().item())
 
 
-@pytest.fixture
-def halo_enabled(monkeypatch):
-    monkeypatch.setenv("DH_CONV_HALO", "1")
-
-
-def test_conv2d_nhwc_matches_torch_conv(db, halo_enabled):
+@pytest.mark.parametrize("halo", ["1", "0"])
+def test_conv2d_nhwc_matches_torch_conv(db, monkeypatch, halo):
+    monkeypatch.setenv("DH_CONV_HALO", halo)          # both main loops (the generic one is the fallback for other shapes)
     """the raw convolution entry point against torch's fp32 conv2d: 1x1 / 3x3 / 7x7, multi-segment input, all tile configs"""
     from droid_amd.update import pack_conv, pack_conv_halo, EPI_LINEAR, EPI_RELU
     torch.manual_seed(0)
     cases = [(3, 12, 16, c) for c in [((128, 64, 8), 128, 3), ((200,), 64, 1), ((8,), 32, 7), ((128,), 576, 1), ((64, 64), 4, 3)]]
-    # W == 64, H % 4 == 0, channel segments % 32 == 0, >= 256 input channels: the halo-tile 3x3 fast path
-    # (image borders, 2 cout tiles); the last case stays on the generic loop
+    # W == 64, H % 4 == 0, channel segments % 32 == 0: the halo-tile 3x3 fast path (image borders, 2 cout tiles,
+    # the 32-cout variant of the heads); (64,) stays on the generic loop (fewer than 128 input channels)
     cases += [(2, 8, 64, c) for c in [((128, 64, 64), 128, 3), ((256,), 256, 3), ((64,), 256, 3), ((256,), 4, 3), ((128,), 1, 3)]]
     for (N, H, W, (cins, cout, k)) in cases:
         xs = [torch.randn(N, H, W, c, device="cuda").half() for c in cins]
