@@ -395,18 +395,6 @@ bool halo_ok(const ConvParams& P) {
   // chunks -- one workgroup per CU -- and strided weight reads was slower than the generic loop inside the iteration.)
   const char* env = getenv("DH_CONV_HALO");
   if (env && atoi(env) == 0) return false;
-  if (!P.wt_halo || P.KH != 3 || P.KW != 3 || P.W != 64 || P.H % 4 || P.CoutPad != 32) return false;
-  for (int i = 0; i < P.nseg; ++i) if (P.segC[i] % HCK) return false;
-  return true;
-}
-
-bool halo_ok(const ConvParams& P) {
-  // Opt-in (DH_CONV_HALO=1).  Measured on MI355X: in isolation (1024 edges, relu epilogue) the halo loop beats the
-  // generic one for long K (448 -> 256: 7.7 vs 8.7 ms) and loses for K = 1152 (prologue/epilogue bound at one
-  // workgroup per CU); inside the full update iteration at 4096 edges with the GRU epilogues it was 5-18% SLOWER
-  // (40.5 vs 38.6 ms, 24.6 vs 20.8 ms), so the production path stays on the generic loop until that is understood.
-  const char* env = getenv("DH_CONV_HALO");
-  if (!env || atoi(env) == 0) return false;
   if (!P.wt_halo || P.KH != 3 || P.KW != 3 || P.W != 64 || P.H % 4 || P.CoutPad % 128 || P.Ctot < 128) return false;
   for (int i = 0; i < P.nseg; ++i) if (P.segC[i] % HCK) return false;
   return true;
