@@ -56,11 +56,14 @@ __device__ __forceinline__ uint4 keep_if(bool ok, const uint4& v) {
 template <int EPI, int TM, int TN>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& P, f32x16 (&acc)[TM][TN], long M, long m0, int n0, int wm0,
                                               int wn0, int lane, int HW) {
+  const int img0 = (int)(m0 / HW);
+  const bool one_img = (m0 + BM - 1) / HW == img0;        // wave-uniform
 #pragma unroll
   for (int b = 0; b < TN; ++b) {
     const int co = n0 + wn0 + b * 32 + (lane & 31);
     const bool co_ok = co < P.Cout;
     const float bias = co < P.CoutPad ? P.bias[co] : 0.f;
+    const float g_one = (one_img && P.gterm && co < P.CoutPad) ? P.gterm[(long)img0 * P.CoutPad + co] : 0.f;
     float glo_sum = 0.f; long glo_img = -1;
 #pragma unroll
     for (int a = 0; a < TM; ++a)
@@ -68,9 +71,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& P, f32x16 (&acc)
       for (int q = 0; q < 16; ++q) {
         const long pix = m0 + wm0 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
         if (pix >= M || !co_ok) continue;
-        const int img = (int)(pix / HW);
-        float v = acc[a][b][q] + bias;
-        if (P.gterm) v += P.gterm[(long)img * P.CoutPad + co];
+        // (a 64-bit division per element is ~100 instructions: the tile normally lies inside one image)
+        const int img = one_img ? img0 : (int)(pix / HW);
+        float v = acc[a][b][q] + bias + (one_img ? g_one : (P.gterm ? P.gterm[(long)img * P.CoutPad + co] : 0.f));
         switch (EPI) {
           case EPI_RELU: v = fmaxf(v, 0.f); break;
           case EPI_SIGMOID: v = sigmoidf_(v); break;
@@ -230,19 +233,20 @@ constexpr int HROWS = 6, HCOLS = 66, HPIX = HROWS * HCOLS;
 constexpr int HPC = HCK / 8;             // 16-byte pieces per pixel / cout row
 
 // BN = 128: waves = 4 image rows x 2 cout halves, 64 px x 64 cout per wave (every 3x3 convolution with >= 128 couts).
+// BN = 64 : waves = 4 image rows x 2 cout halves, 64 px x 32 cout per wave (flow encoder 128 -> 64).
 // BN = 32 : waves = 4 image rows x 2 half rows, 32 px x 32 cout per wave: the 2-/1-channel heads (Cout padded to 32),
 //           where the generic loop is bound by re-reading the activations 9 times from L2 (58 GB at 4096 edges).
 template <int EPI, int BN>
 __global__ __launch_bounds__(512, 4) void conv3x3_halo_kernel(ConvParams P) {
-  constexpr int WM = BN == 128 ? 64 : 32, WN = BN == 128 ? 64 : 32, TM = WM / 32, TN = WN / 32;
+  constexpr int WM = BN == 32 ? 32 : 64, WN = BN == 128 ? 64 : 32, TM = WM / 32, TN = WN / 32;
   constexpr int HSLAB = 9 * BN * HCK;     // halves of one (cout tile, chunk) weight slab
   extern __shared__ __half s_conv[];
   __half* sA = s_conv;                    // [HPIX][HLD]
   __half* sB = s_conv + HPIX * HLD;       // [9][BN][HLD]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wrow = wave & 3;
-  const int wx0 = BN == 128 ? 0 : (wave >> 2) * 32;                 // first image column of the wave's pixels
-  const int wn0 = BN == 128 ? (wave >> 2) * WN : 0, wm0 = wrow * 64 + wx0;
+  const int wx0 = BN == 32 ? (wave >> 2) * 32 : 0;                  // first image column of the wave's pixels
+  const int wn0 = BN == 32 ? 0 : (wave >> 2) * WN, wm0 = wrow * 64 + wx0;
   const long M = (long)P.N * P.H * P.W;
   const long m0 = (long)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
@@ -381,9 +385,9 @@ int launch_halo(const ConvParams& P, hipStream_t st) {
   return DH_OK;
 }
 
-// small-Cout heads (CoutPad == 32): always on when the shape allows it
-bool halo32_ok(const ConvParams& P) {
-  if (!P.wt_halo || P.KH != 3 || P.KW != 3 || P.W != 64 || P.H % 4 || P.CoutPad != 32) return false;
+// small-Cout convolutions (CoutPad == 32 or 64): bound by re-reading the activations in the generic loop
+bool halo_small_ok(const ConvParams& P, int bn) {
+  if (!P.wt_halo || P.KH != 3 || P.KW != 3 || P.W != 64 || P.H % 4 || P.CoutPad != bn) return false;
   for (int i = 0; i < P.nseg; ++i) if (P.segC[i] % HCK) return false;
   return true;
 }
@@ -460,7 +464,14 @@ extern "C" int dh_conv2d_nhwc_f16(const void* const* inputs, const int* in_chann
       default: break;
     }
   }
-  if (halo32_ok(P)) {
+  if (halo_small_ok(P, 64)) {
+    switch (P.epi) {
+      case EPI_LINEAR: return launch_halo<EPI_LINEAR, 64>(P, st);
+      case EPI_RELU: return launch_halo<EPI_RELU, 64>(P, st);
+      default: break;
+    }
+  }
+  if (halo_small_ok(P, 32)) {
     switch (P.epi) {
       case EPI_LINEAR: return launch_halo<EPI_LINEAR, 32>(P, st);
       case EPI_HEADS: return launch_halo<EPI_HEADS, 32>(P, st);

@@ -83,7 +83,7 @@ def pack_conv_halo(weight):
     if kh != 3 or kw != 3 or ctot % 32:
         return None
     cp = _round_up(cout, 32)
-    bn = 32 if cp == 32 else 128            # cout tile of the kernel variant that will take this convolution
+    bn = cp if cp in (32, 64) else 128      # cout tile of the kernel variant that will take this convolution
     if cp % bn:
         return None
     w = torch.zeros(cp, ctot, 9, dtype=torch.float32, device=weight.device)

@@ -146,8 +146,8 @@ int dh_ba_finish(float* poses, float* disps, const int64_t* jj,
  *   weights [CoutPad, Kpad] f16 with k = (dy*KW + dx) * sum(in_channels) + c, zero padded (Kpad % 64 == 0,
  *   CoutPad % 32 == 0);  bias [CoutPad] f32
  *   weights_halo (optional, NULL = none): second copy for the 3x3 halo-tile fast path (W == 64, H % 4 == 0, every
- *   in_channels[i] % 32 == 0; CoutPad == 32 or CoutPad % 128 == 0), laid out [CoutPad/BN][Ctot/16][9 taps][BN][16]
- *   f16 with BN = 32 if CoutPad == 32 else 128
+ *   in_channels[i] % 32 == 0; CoutPad == 32, 64 or a multiple of 128), laid out [CoutPad/BN][Ctot/16][9 taps][BN][16]
+ *   f16 with BN = CoutPad if CoutPad is 32 or 64, else 128
  *   out [N,H,W,out_stride] (f16, or f32 holding fp16-rounded values when out_is_f32), channels [0,Cout) written
  *   epilogue: 0 linear, 1 relu, 2 sigmoid,
  *     3 GRU z|r  (Cout = 256: z = sigmoid(.+g) for cout < 128, r*net for cout >= 128; aux0 = net [.,128]),

@@ -502,7 +502,7 @@ def test_conv2d_nhwc_matches_torch_conv(db, monkeypatch, halo):
     cases = [(3, 12, 16, c) for c in [((128, 64, 8), 128, 3), ((200,), 64, 1), ((8,), 32, 7), ((128,), 576, 1), ((64, 64), 4, 3)]]
     # W == 64, H % 4 == 0, channel segments % 32 == 0: the halo-tile 3x3 fast path (image borders, 2 cout tiles,
     # the 32-cout variant of the heads); (64,) stays on the generic loop (fewer than 128 input channels)
-    cases += [(2, 8, 64, c) for c in [((128, 64, 64), 128, 3), ((256,), 256, 3), ((64,), 256, 3), ((256,), 4, 3), ((128,), 1, 3)]]
+    cases += [(2, 8, 64, c) for c in [((128, 64, 64), 128, 3), ((256,), 256, 3), ((64,), 256, 3), ((256,), 4, 3), ((128,), 1, 3), ((128,), 64, 3)]]
     for (N, H, W, (cins, cout, k)) in cases:
         xs = [torch.randn(N, H, W, c, device="cuda").half() for c in cins]
         wgt = torch.randn(cout, sum(cins), k, k, device="cuda") / (sum(cins) * k * k) ** 0.5
