@@ -558,79 +558,85 @@ __device__ __forceinline__ void load_block64(double* __restrict__ dst, const dou
 // Blocked Cholesky of the stacked panel P = [A_jj ; A_rj] (128 x 64, LDS, leading dimension LDB) by 256 threads:
 // on return rows 0..63 hold L_jj (lower triangle, zeros above) and rows 64..127 hold L_rj = A_rj L_jj^-T, i.e. the
 // triangular solve of the block row comes out of the same elimination and no inverse is needed here.
-// Per 16-column step: EVERY thread factorises the 16x16 diagonal sub-block redundantly in its own registers (pure
+// Per 8-column step: EVERY thread factorises the 8x8 diagonal sub-block redundantly in its own registers (pure
 // register code with compile-time indices: no cross-lane traffic, no barrier before the next phase), one thread
 // per row below substitutes against it (factor taken from registers), and the trailing columns are updated on
-// the fp64 MFMA.  Returns false if a pivot is not positive and finite.
+// the fp64 MFMA.  (8 columns per step: the scalar work of the diagonal factor grows with the cube of the step, the
+// MFMA part does not: 16-column steps took 28 us per 64 columns, see profiles/.)  Returns false if a pivot is not
+// positive and finite.
 __device__ bool chol_panel128_lds(double* __restrict__ P, int tid) {
+  constexpr int PB = 8;                                  // elimination step (columns per step); MFMA tiles stay 16x16
   const int lane = tid & 63, wave = tid >> 6;
   bool ok = true;
 #pragma unroll 1
-  for (int k = 0; k < NB / SB; ++k) {
-    const int o = k * SB;
-    double L[SB][SB];                                  // lower triangle used
-    double dinv[SB];
+  for (int k = 0; k < NB / PB; ++k) {
+    const int o = k * PB;
+    double L[PB][PB];                                  // lower triangle used
+    double dinv[PB];
 #pragma unroll
-    for (int r = 0; r < SB; ++r)
+    for (int r = 0; r < PB; ++r)
 #pragma unroll
       for (int c = 0; c <= r; ++c) L[r][c] = P[(o + r) * LDB + o + c];       // same address in every lane: broadcast
 #pragma unroll
-    for (int c = 0; c < SB; ++c) {
+    for (int c = 0; c < PB; ++c) {
       double piv = L[c][c];
       if (!(piv > 0.0) || !(piv < 1e300)) { ok = false; piv = 1.0; }
       const double rs = fast_rsqrt(piv);
       dinv[c] = rs;
       L[c][c] = piv * rs;
 #pragma unroll
-      for (int r = c + 1; r < SB; ++r) L[r][c] *= rs;
+      for (int r = c + 1; r < PB; ++r) L[r][c] *= rs;
 #pragma unroll
-      for (int c2 = c + 1; c2 < SB; ++c2)
+      for (int c2 = c + 1; c2 < PB; ++c2)
 #pragma unroll
-        for (int r = c2; r < SB; ++r) L[r][c2] -= L[r][c] * L[c2][c];
+        for (int r = c2; r < PB; ++r) L[r][c2] -= L[r][c] * L[c2][c];
     }
     __syncthreads();                                   // everybody has read the sub-block
-    if (tid < SB) {                                    // publish L_kk (thread r writes row r)
+    if (tid < PB) {                                    // publish L_kk (thread r writes row r)
 #pragma unroll
-      for (int r = 0; r < SB; ++r)
+      for (int r = 0; r < PB; ++r)
         if (tid == r) {
 #pragma unroll
-          for (int c = 0; c < SB; ++c) P[(o + r) * LDB + o + c] = (c <= r) ? L[r][c] : 0.0;
+          for (int c = 0; c < PB; ++c) P[(o + r) * LDB + o + c] = (c <= r) ? L[r][c] : 0.0;
         }
     }
     // rows below the sub-block (rest of A_jj and all of A_rj): X[i][:] = A[i][:] L_kk^-T, one thread per row
-    const int nbelow = 2 * NB - o - SB;
+    const int nbelow = 2 * NB - o - PB;
     if (tid < nbelow) {
-      double* prow = P + (o + SB + tid) * LDB + o;
-      double x[SB];
+      double* prow = P + (o + PB + tid) * LDB + o;
+      double x[PB];
 #pragma unroll
-      for (int c = 0; c < SB; ++c) x[c] = prow[c];
+      for (int c = 0; c < PB; ++c) x[c] = prow[c];
 #pragma unroll
-      for (int c = 0; c < SB; ++c) {
+      for (int c = 0; c < PB; ++c) {
         double v = x[c];
 #pragma unroll
         for (int m = 0; m < c; ++m) v -= x[m] * L[c][m];
         x[c] = v * dinv[c];
       }
 #pragma unroll
-      for (int c = 0; c < SB; ++c) prow[c] = x[c];
+      for (int c = 0; c < PB; ++c) prow[c] = x[c];
     }
     __syncthreads();
-    // trailing update on the fp64 MFMA: P[i][j] -= sum_m X[i][m] X[j][m] for column tiles tj < nC and row tiles
-    // ti >= tj (rows and columns both counted from o + 16; the A_rj rows are row tiles nC .. nR-1)
-    const int nC = (NB - o - SB) / SB, nR = nbelow / SB;
-    const int ntiles = nC * nR - nC * (nC - 1) / 2;
+    // trailing update on the fp64 MFMA: P[i][j] -= sum_m X[i][m] X[j][m] over 16x16 tiles (tj = column tile of the
+    // 64 columns, ti >= tj row tile of the 128 rows) that reach past row/column o + 8.  A tile that starts before
+    // o + 8 (even k) also holds rows/columns <= the current step: their operands are taken as 0, so finished
+    // entries are left untouched.
+    const int first = o + PB;                          // first row/column still to be updated
+    const int tj0 = first / SB, nCt = NB / SB - tj0, nRt = 2 * NB / SB - tj0;      // tiles from tj0 on
+    const int ntiles = nCt * nRt - nCt * (nCt - 1) / 2;
     for (int t = wave; t < ntiles; t += 4) {
       int tj = 0, rem = t;
-      while (rem >= nR - tj) { rem -= nR - tj; ++tj; }
-      const int ti = tj + rem;
-      const int r0 = o + SB + ti * SB, c0 = o + SB + tj * SB;
+      while (rem >= nRt - tj) { rem -= nRt - tj; ++tj; }
+      const int r0 = (tj0 + tj + rem) * SB, c0 = (tj0 + tj) * SB;
       f64x4 acc;
 #pragma unroll
       for (int q = 0; q < 4; ++q) acc[q] = P[(r0 + (lane >> 4) + 4 * q) * LDB + c0 + (lane & 15)];
+      const int ra = r0 + (lane & 15), rb = c0 + (lane & 15);
 #pragma unroll
-      for (int kk = 0; kk < SB / 4; ++kk) {
-        const double av = -P[(r0 + (lane & 15)) * LDB + o + kk * 4 + (lane >> 4)];
-        const double bv = P[(c0 + (lane & 15)) * LDB + o + kk * 4 + (lane >> 4)];
+      for (int kk = 0; kk < PB / 4; ++kk) {
+        const double av = ra >= first ? -P[ra * LDB + o + kk * 4 + (lane >> 4)] : 0.0;
+        const double bv = rb >= first ? P[rb * LDB + o + kk * 4 + (lane >> 4)] : 0.0;
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
       }
 #pragma unroll
@@ -716,8 +722,21 @@ __global__ __launch_bounds__(256, 1) void chol_panel_kernel(double* __restrict__
   const int tid = threadIdx.x;
   const int r = j + 1 + blockIdx.x;
   const long d0 = (long)j * NB, r0 = (long)r * NB;
-  load_block64(P, H + d0 * ld + d0, ld, tid);
-  load_block64(P + NB * LDB, H + r0 * ld + d0, ld, tid);
+  {                                          // both blocks in flight together
+    double2 va[8], vb[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int o = tid + 256 * q;
+      va[q] = *reinterpret_cast<const double2*>(H + (d0 + (o >> 5)) * ld + d0 + (o & 31) * 2);
+      vb[q] = *reinterpret_cast<const double2*>(H + (r0 + (o >> 5)) * ld + d0 + (o & 31) * 2);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int o = tid + 256 * q;
+      *reinterpret_cast<double2*>(P + (o >> 5) * LDB + (o & 31) * 2) = va[q];
+      *reinterpret_cast<double2*>(P + (NB + (o >> 5)) * LDB + (o & 31) * 2) = vb[q];
+    }
+  }
   __syncthreads();
   const bool ok = chol_panel128_lds(P, tid);
   if (!ok && tid == 0) meta[1] = 1;
@@ -763,14 +782,25 @@ __global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ H
   double* sB = sA + NB * LDB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long r0 = (long)r * NB, c0 = (long)c * NB, d0 = (long)j * NB;
-  load_block64(sA, H + r0 * ld + d0, ld, tid);
-  load_block64(sB, H + c0 * ld + d0, ld, tid);
-  // the block to be updated travels while the MFMAs run
+  // both operand blocks and the block to be updated are requested in one burst
+  double2 va[8], vb[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int o = tid + 256 * q;
+    va[q] = *reinterpret_cast<const double2*>(H + (r0 + (o >> 5)) * ld + d0 + (o & 31) * 2);
+    vb[q] = *reinterpret_cast<const double2*>(H + (c0 + (o >> 5)) * ld + d0 + (o & 31) * 2);
+  }
   double cur[4][4];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
     for (int q = 0; q < 4; ++q) cur[nt][q] = H[(r0 + wave * 16 + (lane >> 4) + 4 * q) * ld + c0 + nt * 16 + (lane & 15)];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int o = tid + 256 * q;
+    *reinterpret_cast<double2*>(sA + (o >> 5) * LDB + (o & 31) * 2) = va[q];
+    *reinterpret_cast<double2*>(sB + (o >> 5) * LDB + (o & 31) * 2) = vb[q];
+  }
   __syncthreads();
   f64x4 acc[4];
   mfma_abt_64<false>(sA, sB, wave, lane, acc);

@@ -5,6 +5,6 @@ timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p
 grep -o '"ms_per_global_ba": [0-9.]*' gpurun_out/prof_ba.log
 python - <<'PY'
 import csv
-for r in list(csv.DictReader(open('gpurun_out/prof_ba/run_kernel_stats.csv')))[:12]:
+for r in list(csv.DictReader(open('gpurun_out/prof_ba/run_kernel_stats.csv')))[:8]:
     print("%-60s %5s %9.3f ms avg %8.1f us" % (r['Name'].replace('(anonymous namespace)::','').split('(')[0][:60], r['Calls'], int(r['TotalDurationNs'])/1e6, float(r['AverageNs'])/1e3))
 PY
