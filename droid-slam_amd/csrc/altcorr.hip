@@ -164,6 +164,192 @@ __global__ __launch_bounds__(256) void altcorr_bwd_kernel(
   }
 }
 
+// ---- MFMA path (channel-last fp16 features) ------------------------------------------------------------------
+// The feature correlation is a true contraction over the 128 channels, so it belongs on the matrix cores; what keeps
+// it from being a plain GEMM is that every source pixel wants its own 8x8 window of targets.  With a spatially
+// coherent flow the windows of an 8x8 source block overlap almost completely: their union fits a 16x16 target tile.
+// One wave = one source block:
+//   * its 64 source features stay in registers as MFMA B operands (64 VGPRs) for the whole block;
+//   * the target tile is streamed in 4 groups of 4 rows: 64 targets x 128 ch are staged through LDS with fully
+//     coalesced loads (a target row of 16 pixels is 4 KB contiguous in NHWC; out-of-image targets are staged as
+//     zeros, which IS the reference's zero padding), then 32 x v_mfma_f32_32x32x16_f16 give D[target][pixel];
+//   * in D's layout a lane holds one pixel's column, so it writes its own pixel's row of a [pixel][target] fp16 tile
+//     and then reads back the 8 taps of each window row at its own offset (3 aligned 8-byte reads + funnel shift),
+//     interpolates and stores the 49 outputs as the rows arrive.
+// 4x the algorithmic flops (16x16 instead of 8x8 targets per pixel) at ~100x the rate of the VALU version.
+// Blocks whose windows do not fit the tile (incoherent flow) take a per-lane scalar path with the same results.
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int AC = 128;                // channels
+constexpr int SF_LD = AC + 8;          // staged target row stride (halves)
+constexpr int SC_LD = 64 + 4;          // [pixel][64 targets] row stride (halves)
+constexpr int AWPB = 2;                // waves (source blocks) per workgroup
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__global__ __launch_bounds__(AWPB * 64) void altcorr_mfma_kernel(
+    const __half* __restrict__ f1, const __half* __restrict__ f2, const float* __restrict__ coords,
+    const int64_t* __restrict__ us, const int64_t* __restrict__ vs, __half* __restrict__ corr,
+    int H, int W, int H2, int W2, int nblk) {
+  extern __shared__ __half s_alt[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int blk = blockIdx.x * AWPB + wv;
+  if (blk >= nblk) return;                         // whole wave (no workgroup barrier is used below)
+  __half* sF = s_alt + wv * (64 * SF_LD + 64 * SC_LD);
+  __half* sC = sF + 64 * SF_LD;
+  const int m = blockIdx.y;
+  const int nbx = W / 8, by = blk / nbx, bx = blk - by * nbx;
+  const int HW = H * W;
+  const int ix = (int)us[m], jx = (int)vs[m];
+  const int yy = lane >> 3, xx = lane & 7;
+  const int pix = (by * 8 + yy) * W + bx * 8 + xx;
+  const float* cb = coords + (long)m * 2 * HW;
+  const float x0 = cb[pix], y0 = cb[HW + pix];
+  float fxf = floorf(x0), fyf = floorf(y0);
+  const float dx = x0 - fxf, dy = y0 - fyf;
+  fxf = fminf(fmaxf(fxf, -65536.f), 65536.f);
+  fyf = fminf(fmaxf(fyf, -65536.f), 65536.f);
+  const int X0 = (int)fxf - 3, Y0 = (int)fyf - 3;
+  const int Xmin = wave_min_i(X0), Xmax = wave_max_i(X0), Ymin = wave_min_i(Y0), Ymax = wave_max_i(Y0);
+  __half* out = corr + (long)m * 49 * HW + pix;
+  const __half* f1b = f1 + (long)ix * HW * AC;
+  const __half* f2b = f2 + (long)jx * H2 * W2 * AC;
+
+  if (Xmax - Xmin > 8 || Ymax - Ymin > 8) {
+    // ---- incoherent block: per-lane scalar evaluation (same arithmetic order of the blend) ----
+    const __half* a = f1b + (long)pix * AC;
+    float prevs[7];
+    for (int j = 0; j < 8; ++j) {
+      float t[8];
+      for (int i = 0; i < 8; ++i) {
+        const int y2 = Y0 + j, x2 = X0 + i;
+        float s = 0.f;
+        if ((unsigned)y2 < (unsigned)H2 && (unsigned)x2 < (unsigned)W2) {
+          const __half* b = f2b + ((long)y2 * W2 + x2) * AC;
+          for (int c = 0; c < AC; c += 8) {
+            const uint4 av = *reinterpret_cast<const uint4*>(a + c), bv = *reinterpret_cast<const uint4*>(b + c);
+            const __half2* ah = reinterpret_cast<const __half2*>(&av);
+            const __half2* bh = reinterpret_cast<const __half2*>(&bv);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const float2 af = __half22float2(ah[q]), bf = __half22float2(bh[q]); s += af.x * bf.x + af.y * bf.y; }
+          }
+        }
+        t[i] = __half2float(__float2half(s * 0.0625f));
+      }
+      float c7[7];
+      for (int q = 0; q < 7; ++q) c7[q] = t[q] + dx * (t[q + 1] - t[q]);
+      if (j > 0)
+        for (int q = 0; q < 7; ++q) out[(long)(q * 7 + (j - 1)) * HW] = __float2half(prevs[q] + dy * (c7[q] - prevs[q]));
+      for (int q = 0; q < 7; ++q) prevs[q] = c7[q];
+    }
+    return;
+  }
+
+  // ---- source features of the block: B operands, resident ----
+  half8 bfrag[2][8];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int pn = nt * 32 + (lane & 31);
+    const __half* row = f1b + ((long)(by * 8 + (pn >> 3)) * W + bx * 8 + (pn & 7)) * AC + (lane >> 5) * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) bfrag[nt][ks] = *reinterpret_cast<const half8*>(row + ks * 16);
+  }
+
+  float prev[7];
+  const int c0 = X0 - Xmin;                       // first tap column inside the 16-wide tile, 0..8
+  const int sh = (c0 & 3) * 16;                   // funnel shift (bits) inside the aligned 8-byte words
+#pragma unroll 1
+  for (int g = 0; g < 4; ++g) {
+    const int Yg = Ymin + 4 * g;
+    // stage 64 targets (4 rows x 16) x 128 channels: piece id = lane + 64*i -> target id>>4, 16-byte group id&15
+    uint4 st[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int id = lane + 64 * i, tg = id >> 4;
+      const int y = Yg + (tg >> 4), x = Xmin + (tg & 15);
+      const bool ok = (unsigned)y < (unsigned)H2 && (unsigned)x < (unsigned)W2;
+      const uint4 v = *reinterpret_cast<const uint4*>(f2b + ((long)(ok ? y : 0) * W2 + (ok ? x : 0)) * AC + (id & 15) * 8);
+      const uint32_t mk = ok ? 0xffffffffu : 0u;
+      st[i] = uint4{v.x & mk, v.y & mk, v.z & mk, v.w & mk};
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int id = lane + 64 * i;
+      *reinterpret_cast<uint4*>(sF + (id >> 4) * SF_LD + (id & 15) * 8) = st[i];
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0): wave-private tiles
+    __builtin_amdgcn_wave_barrier();
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const half8 af = *reinterpret_cast<const half8*>(sF + (mt * 32 + (lane & 31)) * SF_LD + ks * 16 + (lane >> 5) * 8);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bfrag[nt][ks], acc[mt][nt], 0, 0, 0);
+      }
+    // D[target][pixel] -> sC[pixel][target] (fp16, scaled by 1/16): lane = pixel nt*32 + (lane&31), 4 consecutive targets per store
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          const __half2 lo = __floats2half2_rn(acc[mt][nt][4 * qq] * 0.0625f, acc[mt][nt][4 * qq + 1] * 0.0625f);
+          const __half2 hi = __floats2half2_rn(acc[mt][nt][4 * qq + 2] * 0.0625f, acc[mt][nt][4 * qq + 3] * 0.0625f);
+          uint2 pk; pk.x = __builtin_bit_cast(uint32_t, lo); pk.y = __builtin_bit_cast(uint32_t, hi);
+          *reinterpret_cast<uint2*>(sC + (nt * 32 + (lane & 31)) * SC_LD + mt * 32 + 8 * qq + 4 * (lane >> 5)) = pk;
+        }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    // lane = pixel: consume the rows of this group that belong to its window
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = Yg + r - Y0;                  // window row of this pixel
+      if (j < 0 || j > 7) continue;
+      const __half* rowp = sC + lane * SC_LD + r * 16 + (c0 & ~3);
+      const uint64_t w0 = *reinterpret_cast<const uint64_t*>(rowp);
+      const uint64_t w1 = *reinterpret_cast<const uint64_t*>(rowp + 4);
+      const uint64_t w2 = *reinterpret_cast<const uint64_t*>(rowp + 8);
+      const uint64_t t03 = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
+      const uint64_t t47 = sh ? (w1 >> sh) | (w2 << (64 - sh)) : w1;
+      float t[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        t[i] = (float)__builtin_bit_cast(_Float16, (unsigned short)(t03 >> (16 * i)));
+        t[4 + i] = (float)__builtin_bit_cast(_Float16, (unsigned short)(t47 >> (16 * i)));
+      }
+      float c7[7];
+#pragma unroll
+      for (int q = 0; q < 7; ++q) c7[q] = t[q] + dx * (t[q + 1] - t[q]);
+      if (j > 0) {
+#pragma unroll
+        for (int q = 0; q < 7; ++q) out[(long)(q * 7 + (j - 1)) * HW] = __float2half(prev[q] + dy * (c7[q] - prev[q]));
+      }
+#pragma unroll
+      for (int q = 0; q < 7; ++q) prev[q] = c7[q];
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);           // tile reads done before the next group overwrites it
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 template <typename T>
 int launch_fwd(const void* fmap1, const void* fmap2, const float* coords, const int64_t* ii, const int64_t* jj,
                void* corr, int B, int N1, int N2, int C, int H, int W, int H2, int W2, int M, int radius,
@@ -227,6 +413,21 @@ extern "C" int dh_altcorr_bwd(const void* fmap1, const void* fmap2, const float*
     hipLaunchKernelGGL(altcorr_bwd_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                        (const float*)fmap1, (const float*)fmap2, coords, ii, jj, corr_grad, fmap1_grad,
                        fmap2_grad, B, N1, N2, C, H * W, W, H2, W2, M, radius);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
+extern "C" int dh_altcorr_fwd_nhwc(const void* fmap1, const void* fmap2, const float* coords,
+                                   const int64_t* ii, const int64_t* jj, void* corr,
+                                   int N1, int N2, int C, int H, int W, int H2, int W2, int M, dh_stream_t stream) {
+  if (N1 <= 0 || N2 <= 0 || H <= 0 || W <= 0 || H2 <= 0 || W2 <= 0 || M < 0) return DH_ERR_ARG;
+  if (C != AC || H % 8 || W % 8) return DH_ERR_UNSUPPORTED;
+  if (M == 0) return DH_OK;
+  if (!fmap1 || !fmap2 || !coords || !ii || !jj || !corr) return DH_ERR_ARG;
+  const int nblk = (H / 8) * (W / 8);
+  const size_t lds = (size_t)AWPB * (64 * SF_LD + 64 * SC_LD) * sizeof(__half);
+  hipLaunchKernelGGL(altcorr_mfma_kernel, dim3((nblk + AWPB - 1) / AWPB, M), dim3(AWPB * 64), lds, (hipStream_t)stream,
+                     (const __half*)fmap1, (const __half*)fmap2, coords, ii, jj, (__half*)corr, H, W, H2, W2, nblk);
   DH_LAUNCH_CHECK();
   return DH_OK;
 }

@@ -231,6 +231,23 @@ std::vector<torch::Tensor> altcorr_backward(torch::Tensor fmap1, torch::Tensor f
 }
 
 
+// channel-last MFMA variant (droid_amd.corr.AltCorrBlock): fmap1 [N1,H,W,128], fmap2 [N2,H2,W2,128] f16, coords [M,2,H,W]
+torch::Tensor altcorr_forward_nhwc(torch::Tensor fmap1, torch::Tensor fmap2, torch::Tensor coords, torch::Tensor ii,
+                                   torch::Tensor jj) {
+  CHECK_INPUT(fmap1); CHECK_INPUT(fmap2); CHECK_INPUT(coords); CHECK_INPUT(ii); CHECK_INPUT(jj);
+  CHECK_F32(coords); CHECK_I64(ii); CHECK_I64(jj);
+  TORCH_CHECK(fmap1.scalar_type() == torch::kFloat16 && fmap2.scalar_type() == torch::kFloat16, "fmaps must be float16");
+  TORCH_CHECK(fmap1.dim() == 4 && fmap2.dim() == 4 && coords.dim() == 4 && coords.size(1) == 2, "altcorr_forward_nhwc: shapes");
+  const int N1 = (int)fmap1.size(0), H = (int)fmap1.size(1), W = (int)fmap1.size(2), C = (int)fmap1.size(3);
+  const int N2 = (int)fmap2.size(0), H2 = (int)fmap2.size(1), W2 = (int)fmap2.size(2), M = (int)ii.size(0);
+  TORCH_CHECK(coords.size(0) == M && coords.size(2) == H && coords.size(3) == W && fmap2.size(3) == C, "altcorr_forward_nhwc: shapes");
+  torch::Tensor out = torch::empty({M, 7, 7, H, W}, fmap1.options());
+  check_status(dh_altcorr_fwd_nhwc(fmap1.data_ptr(), fmap2.data_ptr(), coords.data_ptr<float>(), ii.data_ptr<int64_t>(),
+                                   jj.data_ptr<int64_t>(), out.data_ptr(), N1, N2, C, H, W, H2, W2, M, cur_stream()),
+               "altcorr_forward_nhwc");
+  return out;
+}
+
 // ---- MI355X-native correlation pyramid (own layout; droid_amd.corr.CorrBlock) ----------------------------
 torch::Tensor corr_pyramid_build(torch::Tensor fmap1, torch::Tensor fmap2) {
   CHECK_INPUT(fmap1); CHECK_INPUT(fmap2);
@@ -388,6 +405,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   // MI355X extensions (not in the reference module)
   m.def("ba_build", &ba_build, "per-rank reduced camera system (split BA)");
   m.def("ba_finish", &ba_finish, "damp + solve + back-substitute + retract (split BA)");
+  m.def("altcorr_forward_nhwc", &altcorr_forward_nhwc, "on-the-fly correlation on the fp16 MFMA, channel-last features");
   m.def("corr_pyramid_build", &corr_pyramid_build, "all-pairs correlation pyramid, MI355X layout");
   m.def("corr_pyramid_lookup", &corr_pyramid_lookup, "fused 4-level lookup on the MI355X pyramid");
   m.def("corr_pyramid_lookup_nhwc", &corr_pyramid_lookup_nhwc, "fused 4-level lookup, channel-last output for the update operator");

@@ -61,6 +61,11 @@ class CorrBlockRef:
 
 
 class AltCorrBlock:
+    """Reference interface (corr.py:89-117): AltCorrBlock(fmaps [B,N,C,H,W]); block(coords [B,M,H,W,2], ii, jj) ->
+    [B,M,4*49,H,W].  fp16 / 128-channel / H,W % 8 == 0 features (what DROID-SLAM stores, depth_video.py:36) are kept
+    channel-last and go through the MFMA kernel (droid_backends.altcorr_forward_nhwc); anything else takes the
+    reference-layout entry point altcorr_forward."""
+
     def __init__(self, fmaps, num_levels=4, radius=3):
         self.num_levels = num_levels
         self.radius = radius
@@ -71,13 +76,20 @@ class AltCorrBlock:
             self.pyramid.append(f.view(B, N, C, H // 2 ** l, W // 2 ** l))
             if l + 1 < num_levels:
                 f = F.avg_pool2d(f, 2, stride=2)
+        self.mfma = (B == 1 and radius == 3 and C == 128 and fmaps.dtype == torch.float16 and H % 8 == 0 and W % 8 == 0
+                     and fmaps.is_cuda)
+        if self.mfma:
+            self.nhwc = [p[0].permute(0, 2, 3, 1).contiguous() for p in self.pyramid]     # [N,h,w,C] per level
 
     def __call__(self, coords, ii, jj):
         c = coords.permute(0, 1, 4, 2, 3).contiguous()
         outs = []
         for l in range(self.num_levels):
-            corr, = droid_backends.altcorr_forward(self.pyramid[0], self.pyramid[l].contiguous(), c / 2 ** l,
-                                                   ii, jj, self.radius)
+            if self.mfma:
+                corr = droid_backends.altcorr_forward_nhwc(self.nhwc[0], self.nhwc[l], (c[0] / 2 ** l).contiguous(), ii, jj)[None]
+            else:
+                corr, = droid_backends.altcorr_forward(self.pyramid[0], self.pyramid[l].contiguous(), c / 2 ** l,
+                                                       ii, jj, self.radius)
             outs.append(corr.flatten(2, 3))
         return torch.stack(outs, dim=2).flatten(2, 3)
 

@@ -66,6 +66,12 @@ int dh_altcorr_fwd(const void* fmap1, const void* fmap2, const float* coords,
                    const int64_t* ii, const int64_t* jj, void* corr, int dtype,
                    int B, int N1, int N2, int C, int H, int W, int H2, int W2, int M, int radius,
                    dh_stream_t stream);
+/* Same lookup (radius 3) on the fp16 MFMA from channel-last features (the layout droid_amd.corr.AltCorrBlock keeps):
+ *   fmap1 [N1,H,W,128] f16, fmap2 [N2,H2,W2,128] f16, coords [M,2,H,W] f32 (already in fmap2's resolution),
+ *   -> corr [M,7,7,H,W] f16, x offset outer.  H % 8 == 0, W % 8 == 0, C == 128 (else DH_ERR_UNSUPPORTED). */
+int dh_altcorr_fwd_nhwc(const void* fmap1, const void* fmap2, const float* coords,
+                        const int64_t* ii, const int64_t* jj, void* corr,
+                        int N1, int N2, int C, int H, int W, int H2, int W2, int M, dh_stream_t stream);
 /* corr_grad [B,M,2r+1,2r+1,H,W] f32 (x offset outer); fmap1_grad/fmap2_grad f32, ACCUMULATED into
  * (caller zero-fills), shapes of fmap1/fmap2. */
 int dh_altcorr_bwd(const void* fmap1, const void* fmap2, const float* coords,

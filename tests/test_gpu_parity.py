@@ -572,3 +572,29 @@ def test_torch_scatter_dropin(db):
     for k in range(4):
         assert torch.allclose(s[k], x[ix == k].sum(0), atol=1e-6)
         assert torch.allclose(m[k], x[ix == k].mean(0), atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------ MFMA alt-correlation
+@pytest.mark.parametrize("kind", ["smooth", "random"])
+def test_altcorr_mfma_block_vs_oracle_and_reference_layout_path(db, kind):
+    """AltCorrBlock (channel-last MFMA kernel; smooth flow = tile path, random flow = per-lane path, image borders in
+    both) vs the oracle's alt lookup and vs the reference-layout kernel on identical inputs, all 4 levels."""
+    from droid_amd.corr import AltCorrBlock
+    rng = np.random.default_rng(11)
+    N, C, H, W = 4, 128, 16, 24
+    fm = rng.standard_normal((1, N, C, H, W)).astype(np.float16)
+    ii = np.array([0, 1, 3, 2, 2]); jj = np.array([1, 0, 3, 0, 3])
+    M = len(ii)
+    if kind == "smooth":
+        c = _smooth_coords(rng, M, H, W, amp=5.0)
+    else:
+        c = np.stack([rng.uniform(-4, W + 3, (M, H, W)), rng.uniform(-4, H + 3, (M, H, W))], -1).astype(np.float32)
+    blk = AltCorrBlock(dev(fm))
+    assert blk.mfma
+    out = blk(dev(c)[None], dev(ii), dev(jj))[0].float().cpu().numpy()               # [M,196,H,W]
+    ref = ocorr.alt_block_lookup(fm.astype(np.float32), c[None], ii, jj, 3, 4, pool_dtype=np.float16)[0]
+    assert out.shape == ref.shape == (M, 196, H, W)
+    assert np.abs(out - ref).max() <= 2.0 ** -7 * np.abs(ref).max()
+    blk.mfma = False                                                                  # reference-layout kernel
+    out2 = blk(dev(c)[None], dev(ii), dev(jj))[0].float().cpu().numpy()
+    assert np.abs(out - out2).max() <= 2.0 ** -7 * np.abs(ref).max()
