@@ -55,6 +55,19 @@ def test_argument_errors_are_reported_before_any_launch(built):
     lib.dh_ba_workspace_bytes.restype = ctypes.c_size_t
     assert lib.dh_ba_workspace_bytes(8, 32, 48, 64, 1, 8, 0) > 0
     assert lib.dh_ba_workspace_bytes(8, 32, 48, 64, 5, 3, 0) == 0       # t1 < t0
+    # entry points added for the MI355X path: same convention (status codes: 1 = argument, 4 = unsupported)
+    lib.dh_corr_pyramid_bytes.restype = ctypes.c_size_t
+    assert lib.dh_corr_pyramid_bytes(1, 48, 64) == 2 * 64 * 48 * sum((((48 >> l) + 1) * (64 >> l)) * 64 for l in range(4)) // 64
+    assert lib.dh_corr_pyramid_bytes(1, 48, 8) == 0                      # w must be 16, 32 or 64
+    assert lib.dh_corr_pyramid_lookup_nhwc(None, None, None, 4, 48, 64, None) == 1
+    assert lib.dh_altcorr_fwd_nhwc(None, None, None, None, None, None, 2, 2, 64, 48, 64, 48, 64, 3, None) == 4   # C != 128
+    assert lib.dh_altcorr_fwd_nhwc(None, None, None, None, None, None, 2, 2, 128, 48, 64, 48, 64, 3, None) == 1  # null pointers
+    assert lib.dh_segment_mean_f16(None, None, None, None, 3, ctypes.c_long(12), None) == 1                       # row % 8
+    assert lib.dh_conv2d_nhwc_f16(None, None, None, 1, None, None, None, 1, 8, 8, 3, 3, 4, 32, 64, 0,
+                                  None, 0, 4, None, None, 0, None, 0, None, None) == 1
+    rows, cols = ctypes.c_int(), ctypes.c_int()
+    assert lib.dh_ba_system_shape(1, 512, ctypes.byref(rows), ctypes.byref(cols)) == 0
+    assert cols.value == 3072 and rows.value == 3072 + 64
 
 
 def test_droid_backends_module_surface(built):
