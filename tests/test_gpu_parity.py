@@ -598,3 +598,27 @@ def test_altcorr_mfma_block_vs_oracle_and_reference_layout_path(db, kind):
     blk.mfma = False                                                                  # reference-layout kernel
     out2 = blk(dev(c)[None], dev(ii), dev(jj))[0].float().cpu().numpy()
     assert np.abs(out - out2).max() <= 2.0 ** -7 * np.abs(ref).max()
+
+
+# ------------------------------------------------------------------------------------------ full-size BA properties
+def test_ba_config_c3_full_size_properties(db):
+    """BASELINE configs[2] (512 keyframes / 4096 edges / 48x64, global-BA damping): too large for the Python oracle, so
+    the size-independent properties are checked: the weighted reprojection cost falls under repeated BA, quaternions
+    stay unit, fixed frames stay fixed, everything is finite, and the 3066-unknown solve did not fall back to dx = 0."""
+    g = syn.make_graph("C3")
+    N = g["n_frames"]
+    poses = dev(g["poses"]); disps = dev(g["disps"])
+    args = [dev(g[k]) for k in ("intrinsics", "disps_sens", "targets", "weights", "eta", "ii", "jj")]
+    cost = lambda: oba.reprojection_cost(poses.cpu().numpy(), disps.cpu().numpy(), g["intrinsics"], g["targets"],
+                                         g["weights"], g["ii"], g["jj"])
+    costs = [cost()]
+    for _ in range(2):
+        dx, dz = db.ba(poses, disps, *args, 1, N, 2, g["lm"], g["ep"], False)
+        disps.clamp_(min=0.001)
+        costs.append(cost())
+        assert torch.isfinite(dx).all() and torch.isfinite(dz).all() and dx.abs().max() > 0
+    assert costs[1] < 0.5 * costs[0] and costs[2] <= 1.01 * costs[1]
+    p = poses.cpu().numpy()
+    assert np.isfinite(p).all() and np.isfinite(disps.cpu().numpy()).all()
+    assert np.abs(np.linalg.norm(p[:, 3:], axis=-1) - 1).max() < 1e-4
+    assert np.array_equal(p[0], g["poses"][0])
