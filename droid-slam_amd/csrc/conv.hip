@@ -337,6 +337,201 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo_kernel(ConvParams P) {
   conv_epilogue<EPI, TM, TN>(P, acc, M, m0, n0, wm0, wn0, lane, HW);
 }
 
+// ---- 3x3 path with LDS-DMA staging: OPT-IN experiment (DH_CONV_DMA=1), not the default ----------------------------------
+// Built to test whether the halo kernel above is held back by its staging (16-channel chunks use 32 of the 128 bytes of
+// every line they touch, go through VGPRs and cost two barriers per 36 MFMAs).  Here a chunk is 64 channels = ONE full
+// 128-byte line per halo pixel, brought in by `global_load_lds_dwordx4` (no VGPRs, no ds_write pass) into a double-buffered
+// halo (2 x 50 KB) next to a triple-buffered (tap, chunk) weight slab (3 x 16 KB): 148 KB of LDS, one workgroup per CU,
+// one barrier per 16 MFMAs per wave, fragments read one k-step ahead across the barrier (see the loop comment).
+// The LDS image of a DMA is lane-linear (M0 + lane * 16), so rows are 128 B unpadded and bank conflicts are removed by
+// an XOR swizzle of the 16-byte slot with bits 1..3 of the row index -- applied to the per-lane SOURCE address of the
+// halo, baked into the pre-packed weights ([cout tile][chunk][tap][128 couts][8 slots][8]) and applied to the ds_read
+// addresses.  Out-of-image halo pixels read a zero line.
+// Measured on MI355X (1024 edges, scripts/bench_conv.py; DH_DMA_VAR selects the ablations):
+//     448->256: 7.5 ms (864 TFLOP/s)   448->128: 3.6 ms (900)     halo kernel above: 7.5 / 3.7 ms
+//     without the DMA inside the loop (stale operands): 6.1 / 3.1 ms (1.06-1.11 PFLOP/s) -- the ds_read + MFMA + barrier
+//     skeleton alone; DMA only: 3.7 / 1.8 ms.  Moving the DMA issue points (after the barrier / a k-step later / split
+//     between the two waves of a SIMD) or the fragment prefetch distance changes nothing beyond noise.
+// Inside the full update iteration it is SLOWER than the halo kernel (update operator 95.8 vs 92.3 ms at 4096 edges):
+// with one workgroup per CU the prologue (first halo + slabs) and the epilogue are not overlapped with another
+// workgroup's main loop.  Kept, tested (tests/test_gpu_parity.py runs all three main loops) and off by default; what it
+// shows is that staging is not what limits these convolutions: the 64 x 64 wave tile itself tops out near 1.1 PFLOP/s.
+constexpr int DCK = 64;                                   // channels per chunk
+constexpr int DA_PIECES = (HPIX * 8 + 63) / 64;           // 1-KB DMA pieces per halo chunk (396 px x 128 B -> 50)
+constexpr int DA_BYTES = DA_PIECES * 1024;
+constexpr int DB_BYTES = 128 * DCK * 2;                   // one (tap, chunk) weight slab
+constexpr int DB_BUFS = 3;                                // weight slabs are fetched two steps ahead
+constexpr int DMA_LDS_BYTES = 2 * DA_BYTES + DB_BUFS * DB_BYTES;
+typedef __attribute__((address_space(3))) char lds_char;
+__device__ __attribute__((aligned(128))) uint4 g_zero_line[8];
+
+// one wave-wide LDS-DMA: lane l copies the 16 bytes at gptr_ (per lane) to LDS byte address ldsaddr_ + l * 16
+#define GLDS16(gptr_, ldsaddr_)                                                                                      \
+  {                                                                                                                  \
+    unsigned keep_;                                                                                                  \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep_) : "v"(gptr_), "s"(ldsaddr_) : "memory");                                             \
+  }
+
+// VAR: 0 = product; 1/2 = timing ablations (1: no DMA inside the loop, 2: no ds_read/MFMA inside the loop)
+template <int EPI, int VAR = 0>
+__global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(ConvParams P) {
+  extern __shared__ __half s_conv[];
+  const char* const lds = reinterpret_cast<const char*>(s_conv);
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)s_conv;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wrow = wave & 3, wn0 = (wave >> 2) * 64, wm0 = wrow * 64;
+  const long M = (long)P.N * P.H * P.W;
+  const long m0 = (long)blockIdx.x * BM;
+  const int n0 = blockIdx.y * 128;
+  const int HW = P.H * P.W;
+  const int img = (int)(m0 / HW), y0 = (int)((m0 - (long)img * HW) / 64);
+  const int nchunks = P.Ctot / DCK, nsteps = nchunks * 9;
+
+  // halo DMA roles: piece j = t * 8 + wave (t = 0..6) covers halo pixels j*8 .. j*8+7, lane -> (pixel, swizzled slot)
+  int a_src[7];                                          // (image pixel index << 3) | source slot, or -1 (zero line)
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    const int j = t * 8 + wave, hp = j * 8 + (lane >> 3);
+    const int slot = (lane & 7) ^ ((hp >> 1) & 7);
+    const int hy = hp / HCOLS, hx = hp - hy * HCOLS;
+    const int y = y0 - 1 + hy, x = hx - 1;
+    const bool ok = hp < HPIX && (unsigned)y < (unsigned)P.H && (unsigned)x < 64u;
+    a_src[t] = ok ? ((((img * P.H + y) * 64 + x) << 3) | slot) : -1;
+  }
+  const char* const zero_src = reinterpret_cast<const char*>(g_zero_line) + (lane & 7) * 16;
+  const char* const bsrc = reinterpret_cast<const char*>(P.wt_halo) + (long)blockIdx.y * nsteps * DB_BYTES + lane * 16;
+
+  // fragment addressing: A row = halo pixel, B row = cout; 16-byte slot s of row r sits at r*128 + ((s ^ ((r>>1)&7)) << 4)
+  const int pl = wrow * HCOLS + (lane & 31), kh = lane >> 5;
+  int b_row[2], b_x[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int r = wn0 + b * 32 + (lane & 31);
+    b_row[b] = r * 128; b_x[b] = ((r >> 1) & 7) ^ kh;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+
+  // source of the halo chunk `chunk_`: segment base (+ channel offset) and pixel stride in bytes
+#define DMA_SEGMENT(chunk_, base_, stride_)                                                                          \
+  {                                                                                                                  \
+    int cs = (chunk_) * DCK, sgi = 0;                                                                                \
+    _Pragma("unroll") for (int q = 0; q < MAXSEG - 1; ++q)                                                           \
+      if (sgi == q && q + 1 < P.nseg && cs >= P.segC[q]) { cs -= P.segC[q]; sgi = q + 1; }                          \
+    const __half* sb = P.in[0]; int ss = P.segS[0];                                                                  \
+    _Pragma("unroll") for (int q = 1; q < MAXSEG; ++q) if (sgi == q) { sb = P.in[q]; ss = P.segS[q]; }               \
+    base_ = reinterpret_cast<const char*>(sb + cs); stride_ = (long)ss * 2;                                          \
+  }
+#define DMA_HALO_PIECE(t_, base_, stride_, buf_)                                                                     \
+  if ((t_) * 8 + wave < DA_PIECES) {                                                                                 \
+    const int v = a_src[t_];                                                                                         \
+    const char* g = v >= 0 ? (base_) + (long)(v >> 3) * (stride_) + (v & 7) * 16 : zero_src;                         \
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (buf_) * DA_BYTES + ((t_) * 8 + wave) * 1024);        \
+    GLDS16(g, dst)                                                                                                   \
+  }
+#define DMA_SLAB(step_, buf_)                                                                                        \
+  {                                                                                                                  \
+    const char* g = bsrc + (long)(step_) * DB_BYTES + wave * 1024;                                                   \
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + 2 * DA_BYTES + (buf_) * DB_BYTES + wave * 1024);      \
+    GLDS16(g, dst)                                                                                                   \
+    const char* g2 = g + 8 * 1024;                                                                                   \
+    const unsigned dst2 = dst + 8 * 1024;                                                                            \
+    GLDS16(g2, dst2)                                                                                                 \
+  }
+  // every DMA this wave has issued has landed (they were all issued a full step ago), then the workgroup barrier
+#define DMA_WAIT_BARRIER() asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory")
+  // fragment addresses of tap t_: A row = halo pixel of the lane shifted by the tap
+#define SET_TAP(t_)                                                                                                  \
+  {                                                                                                                  \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                                  \
+      const int p = pl + ((t_) / 3) * HCOLS + ((t_) % 3) + a * 32;                                                   \
+      a_row[a] = p * 128; a_x[a] = ((p >> 1) & 7) ^ kh;                                                              \
+    }                                                                                                                \
+  }
+#define LOAD_FRAGS(af_, bf_, A_, B_, ks_)                                                                            \
+  {                                                                                                                  \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                                    \
+      af_[a] = *reinterpret_cast<const half8*>((A_) + a_row[a] + ((((ks_) * 2) ^ a_x[a]) << 4));                     \
+    _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                                    \
+      bf_[b] = *reinterpret_cast<const half8*>((B_) + b_row[b] + ((((ks_) * 2) ^ b_x[b]) << 4));                     \
+    __builtin_amdgcn_sched_barrier(0);   /* keep the reads AHEAD of the previous k-step's MFMAs (hipcc sinks them) */ \
+  }
+#define MFMA_2X2(af_, bf_)                                                                                           \
+  {                                                                                                                  \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                                    \
+      _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                                  \
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af_[a], bf_[b], acc[a][b], 0, 0, 0);                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+  }
+
+  const char* nbase; long nstride;
+  DMA_SEGMENT(0, nbase, nstride)
+#pragma unroll
+  for (int t = 0; t < 7; ++t) DMA_HALO_PIECE(t, nbase, nstride, 0)
+  DMA_SLAB(0, 0)
+  if (nsteps > 1) DMA_SLAB(1, 1)
+  DMA_WAIT_BARRIER();
+
+  // Software pipeline.  Step s (tap t of chunk c) runs four k-steps of 4 MFMAs per wave; the fragments of a k-step are
+  // read from LDS one k-step ahead (two register sets), across step boundaries too.  The ONE barrier of a step sits
+  // between its k-steps 1 and 2: it publishes slab s+1 and the halo pieces issued a step ago (every DMA in flight at that
+  // point was issued after the previous step's barrier, so vmcnt(0) is the exact wait), and right after it -- every wave
+  // has finished step s-1 -- the wave issues the DMA of slab s+2 (into the buffer of slab s-1) and its halo piece of the
+  // next chunk.  No k-step waits on the barrier for its operands, so the MFMA pipe does not drain around it.
+  int a_row[2], a_x[2];
+  half8 af0[2], bf0[2], af1[2], bf1[2];
+  SET_TAP(0)
+  LOAD_FRAGS(af0, bf0, lds, lds + 2 * DA_BYTES, 0)
+  int bcur = 0;                                          // slab buffer of the current step: step % 3
+  for (int c = 0; c < nchunks; ++c) {
+    const bool more = c + 1 < nchunks;
+    if (more) DMA_SEGMENT(c + 1, nbase, nstride)
+    const char* const Acur = lds + (c & 1) * DA_BYTES;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int step = c * 9 + t;
+      const char* const Bcur = lds + 2 * DA_BYTES + bcur * DB_BYTES;
+      const int bnext = bcur == 2 ? 0 : bcur + 1;
+      if (VAR != 2) {
+        LOAD_FRAGS(af1, bf1, Acur, Bcur, 1)
+        MFMA_2X2(af0, bf0)
+        LOAD_FRAGS(af0, bf0, Acur, Bcur, 2)
+        MFMA_2X2(af1, bf1)
+      }
+      DMA_WAIT_BARRIER();
+#define ISSUE_HALO() if (t < 7 && more && (t < 7 ? t : 0) * 8 + wave < DA_PIECES) DMA_HALO_PIECE(t < 7 ? t : 0, nbase, nstride, (c + 1) & 1)
+#define ISSUE_SLAB() if (step + 2 < nsteps) { const int b2 = bcur == 0 ? 2 : bcur - 1; DMA_SLAB(step + 2, b2) }
+      if (VAR != 1) { ISSUE_HALO() ISSUE_SLAB() }
+      if (VAR != 2) {
+        LOAD_FRAGS(af1, bf1, Acur, Bcur, 3)
+        MFMA_2X2(af0, bf0)
+        SET_TAP(t == 8 ? 0 : t + 1)
+        LOAD_FRAGS(af0, bf0, (t == 8 ? lds + ((c + 1) & 1) * DA_BYTES : Acur), lds + 2 * DA_BYTES + bnext * DB_BYTES, 0)
+        MFMA_2X2(af1, bf1)
+      }
+#undef ISSUE_HALO
+#undef ISSUE_SLAB
+      bcur = bnext;
+    }
+  }
+#undef SET_TAP
+#undef LOAD_FRAGS
+#undef MFMA_2X2
+#undef DMA_SEGMENT
+#undef DMA_HALO_PIECE
+#undef DMA_SLAB
+#undef DMA_WAIT_BARRIER
+  conv_epilogue<EPI, 2, 2>(P, acc, M, m0, n0, wm0, wn0, lane, HW);
+}
+
 // mean over the rows of each segment (GraphAgg's scatter_mean over the edges of a source frame, reference
 // droid_net.py:67): out[k] = mean_{e in order[seg_off[k] .. seg_off[k+1])} x[e]; one thread = 8 channels (16 B),
 // fp32 accumulation in a fixed order, one rounding to fp16.
@@ -385,6 +580,51 @@ int launch_halo(const ConvParams& P, hipStream_t st) {
   return DH_OK;
 }
 
+template <int EPI>
+int launch_dma(const ConvParams& P, hipStream_t st) {
+  const long M = (long)P.N * P.H * P.W;
+  const dim3 grid((unsigned)(M / BM), (unsigned)(P.CoutPad / 128));
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma_kernel<EPI>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS_BYTES);
+  if (attr != hipSuccess) return DH_ERR_LAUNCH;
+  if (EPI == EPI_RELU) {                                  // timing ablations (scripts/bench_conv.py), never set in production
+    const char* env = getenv("DH_DMA_VAR");
+    const int var = env ? atoi(env) : 0;
+#define DMA_VARIANT(v_)                                                                                             \
+    if (var == v_) {                                                                                                 \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma_kernel<EPI_RELU, v_>),                      \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS_BYTES) != hipSuccess) return DH_ERR_LAUNCH; \
+      hipLaunchKernelGGL((conv3x3_dma_kernel<EPI_RELU, v_>), grid, dim3(512), DMA_LDS_BYTES, st, P);                 \
+      DH_LAUNCH_CHECK();                                                                                             \
+      return DH_OK;                                                                                                  \
+    }
+    DMA_VARIANT(1) DMA_VARIANT(2)
+#undef DMA_VARIANT
+  }
+  hipLaunchKernelGGL((conv3x3_dma_kernel<EPI>), grid, dim3(512), DMA_LDS_BYTES, st, P);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
+// Layout rule of `weights_halo` (the same rule is applied by the packer, droid_amd/update.py pack_conv_halo): 16-channel
+// slabs of the halo kernel, unless DH_CONV_DMA=1 (read by both sides) AND the cout tile is 128 AND the channel count is a
+// multiple of 64 with at least four chunks (with fewer, the un-overlapped prologue of the one-workgroup-per-CU kernel
+// dominates): then the 64-channel swizzled slabs of the LDS-DMA kernel.
+bool dma_layout(int CoutPad, int Ctot) {
+  const char* env = getenv("DH_CONV_DMA");
+  if (!env || atoi(env) != 1) return false;
+  return CoutPad % 128 == 0 && Ctot % DCK == 0 && Ctot >= 4 * DCK;
+}
+
+bool dma_ok(const ConvParams& P) {
+  const char* env = getenv("DH_CONV_HALO");                 // 0: generic loop only
+  if (env && atoi(env) == 0) return false;
+  if (!dma_layout(P.CoutPad, P.Ctot)) return false;
+  if (!P.wt_halo || P.KH != 3 || P.KW != 3 || P.W != 64 || P.H % 4) return false;
+  for (int i = 0; i < P.nseg; ++i) if (P.segC[i] % DCK || P.segS[i] % 8) return false;
+  return true;
+}
+
 // small-Cout convolutions (CoutPad == 32 or 64): bound by re-reading the activations in the generic loop
 bool halo_small_ok(const ConvParams& P, int bn) {
   if (!P.wt_halo || P.KH != 3 || P.KW != 3 || P.W != 64 || P.H % 4 || P.CoutPad != bn) return false;
@@ -399,6 +639,7 @@ bool halo_ok(const ConvParams& P) {
   // chunks -- one workgroup per CU -- and strided weight reads was slower than the generic loop inside the iteration.)
   const char* env = getenv("DH_CONV_HALO");
   if (env && atoi(env) == 0) return false;
+  if (dma_layout(P.CoutPad, P.Ctot)) return false;          // weights_halo holds the other layout
   if (!P.wt_halo || P.KH != 3 || P.KW != 3 || P.W != 64 || P.H % 4 || P.CoutPad % 128 || P.Ctot < 128) return false;
   for (int i = 0; i < P.nseg; ++i) if (P.segC[i] % HCK) return false;
   return true;
@@ -454,6 +695,16 @@ extern "C" int dh_conv2d_nhwc_f16(const void* const* inputs, const int* in_chann
   P.gterm = gterm; P.aux0 = (const __half*)aux0; P.aux0_stride = aux0_stride;
   P.aux1 = (const __half*)aux1; P.aux1_stride = aux1_stride; P.red = red;
   hipStream_t st = (hipStream_t)stream;
+  if (dma_ok(P)) {
+    switch (P.epi) {
+      case EPI_LINEAR: return launch_dma<EPI_LINEAR>(P, st);
+      case EPI_RELU: return launch_dma<EPI_RELU>(P, st);
+      case EPI_SIGMOID: return launch_dma<EPI_SIGMOID>(P, st);
+      case EPI_GRU_ZR: return launch_dma<EPI_GRU_ZR>(P, st);
+      case EPI_GRU_Q: return launch_dma<EPI_GRU_Q>(P, st);
+      default: break;
+    }
+  }
   if (halo_ok(P)) {
     switch (P.epi) {
       case EPI_LINEAR: return launch_halo<EPI_LINEAR, 128>(P, st);

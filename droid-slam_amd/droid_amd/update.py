@@ -11,6 +11,8 @@ kept NHWC fp16 between layers, the 448-channel GRU input is never concatenated, 
 single launches.  torch is used only for allocation, the per-edge 128-vector "global context" GEMVs and the
 scatter-mean over source frames (index_add_), i.e. plumbing.  There is no CPU path.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -75,19 +77,35 @@ def pack_conv(weight, bias, cin_pad=None):
     return wp.contiguous(), bp.contiguous()
 
 
+def _dma_layout(cout_pad, ctot):
+    """layout rule of `weights_halo`, the same as csrc/conv.hip dma_layout()"""
+    if os.environ.get("DH_CONV_DMA", "0") != "1":
+        return False
+    return cout_pad % 128 == 0 and ctot % 64 == 0 and ctot >= 256
+
+
 def pack_conv_halo(weight):
-    """[Cout,Ctot,3,3] -> [CoutPad/BN, Ctot/16, 9, BN, 16] f16 for the halo-tile 3x3 kernels (csrc/conv.hip; BN = 32 for
-    the small heads, 128 otherwise), or None if the shape is not eligible (Ctot % 32, kernel size)."""
+    """Second, kernel-ordered copy of a 3x3 weight [Cout,Ctot,3,3] (csrc/conv.hip), or None if the shape is not eligible.
+      * DH_CONV_DMA=1 (opt-in experiment), CoutPad % 128 == 0, Ctot % 64 == 0 and Ctot >= 256: [CoutPad/128, Ctot/64, 9, 128, 8, 8] f16 for the LDS-DMA kernel -- one
+        (tap, 64-channel chunk) slab is 128 cout rows of 128 bytes, the 16-byte slot s of row r stored at slot
+        s ^ ((r >> 1) & 7) (the bank swizzle of the kernel's ds_read addresses);
+      * otherwise [CoutPad/BN, Ctot/16, 9, BN, 16] for the halo-tile kernels (BN = 32 / 64 for the small heads, else 128)."""
     cout, ctot, kh, kw = weight.shape
-    ck = 16                                 # HCK of csrc/conv.hip
     if kh != 3 or kw != 3 or ctot % 32:
         return None
-    cp = _round_up(cout, 32)
+    cp = _round_up(cout, 32)                # CoutPad of pack_conv
+    w = torch.zeros(cp, ctot, 9, dtype=torch.float32, device=weight.device)
+    w[:cout] = weight.float().reshape(cout, ctot, 9)
+    if _dma_layout(cp, ctot):
+        w = w.reshape(cp // 128, 128, ctot // 64, 8, 8, 9).permute(0, 2, 5, 1, 3, 4)        # [T, chunk, tap, row, slot, 8]
+        r = torch.arange(128, device=weight.device)
+        src = torch.arange(8, device=weight.device)[None, :] ^ ((r[:, None] >> 1) & 7)        # stored slot s' holds slot s'^sw
+        w = torch.gather(w, 4, src[None, None, None, :, :, None].expand(*w.shape[:3], 128, 8, 8))
+        return w.half().contiguous()
+    ck = 16                                 # HCK of csrc/conv.hip
     bn = cp if cp in (32, 64) else 128      # cout tile of the kernel variant that will take this convolution
     if cp % bn:
         return None
-    w = torch.zeros(cp, ctot, 9, dtype=torch.float32, device=weight.device)
-    w[:cout] = weight.float().reshape(cout, ctot, 9)
     w = w.reshape(cp // bn, bn, ctot // ck, ck, 9).permute(0, 2, 4, 1, 3)
     return w.half().contiguous()
 

@@ -493,16 +493,20 @@ def test_update_operator_vs_oracle(db, shape):
     assert cmp(up[0], ru) <= 3e-2 * max(1.0, ru.abs().max().item())
 
 
-@pytest.mark.parametrize("halo", ["1", "0"])
-def test_conv2d_nhwc_matches_torch_conv(db, monkeypatch, halo):
-    monkeypatch.setenv("DH_CONV_HALO", halo)          # both main loops (the generic one is the fallback for other shapes)
+@pytest.mark.parametrize("halo,dma", [("1", "1"), ("1", "0"), ("0", "1")])
+def test_conv2d_nhwc_matches_torch_conv(db, monkeypatch, halo, dma):
+    monkeypatch.setenv("DH_CONV_HALO", halo)          # all three main loops: LDS-DMA 3x3, halo-tile 3x3, generic (the fallback)
+    monkeypatch.setenv("DH_CONV_DMA", dma)
     """the raw convolution entry point against torch's fp32 conv2d: 1x1 / 3x3 / 7x7, multi-segment input, all tile configs"""
     from droid_amd.update import pack_conv, pack_conv_halo, EPI_LINEAR, EPI_RELU
     torch.manual_seed(0)
     cases = [(3, 12, 16, c) for c in [((128, 64, 8), 128, 3), ((200,), 64, 1), ((8,), 32, 7), ((128,), 576, 1), ((64, 64), 4, 3)]]
-    # W == 64, H % 4 == 0, channel segments % 32 == 0: the halo-tile 3x3 fast path (image borders, 2 cout tiles,
-    # the 32-cout variant of the heads); (64,) stays on the generic loop (fewer than 128 input channels)
-    cases += [(2, 8, 64, c) for c in [((128, 64, 64), 128, 3), ((256,), 256, 3), ((64,), 256, 3), ((256,), 4, 3), ((128,), 1, 3), ((128,), 64, 3)]]
+    # W == 64, H % 4 == 0: the 3x3 fast paths (image borders, 2 cout tiles, one to seven 64-channel chunks, segments
+    # of unequal length, the 32- and 64-cout halo variants of the heads); (160, 96) has the channel count of the LDS-DMA
+    # kernel but segments that are not multiples of 64 channels (generic loop)
+    cases += [(2, 8, 64, c) for c in [((128, 64, 64), 128, 3), ((256,), 256, 3), ((64,), 256, 3), ((256,), 4, 3), ((128,), 1, 3), ((128,), 64, 3),
+                                      ((128, 128, 128, 64), 256, 3), ((96, 32), 128, 3), ((160, 96), 128, 3)]]
+    cases += [(3, 12, 64, ((64, 128), 128, 3))]
     for (N, H, W, (cins, cout, k)) in cases:
         xs = [torch.randn(N, H, W, c, device="cuda").half() for c in cins]
         wgt = torch.randn(cout, sum(cins), k, k, device="cuda") / (sum(cins) * k * k) ** 0.5
