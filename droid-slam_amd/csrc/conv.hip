@@ -350,8 +350,12 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo_kernel(ConvParams P) {
 // Measured on MI355X (1024 edges, scripts/bench_conv.py; DH_DMA_VAR selects the ablations):
 //     448->256: 7.5 ms (864 TFLOP/s)   448->128: 3.6 ms (900)     halo kernel above: 7.5 / 3.7 ms
 //     without the DMA inside the loop (stale operands): 6.1 / 3.1 ms (1.06-1.11 PFLOP/s) -- the ds_read + MFMA + barrier
-//     skeleton alone; DMA only: 3.7 / 1.8 ms.  Moving the DMA issue points (after the barrier / a k-step later / split
-//     between the two waves of a SIMD) or the fragment prefetch distance changes nothing beyond noise.
+//     skeleton alone; DMA only: 3.7 / 1.8 ms.  Skeleton ablations (no DMA): MFMA + barrier on constant operands 4.2 ms
+//     (1.56 PFLOP/s: the ceiling of this tile incl. its exposed prologue/epilogue), ds_read + barrier 2.9 ms, no barrier
+//     5.8 ms: LDS reads and MFMAs add up instead of overlapping, and the barrier is free.  Moving the DMA issue points
+//     (after the barrier / a k-step later / split between the two waves of a SIMD), the fragment prefetch distance, or
+//     running the two waves of each SIMD half a step apart (load phase | MFMA phase ping-pong, two barriers per step:
+//     8.4 ms, skeleton 5.9 ms) changes nothing or loses.
 // Inside the full update iteration it is SLOWER than the halo kernel (update operator 95.8 vs 92.3 ms at 4096 edges):
 // with one workgroup per CU the prologue (first halo + slabs) and the epilogue are not overlapped with another
 // workgroup's main loop.  Kept, tested (tests/test_gpu_parity.py runs all three main loops) and off by default; what it
@@ -373,7 +377,8 @@ __device__ __attribute__((aligned(128))) uint4 g_zero_line[8];
                  : "=&s"(keep_) : "v"(gptr_), "s"(ldsaddr_) : "memory");                                             \
   }
 
-// VAR: 0 = product; 1/2 = timing ablations (1: no DMA inside the loop, 2: no ds_read/MFMA inside the loop)
+// VAR: 0 = product; timing ablations: 1 no DMA inside the loop, 2 no ds_read/MFMA inside the loop; and without DMA:
+// 5 no ds_read (MFMA + barrier), 6 no barrier (ds_read + MFMA), 7 no MFMA (ds_read + barrier)
 template <int EPI, int VAR = 0>
 __global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(ConvParams P) {
   extern __shared__ __half s_conv[];
@@ -457,7 +462,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(ConvParams P) {
     }                                                                                                                \
   }
 #define LOAD_FRAGS(af_, bf_, A_, B_, ks_)                                                                            \
-  {                                                                                                                  \
+  if (VAR != 5) {                                                                                                    \
     _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                                    \
       af_[a] = *reinterpret_cast<const half8*>((A_) + a_row[a] + ((((ks_) * 2) ^ a_x[a]) << 4));                     \
     _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                                    \
@@ -466,9 +471,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(ConvParams P) {
   }
 #define MFMA_2X2(af_, bf_)                                                                                           \
   {                                                                                                                  \
-    _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                                    \
-      _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                                  \
-        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af_[a], bf_[b], acc[a][b], 0, 0, 0);                      \
+    if (VAR == 7) { asm volatile("" :: "v"(af_[0]), "v"(af_[1]), "v"(bf_[0]), "v"(bf_[1])); }                        \
+    else {                                                                                                           \
+      _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                                  \
+        _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                                \
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af_[a], bf_[b], acc[a][b], 0, 0, 0);                    \
+    }                                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
   }
 
@@ -488,6 +496,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(ConvParams P) {
   // next chunk.  No k-step waits on the barrier for its operands, so the MFMA pipe does not drain around it.
   int a_row[2], a_x[2];
   half8 af0[2], bf0[2], af1[2], bf1[2];
+  if (VAR == 5) { const half8 one = {1, 1, 1, 1, 1, 1, 1, 1}; af0[0] = af0[1] = bf0[0] = bf0[1] = af1[0] = af1[1] = bf1[0] = bf1[1] = one; }
   SET_TAP(0)
   LOAD_FRAGS(af0, bf0, lds, lds + 2 * DA_BYTES, 0)
   int bcur = 0;                                          // slab buffer of the current step: step % 3
@@ -506,10 +515,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(ConvParams P) {
         LOAD_FRAGS(af0, bf0, Acur, Bcur, 2)
         MFMA_2X2(af1, bf1)
       }
-      DMA_WAIT_BARRIER();
+      if (VAR != 6) DMA_WAIT_BARRIER();
 #define ISSUE_HALO() if (t < 7 && more && (t < 7 ? t : 0) * 8 + wave < DA_PIECES) DMA_HALO_PIECE(t < 7 ? t : 0, nbase, nstride, (c + 1) & 1)
 #define ISSUE_SLAB() if (step + 2 < nsteps) { const int b2 = bcur == 0 ? 2 : bcur - 1; DMA_SLAB(step + 2, b2) }
-      if (VAR != 1) { ISSUE_HALO() ISSUE_SLAB() }
+      if (VAR != 1 && VAR < 5) { ISSUE_HALO() ISSUE_SLAB() }
       if (VAR != 2) {
         LOAD_FRAGS(af1, bf1, Acur, Bcur, 3)
         MFMA_2X2(af0, bf0)
@@ -598,7 +607,7 @@ int launch_dma(const ConvParams& P, hipStream_t st) {
       DH_LAUNCH_CHECK();                                                                                             \
       return DH_OK;                                                                                                  \
     }
-    DMA_VARIANT(1) DMA_VARIANT(2)
+    DMA_VARIANT(1) DMA_VARIANT(2) DMA_VARIANT(5) DMA_VARIANT(6) DMA_VARIANT(7)
 #undef DMA_VARIANT
   }
   hipLaunchKernelGGL((conv3x3_dma_kernel<EPI>), grid, dim3(512), DMA_LDS_BYTES, st, P);

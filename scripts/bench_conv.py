@@ -23,6 +23,11 @@ for name, cins, cout, k in shapes:
     epi = EPI_LINEAR if cout <= 4 else EPI_RELU
     run = lambda: db.conv2d_nhwc(xs, wp, wh, bp, k, k, cout, epi, out, cout, None, None, None, None)
     run(); torch.cuda.synchronize()
+    if os.environ.get("DH_CHECK"):          # numerics of the first two images against torch's fp32 convolution
+        x = torch.cat([t[:2] for t in xs], -1).float().permute(0, 3, 1, 2)
+        ref = torch.nn.functional.conv2d(x, wgt.half().float(), None, padding=k // 2).permute(0, 2, 3, 1)
+        ref = ref if epi == EPI_LINEAR else ref.clamp_min(0)
+        print("   max |err| = %.4f (ref max %.2f)" % ((out[:2].float() - ref).abs().max().item(), ref.abs().max().item()))
     ts = []
     for _ in range(3):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
