@@ -514,7 +514,10 @@ __global__ void ba_damp_kernel(double* __restrict__ H, int ld, int n, int npad, 
   else H[(long)i * ld + i] = 1.0;
 }
 
-// ---- blocked Cholesky, NB = 64, two launches per block column -----------------------------------------
+// ---- blocked Cholesky, NB = 64 ------------------------------------------------------------------------
+// Default schedule: ONE launch per block column (chol_step_kernel below: trailing update of column j fused with the
+// factorisation of column j+1; 5.79 -> 5.29 ms per global BA at 512 keyframes); DH_CHOL_LOOKAHEAD=0 selects the
+// two-launch schedule described here, which is also what step 0 and the parity tests of both schedules use:
 // step j:  chol_panel_kernel  one workgroup per block row r > j (incl. the rhs row): EVERY workgroup factors the
 //                             diagonal block A_jj itself in LDS (redundant work is free, a separate launch and
 //                             its ~2 us dependency gap are not), inverts the factor (W = L_jj^-1) and forms
@@ -811,6 +814,89 @@ __global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ H
       H[(r0 + wave * 16 + (lane >> 4) + 4 * q) * ld + c0 + nt * 16 + (lane & 15)] = cur[nt][q] - acc[nt][q];
 }
 
+// One launch per block column from the second on ("look-ahead"): step j applies column j to the rest of the matrix and,
+// in the same launch, factors column j+1 -- the panel no longer waits for the whole trailing update of the previous
+// column, only for its own two blocks.
+//   workgroups 0 .. nP-1 (block rows r = j+2 .. incl. the rhs row):  A_{j+1,j+1} -= L_{j+1,j} L_{j+1,j}^T and
+//       A_{r,j+1} -= L_{r,j} L_{j+1,j}^T on the fp64 MFMA, written straight into the stacked LDS panel, then the
+//       same stacked factorisation as chol_panel_kernel -> L_{r,j+1} (workgroup 0 also stores L_{j+1,j+1});
+//   the others: A_rc -= L_rj L_cj^T for j+2 <= c <= r (chol_update_kernel's work minus block column j+1).
+__global__ __launch_bounds__(256, 1) void chol_step_kernel(double* __restrict__ H, int ld, int j, int nbk, int nP,
+                                                           int* __restrict__ meta) {
+  extern __shared__ double s_chol[];
+  double* sA = s_chol;                    // L_rj, later rows 64..127 of the stacked panel
+  double* sB = sA + NB * LDB;             // L_cj
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool panel = (int)blockIdx.x < nP;
+  int r, c;
+  if (panel) { r = j + 2 + blockIdx.x; c = j + 1; }
+  else {
+    const int u = blockIdx.x - nP, side = nP;          // block rows / columns j+2 .. j+1+side
+    r = j + 2 + u / side; c = j + 2 + u % side;
+    if (c > r || c >= nbk) return;
+  }
+  const long r0 = (long)r * NB, c0 = (long)c * NB, d0 = (long)j * NB;
+  double2 va[8], vb[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int o = tid + 256 * q;
+    va[q] = *reinterpret_cast<const double2*>(H + (r0 + (o >> 5)) * ld + d0 + (o & 31) * 2);
+    vb[q] = *reinterpret_cast<const double2*>(H + (c0 + (o >> 5)) * ld + d0 + (o & 31) * 2);
+  }
+  double cur[4][4], curd[4][4];             // A_rc and, for a panel workgroup, the diagonal block A_cc
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      cur[nt][q] = H[(r0 + wave * 16 + (lane >> 4) + 4 * q) * ld + c0 + nt * 16 + (lane & 15)];
+      if (panel) curd[nt][q] = H[(c0 + wave * 16 + (lane >> 4) + 4 * q) * ld + c0 + nt * 16 + (lane & 15)];
+    }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int o = tid + 256 * q;
+    *reinterpret_cast<double2*>(sA + (o >> 5) * LDB + (o & 31) * 2) = va[q];
+    *reinterpret_cast<double2*>(sB + (o >> 5) * LDB + (o & 31) * 2) = vb[q];
+  }
+  __syncthreads();
+  f64x4 acc[4];
+  mfma_abt_64<false>(sA, sB, wave, lane, acc);
+  if (!panel) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        H[(r0 + wave * 16 + (lane >> 4) + 4 * q) * ld + c0 + nt * 16 + (lane & 15)] = cur[nt][q] - acc[nt][q];
+    return;
+  }
+  f64x4 accd[4];
+  mfma_abt_64<false>(sB, sB, wave, lane, accd);
+  __syncthreads();                          // every wave has read both operand blocks: the panel may overwrite them
+  double* P = s_chol;                       // [128][LDB]: updated A_cc over updated A_rc
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = wave * 16 + (lane >> 4) + 4 * q, col = nt * 16 + (lane & 15);
+      P[row * LDB + col] = curd[nt][q] - accd[nt][q];
+      P[(NB + row) * LDB + col] = cur[nt][q] - acc[nt][q];
+    }
+  __syncthreads();
+  const bool ok = chol_panel128_lds(P, tid);
+  if (!ok && tid == 0) meta[1] = 1;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int o = tid + 256 * q;
+    *reinterpret_cast<double2*>(H + (r0 + (o >> 5)) * ld + c0 + (o & 31) * 2) = *reinterpret_cast<const double2*>(P + (NB + (o >> 5)) * LDB + (o & 31) * 2);
+  }
+  if (blockIdx.x == 0) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int o = tid + 256 * q;
+      *reinterpret_cast<double2*>(H + (c0 + (o >> 5)) * ld + c0 + (o & 31) * 2) = *reinterpret_cast<const double2*>(P + (o >> 5) * LDB + (o & 31) * 2);
+    }
+  }
+}
+
 // back substitution of L^T x = y (y = row `brow` of H) in groups of BG block rows per launch:
 // every workgroup solves the group's triangular system itself (x_g = W_g^T (y_g - sum_{g' > g in group} L_g'g^T x_g')),
 // workgroup 0 publishes x, workgroup 1 + q applies the group's contribution to y_q for its own q < group start.
@@ -1004,6 +1090,9 @@ int run_finish(const BaLayout& L, char* ws, float* poses, float* disps, const in
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_update_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
       if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_step_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+      if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_backsub_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
       return e;
@@ -1015,12 +1104,24 @@ int run_finish(const BaLayout& L, char* ws, float* poses, float* disps, const in
     const size_t lds_panel = sizeof(double) * 2 * NB * LDB;
     const size_t lds_inv = sizeof(double) * (2 * NB * LDB + 3 * SB * (SB + 1) + NB);
     const size_t lds_upd = sizeof(double) * 2 * NB * LDB;
-    for (int j = 0; j < L.nbk; ++j) {
-      const int m = nbrows - j - 1;
-      hipLaunchKernelGGL(chol_panel_kernel, dim3(m), dim3(256), lds_panel, st, H, L.ld, j, meta);
+    const char* la_env = getenv("DH_CHOL_LOOKAHEAD");
+    const bool two_launch = la_env && atoi(la_env) == 0;
+    if (two_launch) {                                    // reference schedule: panel, then the whole trailing update
+      for (int j = 0; j < L.nbk; ++j) {
+        const int m = nbrows - j - 1;
+        hipLaunchKernelGGL(chol_panel_kernel, dim3(m), dim3(256), lds_panel, st, H, L.ld, j, meta);
+        DH_LAUNCH_CHECK();
+        if (m > 1) hipLaunchKernelGGL(chol_update_kernel, dim3(m - 1, m), dim3(256), lds_upd, st, H, L.ld, j, L.nbk);
+        DH_LAUNCH_CHECK();
+      }
+    } else {
+      hipLaunchKernelGGL(chol_panel_kernel, dim3(nbrows - 1), dim3(256), lds_panel, st, H, L.ld, 0, meta);
       DH_LAUNCH_CHECK();
-      if (m > 1) hipLaunchKernelGGL(chol_update_kernel, dim3(m - 1, m), dim3(256), lds_upd, st, H, L.ld, j, L.nbk);
-      DH_LAUNCH_CHECK();
+      for (int j = 0; j + 1 < L.nbk; ++j) {
+        const int nP = nbrows - j - 2;                   // block rows below the diagonal block of column j+1
+        hipLaunchKernelGGL(chol_step_kernel, dim3(nP + nP * nP), dim3(256), lds_panel, st, H, L.ld, j, L.nbk, nP, meta);
+        DH_LAUNCH_CHECK();
+      }
     }
     hipLaunchKernelGGL(chol_inverse_kernel, dim3(L.nbk), dim3(256), lds_inv, st, (const double*)H, L.ld, Linv);
     DH_LAUNCH_CHECK();
