@@ -26,10 +26,11 @@
 //
 // Build: per level a true contraction over the 128 feature channels on the fp16 MFMA
 // (v_mfma_f32_16x16x32_f16), V_l = f1^T * pool_l(f2) / 16 (pooling commutes with the contraction; the
-// reference's alt path pools features the same way, corr.py:89-101).  One wave owns a source block (A
-// fragments stay in registers for the whole kernel) and streams target chunks of 64 pixels; the 64x64
-// result goes through a wave-private LDS tile that is written in skewed order and read back as 16-byte
-// pieces, so HBM only sees 16-byte aligned runs (8 per lane per chunk).
+// reference's alt path pools features the same way, corr.py:89-101).  Default: the row-ring kernel
+// (pyr_build_ring_kernel: a workgroup walks the target rows of a level, a ring of 8 >> l displacement rows in
+// LDS completes one row per step and leaves as one contiguous run of full lines; 2.75 ms per 256 edges).  The
+// first form (pyr_build_kernel, DH_PYR_BUILD=chunk: one wave per 64-target chunk, wave-private skewed LDS tile,
+// 32-byte pieces to HBM; 5.3 ms) is kept for A/B runs and as the bit-exactness partner of the ring kernel.
 //
 // Lookup: workgroup = 8-row strip of one edge (w/8 waves, one per 8x8 block), all 4 levels in one launch
 // (coords read once), separable bilinear interpolation in fp32 registers, results staged per level in
@@ -119,6 +120,7 @@ __global__ __launch_bounds__(128) void pyr_pool_kernel(__half* __restrict__ f2T,
 // ---------------------------------------------------------------------------------------- build
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 
 __device__ __forceinline__ int wrap(int a, int n) { return a < 0 ? a + n : (a >= n ? a - n : a); }
 
@@ -228,6 +230,147 @@ __global__ __launch_bounds__(256) void pyr_build_kernel(const __half* __restrict
     const int n16 = D.w2[l] * 64 / 8;
     for (int o = tid; o < n16; o += 256) z[o] = uint4{0u, 0u, 0u, 0u};
   }
+}
+
+// ---- build, second form: row ring ------------------------------------------------------------------------------------
+// The chunk kernel above hands HBM 32-byte pieces (a 128-byte line per piece on the store path) and every wave reloads
+// its target rows in half-line fragments: measured 5.3 ms per 256 edges, bound by the vector-memory path, not by the
+// MFMA or HBM.  Here a workgroup (one 8x8 source block, 4 waves = 4 source row pairs) walks the target rows of a level
+// in order.  A target row y2 contributes to the displacement rows v = y2 - y1 of the block's source rows, so a ring
+// of R = 8 >> l displacement rows in LDS ([cell pair][pixel][2], the HBM order, dword-swizzled so that the 2-byte
+// scatter of the MFMA result is conflict-free) completes exactly one row per step, which leaves as ONE contiguous run
+// (8 KB at level 0) of full lines.  The target row itself is staged once per workgroup in full 128-byte lines (LDS,
+// quad-swizzled for the ds_read_b128 of the B fragments) and prefetched a step ahead.  Steps h2 .. h2+R-2 revisit the
+// first target rows for the displacement rows that wrap around (15 % more MFMA work at level 0, nothing else).
+// one level of the ring build; NTL = 16-target tiles per target row (compile time: everything below stays in registers)
+template <int NTL>
+__device__ __forceinline__ void ring_level(const half8 (&afrag)[4], const __half* __restrict__ trow0, __half* __restrict__ lbase,
+                                           unsigned char* __restrict__ ring, unsigned char* __restrict__ sB,
+                                           int l, int h2, int w2, int by, int bx, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, yy = 2 * wave + (lane >> 5), xq = ((lane >> 4) & 1) * 4;     // pixel p_r = yy*8 + xq + r
+  const int R = 8 >> l, ybase = (by * 8) >> l;
+  const int rowbytes = w2 * 128;                                  // one displacement row: w2/2 pairs x 64 px x 4 B
+  const int nsteps = h2 + R - 1;
+  const int d = ((by * 8 + yy) >> l) - ybase;                      // this lane's source row offset inside the block
+  // byte offset inside a ring row of the value (tile nt, register r) of this lane -- the same at every step -- or -1
+  // for the padding columns of a row shorter than 16 targets
+  int soff[NTL][4];
+#pragma unroll
+  for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int x2 = nt * 16 + j, x1l = (bx * 8 + xq + r) >> l;
+      const int u = wrap(x2 - x1l, w2), up = u >> 1, p = yy * 8 + xq + r;
+      const int f = (up & 3) | ((up & 4) << 2);
+      soff[nt][r] = x2 < w2 ? ((up * 64 + (p ^ f)) << 2) + ((u & 1) << 1) : -1;
+    }
+  // B staging role: piece id = tid + 256*q -> (target id>>4, quad id&15), q < NTL.  Target rows are fetched THREE steps
+  // ahead into registers.  (A __syncthreads() would drain vmcnt and with it the prefetch: the LDS traffic of a step only
+  // needs lgkmcnt(0) + s_barrier.)
+  u32x4 breg[3][NTL];     // (native vectors: arrays of HIP's uint4 struct assigned under a condition end up in scratch)
+  int b_src[NTL], b_dst[NTL];
+#pragma unroll
+  for (int q = 0; q < NTL; ++q) {
+    const int id = tid + 256 * q, row = id >> 4, quad = id & 15;
+    b_src[q] = min(row, w2 - 1) * CH + quad * 8;
+    b_dst[q] = row * 256 + ((quad ^ (row & 15)) << 4);
+  }
+#define RING_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define RING_FETCH_B(k_, s_)                                                                                         \
+  if ((k_) < nsteps) {                                                                                               \
+    const __half* trow = trow0 + (long)((ybase + (k_)) % h2) * w2 * CH;                                              \
+    _Pragma("unroll") for (int q = 0; q < NTL; ++q) breg[s_][q] = *reinterpret_cast<const u32x4*>(trow + b_src[q]);  \
+  }
+#define RING_STEP(k_, s_)                                                                                            \
+  if ((k_) < nsteps) {                                                                                               \
+    const int k = (k_);                                                                                              \
+    _Pragma("unroll") for (int q = 0; q < NTL; ++q) *reinterpret_cast<u32x4*>(sB + b_dst[q]) = breg[s_][q];          \
+    RING_BARRIER();                         /* target row staged; last step's completed row has been read out */    \
+    RING_FETCH_B(k + 3, s_)                                                                                          \
+    const int v = k - d;                    /* displacement row this lane's pixels contribute to */                  \
+    const bool vok = v >= 0 && v < h2;                                                                               \
+    unsigned char* const rslot = ring + (v & (R - 1)) * rowbytes;                                                    \
+    f32x4 acc[NTL];                                                                                                  \
+    _Pragma("unroll") for (int nt = 0; nt < NTL; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};                          \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {        /* the tiles' accumulation chains interleaved */       \
+      half8 b[NTL];                                                                                                  \
+      _Pragma("unroll") for (int nt = 0; nt < NTL; ++nt)                                                             \
+        b[nt] = *reinterpret_cast<const half8*>(sB + (nt * 16 + j) * 256 + (((ks * 4 + (lane >> 4)) ^ j) << 4));     \
+      _Pragma("unroll") for (int nt = 0; nt < NTL; ++nt)                                                             \
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag[ks], b[nt], acc[nt], 0, 0, 0);                        \
+    }                                                                                                                \
+    if (vok) {                                                                                                       \
+      _Pragma("unroll") for (int nt = 0; nt < NTL; ++nt)                                                             \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                                \
+          if (NTL > 1 || soff[nt][r] >= 0)                                                                           \
+            *reinterpret_cast<__half*>(rslot + soff[nt][r]) = __float2half(acc[nt][r] * 0.0625f);                    \
+    }                                                                                                                \
+    RING_BARRIER();                         /* scatter complete */                                                  \
+    const int vdone = k - (R - 1);                                                                                   \
+    if (vdone >= 0 && vdone < h2) {                                                                                  \
+      const unsigned char* src = ring + (vdone & (R - 1)) * rowbytes;                                                \
+      __half* dst = lbase + (long)vdone * (rowbytes >> 1);                                                           \
+      for (int n4 = tid; n4 < w2 * 8; n4 += 256) {                                                                   \
+        const int up = n4 >> 4, p0 = (n4 & 15) << 2;                                                                 \
+        const int f = (up & 3) | ((up & 4) << 2);                                                                    \
+        const uint4 c = *reinterpret_cast<const uint4*>(src + ((up * 64 + (p0 ^ (f & 16))) << 2));                   \
+        const int sw = f & 3;               /* out[i] = in[i ^ sw] */                                                \
+        u32x4 o;            /* a native vector: member-wise built HIP uint4 stores are split into 4 dword stores */ \
+        o[0] = sw == 0 ? c.x : sw == 1 ? c.y : sw == 2 ? c.z : c.w;                                                  \
+        o[1] = sw == 0 ? c.y : sw == 1 ? c.x : sw == 2 ? c.w : c.z;                                                  \
+        o[2] = sw == 0 ? c.z : sw == 1 ? c.w : sw == 2 ? c.x : c.y;                                                  \
+        o[3] = sw == 0 ? c.w : sw == 1 ? c.z : sw == 2 ? c.y : c.x;                                                  \
+        *reinterpret_cast<u32x4*>(dst + (long)n4 * 8) = o;                                                           \
+      }                                                                                                              \
+    }                                                                                                                \
+  }
+  RING_FETCH_B(0, 0) RING_FETCH_B(1, 1) RING_FETCH_B(2, 2)
+  for (int k3 = 0; k3 < nsteps; k3 += 3) {
+    RING_STEP(k3, 0)
+    RING_STEP(k3 + 1, 1)
+    RING_STEP(k3 + 2, 2)
+  }
+#undef RING_STEP
+#undef RING_FETCH_B
+  RING_BARRIER();                           // the ring is reused by the next level
+#undef RING_BARRIER
+  // the all-zero row v = h2 of this level
+  uint4* z = reinterpret_cast<uint4*>(lbase + (long)h2 * w2 * 64);
+  for (int o = tid; o < w2 * 8; o += 256) z[o] = uint4{0u, 0u, 0u, 0u};
+}
+
+template <int W>
+__global__ __launch_bounds__(256) void pyr_build_ring_kernel(const __half* __restrict__ f1T, const __half* __restrict__ f2T,
+                                                             __half* __restrict__ pyr, PyrDims D, long f1_stride_e,
+                                                             long f2_stride_e) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_ring_raw[];
+  unsigned char* const ring = s_ring_raw;                          // [R][w2 * 32 dwords]
+  unsigned char* const sB = s_ring_raw + (size_t)W * 1024;         // [target][256 B], 16-byte quads XOR-ed with row & 15
+  const int e = blockIdx.y, sb = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int nbx = W / 8;
+  const int by = sb / nbx, bx = sb - by * nbx;
+  // A fragments of this wave's 16 source pixels (rows yy = 2*wave, 2*wave+1): lane holds A[i = lane&15][k = (lane>>4)*8..+8]
+  half8 afrag[4];
+  {
+    const int p = wave * 16 + (lane & 15);
+    const __half* row = f1T + (long)e * f1_stride_e + ((long)(by * 8 + (p >> 3)) * W + bx * 8 + (p & 7)) * CH;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) afrag[ks] = *reinterpret_cast<const half8*>(row + ks * 32 + (lane >> 4) * 8);
+  }
+  const __half* bbase = f2T + (long)e * f2_stride_e;
+  __half* obase = pyr + (long)e * D.edge_elems;
+  const int h = D.h;
+#define RING_LEVEL(l_)                                                                                               \
+  {                                                                                                                  \
+    constexpr int w2 = W >> (l_);                                                                                    \
+    constexpr int NTL = w2 >= 16 ? w2 / 16 : 1;                                                                      \
+    ring_level<NTL>(afrag, bbase + (long)D.tgt_off[l_] * CH, obase + D.lev_off[l_] + (long)sb * D.blk_elems[l_],     \
+                    ring, sB, l_, h >> (l_), w2, by, bx, tid);                                                       \
+  }
+  RING_LEVEL(0) RING_LEVEL(1) RING_LEVEL(2) RING_LEVEL(3)
+#undef RING_LEVEL
 }
 
 // ---------------------------------------------------------------------------------------- lookup
@@ -503,8 +646,27 @@ extern "C" int dh_corr_pyramid_build(const void* fmap1, const void* fmap2, void*
   for (int l = 1; l < NLEV; ++l)
     hipLaunchKernelGGL(pyr_pool_kernel, dim3(D.h2[l] * D.w2[l], E), dim3(CH), 0, st, f2T, s2, D.tgt_off[l - 1],
                        D.tgt_off[l], D.h2[l - 1], D.w2[l - 1]);
-  hipLaunchKernelGGL(pyr_build_kernel, dim3(D.nblk, E), dim3(256), 0, st, (const __half*)f1T, (const __half*)f2T,
-                     (__half*)pyramid, D, s1, s2);
+  const char* env = getenv("DH_PYR_BUILD");              // "chunk": the first form of the build kernel (A/B measurements)
+  if (env && env[0] == 'c') {
+    hipLaunchKernelGGL(pyr_build_kernel, dim3(D.nblk, E), dim3(256), 0, st, (const __half*)f1T, (const __half*)f2T,
+                       (__half*)pyramid, D, s1, s2);
+  } else {
+    const size_t lds = (size_t)w * 1024 + (size_t)(w > 16 ? w : 16) * 256;       // row ring + one staged target row
+    const dim3 grid(D.nblk, E);
+    if (w == 64) {
+      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&pyr_build_ring_kernel<64>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      if (attr != hipSuccess) return DH_ERR_LAUNCH;
+      hipLaunchKernelGGL(pyr_build_ring_kernel<64>, grid, dim3(256), lds, st, (const __half*)f1T, (const __half*)f2T,
+                         (__half*)pyramid, D, s1, s2);
+    } else if (w == 32) {
+      hipLaunchKernelGGL(pyr_build_ring_kernel<32>, grid, dim3(256), lds, st, (const __half*)f1T, (const __half*)f2T,
+                         (__half*)pyramid, D, s1, s2);
+    } else {
+      hipLaunchKernelGGL(pyr_build_ring_kernel<16>, grid, dim3(256), lds, st, (const __half*)f1T, (const __half*)f2T,
+                         (__half*)pyramid, D, s1, s2);
+    }
+  }
   DH_LAUNCH_CHECK();
   return DH_OK;
 }

@@ -444,6 +444,20 @@ def test_native_pyramid_matches_reference_layout_path_full_size(db):
     assert (a - b).abs().max() <= 2.0 ** -7 * b.abs().max()
 
 
+def test_native_pyramid_build_kernels_are_bit_identical(db, monkeypatch):
+    """the row-ring build kernel (default) and the chunk kernel (DH_PYR_BUILD=chunk) accumulate every cell in the same
+    order: the stored pyramids must be equal bit for bit, at all three supported widths"""
+    torch.manual_seed(11)
+    for (E, h, w) in [(3, 48, 64), (2, 16, 32), (2, 8, 16), (1, 24, 64)]:
+        f1 = torch.randn(E, 128, h, w, device="cuda").half()
+        f2 = torch.randn(E, 128, h, w, device="cuda").half()
+        monkeypatch.setenv("DH_PYR_BUILD", "chunk")
+        a = db.corr_pyramid_build(f1, f2)
+        monkeypatch.setenv("DH_PYR_BUILD", "ring")
+        b = db.corr_pyramid_build(f1, f2)
+        assert torch.equal(a, b)
+
+
 def test_native_pyramid_cat_and_index(db):
     from droid_amd.corr import CorrBlock
     torch.manual_seed(4)
