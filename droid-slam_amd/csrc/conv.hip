@@ -218,6 +218,88 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_kernel(ConvParams P) {
   conv_epilogue<EPI, TM, TN>(P, acc, M, m0, n0, wm0, wn0, lane, HW);
 }
 
+// ---- LDS-staged epilogue of the 256 px x 128 cout workgroup tile (halo kernel, BN = 128) -----------------------------
+// The per-element epilogue above stores 2 bytes per lane (64 store instructions per lane, two half-used lines each) and
+// gathers the GRU operands the same way; measured, prologue + epilogue cost a workgroup 11 us next to 5.5 us per
+// 16-channel chunk.  Here every wave applies bias + activation to its accumulators and parks the fp16 results in an
+// LDS tile [256 px][128 cout] (row stride 272 B); then the workgroup walks the tile in 16-byte pieces (8 couts of one
+// pixel): the GRU operands arrive as 16-byte loads, the gate algebra is applied, and a pixel's 128 couts leave as one
+// 256-byte run.  Same operations and roundings per element as conv_epilogue.
+constexpr int ELD = 128 + 8;            // LDS row stride of the staged tile (halves)
+
+template <int EPI>
+inline bool staged_epilogue_ok(const ConvParams& P) {
+  const char* env = getenv("DH_CONV_EPI_STAGED");         // 0: per-element epilogue everywhere (A/B runs)
+  if (env && atoi(env) == 0) return false;
+  if (P.out_f32 || P.Cout % 8 || P.out_stride % 8 || ((uintptr_t)P.out) % 16) return false;
+  if (EPI == EPI_GRU_ZR && (P.aux0_stride % 8 || ((uintptr_t)P.aux0) % 16)) return false;
+  if (EPI == EPI_GRU_Q && (P.aux0_stride % 8 || P.aux1_stride % 8 || ((uintptr_t)P.aux0) % 16 || ((uintptr_t)P.aux1) % 16)) return false;
+  return true;
+}
+
+template <int EPI>
+__device__ __forceinline__ void staged_epilogue(const ConvParams& P, f32x16 (&acc)[2][2], __half* __restrict__ sT, long m0, int n0,
+                                                int wm0, int wn0, int tid, int HW) {
+  const int lane = tid & 63;
+  const int img = (int)(m0 / HW);
+  __syncthreads();                        // the operand tiles of the main loop are dead
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int cl = wn0 + b * 32 + (lane & 31), co = n0 + cl;
+    const float add = (co < P.CoutPad ? P.bias[co] : 0.f) + ((P.gterm && co < P.CoutPad) ? P.gterm[(long)img * P.CoutPad + co] : 0.f);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = wm0 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        float v = acc[a][b][q] + add;
+        switch (EPI) {
+          case EPI_RELU: v = fmaxf(v, 0.f); break;
+          case EPI_SIGMOID: case EPI_GRU_ZR: v = sigmoidf_(v); break;
+          case EPI_GRU_Q: v = tanhf_(v); break;
+          default: break;
+        }
+        sT[row * ELD + cl] = __float2half(v);
+      }
+  }
+  __syncthreads();
+  // 256 px x 16 pieces; thread -> (pixel row, piece): 16 consecutive lanes cover the 256 bytes of one pixel
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int id = tid + 512 * it, row = id >> 4, c8 = (id & 15) * 8;
+    const int co = n0 + c8;
+    if (co >= P.Cout) continue;
+    const long pix = m0 + row;
+    uint4 v = *reinterpret_cast<const uint4*>(sT + row * ELD + c8);
+    if (EPI == EPI_GRU_ZR) {
+      if (co >= 128) {                                                                   // r * net
+        const uint4 hv = *reinterpret_cast<const uint4*>(P.aux0 + pix * P.aux0_stride + co - 128);
+        const __half2* a2 = reinterpret_cast<const __half2*>(&v); const __half2* h2 = reinterpret_cast<const __half2*>(&hv);
+        uint4 o; __half2* o2 = reinterpret_cast<__half2*>(&o);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float2 af = __half22float2(a2[k]), hf = __half22float2(h2[k]);
+          o2[k] = __floats2half2_rn(af.x * hf.x, af.y * hf.y);
+        }
+        v = uint4{o.x, o.y, o.z, o.w};
+      }
+    } else if (EPI == EPI_GRU_Q) {
+      const uint4 zv = *reinterpret_cast<const uint4*>(P.aux1 + pix * P.aux1_stride + co);
+      const uint4 hv = *reinterpret_cast<const uint4*>(P.aux0 + pix * P.aux0_stride + co);
+      const __half2* q2 = reinterpret_cast<const __half2*>(&v); const __half2* z2 = reinterpret_cast<const __half2*>(&zv);
+      const __half2* h2 = reinterpret_cast<const __half2*>(&hv);
+      uint4 o; __half2* o2 = reinterpret_cast<__half2*>(&o);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float2 qf = __half22float2(q2[k]), zf = __half22float2(z2[k]), hf = __half22float2(h2[k]);
+        o2[k] = __floats2half2_rn((1.f - zf.x) * hf.x + zf.x * qf.x, (1.f - zf.y) * hf.y + zf.y * qf.y);
+      }
+      v = uint4{o.x, o.y, o.z, o.w};
+    }
+    *reinterpret_cast<uint4*>(reinterpret_cast<__half*>(P.out) + pix * P.out_stride + co) = v;
+  }
+}
+
 // ---- 3x3 fast path: halo tile -----------------------------------------------------------------------------------
 // For W == 64 the 256 consecutive pixels of a workgroup are 4 full image rows.  Per 16-channel chunk the 6 x 66 pixel
 // halo of the tile is staged ONCE and all 9 taps read their A fragments from it at shifted pixel addresses, next to
@@ -236,7 +318,7 @@ constexpr int HPC = HCK / 8;             // 16-byte pieces per pixel / cout row
 // BN = 64 : waves = 4 image rows x 2 cout halves, 64 px x 32 cout per wave (flow encoder 128 -> 64).
 // BN = 32 : waves = 4 image rows x 2 half rows, 32 px x 32 cout per wave: the 2-/1-channel heads (Cout padded to 32),
 //           where the generic loop is bound by re-reading the activations 9 times from L2 (58 GB at 4096 edges).
-template <int EPI, int BN>
+template <int EPI, int BN, bool STAGED = false>
 __global__ __launch_bounds__(512, 4) void conv3x3_halo_kernel(ConvParams P) {
   constexpr int WM = BN == 32 ? 32 : 64, WN = BN == 128 ? 64 : 32, TM = WM / 32, TN = WN / 32;
   constexpr int HSLAB = 9 * BN * HCK;     // halves of one (cout tile, chunk) weight slab
@@ -334,7 +416,8 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo_kernel(ConvParams P) {
   }
 #undef HALO_FETCH
 #undef HALO_STAGE
-  conv_epilogue<EPI, TM, TN>(P, acc, M, m0, n0, wm0, wn0, lane, HW);
+  if constexpr (STAGED) staged_epilogue<EPI>(P, acc, s_conv, m0, n0, wm0, wn0, tid, HW);
+  else conv_epilogue<EPI, TM, TN>(P, acc, M, m0, n0, wm0, wn0, lane, HW);
 }
 
 // ---- 3x3 path with LDS-DMA staging: OPT-IN experiment (DH_CONV_DMA=1), not the default ----------------------------------
@@ -584,6 +667,16 @@ int launch_halo(const ConvParams& P, hipStream_t st) {
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<EPI, BN>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
   if (attr != hipSuccess) return DH_ERR_LAUNCH;
+  if constexpr (BN == 128 && (EPI == EPI_LINEAR || EPI == EPI_RELU || EPI == EPI_SIGMOID || EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q)) {
+    if (staged_epilogue_ok<EPI>(P)) {
+      static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<EPI, BN, true>),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      if (attr2 != hipSuccess) return DH_ERR_LAUNCH;
+      hipLaunchKernelGGL((conv3x3_halo_kernel<EPI, BN, true>), grid, dim3(512), lds, st, P);
+      DH_LAUNCH_CHECK();
+      return DH_OK;
+    }
+  }
   hipLaunchKernelGGL((conv3x3_halo_kernel<EPI, BN>), grid, dim3(512), lds, st, P);
   DH_LAUNCH_CHECK();
   return DH_OK;
