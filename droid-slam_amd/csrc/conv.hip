@@ -111,8 +111,92 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& P, f32x16 (&acc)
   }
 }
 
+// ---- LDS-staged epilogue of the 256 px x 128 cout workgroup tile (halo kernel, BN = 128) -----------------------------
+// The per-element epilogue above stores 2 bytes per lane (64 store instructions per lane, two half-used lines each) and
+// gathers the GRU operands the same way; measured, prologue + epilogue cost a workgroup 11 us next to 5.5 us per
+// 16-channel chunk.  Here every wave applies bias + activation to its accumulators and parks the fp16 results in an
+// LDS tile [256 px][128 cout] (row stride 272 B); then the workgroup walks the tile in 16-byte pieces (8 couts of one
+// pixel): the GRU operands arrive as 16-byte loads, the gate algebra is applied, and a pixel's 128 couts leave as one
+// 256-byte run.  Same operations and roundings per element as conv_epilogue.
+
+template <int EPI>
+inline bool staged_epilogue_ok(const ConvParams& P) {
+  const char* env = getenv("DH_CONV_EPI_STAGED");         // 0: per-element epilogue everywhere (A/B runs)
+  if (env && atoi(env) == 0) return false;
+  if (P.out_f32 || P.Cout % 8 || P.out_stride % 8 || ((uintptr_t)P.out) % 16) return false;
+  if (EPI == EPI_GRU_ZR && (P.aux0_stride % 8 || ((uintptr_t)P.aux0) % 16)) return false;
+  if (EPI == EPI_GRU_Q && (P.aux0_stride % 8 || P.aux1_stride % 8 || ((uintptr_t)P.aux0) % 16 || ((uintptr_t)P.aux1) % 16)) return false;
+  return true;
+}
+
+// TN = 32-cout accumulator tiles per wave, BNT = couts of the workgroup tile (128 or 64)
+template <int EPI, int TN, int BNT>
+__device__ __forceinline__ void staged_epilogue(const ConvParams& P, f32x16 (&acc)[2][TN], __half* __restrict__ sT, long m0, int n0,
+                                                int wm0, int wn0, int tid, int HW) {
+  constexpr int ELD = BNT + 8;            // LDS row stride of the staged tile (halves)
+  constexpr int PPR = BNT / 8;            // 16-byte pieces per pixel row
+  const int lane = tid & 63;
+  const int img = (int)(m0 / HW);
+  __syncthreads();                        // the operand tiles of the main loop are dead
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const int cl = wn0 + b * 32 + (lane & 31), co = n0 + cl;
+    const float add = (co < P.CoutPad ? P.bias[co] : 0.f) + ((P.gterm && co < P.CoutPad) ? P.gterm[(long)img * P.CoutPad + co] : 0.f);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = wm0 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        float v = acc[a][b][q] + add;
+        switch (EPI) {
+          case EPI_RELU: v = fmaxf(v, 0.f); break;
+          case EPI_SIGMOID: case EPI_GRU_ZR: v = sigmoidf_(v); break;
+          case EPI_GRU_Q: v = tanhf_(v); break;
+          default: break;
+        }
+        sT[row * ELD + cl] = __float2half(v);
+      }
+  }
+  __syncthreads();
+  // 256 px x PPR pieces; thread -> (pixel row, piece): PPR consecutive lanes cover the couts of one pixel
+#pragma unroll
+  for (int it = 0; it < PPR / 2; ++it) {
+    const int id = tid + 512 * it, row = id / PPR, c8 = (id % PPR) * 8;
+    const int co = n0 + c8;
+    if (co >= P.Cout) continue;
+    const long pix = m0 + row;
+    uint4 v = *reinterpret_cast<const uint4*>(sT + row * ELD + c8);
+    if (EPI == EPI_GRU_ZR) {
+      if (co >= 128) {                                                                   // r * net
+        const uint4 hv = *reinterpret_cast<const uint4*>(P.aux0 + pix * P.aux0_stride + co - 128);
+        const __half2* a2 = reinterpret_cast<const __half2*>(&v); const __half2* h2 = reinterpret_cast<const __half2*>(&hv);
+        uint4 o; __half2* o2 = reinterpret_cast<__half2*>(&o);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float2 af = __half22float2(a2[k]), hf = __half22float2(h2[k]);
+          o2[k] = __floats2half2_rn(af.x * hf.x, af.y * hf.y);
+        }
+        v = uint4{o.x, o.y, o.z, o.w};
+      }
+    } else if (EPI == EPI_GRU_Q) {
+      const uint4 zv = *reinterpret_cast<const uint4*>(P.aux1 + pix * P.aux1_stride + co);
+      const uint4 hv = *reinterpret_cast<const uint4*>(P.aux0 + pix * P.aux0_stride + co);
+      const __half2* q2 = reinterpret_cast<const __half2*>(&v); const __half2* z2 = reinterpret_cast<const __half2*>(&zv);
+      const __half2* h2 = reinterpret_cast<const __half2*>(&hv);
+      uint4 o; __half2* o2 = reinterpret_cast<__half2*>(&o);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float2 qf = __half22float2(q2[k]), zf = __half22float2(z2[k]), hf = __half22float2(h2[k]);
+        o2[k] = __floats2half2_rn((1.f - zf.x) * hf.x + zf.x * qf.x, (1.f - zf.y) * hf.y + zf.y * qf.y);
+      }
+      v = uint4{o.x, o.y, o.z, o.w};
+    }
+    *reinterpret_cast<uint4*>(reinterpret_cast<__half*>(P.out) + pix * P.out_stride + co) = v;
+  }
+}
+
 // WM x WN = per-wave output tile, waves arranged (BM / WM) x (BN / WN)
-template <int WM, int WN, int BN, int EPI>
+template <int WM, int WN, int BN, int EPI, bool STAGED = false>
 __global__ __launch_bounds__(512, 4) void conv_igemm_kernel(ConvParams P) {
   constexpr int WAVES_M = BM / WM, TM = WM / 32, TN = WN / 32;
   static_assert(WAVES_M * (BN / WN) == 8, "8 waves");
@@ -215,89 +299,8 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_kernel(ConvParams P) {
         for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
     }
   }
-  conv_epilogue<EPI, TM, TN>(P, acc, M, m0, n0, wm0, wn0, lane, HW);
-}
-
-// ---- LDS-staged epilogue of the 256 px x 128 cout workgroup tile (halo kernel, BN = 128) -----------------------------
-// The per-element epilogue above stores 2 bytes per lane (64 store instructions per lane, two half-used lines each) and
-// gathers the GRU operands the same way; measured, prologue + epilogue cost a workgroup 11 us next to 5.5 us per
-// 16-channel chunk.  Here every wave applies bias + activation to its accumulators and parks the fp16 results in an
-// LDS tile [256 px][128 cout] (row stride 272 B); then the workgroup walks the tile in 16-byte pieces (8 couts of one
-// pixel): the GRU operands arrive as 16-byte loads, the gate algebra is applied, and a pixel's 128 couts leave as one
-// 256-byte run.  Same operations and roundings per element as conv_epilogue.
-constexpr int ELD = 128 + 8;            // LDS row stride of the staged tile (halves)
-
-template <int EPI>
-inline bool staged_epilogue_ok(const ConvParams& P) {
-  const char* env = getenv("DH_CONV_EPI_STAGED");         // 0: per-element epilogue everywhere (A/B runs)
-  if (env && atoi(env) == 0) return false;
-  if (P.out_f32 || P.Cout % 8 || P.out_stride % 8 || ((uintptr_t)P.out) % 16) return false;
-  if (EPI == EPI_GRU_ZR && (P.aux0_stride % 8 || ((uintptr_t)P.aux0) % 16)) return false;
-  if (EPI == EPI_GRU_Q && (P.aux0_stride % 8 || P.aux1_stride % 8 || ((uintptr_t)P.aux0) % 16 || ((uintptr_t)P.aux1) % 16)) return false;
-  return true;
-}
-
-template <int EPI>
-__device__ __forceinline__ void staged_epilogue(const ConvParams& P, f32x16 (&acc)[2][2], __half* __restrict__ sT, long m0, int n0,
-                                                int wm0, int wn0, int tid, int HW) {
-  const int lane = tid & 63;
-  const int img = (int)(m0 / HW);
-  __syncthreads();                        // the operand tiles of the main loop are dead
-#pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const int cl = wn0 + b * 32 + (lane & 31), co = n0 + cl;
-    const float add = (co < P.CoutPad ? P.bias[co] : 0.f) + ((P.gterm && co < P.CoutPad) ? P.gterm[(long)img * P.CoutPad + co] : 0.f);
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int row = wm0 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-        float v = acc[a][b][q] + add;
-        switch (EPI) {
-          case EPI_RELU: v = fmaxf(v, 0.f); break;
-          case EPI_SIGMOID: case EPI_GRU_ZR: v = sigmoidf_(v); break;
-          case EPI_GRU_Q: v = tanhf_(v); break;
-          default: break;
-        }
-        sT[row * ELD + cl] = __float2half(v);
-      }
-  }
-  __syncthreads();
-  // 256 px x 16 pieces; thread -> (pixel row, piece): 16 consecutive lanes cover the 256 bytes of one pixel
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int id = tid + 512 * it, row = id >> 4, c8 = (id & 15) * 8;
-    const int co = n0 + c8;
-    if (co >= P.Cout) continue;
-    const long pix = m0 + row;
-    uint4 v = *reinterpret_cast<const uint4*>(sT + row * ELD + c8);
-    if (EPI == EPI_GRU_ZR) {
-      if (co >= 128) {                                                                   // r * net
-        const uint4 hv = *reinterpret_cast<const uint4*>(P.aux0 + pix * P.aux0_stride + co - 128);
-        const __half2* a2 = reinterpret_cast<const __half2*>(&v); const __half2* h2 = reinterpret_cast<const __half2*>(&hv);
-        uint4 o; __half2* o2 = reinterpret_cast<__half2*>(&o);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float2 af = __half22float2(a2[k]), hf = __half22float2(h2[k]);
-          o2[k] = __floats2half2_rn(af.x * hf.x, af.y * hf.y);
-        }
-        v = uint4{o.x, o.y, o.z, o.w};
-      }
-    } else if (EPI == EPI_GRU_Q) {
-      const uint4 zv = *reinterpret_cast<const uint4*>(P.aux1 + pix * P.aux1_stride + co);
-      const uint4 hv = *reinterpret_cast<const uint4*>(P.aux0 + pix * P.aux0_stride + co);
-      const __half2* q2 = reinterpret_cast<const __half2*>(&v); const __half2* z2 = reinterpret_cast<const __half2*>(&zv);
-      const __half2* h2 = reinterpret_cast<const __half2*>(&hv);
-      uint4 o; __half2* o2 = reinterpret_cast<__half2*>(&o);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float2 qf = __half22float2(q2[k]), zf = __half22float2(z2[k]), hf = __half22float2(h2[k]);
-        o2[k] = __floats2half2_rn((1.f - zf.x) * hf.x + zf.x * qf.x, (1.f - zf.y) * hf.y + zf.y * qf.y);
-      }
-      v = uint4{o.x, o.y, o.z, o.w};
-    }
-    *reinterpret_cast<uint4*>(reinterpret_cast<__half*>(P.out) + pix * P.out_stride + co) = v;
-  }
+  if constexpr (STAGED) staged_epilogue<EPI, TN, BN>(P, acc, s_conv, m0, n0, wm0, wn0, tid, HW);
+  else conv_epilogue<EPI, TM, TN>(P, acc, M, m0, n0, wm0, wn0, lane, HW);
 }
 
 // ---- 3x3 fast path: halo tile -----------------------------------------------------------------------------------
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo_kernel(ConvParams P) {
   }
 #undef HALO_FETCH
 #undef HALO_STAGE
-  if constexpr (STAGED) staged_epilogue<EPI>(P, acc, s_conv, m0, n0, wm0, wn0, tid, HW);
+  if constexpr (STAGED) staged_epilogue<EPI, TN, BN>(P, acc, s_conv, m0, n0, wm0, wn0, tid, HW);
   else conv_epilogue<EPI, TM, TN>(P, acc, M, m0, n0, wm0, wn0, lane, HW);
 }
 
@@ -654,6 +657,18 @@ int launch_epi(const ConvParams& P, hipStream_t st) {
   const long M = (long)P.N * P.H * P.W;
   const dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((P.CoutPad + BN - 1) / BN));
   const size_t lds = (size_t)(BM + BN) * LDT * sizeof(__half);
+  if constexpr (BN == 128 && WM == 64 && WN == 64 && (EPI == EPI_LINEAR || EPI == EPI_RELU || EPI == EPI_SIGMOID)) {
+    // whole tiles inside one image: the LDS-staged epilogue (its tile is larger than the operand tiles of the loop)
+    if (M % BM == 0 && ((long)P.H * P.W) % BM == 0 && staged_epilogue_ok<EPI>(P)) {
+      constexpr size_t lds_st = (size_t)BM * (BN + 8) * sizeof(__half);
+      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WM, WN, BN, EPI, true>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      if (attr != hipSuccess) return DH_ERR_LAUNCH;
+      hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, BN, EPI, true>), grid, dim3(512), lds_st > lds ? lds_st : lds, st, P);
+      DH_LAUNCH_CHECK();
+      return DH_OK;
+    }
+  }
   hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, BN, EPI>), grid, dim3(512), lds, st, P);
   DH_LAUNCH_CHECK();
   return DH_OK;
@@ -667,7 +682,7 @@ int launch_halo(const ConvParams& P, hipStream_t st) {
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<EPI, BN>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
   if (attr != hipSuccess) return DH_ERR_LAUNCH;
-  if constexpr (BN == 128 && (EPI == EPI_LINEAR || EPI == EPI_RELU || EPI == EPI_SIGMOID || EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q)) {
+  if constexpr ((BN == 128 || BN == 64) && (EPI == EPI_LINEAR || EPI == EPI_RELU || EPI == EPI_SIGMOID || EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q)) {
     if (staged_epilogue_ok<EPI>(P)) {
       static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<EPI, BN, true>),
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
