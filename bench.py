@@ -221,6 +221,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # setup, not part of the W warm-up steps: the first two passes load the code objects, opt kernels into >64 KB of LDS
+    # and let torch's caching allocator reach its steady-state pool (its hipMallocs synchronise the device)
+    for _ in range(2):
+        step(False)
     for _ in range(args.warmup):
         step(False)
     barrier()
