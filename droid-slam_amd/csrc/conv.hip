@@ -123,6 +123,7 @@ template <int EPI>
 inline bool staged_epilogue_ok(const ConvParams& P) {
   const char* env = getenv("DH_CONV_EPI_STAGED");         // 0: per-element epilogue everywhere (A/B runs)
   if (env && atoi(env) == 0) return false;
+  if (EPI == EPI_GLO) return P.Cout % 8 == 0 && P.aux0_stride % 8 == 0 && ((uintptr_t)P.aux0) % 16 == 0;
   if (P.out_f32 || P.Cout % 8 || P.out_stride % 8 || ((uintptr_t)P.out) % 16) return false;
   if (EPI == EPI_GRU_ZR && (P.aux0_stride % 8 || ((uintptr_t)P.aux0) % 16)) return false;
   if (EPI == EPI_GRU_Q && (P.aux0_stride % 8 || P.aux1_stride % 8 || ((uintptr_t)P.aux0) % 16 || ((uintptr_t)P.aux1) % 16)) return false;
@@ -192,6 +193,62 @@ __device__ __forceinline__ void staged_epilogue(const ConvParams& P, f32x16 (&ac
       v = uint4{o.x, o.y, o.z, o.w};
     }
     *reinterpret_cast<uint4*>(reinterpret_cast<__half*>(P.out) + pix * P.out_stride + co) = v;
+  }
+}
+
+// EPI_GLO through the same staged tile: sigmoid gate -> LDS, gate * feature with 16-byte operand loads, per-cout sum
+// over the 256 pixels of the tile in registers / cross-lane / LDS, ONE atomic per (workgroup, cout) instead of one per
+// (wave, cout) fed by 2-byte gathers.  Needs the whole tile inside one image.
+__device__ __forceinline__ void staged_glo_epilogue(const ConvParams& P, f32x16 (&acc)[2][2], __half* __restrict__ sT, long m0, int n0,
+                                                    int wm0, int wn0, int tid, int HW) {
+  constexpr int ELD = 128 + 8;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int img = (int)(m0 / HW);
+  __syncthreads();
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int cl = wn0 + b * 32 + (lane & 31), co = n0 + cl;
+    const float add = co < P.CoutPad ? P.bias[co] : 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = wm0 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        sT[row * ELD + cl] = __float2half(sigmoidf_(acc[a][b][q] + add));
+      }
+  }
+  __syncthreads();
+  const int c8 = (tid & 15) * 8, co = n0 + c8;
+  float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (co < P.Cout) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = (tid >> 4) + 32 * it;
+      const uint4 g = *reinterpret_cast<const uint4*>(sT + row * ELD + c8);
+      const uint4 f = *reinterpret_cast<const uint4*>(P.aux0 + (m0 + row) * P.aux0_stride + co);
+      const __half2* g2 = reinterpret_cast<const __half2*>(&g); const __half2* f2 = reinterpret_cast<const __half2*>(&f);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float2 gf = __half22float2(g2[k]), ff = __half22float2(f2[k]);
+        sum[2 * k] += round_h(gf.x * ff.x); sum[2 * k + 1] += round_h(gf.y * ff.y);
+      }
+    }
+  }
+  // lanes l, l^16, l^32, l^48 hold the same couts
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { sum[k] += __shfl_xor(sum[k], 16, 64); sum[k] += __shfl_xor(sum[k], 32, 64); }
+  __syncthreads();                          // the staged tile is dead: reuse its head as [8 waves][128] floats
+  float* sR = reinterpret_cast<float*>(sT);
+  if (lane < 16) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sR[wave * 128 + c8 + k] = sum[k];
+  }
+  __syncthreads();
+  if (tid < 128 && n0 + tid < P.Cout) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) t += sR[w * 128 + tid];
+    atomicAdd(&P.red[(long)img * P.Cout + n0 + tid], t);
   }
 }
 
@@ -299,7 +356,8 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_kernel(ConvParams P) {
         for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
     }
   }
-  if constexpr (STAGED) staged_epilogue<EPI, TN, BN>(P, acc, s_conv, m0, n0, wm0, wn0, tid, HW);
+  if constexpr (STAGED && EPI == EPI_GLO) staged_glo_epilogue(P, acc, s_conv, m0, n0, wm0, wn0, tid, HW);
+  else if constexpr (STAGED) staged_epilogue<EPI, TN, BN>(P, acc, s_conv, m0, n0, wm0, wn0, tid, HW);
   else conv_epilogue<EPI, TM, TN>(P, acc, M, m0, n0, wm0, wn0, lane, HW);
 }
 
@@ -657,7 +715,7 @@ int launch_epi(const ConvParams& P, hipStream_t st) {
   const long M = (long)P.N * P.H * P.W;
   const dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((P.CoutPad + BN - 1) / BN));
   const size_t lds = (size_t)(BM + BN) * LDT * sizeof(__half);
-  if constexpr (BN == 128 && WM == 64 && WN == 64 && (EPI == EPI_LINEAR || EPI == EPI_RELU || EPI == EPI_SIGMOID)) {
+  if constexpr (BN == 128 && WM == 64 && WN == 64 && (EPI == EPI_LINEAR || EPI == EPI_RELU || EPI == EPI_SIGMOID || EPI == EPI_GLO)) {
     // whole tiles inside one image: the LDS-staged epilogue (its tile is larger than the operand tiles of the loop)
     if (M % BM == 0 && ((long)P.H * P.W) % BM == 0 && staged_epilogue_ok<EPI>(P)) {
       constexpr size_t lds_st = (size_t)BM * (BN + 8) * sizeof(__half);
