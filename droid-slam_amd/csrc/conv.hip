@@ -370,10 +370,11 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_kernel(ConvParams P) {
 // slab is read from a second, pre-packed copy [cout tile][chunk][tap][128][16] in which a chunk's slab is one
 // contiguous 36 KB run (fully coalesced 1 KB wave loads) and the halo is read as 32-byte runs per pixel.  The generic
 // loop moves ~9x the activations through the L2->L1 path (measured 8.5 TB/s on a 128->128 convolution: at its limit).
-constexpr int HCK = 16;                  // channels per chunk
-constexpr int HLD = HCK + 8;             // LDS row stride (halves): 80 B, 16 consecutive rows hit 16 disjoint bank quads
+// channels per chunk: 16 for the 128-cout tile (74 KB of LDS, two workgroups per CU), 32 for the 64- and 32-cout
+// tiles, whose weight slabs are small and whose time goes into fetching the halo (64-byte instead of 32-byte runs
+// per pixel: half the lines touched per channel)
+constexpr int halo_ck(int bn) { return bn == 128 ? 16 : 32; }
 constexpr int HROWS = 6, HCOLS = 66, HPIX = HROWS * HCOLS;
-constexpr int HPC = HCK / 8;             // 16-byte pieces per pixel / cout row
 
 // BN = 128: waves = 4 image rows x 2 cout halves, 64 px x 64 cout per wave (every 3x3 convolution with >= 128 couts).
 // BN = 64 : waves = 4 image rows x 2 cout halves, 64 px x 32 cout per wave (flow encoder 128 -> 64).
@@ -382,6 +383,9 @@ constexpr int HPC = HCK / 8;             // 16-byte pieces per pixel / cout row
 template <int EPI, int BN, bool STAGED = false>
 __global__ __launch_bounds__(512, 4) void conv3x3_halo_kernel(ConvParams P) {
   constexpr int WM = BN == 32 ? 32 : 64, WN = BN == 128 ? 64 : 32, TM = WM / 32, TN = WN / 32;
+  constexpr int HCK = halo_ck(BN);        // channels per chunk
+  constexpr int HLD = HCK + 8;            // LDS row stride (halves): 48 or 80 B, 16 consecutive rows hit 16 disjoint bank quads
+  constexpr int HPC = HCK / 8;            // 16-byte pieces per pixel / cout row
   constexpr int HSLAB = 9 * BN * HCK;     // halves of one (cout tile, chunk) weight slab
   extern __shared__ __half s_conv[];
   __half* sA = s_conv;                    // [HPIX][HLD]
@@ -736,7 +740,7 @@ template <int EPI, int BN>
 int launch_halo(const ConvParams& P, hipStream_t st) {
   const long M = (long)P.N * P.H * P.W;
   const dim3 grid((unsigned)(M / BM), (unsigned)(P.CoutPad / BN));
-  const size_t lds = (size_t)(HPIX + 9 * BN) * HLD * sizeof(__half);
+  const size_t lds = (size_t)(HPIX + 9 * BN) * (halo_ck(BN) + 8) * sizeof(__half);
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<EPI, BN>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
   if (attr != hipSuccess) return DH_ERR_LAUNCH;
@@ -803,7 +807,7 @@ bool dma_ok(const ConvParams& P) {
 // small-Cout convolutions (CoutPad == 32 or 64): bound by re-reading the activations in the generic loop
 bool halo_small_ok(const ConvParams& P, int bn) {
   if (!P.wt_halo || P.KH != 3 || P.KW != 3 || P.W != 64 || P.H % 4 || P.CoutPad != bn) return false;
-  for (int i = 0; i < P.nseg; ++i) if (P.segC[i] % HCK) return false;
+  for (int i = 0; i < P.nseg; ++i) if (P.segC[i] % halo_ck(bn)) return false;
   return true;
 }
 
@@ -816,7 +820,7 @@ bool halo_ok(const ConvParams& P) {
   if (env && atoi(env) == 0) return false;
   if (dma_layout(P.CoutPad, P.Ctot)) return false;          // weights_halo holds the other layout
   if (!P.wt_halo || P.KH != 3 || P.KW != 3 || P.W != 64 || P.H % 4 || P.CoutPad % 128 || P.Ctot < 128) return false;
-  for (int i = 0; i < P.nseg; ++i) if (P.segC[i] % HCK) return false;
+  for (int i = 0; i < P.nseg; ++i) if (P.segC[i] % halo_ck(128)) return false;
   return true;
 }
 

@@ -89,7 +89,8 @@ def pack_conv_halo(weight):
       * DH_CONV_DMA=1 (opt-in experiment), CoutPad % 128 == 0, Ctot % 64 == 0 and Ctot >= 256: [CoutPad/128, Ctot/64, 9, 128, 8, 8] f16 for the LDS-DMA kernel -- one
         (tap, 64-channel chunk) slab is 128 cout rows of 128 bytes, the 16-byte slot s of row r stored at slot
         s ^ ((r >> 1) & 7) (the bank swizzle of the kernel's ds_read addresses);
-      * otherwise [CoutPad/BN, Ctot/16, 9, BN, 16] for the halo-tile kernels (BN = 32 / 64 for the small heads, else 128)."""
+      * otherwise [CoutPad/BN, Ctot/CK, 9, BN, CK] for the halo-tile kernels (BN = 32 / 64 with 32-channel chunks for the
+        small heads, else BN = 128 with 16-channel chunks)."""
     cout, ctot, kh, kw = weight.shape
     if kh != 3 or kw != 3 or ctot % 32:
         return None
@@ -102,8 +103,8 @@ def pack_conv_halo(weight):
         src = torch.arange(8, device=weight.device)[None, :] ^ ((r[:, None] >> 1) & 7)        # stored slot s' holds slot s'^sw
         w = torch.gather(w, 4, src[None, None, None, :, :, None].expand(*w.shape[:3], 128, 8, 8))
         return w.half().contiguous()
-    ck = 16                                 # HCK of csrc/conv.hip
     bn = cp if cp in (32, 64) else 128      # cout tile of the kernel variant that will take this convolution
+    ck = 16 if bn == 128 else 32            # halo_ck() of csrc/conv.hip
     if cp % bn:
         return None
     w = w.reshape(cp // bn, bn, ctot // ck, ck, 9).permute(0, 2, 4, 1, 3)
