@@ -374,6 +374,7 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_kernel(ConvParams P) {
 // tiles, whose weight slabs are small and whose time goes into fetching the halo (64-byte instead of 32-byte runs
 // per pixel: half the lines touched per channel)
 constexpr int halo_ck(int bn) { return bn == 128 ? 16 : 32; }
+constexpr int halo_afc(int bn) { return bn == 32 ? 2 : 1; }     // chunks per halo fetch (see the kernel)
 constexpr int HROWS = 6, HCOLS = 66, HPIX = HROWS * HCOLS;
 
 // BN = 128: waves = 4 image rows x 2 cout halves, 64 px x 64 cout per wave (every 3x3 convolution with >= 128 couts).
@@ -400,23 +401,32 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo_kernel(ConvParams P) {
   const int HW = P.H * P.W;
   const int img = (int)(m0 / HW), y0 = (int)((m0 - (long)img * HW) / 64);
 
-  constexpr int A_PIECES = (HPIX * HPC + 511) / 512, B_PIECES = (9 * BN * HPC + 511) / 512;     // 4; 9 or 3
+  // Measured (448->256, 1024 edges): without the halo fetch 7.2 -> 5.2 ms, without the weight fetch 5.8 ms, without
+  // both 4.2 ms = 1.56 PFLOP/s -- the fetch path (cost ~ 128-byte lines touched per wave load, not bytes) is what holds
+  // this kernel back.  Where registers allow (the 32-cout tile) the halo is therefore FETCHED for AFC = 2 chunks at a
+  // time (full 128-byte lines per pixel) and staged one chunk at a time: a thread's pieces all belong to the same chunk
+  // of the pair (512 % APP == 0), so at each chunk the threads of that chunk write theirs.  On the 128- and 64-cout
+  // tiles the 8-16 extra registers spill inside the loop at the 128-VGPR budget of two workgroups per CU (9.6 vs 7.2 ms).
+  constexpr int AFC = halo_afc(BN), APP = AFC * HPC;            // chunks per halo fetch, 16-byte pieces per pixel per fetch
+  constexpr int A_PIECES = (HPIX * APP + 511) / 512, B_PIECES = (9 * BN * HPC + 511) / 512;
   int a_off[A_PIECES]; bool a_ok[A_PIECES];
 #pragma unroll
   for (int i = 0; i < A_PIECES; ++i) {
-    const int id = tid + 512 * i, hp = id / HPC;
+    const int id = tid + 512 * i, hp = id / APP;
     const int hy = hp / HCOLS, hx = hp - hy * HCOLS;
     const int y = y0 - 1 + hy, x = hx - 1;
     a_ok[i] = hp < HPIX && (unsigned)y < (unsigned)P.H && (unsigned)x < 64u;
     a_off[i] = a_ok[i] ? (img * P.H + y) * 64 + x : 0;
   }
+  const int aq = tid % APP;                                     // this thread's piece inside the pixel's fetched run
+  const int a_phase = aq / HPC, a_c8 = (aq % HPC) * 8;          // chunk of the pair it belongs to, offset inside the LDS row
   const int c8 = (tid % HPC) * 8;
   const int nchunks = P.Ctot / HCK;
   const __half* bslab = P.wt_halo + ((long)blockIdx.y * nchunks) * HSLAB + tid * 8;     // + chunk * HSLAB + i * 4096
 
   uint4 ra[A_PIECES], rb[B_PIECES];
   // (written as macros: with by-reference lambdas hipcc keeps ra/rb in scratch memory)
-#define HALO_FETCH(chunk_)                                                                                           \
+#define HALO_FETCH_A(chunk_)                                                                                         \
   {                                                                                                                  \
     int cs = (chunk_) * HCK, sgi = 0;                                                                                \
     _Pragma("unroll") for (int q = 0; q < MAXSEG - 1; ++q)                                                           \
@@ -424,9 +434,12 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo_kernel(ConvParams P) {
     const __half* base = P.in[0]; int segs = P.segS[0];                                                              \
     _Pragma("unroll") for (int q = 1; q < MAXSEG; ++q) if (sgi == q) { base = P.in[q]; segs = P.segS[q]; }           \
     _Pragma("unroll") for (int i = 0; i < A_PIECES; ++i) {                                                           \
-      const uint4 v = *reinterpret_cast<const uint4*>(base + (long)a_off[i] * segs + cs + c8);                       \
+      const uint4 v = *reinterpret_cast<const uint4*>(base + (long)a_off[i] * segs + cs + aq * 8);                   \
       ra[i] = keep_if(a_ok[i], v);                                                                                   \
     }                                                                                                                \
+  }
+#define HALO_FETCH_B(chunk_)                                                                                         \
+  {                                                                                                                  \
     _Pragma("unroll") for (int i = 0; i < B_PIECES; ++i)                                                             \
     {                                                                                                                \
       const bool inb = tid + 512 * i < 9 * BN * HPC;                                                                 \
@@ -434,11 +447,13 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo_kernel(ConvParams P) {
       rb[i] = uint4{v.x, v.y, v.z, v.w};                                                                             \
     }                                                                                                                \
   }
-#define HALO_STAGE()                                                                                                 \
+#define HALO_STAGE(chunk_)                                                                                           \
   {                                                                                                                  \
-    _Pragma("unroll") for (int i = 0; i < A_PIECES; ++i) {                                                           \
-      const int id = tid + 512 * i;                                                                                  \
-      if (id < HPIX * HPC) *reinterpret_cast<uint4*>(sA + (id / HPC) * HLD + c8) = ra[i];                            \
+    if (a_phase == ((chunk_) % AFC)) {                                                                               \
+      _Pragma("unroll") for (int i = 0; i < A_PIECES; ++i) {                                                         \
+        const int id = tid + 512 * i;                                                                                \
+        if (id < HPIX * APP) *reinterpret_cast<uint4*>(sA + (id / APP) * HLD + a_c8) = ra[i];                        \
+      }                                                                                                              \
     }                                                                                                                \
     _Pragma("unroll") for (int i = 0; i < B_PIECES; ++i) {                                                           \
       const int id = tid + 512 * i;                                                                                  \
@@ -454,12 +469,16 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo_kernel(ConvParams P) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
 
-  HALO_FETCH(0)
+  HALO_FETCH_A(0)
+  HALO_FETCH_B(0)
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     __syncthreads();
-    HALO_STAGE()
+    HALO_STAGE(chunk)
     __syncthreads();
-    if (chunk + 1 < nchunks) HALO_FETCH(chunk + 1)
+    if (chunk + 1 < nchunks) {
+      HALO_FETCH_B(chunk + 1)
+      if ((chunk + 1) % AFC == 0) HALO_FETCH_A(chunk + 1)      // the registers of the pair were released by this chunk's stage
+    }
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const int dy = t / 3, dx = t - dy * 3;
@@ -479,7 +498,8 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo_kernel(ConvParams P) {
       }
     }
   }
-#undef HALO_FETCH
+#undef HALO_FETCH_A
+#undef HALO_FETCH_B
 #undef HALO_STAGE
   if constexpr (STAGED) staged_epilogue<EPI, TN, BN>(P, acc, s_conv, m0, n0, wm0, wn0, tid, HW);
   else conv_epilogue<EPI, TM, TN>(P, acc, M, m0, n0, wm0, wn0, lane, HW);
@@ -807,7 +827,7 @@ bool dma_ok(const ConvParams& P) {
 // small-Cout convolutions (CoutPad == 32 or 64): bound by re-reading the activations in the generic loop
 bool halo_small_ok(const ConvParams& P, int bn) {
   if (!P.wt_halo || P.KH != 3 || P.KW != 3 || P.W != 64 || P.H % 4 || P.CoutPad != bn) return false;
-  for (int i = 0; i < P.nseg; ++i) if (P.segC[i] % halo_ck(bn)) return false;
+  for (int i = 0; i < P.nseg; ++i) if (P.segC[i] % (halo_afc(bn) * halo_ck(bn))) return false;
   return true;
 }
 
