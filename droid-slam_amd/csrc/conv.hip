@@ -709,6 +709,140 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(ConvParams P) {
   conv_epilogue<EPI, 2, 2>(P, acc, M, m0, n0, wm0, wn0, lane, HW);
 }
 
+// ---- 3x3, 128-cout tile, second form: weights by LDS-DMA, halo in 64-byte runs ----------------------------------------
+// The ablation of conv3x3_halo_kernel says its fetch path is the bound (no halo fetch 7.2 -> 5.2 ms, no weight fetch
+// 5.8 ms, neither 4.2 ms at 448->256 / 1024 edges) and that the cost goes with the 128-byte lines a wave load touches; a
+// 64-byte run per halo pixel would halve the halo's lines but its staging registers do not fit next to the weight
+// staging registers in the 128-VGPR budget of two workgroups per CU.  So here the WEIGHTS do not pass through registers
+// at all: a (32-channel chunk, kernel row dy) group = 3 taps x 128 couts x 64 B = 24 KB arrives by
+// `global_load_lds_dwordx4` into one of two LDS buffers while the previous group is being multiplied, and the halo is
+// fetched 32 channels at a time (one 64-byte run per pixel, 16 registers) and staged once per chunk.  LDS rows are 64 B
+// unpadded, 16-byte slots XOR-swizzled with bits 2..3 of the row index (conflict-free ds_read_b128; the weights are
+// pre-packed in that order: [cout tile][chunk][dy][dx][128][4 slots][8]).  74.5 KB of LDS, two workgroups per CU, one
+// barrier per 24 MFMAs per wave plus one per chunk for the halo hand-over; the epilogue is the LDS-staged one.
+// Measured at 448->256, 1024 edges: 6.84 ms against 7.18-7.33 ms; without the halo fetch 5.64, without the weight DMA 5.96,
+// without both 4.55 ms (the first halo kernel: 5.24 / 5.83 / 4.17) -- the fetch path costs 2.3 instead of 3.0 ms, the
+// skeleton with its smaller steps 0.4 ms more; inside the full iteration 80.9 against 84.4 ms per step.
+constexpr int H2CK = 32;
+constexpr int H2A_BYTES = HPIX * H2CK * 2;               // 25,344: halo [396 px][32 ch]
+constexpr int H2B_BYTES = 3 * 128 * H2CK * 2;            // 24,576: one (chunk, dy) weight group
+constexpr int H2_LDS_BYTES = H2A_BYTES + 2 * H2B_BYTES;  // 74,496 (the staged epilogue tile needs 69,632)
+
+template <int EPI>
+__global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
+  extern __shared__ __half s_conv[];
+  char* const lds = reinterpret_cast<char*>(s_conv);
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)s_conv;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wrow = wave & 3, wn0 = (wave >> 2) * 64, wm0 = wrow * 64;
+  const long m0 = (long)blockIdx.x * BM;
+  const int n0 = blockIdx.y * 128;
+  const int HW = P.H * P.W;
+  const int img = (int)(m0 / HW), y0 = (int)((m0 - (long)img * HW) / 64);
+  const int nchunks = P.Ctot / H2CK, nsteps = nchunks * 3;
+
+  // halo roles: piece id = tid + 512*i -> (halo pixel id >> 2, 16-byte slot id & 3 of its 64-byte run)
+  constexpr int A_PIECES = (HPIX * 4 + 511) / 512;       // 4
+  int a_off[A_PIECES]; bool a_ok[A_PIECES];
+#pragma unroll
+  for (int i = 0; i < A_PIECES; ++i) {
+    const int hp = (tid >> 2) + 128 * i;
+    const int hy = hp / HCOLS, hx = hp - hy * HCOLS;
+    const int y = y0 - 1 + hy, x = hx - 1;
+    a_ok[i] = hp < HPIX && (unsigned)y < (unsigned)P.H && (unsigned)x < 64u;
+    a_off[i] = a_ok[i] ? (img * P.H + y) * 64 + x : 0;
+  }
+  const int aq = tid & 3;
+  const int a_dst0 = (tid >> 2) * 64 + ((aq ^ ((tid >> 4) & 3)) << 4);      // + i * 128 * 64 (the swizzle term is the same for every i)
+  const char* const bsrc = reinterpret_cast<const char*>(P.wt_halo) + (long)blockIdx.y * nsteps * H2B_BYTES + lane * 16;
+
+  // fragment addressing: 16-byte slot s of row r sits at r*64 + ((s ^ ((r >> 2) & 3)) << 4)
+  const int pl = wrow * HCOLS + (lane & 31), kh = lane >> 5;
+  int b_row[2], b_x[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int r = wn0 + b * 32 + (lane & 31);
+    b_row[b] = r * 64; b_x[b] = ((r >> 2) & 3) ^ kh;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+
+  uint4 ra[A_PIECES];
+#define H2_FETCH_A(chunk_)                                                                                           \
+  {                                                                                                                  \
+    int cs = (chunk_) * H2CK, sgi = 0;                                                                               \
+    _Pragma("unroll") for (int q = 0; q < MAXSEG - 1; ++q)                                                           \
+      if (sgi == q && q + 1 < P.nseg && cs >= P.segC[q]) { cs -= P.segC[q]; sgi = q + 1; }                          \
+    const __half* base = P.in[0]; int segs = P.segS[0];                                                              \
+    _Pragma("unroll") for (int q = 1; q < MAXSEG; ++q) if (sgi == q) { base = P.in[q]; segs = P.segS[q]; }           \
+    _Pragma("unroll") for (int i = 0; i < A_PIECES; ++i) {                                                           \
+      const uint4 v = *reinterpret_cast<const uint4*>(base + (long)a_off[i] * segs + cs + aq * 8);                   \
+      ra[i] = keep_if(a_ok[i], v);                                                                                   \
+    }                                                                                                                \
+  }
+#define H2_DMA_B(step_)                                                                                              \
+  {                                                                                                                  \
+    _Pragma("unroll") for (int q = 0; q < 3; ++q) {                                                                  \
+      const char* g = bsrc + (long)(step_) * H2B_BYTES + (wave + 8 * q) * 1024;                                      \
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + H2A_BYTES + ((step_) & 1) * H2B_BYTES + (wave + 8 * q) * 1024); \
+      GLDS16(g, dst)                                                                                                 \
+    }                                                                                                                \
+  }
+
+  H2_FETCH_A(0)
+  H2_DMA_B(0)
+  for (int c = 0; c < nchunks; ++c) {
+    // every wave has finished the previous chunk's reads of the halo tile
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < A_PIECES; ++i)
+      if ((tid >> 2) + 128 * i < HPIX) *reinterpret_cast<uint4*>(lds + a_dst0 + i * 128 * 64) = ra[i];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int step = c * 3 + dy;
+      // this wave's DMA pieces of group `step` (issued a step ago) have landed, its halo stores are done; then the barrier.
+      // At dy == 1 the halo loads of the next chunk, issued AFTER those pieces one step ago, may stay in flight (vector
+      // memory operations complete in order): they get two steps to land instead of one.
+      if (dy == 1 && c + 1 < nchunks) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (step + 1 < nsteps) H2_DMA_B(step + 1)           // into the buffer last read in step - 1
+      if (dy == 0 && c + 1 < nchunks) H2_FETCH_A(c + 1)
+      const char* const Bcur = lds + H2A_BYTES + (step & 1) * H2B_BYTES;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        int a_row[2], a_x[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const int p = pl + dy * HCOLS + dx + a * 32;
+          a_row[a] = p * 64; a_x[a] = ((p >> 2) & 3) ^ kh;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          half8 af[2], bf[2];
+#pragma unroll
+          for (int a = 0; a < 2; ++a) af[a] = *reinterpret_cast<const half8*>(lds + a_row[a] + (((ks * 2) ^ a_x[a]) << 4));
+#pragma unroll
+          for (int b = 0; b < 2; ++b) bf[b] = *reinterpret_cast<const half8*>(Bcur + dx * (128 * 64) + b_row[b] + (((ks * 2) ^ b_x[b]) << 4));
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+      }
+    }
+  }
+#undef H2_FETCH_A
+#undef H2_DMA_B
+  staged_epilogue<EPI, 2, 128>(P, acc, s_conv, m0, n0, wm0, wn0, tid, HW);
+}
+
 // mean over the rows of each segment (GraphAgg's scatter_mean over the edges of a source frame, reference
 // droid_net.py:67): out[k] = mean_{e in order[seg_off[k] .. seg_off[k+1])} x[e]; one thread = 8 channels (16 B),
 // fp32 accumulation in a fixed order, one rounding to fp16.
@@ -805,6 +939,37 @@ int launch_dma(const ConvParams& P, hipStream_t st) {
   return DH_OK;
 }
 
+template <int EPI>
+int launch_halo2(const ConvParams& P, hipStream_t st) {
+  const long M = (long)P.N * P.H * P.W;
+  const dim3 grid((unsigned)(M / BM), (unsigned)(P.CoutPad / 128));
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo2_kernel<EPI>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  if (attr != hipSuccess) return DH_ERR_LAUNCH;
+  hipLaunchKernelGGL((conv3x3_halo2_kernel<EPI>), grid, dim3(512), H2_LDS_BYTES, st, P);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
+// halo2 layout of `weights_halo`: cout tile 128, channel count a multiple of 32 (DH_CONV_HALO2=0, read by both sides,
+// selects the 16-channel slabs of the first halo kernel instead)
+bool dma_layout(int CoutPad, int Ctot);
+bool halo2_layout(int CoutPad, int Ctot) {
+  const char* env = getenv("DH_CONV_HALO2");
+  if (env && atoi(env) == 0) return false;
+  return !dma_layout(CoutPad, Ctot) && CoutPad % 128 == 0 && Ctot % H2CK == 0;
+}
+
+template <int EPI>
+bool halo2_ok(const ConvParams& P) {
+  const char* env = getenv("DH_CONV_HALO");                 // 0: generic loop only
+  if (env && atoi(env) == 0) return false;
+  if (!halo2_layout(P.CoutPad, P.Ctot)) return false;
+  if (!P.wt_halo || P.KH != 3 || P.KW != 3 || P.W != 64 || P.H % 4) return false;
+  for (int i = 0; i < P.nseg; ++i) if (P.segC[i] % H2CK) return false;
+  return staged_epilogue_ok<EPI>(P);
+}
+
 // Layout rule of `weights_halo` (the same rule is applied by the packer, droid_amd/update.py pack_conv_halo): 16-channel
 // slabs of the halo kernel, unless DH_CONV_DMA=1 (read by both sides) AND the cout tile is 128 AND the channel count is a
 // multiple of 64 with at least four chunks (with fewer, the un-overlapped prologue of the one-workgroup-per-CU kernel
@@ -838,7 +1003,7 @@ bool halo_ok(const ConvParams& P) {
   // chunks -- one workgroup per CU -- and strided weight reads was slower than the generic loop inside the iteration.)
   const char* env = getenv("DH_CONV_HALO");
   if (env && atoi(env) == 0) return false;
-  if (dma_layout(P.CoutPad, P.Ctot)) return false;          // weights_halo holds the other layout
+  if (dma_layout(P.CoutPad, P.Ctot) || halo2_layout(P.CoutPad, P.Ctot)) return false;     // weights_halo holds another layout
   if (!P.wt_halo || P.KH != 3 || P.KW != 3 || P.W != 64 || P.H % 4 || P.CoutPad % 128 || P.Ctot < 128) return false;
   for (int i = 0; i < P.nseg; ++i) if (P.segC[i] % halo_ck(128)) return false;
   return true;
@@ -903,6 +1068,14 @@ extern "C" int dh_conv2d_nhwc_f16(const void* const* inputs, const int* in_chann
       case EPI_GRU_Q: return launch_dma<EPI_GRU_Q>(P, st);
       default: break;
     }
+  }
+  switch (P.epi) {
+    case EPI_LINEAR: if (halo2_ok<EPI_LINEAR>(P)) return launch_halo2<EPI_LINEAR>(P, st); break;
+    case EPI_RELU: if (halo2_ok<EPI_RELU>(P)) return launch_halo2<EPI_RELU>(P, st); break;
+    case EPI_SIGMOID: if (halo2_ok<EPI_SIGMOID>(P)) return launch_halo2<EPI_SIGMOID>(P, st); break;
+    case EPI_GRU_ZR: if (halo2_ok<EPI_GRU_ZR>(P)) return launch_halo2<EPI_GRU_ZR>(P, st); break;
+    case EPI_GRU_Q: if (halo2_ok<EPI_GRU_Q>(P)) return launch_halo2<EPI_GRU_Q>(P, st); break;
+    default: break;
   }
   if (halo_ok(P)) {
     switch (P.epi) {

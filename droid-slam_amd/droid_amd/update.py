@@ -84,11 +84,21 @@ def _dma_layout(cout_pad, ctot):
     return cout_pad % 128 == 0 and ctot % 64 == 0 and ctot >= 256
 
 
+def _halo2_layout(cout_pad, ctot):
+    """the same rule as csrc/conv.hip halo2_layout()"""
+    if os.environ.get("DH_CONV_HALO2", "1") == "0":
+        return False
+    return not _dma_layout(cout_pad, ctot) and cout_pad % 128 == 0 and ctot % 32 == 0
+
+
 def pack_conv_halo(weight):
     """Second, kernel-ordered copy of a 3x3 weight [Cout,Ctot,3,3] (csrc/conv.hip), or None if the shape is not eligible.
       * DH_CONV_DMA=1 (opt-in experiment), CoutPad % 128 == 0, Ctot % 64 == 0 and Ctot >= 256: [CoutPad/128, Ctot/64, 9, 128, 8, 8] f16 for the LDS-DMA kernel -- one
         (tap, 64-channel chunk) slab is 128 cout rows of 128 bytes, the 16-byte slot s of row r stored at slot
         s ^ ((r >> 1) & 7) (the bank swizzle of the kernel's ds_read addresses);
+      * CoutPad % 128 == 0 and Ctot % 32 == 0 (default; DH_CONV_HALO2=0 disables): [CoutPad/128, Ctot/32, 3, 3, 128, 4, 8] for
+        conv3x3_halo2_kernel -- a (32-channel chunk, kernel row) group is 3 x 128 rows of 64 bytes, the 16-byte slot s of
+        row r stored at slot s ^ ((r >> 2) & 3);
       * otherwise [CoutPad/BN, Ctot/CK, 9, BN, CK] for the halo-tile kernels (BN = 32 / 64 with 32-channel chunks for the
         small heads, else BN = 128 with 16-channel chunks)."""
     cout, ctot, kh, kw = weight.shape
@@ -102,6 +112,12 @@ def pack_conv_halo(weight):
         r = torch.arange(128, device=weight.device)
         src = torch.arange(8, device=weight.device)[None, :] ^ ((r[:, None] >> 1) & 7)        # stored slot s' holds slot s'^sw
         w = torch.gather(w, 4, src[None, None, None, :, :, None].expand(*w.shape[:3], 128, 8, 8))
+        return w.half().contiguous()
+    if _halo2_layout(cp, ctot):
+        w = w.reshape(cp // 128, 128, ctot // 32, 4, 8, 3, 3).permute(0, 2, 5, 6, 1, 3, 4)   # [T, chunk, dy, dx, row, slot, 8]
+        r = torch.arange(128, device=weight.device)
+        src = torch.arange(4, device=weight.device)[None, :] ^ ((r[:, None] >> 2) & 3)        # stored slot s' holds slot s'^sw
+        w = torch.gather(w, 5, src[None, None, None, None, :, :, None].expand(*w.shape[:4], 128, 4, 8))
         return w.half().contiguous()
     bn = cp if cp in (32, 64) else 128      # cout tile of the kernel variant that will take this convolution
     ck = 16 if bn == 128 else 32            # halo_ck() of csrc/conv.hip

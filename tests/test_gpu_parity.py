@@ -519,10 +519,12 @@ def test_update_operator_vs_oracle(db, shape):
     assert cmp(up[0], ru) <= 3e-2 * max(1.0, ru.abs().max().item())
 
 
-@pytest.mark.parametrize("halo,dma", [("1", "1"), ("1", "0"), ("0", "1")])
-def test_conv2d_nhwc_matches_torch_conv(db, monkeypatch, halo, dma):
-    monkeypatch.setenv("DH_CONV_HALO", halo)          # all three main loops: LDS-DMA 3x3, halo-tile 3x3, generic (the fallback)
+@pytest.mark.parametrize("halo,dma,halo2", [("1", "0", "1"), ("1", "0", "0"), ("1", "1", "1"), ("0", "0", "1")])
+def test_conv2d_nhwc_matches_torch_conv(db, monkeypatch, halo, dma, halo2):
+    # all four main loops: halo2 (DMA weights, the default for 128-cout tiles), halo-tile, opt-in LDS-DMA, generic (fallback)
+    monkeypatch.setenv("DH_CONV_HALO", halo)
     monkeypatch.setenv("DH_CONV_DMA", dma)
+    monkeypatch.setenv("DH_CONV_HALO2", halo2)
     """the raw convolution entry point against torch's fp32 conv2d: 1x1 / 3x3 / 7x7, multi-segment input, all tile configs"""
     from droid_amd.update import pack_conv, pack_conv_halo, EPI_LINEAR, EPI_RELU
     torch.manual_seed(0)
