@@ -121,10 +121,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a ROCm device (no CPU fallback)"
+    local = local % torch.cuda.device_count()            # (several ranks on one device only in the gloo self-test below)
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # RCCL ("nccl") is the product path; DH_BENCH_BACKEND=gloo exists to exercise the multi-rank code path on a box
+        # with a single GPU (RCCL refuses two ranks on one device)
+        dist.init_process_group(os.environ.get("DH_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
     dev = torch.device("cuda", local)
 
     import droid_backends as db

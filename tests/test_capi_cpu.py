@@ -115,3 +115,43 @@ def test_unmodified_reference_modules_import_against_this_repo(built):
             "print('closure ok')\n") % (PKG, ref, PKG, PKG)
     r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd="/tmp")
     assert r.returncode == 0 and "closure ok" in r.stdout, r.stdout[-2000:]
+
+
+def test_convolution_weight_packing_layouts(built, monkeypatch):
+    """host logic of the update operator: the kernel-ordered weight copies (`pack_conv_halo`) follow the layout rules that
+    csrc/conv.hip applies on its side (halo2 / 16- and 32-channel halo slabs / opt-in LDS-DMA), checked element by element"""
+    import random
+    import torch
+    from droid_amd import update as U
+    rnd = random.Random(0)
+    w = torch.randn(256, 448, 3, 3).half()
+    # default: conv3x3_halo2_kernel, [T, chunk32, dy, dx, row, slot', 8] with slot' = slot ^ ((row >> 2) & 3)
+    monkeypatch.delenv("DH_CONV_DMA", raising=False); monkeypatch.delenv("DH_CONV_HALO2", raising=False)
+    p = U.pack_conv_halo(w)
+    assert tuple(p.shape) == (2, 14, 3, 3, 128, 4, 8)
+    for _ in range(500):
+        T, c, dy, dx, r, sp, e = (rnd.randrange(n) for n in (2, 14, 3, 3, 128, 4, 8))
+        assert p[T, c, dy, dx, r, sp, e] == w[T * 128 + r, c * 32 + (sp ^ ((r >> 2) & 3)) * 8 + e, dy, dx]
+    # first halo kernel: [T, chunk16, tap, 128, 16]
+    monkeypatch.setenv("DH_CONV_HALO2", "0")
+    p = U.pack_conv_halo(w)
+    assert tuple(p.shape) == (2, 28, 9, 128, 16)
+    for _ in range(500):
+        T, c, t, r, e = (rnd.randrange(n) for n in (2, 28, 9, 128, 16))
+        assert p[T, c, t, r, e] == w[T * 128 + r, c * 16 + e, t // 3, t % 3]
+    # opt-in LDS-DMA kernel: [T, chunk64, tap, row, slot', 8] with slot' = slot ^ ((row >> 1) & 7)
+    monkeypatch.setenv("DH_CONV_DMA", "1")
+    p = U.pack_conv_halo(w)
+    assert tuple(p.shape) == (2, 7, 9, 128, 8, 8)
+    for _ in range(500):
+        T, c, t, r, sp, e = (rnd.randrange(n) for n in (2, 7, 9, 128, 8, 8))
+        assert p[T, c, t, r, sp, e] == w[T * 128 + r, c * 64 + (sp ^ ((r >> 1) & 7)) * 8 + e, t // 3, t % 3]
+    monkeypatch.delenv("DH_CONV_DMA"); monkeypatch.delenv("DH_CONV_HALO2")
+    # small cout tiles: 32-channel slabs, cout padded to the tile
+    p = U.pack_conv_halo(torch.randn(4, 256, 3, 3).half())
+    assert tuple(p.shape) == (1, 8, 9, 32, 32) and torch.count_nonzero(p[0, :, :, 4:]) == 0
+    assert tuple(U.pack_conv_halo(torch.randn(64, 128, 3, 3).half()).shape) == (1, 4, 9, 64, 32)
+    assert U.pack_conv_halo(torch.randn(128, 8, 7, 7).half()) is None              # not a 3x3 kernel
+    # correlation channel map: our level-planar (yoff, xoff) order against the reference's (xoff, yoff) order
+    m = U.corr_channel_map()
+    assert m.numel() == 224 and (m >= 0).sum() == 196 and sorted(m[m >= 0].tolist()) == list(range(196))
