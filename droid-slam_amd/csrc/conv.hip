@@ -24,6 +24,7 @@ using namespace dh;
 
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 
 constexpr int BM = 256;            // pixels per workgroup
 constexpr int BK = 64;             // K chunk
@@ -742,20 +743,21 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
   const int img = (int)(m0 / HW), y0 = (int)((m0 - (long)img * HW) / 64);
   const int nchunks = P.Ctot / H2CK, nsteps = nchunks * 3;
 
-  // halo roles: piece id = tid + 512*i -> (halo pixel id >> 2, 16-byte slot id & 3 of its 64-byte run)
-  constexpr int A_PIECES = (HPIX * 4 + 511) / 512;       // 4
-  int a_off[A_PIECES]; bool a_ok[A_PIECES];
-#pragma unroll
-  for (int i = 0; i < A_PIECES; ++i) {
-    const int hp = (tid >> 2) + 128 * i;
-    const int hy = hp / HCOLS, hx = hp - hy * HCOLS;
-    const int y = y0 - 1 + hy, x = hx - 1;
-    a_ok[i] = hp < HPIX && (unsigned)y < (unsigned)P.H && (unsigned)x < 64u;
-    a_off[i] = a_ok[i] ? (img * P.H + y) * 64 + x : 0;
+  // halo roles.  The first and last column of the 6 x 66 halo lie outside the 64-pixel-wide image for every tile: they are
+  // zeroed once, and the 6 x 64 interior is exactly 3 pieces per thread: piece id = tid + 512*i -> (row 2i + (tid >> 8),
+  // column (tid >> 2) & 63, 16-byte slot tid & 3 of the pixel's 64-byte run)
+  constexpr int A_PIECES = 3;
+  const int aq = tid & 3, ax = (tid >> 2) & 63, ahy = tid >> 8;
+  // (offsets are recomputed from these three where they are used: the kernel sits at its 128-register budget, and a
+  // spilled address register is reloaded with a vmcnt(0) wait that serialises the halo loads)
+  const int a_pix0 = (img * P.H + y0 - 1 + ahy) * 64 + ax;      // image pixel of piece 0; piece i is two rows further down
+  if (tid < 48) {                                        // 12 edge pixels x 4 slots
+    const int hp = (tid >> 3) * HCOLS + ((tid >> 2) & 1) * (HCOLS - 1);
+    *reinterpret_cast<uint4*>(lds + hp * 64 + aq * 16) = uint4{0u, 0u, 0u, 0u};
   }
-  const int aq = tid & 3;
-  const int a_dst0 = (tid >> 2) * 64 + ((aq ^ ((tid >> 4) & 3)) << 4);      // + i * 128 * 64 (the swizzle term is the same for every i)
-  const char* const bsrc = reinterpret_cast<const char*>(P.wt_halo) + (long)blockIdx.y * nsteps * H2B_BYTES + lane * 16;
+  // weight DMA: per-lane offset (one register for every piece) + wave-uniform base pointer in SGPRs
+  const int b_voff = lane * 16;
+  const char* const bsrc = reinterpret_cast<const char*>(P.wt_halo) + (long)blockIdx.y * nsteps * H2B_BYTES;
 
   // fragment addressing: 16-byte slot s of row r sits at r*64 + ((s ^ ((r >> 2) & 3)) << 4)
   const int pl = wrow * HCOLS + (lane & 31), kh = lane >> 5;
@@ -774,7 +776,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
 
-  uint4 ra[A_PIECES];
+  u32x4 ra[A_PIECES];
 #define H2_FETCH_A(chunk_)                                                                                           \
   {                                                                                                                  \
     int cs = (chunk_) * H2CK, sgi = 0;                                                                               \
@@ -782,17 +784,29 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
       if (sgi == q && q + 1 < P.nseg && cs >= P.segC[q]) { cs -= P.segC[q]; sgi = q + 1; }                          \
     const __half* base = P.in[0]; int segs = P.segS[0];                                                              \
     _Pragma("unroll") for (int q = 1; q < MAXSEG; ++q) if (sgi == q) { base = P.in[q]; segs = P.segS[q]; }           \
-    _Pragma("unroll") for (int i = 0; i < A_PIECES; ++i) {                                                           \
-      const uint4 v = *reinterpret_cast<const uint4*>(base + (long)a_off[i] * segs + cs + aq * 8);                   \
-      ra[i] = keep_if(a_ok[i], v);                                                                                   \
+    int pix0 = a_pix0;                                                                                               \
+    asm volatile("" : "+v"(pix0));          /* opaque: hipcc would hoist the three offsets out of the loop and spill them */ \
+    _Pragma("unroll") for (int i = 0; i < A_PIECES; ++i) {    /* raw loads: masking them here would wait for them here */ \
+      const bool ok = (unsigned)(y0 - 1 + ahy + 2 * i) < (unsigned)P.H;                                              \
+      ra[i] = *reinterpret_cast<const u32x4*>(base + (long)(ok ? pix0 + 128 * i : 0) * segs + cs + aq * 8);          \
     }                                                                                                                \
+  }
+  // one wave-wide LDS-DMA with a uniform base: lane l copies 16 bytes from sbase_ + voff_ (per lane) to LDS ldsaddr_ + l*16
+#define GLDS16S(sbase_, voff_, ldsaddr_)                                                                             \
+  {                                                                                                                  \
+    unsigned keep_;                                                                                                  \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep_) : "v"(voff_), "s"(sbase_), "s"(ldsaddr_) : "memory");                                \
   }
 #define H2_DMA_B(step_)                                                                                              \
   {                                                                                                                  \
     _Pragma("unroll") for (int q = 0; q < 3; ++q) {                                                                  \
-      const char* g = bsrc + (long)(step_) * H2B_BYTES + (wave + 8 * q) * 1024;                                      \
+      const unsigned long gaddr = (unsigned long)(bsrc + (long)(step_) * H2B_BYTES + (wave + 8 * q) * 1024);          \
+      const unsigned glo = __builtin_amdgcn_readfirstlane((unsigned)gaddr);                                          \
+      const unsigned ghi = __builtin_amdgcn_readfirstlane((unsigned)(gaddr >> 32));                                  \
+      const void* gs = reinterpret_cast<const void*>(((unsigned long)ghi << 32) | glo);                              \
       const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + H2A_BYTES + ((step_) & 1) * H2B_BYTES + (wave + 8 * q) * 1024); \
-      GLDS16(g, dst)                                                                                                 \
+      GLDS16S(gs, b_voff, dst)                                                                                       \
     }                                                                                                                \
   }
 
@@ -801,26 +815,33 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
   for (int c = 0; c < nchunks; ++c) {
     // every wave has finished the previous chunk's reads of the halo tile
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    int ahy_o = ahy, ax_o = ax;
+    asm volatile("" : "+v"(ahy_o), "+v"(ax_o));         // opaque (see H2_FETCH_A): keep the offset arithmetic inside the loop
 #pragma unroll
-    for (int i = 0; i < A_PIECES; ++i)
-      if ((tid >> 2) + 128 * i < HPIX) *reinterpret_cast<uint4*>(lds + a_dst0 + i * 128 * 64) = ra[i];
+    for (int i = 0; i < A_PIECES; ++i) {
+      const int hp = (2 * i + ahy_o) * HCOLS + ax_o + 1;
+      const uint32_t m = (unsigned)(y0 - 1 + ahy_o + 2 * i) < (unsigned)P.H ? 0xffffffffu : 0u;  // rows outside the image are zero
+      *reinterpret_cast<u32x4*>(lds + hp * 64 + ((aq ^ ((hp >> 2) & 3)) << 4)) = ra[i] & m;
+    }
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
       const int step = c * 3 + dy;
       // this wave's DMA pieces of group `step` (issued a step ago) have landed, its halo stores are done; then the barrier.
       // At dy == 1 the halo loads of the next chunk, issued AFTER those pieces one step ago, may stay in flight (vector
       // memory operations complete in order): they get two steps to land instead of one.
-      if (dy == 1 && c + 1 < nchunks) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (dy == 1 && c + 1 < nchunks) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       if (step + 1 < nsteps) H2_DMA_B(step + 1)           // into the buffer last read in step - 1
       if (dy == 0 && c + 1 < nchunks) H2_FETCH_A(c + 1)
       const char* const Bcur = lds + H2A_BYTES + (step & 1) * H2B_BYTES;
+      int pl_o = pl;
+      asm volatile("" : "+v"(pl_o));                      // opaque: the 18 tap addresses are cheap to form, expensive to keep
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
         int a_row[2], a_x[2];
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-          const int p = pl + dy * HCOLS + dx + a * 32;
+          const int p = pl_o + dy * HCOLS + dx + a * 32;
           a_row[a] = p * 64; a_x[a] = ((p >> 2) & 3) ^ kh;
         }
 #pragma unroll
@@ -840,6 +861,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
   }
 #undef H2_FETCH_A
 #undef H2_DMA_B
+#undef GLDS16S
   staged_epilogue<EPI, 2, 128>(P, acc, s_conv, m0, n0, wm0, wn0, tid, HW);
 }
 
