@@ -723,7 +723,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(ConvParams P) {
 // barrier per 24 MFMAs per wave plus one per chunk for the halo hand-over; the epilogue is the LDS-staged one.
 // Measured at 448->256, 1024 edges: 6.84 ms against 7.18-7.33 ms; without the halo fetch 5.64, without the weight DMA 5.96,
 // without both 4.55 ms (the first halo kernel: 5.24 / 5.83 / 4.17) -- the fetch path costs 2.3 instead of 3.0 ms, the
-// skeleton with its smaller steps 0.4 ms more; inside the full iteration 80.9 against 84.4 ms per step.
+// skeleton with its smaller steps 0.4 ms more; inside the full iteration 80.9 against 84.4 ms per step.  Those numbers are
+// from the version whose loop still spilled (hoisted tap addresses, see the `opaque` notes below); spill-free it runs
+// 448->256 in 5.95 ms (1.09 PFLOP/s) and the full iteration in 70.1 ms.
 constexpr int H2CK = 32;
 constexpr int H2A_BYTES = HPIX * H2CK * 2;               // 25,344: halo [396 px][32 ch]
 constexpr int H2B_BYTES = 3 * 128 * H2CK * 2;            // 24,576: one (chunk, dy) weight group
