@@ -277,6 +277,23 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch_group": lookup_bytes},
         }
+        if upd is not None and up > 0:
+            # secondary roofline (the contract's `roofline` object stays the HBM-bound lookup named by north_star): the
+            # update operator is where the step time goes; algorithmic flops of this rank's convolutions (edge-level ones
+            # per edge-pixel, GraphAgg's conv2 / eta / upmask per frame-pixel) over the live HIP-event time of the operator
+          try:
+            from droid_amd.update import PARAM_SHAPES
+            frame_level = ("agg.conv2", "agg.eta.0", "agg.upmask.0")
+            glo_vectors = ("gru.convz_glo", "gru.convr_glo", "gru.convq_glo")          # 1x1 on one vector per edge
+            macs = lambda names: sum(co * ci * k * k for n, (co, ci, k) in PARAM_SHAPES.items() if n in names)
+            edge_macs = macs([n for n in PARAM_SHAPES if n not in frame_level + glo_vectors])
+            flops = 2.0 * (edge_macs * E * HW + macs(frame_level) * len(uniq_ii) * HW + macs(glo_vectors) * E)
+            tf = flops / (up * 1e-3) / 1e12
+            out["roofline_update_operator"] = {"kernel": "conv3x3_halo2_kernel / conv3x3_halo_kernel / conv_igemm_kernel (all of one "
+                                               "UpdateModule.forward)", "bound": "mfma", "achieved": tf, "peak": 2500.0,
+                                               "unit": "TFLOP/s", "frac": tf / 2500.0, "algorithmic_flops": flops}
+          except Exception as exc:                        # an informational field must never cost the bench line
+            out["roofline_update_operator"] = {"error": repr(exc)}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(g)
         print(json.dumps(out))
