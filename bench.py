@@ -49,10 +49,12 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(g, n_frames_sample=96, n_lookup_edges=8, n_update_edges=8):
+def cpu_baseline(g, n_frames_sample=128, n_lookup_edges=32, n_update_edges=32):
     """Oracle (numpy / torch-CPU restatement of the reference kernels, kind "port") on a bounded sample of the same
     workload, single-threaded (threadpoolctl + torch.set_num_threads(1)): one update iteration = lookup + update
-    operator + ba(itrs) per edge-pixel, each leg timed on its own sample and summed per edge-pixel."""
+    operator + ba(itrs) per edge-pixel, each leg timed on its own sample and summed per edge-pixel.  The samples are sized
+    for about 10 s of timed work on the bench host and to fall out of its caches like the full workload does (with an
+    8-edge lookup sample the per-edge-pixel cost came out 4x lower than with 32 edges)."""
     from oracle import ba as oba, corr as ocorr, update as oupd
     from droid_amd.weights import deterministic_state_dict
     import threadpoolctl
