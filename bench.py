@@ -296,7 +296,7 @@ def main():
                                                "unit": "TFLOP/s", "frac": tf / 2500.0, "algorithmic_flops": flops}
           except Exception as exc:                        # an informational field must never cost the bench line
             out["roofline_update_operator"] = {"error": repr(exc)}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:        # rank 0 at N = 1 only (the other ranks would wait in teardown)
             out["cpu_baseline"] = cpu_baseline(g)
         print(json.dumps(out))
     if world > 1:
