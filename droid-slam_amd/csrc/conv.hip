@@ -17,6 +17,17 @@
 //       Q    net' = (1 - z) * net + z * tanh(acc + b + g)   (in place on net)
 //       GLO  sum over pixels of sigmoid(acc + b) * net  -> per-image fp32 accumulators (global context)
 //   where g[image][cout] is the 1x1 "global context" term of the ConvGRU.
+//
+// Kernels in this file, in the order a convolution is dispatched (dh_conv2d_nhwc_f16 at the bottom):
+//   conv3x3_dma_kernel    opt-in experiment (DH_CONV_DMA=1): everything by LDS-DMA, one workgroup per CU;
+//   conv3x3_halo2_kernel  3x3, cout tiles of 128 (the GRU gates, corr/flow encoders' second layers, first head layers):
+//                         weights by LDS-DMA, halo in 64-byte runs, LDS-staged epilogue -- the kernel most of an update
+//                         iteration is spent in (1.1 PFLOP/s); kept free of scratch by a build-time ISA audit (build.py);
+//   conv3x3_halo_kernel   3x3 halo-tile loop with register staging: cout tiles of 64 and 32 (small heads), and the first
+//                         form of the 128-cout tile (DH_CONV_HALO2=0);
+//   conv_igemm_kernel     the generic loop described above: 1x1 and 7x7 convolutions, images that are not 64 wide, fallback;
+//   staged_epilogue / staged_glo_epilogue   results parked in LDS and finished in 16-byte pieces (coalesced stores and GRU
+//                         operand loads); conv_epilogue is the per-element form for tiles that straddle images or write fp32.
 #include "common.h"
 
 namespace {
