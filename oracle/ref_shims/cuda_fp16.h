@@ -1,0 +1,3 @@
+// Test infrastructure only (oracle/): see cuda.h in this directory.
+#pragma once
+#include <hip/hip_fp16.h>
