@@ -151,8 +151,10 @@ __global__ __launch_bounds__(256) void altcorr_bwd_kernel(
   auto G = [&](int xo, int yo) -> float {
     return (xo >= 0 && xo < rd && yo >= 0 && yo < rd) ? gb[(long)(xo * rd + yo) * HW] : 0.f;
   };
-  const float g = 0.0625f * (G(tj, ti) * (1.f - dx) * (1.f - dy) + G(tj - 1, ti) * dx * (1.f - dy) +
-                             G(tj, ti - 1) * (1.f - dx) * dy + G(tj - 1, ti - 1) * dx * dy);
+  // NOT scaled by 1/16: the reference's corr_backward_kernel (altcorr_kernel.cu:117-125) multiplies the gradient with
+  // the raw features although its forward divides both by 4 -- reproduced (found by the oracle/_ref parity test)
+  const float g = G(tj, ti) * (1.f - dx) * (1.f - dy) + G(tj - 1, ti) * dx * (1.f - dy) +
+                  G(tj, ti - 1) * (1.f - dx) * dy + G(tj - 1, ti - 1) * dx * dy;
   if (g == 0.f) return;
   const T* f1 = fmap1 + ((long)(b * N1 + ix) * C) * HW + p;
   const T* f2 = fmap2 + ((long)(b * N2 + jx) * C) * (long)H2 * W2 + (long)y1 * W2 + x1;

@@ -18,24 +18,29 @@ for the hot path (every function cites the reference file:line it follows):
                                               droid_slam/geom/projective_ops.py)
 * ``oracle.update`` UpdateModule / ConvGRU / GraphAgg in fp32 torch-CPU
                                              (droid_slam/droid_net.py:44-143, modules/gru.py)
-* ``oracle/c``      C restatement of the BA kernels used as the timed CPU baseline.
+* ``oracle/build_ref.py`` + ``ref_extras.cu`` + ``ref_shims/``: recipe that compiles the REFERENCE's own
+  ``src/droid.cpp`` + three ``.cu`` files for gfx950 where they lie under /root/reference into
+  ``oracle/_ref/droid_backends_ref.so`` (git-ignored; travels to the GPU box).  The four CUDA include names map to
+  the HIP / ATen-hip headers; Eigen (absent) is stood in by a dense fp64 LLT with SparseBlock's contract.
 
-Pinning status: the reference ships NO golden vectors, known-answer tests or
-fixtures for this path, and its CUDA extension cannot be
-built here (no nvcc, no Eigen, no NVIDIA GPU).  What pins the oracle instead:
+Pinning status: **pinned by the reference itself.**  The reference ships no golden vectors,
+so they were produced here from its own code:
 
-1. the reference's own *Python* formulation of the same math
-   (``droid_slam/geom/ba.py``, ``geom/projective_ops.py``, ``modules/corr.py``,
-   ``droid_net.py``) imported from /root/reference by
-   ``tests/golden/make_golden.py`` on CPU (with small shims for the un-vendored
-   ``lietorch`` / ``torch_scatter``); its outputs are committed under
-   ``tests/golden/`` and ``tests/test_oracle_golden.py`` checks the oracle
-   against them;
-2. self-consistency properties (finite-difference Jacobians, sparse-vs-dense
-   Gauss-Newton agreement, cost decrease).
+1. ``tests/golden/ref_cuda.npz`` -- outputs of the reference's CUDA kernels (``ba`` incl. stereo / sensor-depth /
+   t0 > 1 / motion-only / failure cases, the per-edge blocks of ``projective_transform_kernel``, the reduced camera
+   system before ``SparseBlock::solve``, ``corr_index_forward/backward`` in fp32 and fp16, ``altcorr_forward/backward``,
+   ``frame_distance``, ``projmap``, ``iproj``, ``depth_filter``) written on an MI355X by
+   ``tests/golden/make_ref_golden.py`` from ``oracle/_ref``; ``tests/test_oracle_ref_golden.py`` checks the oracle
+   against them on CPU.  This pins ``ba_cuda``'s damping placement, MIN_DEPTH = 0.25, the ``EvT6x1`` row skip, the
+   fp16 lookup and the unscaled ``altcorr`` backward.
+2. the reference's own *Python* formulation (``droid_slam/geom/ba.py``, ``geom/projective_ops.py``,
+   ``modules/corr.py``, ``droid_net.py``) imported from /root/reference by ``tests/golden/make_golden.py`` on CPU
+   (small shims for the un-vendored ``lietorch`` / ``torch_scatter``) -> ``tests/golden/*_python.npz``,
+   checked by ``tests/test_oracle_golden.py``.
+3. on the GPU, ``tests/test_ref_parity.py`` runs the HIP product and ``oracle/_ref`` side by side on identical
+   inputs up to the headline 512-keyframe / 4096-edge configuration.
 
-The CUDA-only semantics that the Python formulation does not exercise
-(``ba_cuda``'s damping placement, MIN_DEPTH=0.25, the ``EvT6x1`` row skip, the
-fp16 accumulation order of the lookup kernels) are restated from the source
-but are **parity unpinned** by any reference-produced vector.
+What remains unpinned: Eigen's SimplicialLLT itself (a dense LLT computes the same factorisation up to fp64
+round-off; AMD ordering only permutes the operations), and the un-vendored ``lietorch`` beyond the SE3 formulas that
+``src/droid_kernels.cu:67-184`` restates in-tree.
 """

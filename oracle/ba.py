@@ -226,6 +226,8 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj,
         _retract_poses(poses, dx, t0, t1, dtype)
         dflat = disps.reshape(disps.shape[0], HW)
         dflat[kx] = (dflat[kx].astype(dtype) + dz).astype(disps.dtype)
+        if not np.shares_memory(dflat, disps):                     # caller's buffer is not C-contiguous: reshape copied
+            disps[...] = dflat.reshape(disps.shape)
         info = dict(ok=ok, H=Hsys, b=bsys, C=C, w=w, kx=kx, A=A, S=S, bA=bA, bS=bS,
                     Hs=Hs, vs=vs, Erow=Erow, Q=Q, ii_exp=ii_exp, jj_exp=jj_exp, kk_exp=kk_exp) if return_system else dict(ok=ok)
     if return_system:

@@ -154,6 +154,52 @@ def altcorr_forward(fmap1, fmap2, coords, ii, jj, radius):
     return out
 
 
+def altcorr_backward(fmap1, fmap2, coords, corr_grad, ii, jj, radius):
+    """Gradients of the alt lookup w.r.t. both feature maps (altcorr_kernel.cu:78-129, 175-225).
+
+    corr_grad [B,M,2r+1,2r+1,H,W] is given in the forward's OUTPUT layout (x-offset outer); the wrapper permutes it
+    back (:189), spreads it onto the (2r+2)^2 integer taps with the bilinear weights (:196-205) and the kernel
+    scatters g*fmap2 / g*fmap1 (:117-125).  QUIRK, pinned by the reference-produced golden vectors: the kernel
+    multiplies with the RAW features, i.e. the backward is NOT scaled by the 1/16 the forward applies (f1/4 * f2/4),
+    so it is 16x the true adjoint.  Returns (fmap1_grad, fmap2_grad) in float64."""
+    B, M = coords.shape[:2]
+    H, W = coords.shape[3:]
+    H2, W2 = fmap2.shape[3:]
+    R = radius
+    D = 2 * R + 2
+    f1 = fmap1.astype(np.float64)
+    f2 = fmap2.astype(np.float64)
+    g1 = np.zeros_like(f1)
+    g2 = np.zeros_like(f2)
+    for b in range(B):
+        for m in range(M):
+            ix, jx = int(ii[m]), int(jj[m])
+            x = coords[b, m, 0].astype(np.float32)
+            y = coords[b, m, 1].astype(np.float32)
+            fxq = np.floor(x); fyq = np.floor(y)
+            dx = (x - fxq).astype(np.float64); dy = (y - fyq).astype(np.float64)
+            g = np.transpose(corr_grad[b, m].astype(np.float64), (1, 0, 2, 3))      # -> [y-off, x-off, H, W]
+            tap = np.zeros((D, D, H, W))
+            tap[:D - 1, :D - 1] += (1 - dx) * (1 - dy) * g
+            tap[:D - 1, 1:] += dx * (1 - dy) * g
+            tap[1:, :D - 1] += (1 - dx) * dy * g
+            tap[1:, 1:] += dx * dy * g
+            yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+            for ti in range(D):
+                for tj in range(D):
+                    i1 = fyq.astype(np.int64) + (ti - R)
+                    j1 = fxq.astype(np.int64) + (tj - R)
+                    ok = (i1 >= 0) & (i1 < H2) & (j1 >= 0) & (j1 < W2)
+                    if not ok.any():
+                        continue
+                    gv = tap[ti, tj][ok]                                              # [n]
+                    a = f1[b, ix][:, yy[ok], xx[ok]]                                  # [C,n]
+                    t = f2[b, jx][:, i1[ok], j1[ok]]                                  # [C,n]
+                    np.add.at(g1[b, ix], (slice(None), yy[ok], xx[ok]), gv * t)
+                    np.add.at(g2[b, jx], (slice(None), i1[ok], j1[ok]), gv * a)
+    return g1, g2
+
+
 def feature_pyramid(fmaps, num_levels=4):
     """AltCorrBlock.__init__: fmaps [B,N,C,H,W] -> list of avg-pooled levels."""
     pyr = []
