@@ -42,7 +42,7 @@ constexpr float ALPHA_PRIOR = 0.05f;   // src/droid_kernels.cu:1405
 struct BaLayout {
   size_t kmap, kx, eoff, cursor, eidx, meta;          // int32 arrays
   size_t Q, W, Ei, Ej, Hpart;                          // f32
-  size_t H, x, Linv;                                   // f64
+  size_t H, x, Linv, Ldiag;                            // f64
   size_t dx;                                           // f32 [P,6]
   size_t total;
   int P, n, nbk, npad, ld, NS, Kmax;
@@ -77,16 +77,19 @@ BaLayout make_layout(int F, int E, int HW, int t0, int t1, int motion_only) {
   L.H = take(sizeof(double) * (size_t)(L.npad + NB) * L.ld);
   L.x = take(sizeof(double) * (size_t)L.npad);
   L.Linv = take(sizeof(double) * (size_t)L.nbk * NB * NB);
+  L.Ldiag = take(sizeof(double) * (size_t)L.nbk * NB * NB);
   L.dx = take(sizeof(float) * (size_t)(L.P > 0 ? L.P : 1) * 6);
   L.total = off;
   return L;
 }
 
-// meta[0] = K (number of depth blocks), meta[1] = Cholesky failure flag, meta[2] = bad-index flag
+// meta[0] = K (number of depth blocks), meta[1] = Cholesky failure flag of the CURRENT iteration (cleared by
+// ba_damp_kernel), meta[2] = argument flags: bit 0 an edge with ii or jj outside [0, F) (such edges are dropped),
+// bit 1 eta does not have one row per depth block.  Any bit of meta[2] turns the whole call into a no-op update.
 
 // ------------------------------------------------------------------------------------------ prep
 __global__ __launch_bounds__(1024) void ba_prep_kernel(
-    const int64_t* __restrict__ ii, int E, int F, int t0, int t1,
+    const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, int E, int F, int t0, int t1, int n_eta_rows,
     int* __restrict__ kmap, int* __restrict__ kx, int* __restrict__ eoff, int* __restrict__ cursor,
     int* __restrict__ eidx, int* __restrict__ meta) {
   __shared__ int s_part[1024];
@@ -97,9 +100,9 @@ __global__ __launch_bounds__(1024) void ba_prep_kernel(
   if (tid == 0) { meta[1] = 0; meta[2] = 0; }
   __syncthreads();
   for (int e = tid; e < E; e += 1024) {
-    long f = ii[e];
-    if (f >= 0 && f < F) { kmap[f] = 1; atomicAdd(&cursor[f], 1); }
-    else meta[2] = 1;
+    const long f = ii[e], j = jj[e];
+    if (f >= 0 && f < F && j >= 0 && j < F) { kmap[f] = 1; atomicAdd(&cursor[f], 1); }
+    else atomicOr(&meta[2], 1);                       // edge dropped: it never enters the CSR
   }
   __syncthreads();
   // block scan over frames: each thread owns a contiguous chunk
@@ -129,11 +132,14 @@ __global__ __launch_bounds__(1024) void ba_prep_kernel(
   if (tid == 1023) { meta[0] = s_part[1023]; }
   __syncthreads();
   const int K = meta[0];
-  if (tid == 0) eoff[K] = s_part2[1023];
+  if (tid == 0) {
+    eoff[K] = s_part2[1023];
+    if (n_eta_rows >= 0 && n_eta_rows != K) atomicOr(&meta[2], 2);      // the reference's broadcast would fail (:1407)
+  }
   __syncthreads();
   for (int e = tid; e < E; e += 1024) {
-    long f = ii[e];
-    if (f >= 0 && f < F) {
+    const long f = ii[e], j = jj[e];
+    if (f >= 0 && f < F && j >= 0 && j < F) {
       const int k = kmap[f];
       const int slot = atomicAdd(&cursor[f], 1);
       eidx[eoff[k] + slot] = e;
@@ -279,14 +285,14 @@ __global__ __launch_bounds__(256) void ba_build_kernel(
   }
 
   if (!MOTION_ONLY) {
-    const int krow = k < n_eta_rows ? k : (n_eta_rows > 0 ? n_eta_rows - 1 : 0);
+    const bool eta_ok = k < n_eta_rows;                  // a row-count mismatch is flagged by prep (meta[2] bit 1)
 #pragma unroll
     for (int q = 0; q < PPT; ++q) {
       if (!ok[q]) continue;
       const int p = px[q];
       const float ds = disps_sens[(long)f * HW + p];
       const bool m = ds > 0.f;
-      const float C = Cs[q] + (m ? ALPHA_PRIOR : (n_eta_rows > 0 ? eta[(long)krow * HW + p] : 0.f));
+      const float C = Cs[q] + (m ? ALPHA_PRIOR : (eta_ok ? eta[(long)k * HW + p] : 1.f));
       const float w = Ws[q] - (m ? ALPHA_PRIOR * (h[q] - ds) : 0.f);
       Q[(long)k * HW + p] = 1.f / C;
       W[(long)k * HW + p] = w;
@@ -299,10 +305,11 @@ __global__ __launch_bounds__(256) void ba_build_kernel(
 // ---- per-edge pose Hessian blocks from the reduced Hjj / vj via the adjoint ---------------------
 __global__ __launch_bounds__(64) void ba_pose_blocks_kernel(
     const float* __restrict__ poses, const int64_t* __restrict__ ii, const int64_t* __restrict__ jj,
-    const float* __restrict__ Hpart, int E, int NS, int t0, int P, double* __restrict__ H, int ld, int brow) {
+    const float* __restrict__ Hpart, int E, int F, int NS, int t0, int P, double* __restrict__ H, int ld, int brow) {
   const int e = blockIdx.x;
   const int tid = threadIdx.x;
   __shared__ double s_h[6][6], s_v[6], s_A[6][6], s_AH[6][6];
+  if (ii[e] < 0 || ii[e] >= F || jj[e] < 0 || jj[e] >= F) return;   // dropped edge (flagged by prep): its Hpart rows were never written
   const int i = (int)ii[e], j = (int)jj[e];
   if (i == j) return;                                    // stereo pair: no pose terms
   const int pi = i - t0, pj = j - t0;
@@ -507,8 +514,10 @@ __global__ __launch_bounds__(256) void ba_gram_kernel(
 }
 
 // ------------------------------------------------------------------------------------------ solve
-__global__ void ba_damp_kernel(double* __restrict__ H, int ld, int n, int npad, double lm, double ep) {
+// (also clears the Cholesky failure flag: SparseBlock::solve judges every iteration on its own, droid_kernels.cu:1201-1221)
+__global__ void ba_damp_kernel(double* __restrict__ H, int ld, int n, int npad, double lm, double ep, int* __restrict__ meta) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) meta[1] = 0;
   if (i >= npad) return;
   if (i < n) { const double d = H[(long)i * ld + i]; H[(long)i * ld + i] = d + ep + lm * d; }
   else H[(long)i * ld + i] = 1.0;
@@ -719,7 +728,8 @@ __device__ __forceinline__ void mfma_abt_64(const double* __restrict__ A, const 
   }
 }
 
-__global__ __launch_bounds__(256, 1) void chol_panel_kernel(double* __restrict__ H, int ld, int j, int* __restrict__ meta) {
+__global__ __launch_bounds__(256, 1) void chol_panel_kernel(double* __restrict__ H, int ld, int j, int* __restrict__ meta,
+                                                            double* __restrict__ Ldiag) {
   extern __shared__ double s_chol[];
   double* P = s_chol;                     // [128][LDB]: A_jj over A_rj
   const int tid = threadIdx.x;
@@ -743,7 +753,8 @@ __global__ __launch_bounds__(256, 1) void chol_panel_kernel(double* __restrict__
   __syncthreads();
   const bool ok = chol_panel128_lds(P, tid);
   if (!ok && tid == 0) meta[1] = 1;
-  // L_rj back to the matrix; workgroup 0 also stores L_jj (chol_inverse_kernel and nobody else reads it)
+  // L_rj back to the matrix.  Workgroup 0 also publishes L_jj -- into Ldiag, NOT in place: the other workgroups of
+  // this launch read A_jj from H at their own pace (no grid-level ordering), and only chol_inverse_kernel needs L_jj
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const int o = tid + 256 * q;
@@ -753,22 +764,21 @@ __global__ __launch_bounds__(256, 1) void chol_panel_kernel(double* __restrict__
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int o = tid + 256 * q;
-      *reinterpret_cast<double2*>(H + (d0 + (o >> 5)) * ld + d0 + (o & 31) * 2) = *reinterpret_cast<const double2*>(P + (o >> 5) * LDB + (o & 31) * 2);
+      *reinterpret_cast<double2*>(Ldiag + (long)j * NB * NB + (o >> 5) * NB + (o & 31) * 2) = *reinterpret_cast<const double2*>(P + (o >> 5) * LDB + (o & 31) * 2);
     }
   }
 }
 
 // W_j = L_jj^-1 for every diagonal block (needed by the back substitution only): one workgroup per block, after
 // the factorisation, off its critical path
-__global__ __launch_bounds__(256) void chol_inverse_kernel(const double* __restrict__ H, int ld, double* __restrict__ Linv) {
+__global__ __launch_bounds__(256) void chol_inverse_kernel(const double* __restrict__ Ldiag, double* __restrict__ Linv) {
   extern __shared__ double s_chol[];
   double* S = s_chol;
   double* Wm = S + NB * LDB;
   double* T = Wm + NB * LDB;
   double* dinv = T + 3 * SB * (SB + 1);
   const int tid = threadIdx.x, j = blockIdx.x;
-  const long d0 = (long)j * NB;
-  load_block64(S, H + d0 * ld + d0, ld, tid);
+  load_block64(S, Ldiag + (long)j * NB * NB, NB, tid);
   __syncthreads();
   if (tid < NB) dinv[tid] = 1.0 / S[tid * LDB + tid];
   __syncthreads();
@@ -822,7 +832,7 @@ __global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ H
 //       same stacked factorisation as chol_panel_kernel -> L_{r,j+1} (workgroup 0 also stores L_{j+1,j+1});
 //   the others: A_rc -= L_rj L_cj^T for j+2 <= c <= r (chol_update_kernel's work minus block column j+1).
 __global__ __launch_bounds__(256, 1) void chol_step_kernel(double* __restrict__ H, int ld, int j, int nbk, int nP,
-                                                           int* __restrict__ meta) {
+                                                           int* __restrict__ meta, double* __restrict__ Ldiag) {
   extern __shared__ double s_chol[];
   double* sA = s_chol;                    // L_rj, later rows 64..127 of the stacked panel
   double* sB = sA + NB * LDB;             // L_cj
@@ -892,7 +902,7 @@ __global__ __launch_bounds__(256, 1) void chol_step_kernel(double* __restrict__ 
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int o = tid + 256 * q;
-      *reinterpret_cast<double2*>(H + (c0 + (o >> 5)) * ld + c0 + (o & 31) * 2) = *reinterpret_cast<const double2*>(P + (o >> 5) * LDB + (o & 31) * 2);
+      *reinterpret_cast<double2*>(Ldiag + (long)c * NB * NB + (o >> 5) * NB + (o & 31) * 2) = *reinterpret_cast<const double2*>(P + (o >> 5) * LDB + (o & 31) * 2);
     }
   }
 }
@@ -967,7 +977,7 @@ __global__ void ba_dx_kernel(const double* __restrict__ x, const int* __restrict
                              float* __restrict__ dx_ws, float* __restrict__ dx_out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float v = meta[1] ? 0.f : (float)x[i];
+  const float v = (meta[1] | meta[2]) ? 0.f : (float)x[i];
   dx_ws[i] = v;
   if (dx_out) dx_out[i] = v;
 }
@@ -1001,7 +1011,7 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(
       for (int a = 0; a < 6; ++a) s += Ej[((long)e * 6 + a) * HW + p] * dx[6 * r + a];
     }
   }
-  const float dz = Q[(long)k * HW + p] * (W[(long)k * HW + p] - s);
+  const float dz = meta[2] ? 0.f : Q[(long)k * HW + p] * (W[(long)k * HW + p] - s);      // flagged arguments: no update at all
   disps[(long)f * HW + p] += dz;
   if (dz_out && k < n_dz_rows) dz_out[(long)k * HW + p] = dz;
 }
@@ -1023,8 +1033,9 @@ int check_args(int F, int E, int ht, int wd, int t0, int t1) {
   return DH_OK;
 }
 
-int run_prep(const BaLayout& L, char* ws, const int64_t* ii, int E, int F, int t0, int t1, hipStream_t st) {
-  hipLaunchKernelGGL(ba_prep_kernel, dim3(1), dim3(1024), 0, st, ii, E, F, t0, t1,
+int run_prep(const BaLayout& L, char* ws, const int64_t* ii, const int64_t* jj, int E, int F, int t0, int t1, int n_eta_rows,
+             hipStream_t st) {
+  hipLaunchKernelGGL(ba_prep_kernel, dim3(1), dim3(1024), 0, st, ii, jj, E, F, t0, t1, n_eta_rows,
                      (int*)(ws + L.kmap), (int*)(ws + L.kx), (int*)(ws + L.eoff), (int*)(ws + L.cursor),
                      (int*)(ws + L.eidx), (int*)(ws + L.meta));
   DH_LAUNCH_CHECK();
@@ -1052,7 +1063,7 @@ int run_build(const BaLayout& L, char* ws, const float* poses, const float* disp
   DH_LAUNCH_CHECK();
   if (E > 0 && L.P > 0) {
     hipLaunchKernelGGL(ba_pose_blocks_kernel, dim3(E), dim3(64), 0, st, poses, ii, jj,
-                       (const float*)(ws + L.Hpart), E, L.NS, t0, L.P, H, L.ld, L.npad);
+                       (const float*)(ws + L.Hpart), E, F, L.NS, t0, L.P, H, L.ld, L.npad);
     DH_LAUNCH_CHECK();
   }
   if (!motion_only && L.P > 0) {
@@ -1078,52 +1089,36 @@ int run_finish(const BaLayout& L, char* ws, float* poses, float* disps, const in
   float* dxw = (float*)(ws + L.dx);
   if (L.P > 0) {
     hipLaunchKernelGGL(ba_damp_kernel, dim3((L.npad + 255) / 256), dim3(256), 0, st, H, L.ld, L.n, L.npad,
-                       (double)lm, (double)ep);
+                       (double)lm, (double)ep, meta);
     const int nbrows = L.nbk + 1;                        // + rhs block row
-    static const hipError_t lds_err = [] {               // > 64 KB of dynamic LDS must be opted into
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_panel_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_inverse_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_update_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_step_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_backsub_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
-      return e;
-    }();
-    if (lds_err != hipSuccess) {
-      if (getenv("DH_DEBUG")) fprintf(stderr, "libdroid_hip: hipFuncSetAttribute: %s\n", hipGetErrorString(lds_err));
-      return DH_ERR_LAUNCH;
-    }
+    DH_LDS_OPTIN(&chol_panel_kernel, 72 * 1024);
+    DH_LDS_OPTIN(&chol_inverse_kernel, 80 * 1024);
+    DH_LDS_OPTIN(&chol_update_kernel, 72 * 1024);
+    DH_LDS_OPTIN(&chol_step_kernel, 72 * 1024);
+    DH_LDS_OPTIN(&chol_backsub_kernel, 112 * 1024);
     const size_t lds_panel = sizeof(double) * 2 * NB * LDB;
     const size_t lds_inv = sizeof(double) * (2 * NB * LDB + 3 * SB * (SB + 1) + NB);
     const size_t lds_upd = sizeof(double) * 2 * NB * LDB;
-    const char* la_env = getenv("DH_CHOL_LOOKAHEAD");
-    const bool two_launch = la_env && atoi(la_env) == 0;
+    const bool two_launch = opts().chol_lookahead == 0;
+    double* Ldiag = (double*)(ws + L.Ldiag);
     if (two_launch) {                                    // reference schedule: panel, then the whole trailing update
       for (int j = 0; j < L.nbk; ++j) {
         const int m = nbrows - j - 1;
-        hipLaunchKernelGGL(chol_panel_kernel, dim3(m), dim3(256), lds_panel, st, H, L.ld, j, meta);
+        hipLaunchKernelGGL(chol_panel_kernel, dim3(m), dim3(256), lds_panel, st, H, L.ld, j, meta, Ldiag);
         DH_LAUNCH_CHECK();
         if (m > 1) hipLaunchKernelGGL(chol_update_kernel, dim3(m - 1, m), dim3(256), lds_upd, st, H, L.ld, j, L.nbk);
         DH_LAUNCH_CHECK();
       }
     } else {
-      hipLaunchKernelGGL(chol_panel_kernel, dim3(nbrows - 1), dim3(256), lds_panel, st, H, L.ld, 0, meta);
+      hipLaunchKernelGGL(chol_panel_kernel, dim3(nbrows - 1), dim3(256), lds_panel, st, H, L.ld, 0, meta, Ldiag);
       DH_LAUNCH_CHECK();
       for (int j = 0; j + 1 < L.nbk; ++j) {
         const int nP = nbrows - j - 2;                   // block rows below the diagonal block of column j+1
-        hipLaunchKernelGGL(chol_step_kernel, dim3(nP + nP * nP), dim3(256), lds_panel, st, H, L.ld, j, L.nbk, nP, meta);
+        hipLaunchKernelGGL(chol_step_kernel, dim3(nP + nP * nP), dim3(256), lds_panel, st, H, L.ld, j, L.nbk, nP, meta, Ldiag);
         DH_LAUNCH_CHECK();
       }
     }
-    hipLaunchKernelGGL(chol_inverse_kernel, dim3(L.nbk), dim3(256), lds_inv, st, (const double*)H, L.ld, Linv);
+    hipLaunchKernelGGL(chol_inverse_kernel, dim3(L.nbk), dim3(256), lds_inv, st, (const double*)Ldiag, Linv);
     DH_LAUNCH_CHECK();
     for (int jhi = L.nbk - 1; jhi >= 0; jhi -= BG)
       hipLaunchKernelGGL(chol_backsub_kernel, dim3(std::max(1, jhi - BG + 2)), dim3(256),
@@ -1175,7 +1170,7 @@ extern "C" int dh_ba_build(const float* poses, const float* disps, const float* 
   if (workspace_bytes < L.total) return DH_ERR_WORKSPACE;
   char* ws = (char*)workspace;
   hipStream_t st = (hipStream_t)stream;
-  rc = run_prep(L, ws, ii, n_edges, num_frames, t0, t1, st);
+  rc = run_prep(L, ws, ii, jj, n_edges, num_frames, t0, t1, motion_only ? -1 : n_eta_rows, st);
   if (rc != DH_OK) return rc;
   rc = run_build(L, ws, poses, disps, intrinsics, disps_sens, targets, weights, eta, n_eta_rows, ii, jj,
                  num_frames, n_edges, ht * wd, wd, t0, motion_only, st);
@@ -1215,7 +1210,7 @@ extern "C" int dh_ba(float* poses, float* disps, const float* intrinsics, const 
   if (workspace_bytes < L.total) return DH_ERR_WORKSPACE;
   char* ws = (char*)workspace;
   hipStream_t st = (hipStream_t)stream;
-  rc = run_prep(L, ws, ii, n_edges, num_frames, t0, t1, st);
+  rc = run_prep(L, ws, ii, jj, n_edges, num_frames, t0, t1, motion_only ? -1 : n_eta_rows, st);
   if (rc != DH_OK) return rc;
   for (int it = 0; it < iterations; ++it) {
     rc = run_build(L, ws, poses, disps, intrinsics, disps_sens, targets, weights, eta, n_eta_rows, ii, jj,
@@ -1225,6 +1220,12 @@ extern "C" int dh_ba(float* poses, float* disps, const float* intrinsics, const 
     rc = run_finish(L, ws, poses, disps, jj, num_frames, HW, t0, lm, ep, motion_only,
                     last ? dx_out : nullptr, last ? dz_out : nullptr, n_eta_rows, st);
     if (rc != DH_OK) return rc;
+  }
+  if (opts().ba_strict) {                                   // opt-in: synchronise and report flagged arguments as an error
+    int flags[4] = {0, 0, 0, 0};
+    if (hipMemcpyAsync(flags, ws + L.meta, sizeof(flags), hipMemcpyDeviceToHost, st) != hipSuccess) return DH_ERR_LAUNCH;
+    if (hipStreamSynchronize(st) != hipSuccess) return DH_ERR_LAUNCH;
+    if (flags[2]) return DH_ERR_ARG;
   }
   return DH_OK;
 }

@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include "../../include/droid_hip.h"
+#include "options.h"
 
 #define DH_WAVE 64
 #define DH_MIN_DEPTH 0.25f        // kernels' depth threshold (src/droid_kernels.cu:35)
@@ -17,9 +18,27 @@
   do {                                                                                     \
     const hipError_t dh_e_ = hipGetLastError();                                            \
     if (dh_e_ != hipSuccess) {                                                             \
-      if (getenv("DH_DEBUG")) fprintf(stderr, "libdroid_hip: %s at %s:%d\n", hipGetErrorString(dh_e_), __FILE__, __LINE__); \
+      if (dh::opts().debug) fprintf(stderr, "libdroid_hip: %s at %s:%d\n", hipGetErrorString(dh_e_), __FILE__, __LINE__); \
       return DH_ERR_LAUNCH;                                                                \
     }                                                                                      \
+  } while (0)
+
+// > 64 KB of dynamic LDS must be opted into per kernel AND per device (the attribute is per device on HIP): done once
+// per (call site, device), so a process that drives several GPUs gets it on each of them.
+#define DH_LDS_OPTIN(fn_, bytes_)                                                                                   \
+  do {                                                                                                               \
+    static unsigned char dh_done_[64];                                                                               \
+    int dh_dev_ = 0;                                                                                                 \
+    if (hipGetDevice(&dh_dev_) != hipSuccess) return DH_ERR_LAUNCH;                                                  \
+    if (dh_dev_ < 0 || dh_dev_ >= 64 || !dh_done_[dh_dev_]) {                                                        \
+      const hipError_t dh_e2_ = hipFuncSetAttribute(reinterpret_cast<const void*>(fn_),                              \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (bytes_));           \
+      if (dh_e2_ != hipSuccess) {                                                                                    \
+        if (dh::opts().debug) fprintf(stderr, "libdroid_hip: hipFuncSetAttribute: %s at %s:%d\n", hipGetErrorString(dh_e2_), __FILE__, __LINE__); \
+        return DH_ERR_LAUNCH;                                                                                        \
+      }                                                                                                              \
+      if (dh_dev_ >= 0 && dh_dev_ < 64) dh_done_[dh_dev_] = 1;                                                       \
+    }                                                                                                                \
   } while (0)
 
 namespace dh {

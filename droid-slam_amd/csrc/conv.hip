@@ -133,8 +133,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& P, f32x16 (&acc)
 
 template <int EPI>
 inline bool staged_epilogue_ok(const ConvParams& P) {
-  const char* env = getenv("DH_CONV_EPI_STAGED");         // 0: per-element epilogue everywhere (A/B runs)
-  if (env && atoi(env) == 0) return false;
+  if (!opts().conv_epi_staged) return false;                // 0: per-element epilogue everywhere (A/B runs)
   if (EPI == EPI_GLO) return P.Cout % 8 == 0 && P.aux0_stride % 8 == 0 && ((uintptr_t)P.aux0) % 16 == 0;
   if (P.out_f32 || P.Cout % 8 || P.out_stride % 8 || ((uintptr_t)P.out) % 16) return false;
   if (EPI == EPI_GRU_ZR && (P.aux0_stride % 8 || ((uintptr_t)P.aux0) % 16)) return false;
@@ -912,9 +911,7 @@ int launch_epi(const ConvParams& P, hipStream_t st) {
     // whole tiles inside one image: the LDS-staged epilogue (its tile is larger than the operand tiles of the loop)
     if (M % BM == 0 && ((long)P.H * P.W) % BM == 0 && staged_epilogue_ok<EPI>(P)) {
       constexpr size_t lds_st = (size_t)BM * (BN + 8) * sizeof(__half);
-      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WM, WN, BN, EPI, true>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-      if (attr != hipSuccess) return DH_ERR_LAUNCH;
+      DH_LDS_OPTIN((&conv_igemm_kernel<WM, WN, BN, EPI, true>), 80 * 1024);
       hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, BN, EPI, true>), grid, dim3(512), lds_st > lds ? lds_st : lds, st, P);
       DH_LAUNCH_CHECK();
       return DH_OK;
@@ -930,14 +927,10 @@ int launch_halo(const ConvParams& P, hipStream_t st) {
   const long M = (long)P.N * P.H * P.W;
   const dim3 grid((unsigned)(M / BM), (unsigned)(P.CoutPad / BN));
   const size_t lds = (size_t)(HPIX + 9 * BN) * (halo_ck(BN) + 8) * sizeof(__half);
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<EPI, BN>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-  if (attr != hipSuccess) return DH_ERR_LAUNCH;
+  DH_LDS_OPTIN((&conv3x3_halo_kernel<EPI, BN>), 128 * 1024);
   if constexpr ((BN == 128 || BN == 64) && (EPI == EPI_LINEAR || EPI == EPI_RELU || EPI == EPI_SIGMOID || EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q)) {
     if (staged_epilogue_ok<EPI>(P)) {
-      static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<EPI, BN, true>),
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-      if (attr2 != hipSuccess) return DH_ERR_LAUNCH;
+      DH_LDS_OPTIN((&conv3x3_halo_kernel<EPI, BN, true>), 128 * 1024);
       hipLaunchKernelGGL((conv3x3_halo_kernel<EPI, BN, true>), grid, dim3(512), lds, st, P);
       DH_LAUNCH_CHECK();
       return DH_OK;
@@ -952,16 +945,12 @@ template <int EPI>
 int launch_dma(const ConvParams& P, hipStream_t st) {
   const long M = (long)P.N * P.H * P.W;
   const dim3 grid((unsigned)(M / BM), (unsigned)(P.CoutPad / 128));
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma_kernel<EPI>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS_BYTES);
-  if (attr != hipSuccess) return DH_ERR_LAUNCH;
+  DH_LDS_OPTIN((&conv3x3_dma_kernel<EPI>), DMA_LDS_BYTES);
   if (EPI == EPI_RELU) {                                  // timing ablations (scripts/bench_conv.py), never set in production
-    const char* env = getenv("DH_DMA_VAR");
-    const int var = env ? atoi(env) : 0;
+    const int var = opts().dma_var;
 #define DMA_VARIANT(v_)                                                                                             \
     if (var == v_) {                                                                                                 \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma_kernel<EPI_RELU, v_>),                      \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS_BYTES) != hipSuccess) return DH_ERR_LAUNCH; \
+      DH_LDS_OPTIN((&conv3x3_dma_kernel<EPI_RELU, v_>), DMA_LDS_BYTES);                                              \
       hipLaunchKernelGGL((conv3x3_dma_kernel<EPI_RELU, v_>), grid, dim3(512), DMA_LDS_BYTES, st, P);                 \
       DH_LAUNCH_CHECK();                                                                                             \
       return DH_OK;                                                                                                  \
@@ -978,9 +967,7 @@ template <int EPI>
 int launch_halo2(const ConvParams& P, hipStream_t st) {
   const long M = (long)P.N * P.H * P.W;
   const dim3 grid((unsigned)(M / BM), (unsigned)(P.CoutPad / 128));
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo2_kernel<EPI>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-  if (attr != hipSuccess) return DH_ERR_LAUNCH;
+  DH_LDS_OPTIN((&conv3x3_halo2_kernel<EPI>), 80 * 1024);
   hipLaunchKernelGGL((conv3x3_halo2_kernel<EPI>), grid, dim3(512), H2_LDS_BYTES, st, P);
   DH_LAUNCH_CHECK();
   return DH_OK;
@@ -990,15 +977,13 @@ int launch_halo2(const ConvParams& P, hipStream_t st) {
 // selects the 16-channel slabs of the first halo kernel instead)
 bool dma_layout(int CoutPad, int Ctot);
 bool halo2_layout(int CoutPad, int Ctot) {
-  const char* env = getenv("DH_CONV_HALO2");
-  if (env && atoi(env) == 0) return false;
+  if (!opts().conv_halo2) return false;
   return !dma_layout(CoutPad, Ctot) && CoutPad % 128 == 0 && Ctot % H2CK == 0;
 }
 
 template <int EPI>
 bool halo2_ok(const ConvParams& P) {
-  const char* env = getenv("DH_CONV_HALO");                 // 0: generic loop only
-  if (env && atoi(env) == 0) return false;
+  if (!opts().conv_halo) return false;                      // 0: generic loop only
   if (!halo2_layout(P.CoutPad, P.Ctot)) return false;
   if (!P.wt_halo || P.KH != 3 || P.KW != 3 || P.W != 64 || P.H % 4) return false;
   for (int i = 0; i < P.nseg; ++i) if (P.segC[i] % H2CK) return false;
@@ -1010,14 +995,12 @@ bool halo2_ok(const ConvParams& P) {
 // multiple of 64 with at least four chunks (with fewer, the un-overlapped prologue of the one-workgroup-per-CU kernel
 // dominates): then the 64-channel swizzled slabs of the LDS-DMA kernel.
 bool dma_layout(int CoutPad, int Ctot) {
-  const char* env = getenv("DH_CONV_DMA");
-  if (!env || atoi(env) != 1) return false;
+  if (opts().conv_dma != 1) return false;
   return CoutPad % 128 == 0 && Ctot % DCK == 0 && Ctot >= 4 * DCK;
 }
 
 bool dma_ok(const ConvParams& P) {
-  const char* env = getenv("DH_CONV_HALO");                 // 0: generic loop only
-  if (env && atoi(env) == 0) return false;
+  if (!opts().conv_halo) return false;                      // 0: generic loop only
   if (!dma_layout(P.CoutPad, P.Ctot)) return false;
   if (!P.wt_halo || P.KH != 3 || P.KW != 3 || P.W != 64 || P.H % 4) return false;
   for (int i = 0; i < P.nseg; ++i) if (P.segC[i] % DCK || P.segS[i] % 8) return false;
@@ -1036,8 +1019,7 @@ bool halo_ok(const ConvParams& P) {
   // update iteration: 91.9 vs 104.1 ms for the update operator (step 100.8 vs 113.1 ms); in isolation at 1024 edges
   // 448->256: 7.3 vs 8.7 ms, 448->128: 3.7 vs 4.3 ms, 128->128: 1.37 vs 1.45 ms.  (A first version with 32-channel
   // chunks -- one workgroup per CU -- and strided weight reads was slower than the generic loop inside the iteration.)
-  const char* env = getenv("DH_CONV_HALO");
-  if (env && atoi(env) == 0) return false;
+  if (!opts().conv_halo) return false;
   if (dma_layout(P.CoutPad, P.Ctot) || halo2_layout(P.CoutPad, P.Ctot)) return false;     // weights_halo holds another layout
   if (!P.wt_halo || P.KH != 3 || P.KW != 3 || P.W != 64 || P.H % 4 || P.CoutPad % 128 || P.Ctot < 128) return false;
   for (int i = 0; i < P.nseg; ++i) if (P.segC[i] % halo_ck(128)) return false;

@@ -646,17 +646,14 @@ extern "C" int dh_corr_pyramid_build(const void* fmap1, const void* fmap2, void*
   for (int l = 1; l < NLEV; ++l)
     hipLaunchKernelGGL(pyr_pool_kernel, dim3(D.h2[l] * D.w2[l], E), dim3(CH), 0, st, f2T, s2, D.tgt_off[l - 1],
                        D.tgt_off[l], D.h2[l - 1], D.w2[l - 1]);
-  const char* env = getenv("DH_PYR_BUILD");              // "chunk": the first form of the build kernel (A/B measurements)
-  if (env && env[0] == 'c') {
+  if (opts().pyr_build_chunk) {                            // the first form of the build kernel (A/B measurements)
     hipLaunchKernelGGL(pyr_build_kernel, dim3(D.nblk, E), dim3(256), 0, st, (const __half*)f1T, (const __half*)f2T,
                        (__half*)pyramid, D, s1, s2);
   } else {
     const size_t lds = (size_t)w * 1024 + (size_t)(w > 16 ? w : 16) * 256;       // row ring + one staged target row
     const dim3 grid(D.nblk, E);
     if (w == 64) {
-      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&pyr_build_ring_kernel<64>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-      if (attr != hipSuccess) return DH_ERR_LAUNCH;
+      DH_LDS_OPTIN((&pyr_build_ring_kernel<64>), 80 * 1024);
       hipLaunchKernelGGL(pyr_build_ring_kernel<64>, grid, dim3(256), lds, st, (const __half*)f1T, (const __half*)f2T,
                          (__half*)pyramid, D, s1, s2);
     } else if (w == 32) {

@@ -415,4 +415,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("se3_op", &se3_op, "SE3 inv/mul/exp/retr");
   m.def("se3_map", &se3_map, "SE3 act4/adjT");
   m.def("version", []() { return std::string(dh_version()); });
+  m.def("set_option", [](const std::string& name, int value) { check_status(dh_set_option(name.c_str(), value), "set_option"); });
+  m.def("get_option", [](const std::string& name) { int v = 0; check_status(dh_get_option(name.c_str(), &v), "get_option"); return v; });
 }

@@ -1,0 +1,21 @@
+// Process-wide switches of libdroid_hip (A/B measurements, fallbacks for the parity tests).  Read from the environment
+// ONCE, when the library is loaded; afterwards only dh_set_option() changes them -- nothing on a launch path calls getenv().
+#pragma once
+
+namespace dh {
+
+struct Options {
+  int debug;            // DH_DEBUG=1: print HIP errors to stderr
+  int chol_lookahead;   // DH_CHOL_LOOKAHEAD (1): one fused launch per block column of the Cholesky; 0 = two launches
+  int conv_epi_staged;  // DH_CONV_EPI_STAGED (1): LDS-staged convolution epilogues
+  int conv_halo;        // DH_CONV_HALO (1): 3x3 halo-tile kernels; 0 = generic loop only
+  int conv_halo2;       // DH_CONV_HALO2 (1): weights by LDS-DMA for 128-cout tiles; 0 = first halo kernel
+  int conv_dma;         // DH_CONV_DMA (0): opt-in one-workgroup-per-CU LDS-DMA experiment
+  int dma_var;          // DH_DMA_VAR (0): timing ablations of that experiment
+  int pyr_build_chunk;  // DH_PYR_BUILD=chunk (0): first form of the pyramid build kernel
+  int ba_strict;        // DH_BA_STRICT (0): dh_ba synchronises and returns DH_ERR_ARG on bad indices / eta rows
+};
+
+Options& opts();
+
+}  // namespace dh

@@ -11,8 +11,6 @@ kept NHWC fp16 between layers, the 448-channel GRU input is never concatenated, 
 single launches.  torch is used only for allocation, the per-edge 128-vector "global context" GEMVs and the
 scatter-mean over source frames (index_add_), i.e. plumbing.  There is no CPU path.
 """
-import os
-
 import torch
 import torch.nn.functional as F
 
@@ -79,14 +77,14 @@ def pack_conv(weight, bias, cin_pad=None):
 
 def _dma_layout(cout_pad, ctot):
     """layout rule of `weights_halo`, the same as csrc/conv.hip dma_layout()"""
-    if os.environ.get("DH_CONV_DMA", "0") != "1":
+    if droid_backends.get_option("conv_dma") != 1:
         return False
     return cout_pad % 128 == 0 and ctot % 64 == 0 and ctot >= 256
 
 
 def _halo2_layout(cout_pad, ctot):
     """the same rule as csrc/conv.hip halo2_layout()"""
-    if os.environ.get("DH_CONV_HALO2", "1") == "0":
+    if droid_backends.get_option("conv_halo2") == 0:
         return False
     return not _dma_layout(cout_pad, ctot) and cout_pad % 128 == 0 and ctot % 32 == 0
 

@@ -43,6 +43,16 @@ typedef void* dh_stream_t;
 const char* dh_version(void);
 const char* dh_status_string(int status);
 
+/* Process-wide switches (A/B measurements and the fallbacks the parity tests exercise).  Initialised from the
+ * environment variables DH_<NAME> once, when the library is loaded; nothing on a launch path reads the environment.
+ * names: "debug", "chol_lookahead", "conv_epi_staged", "conv_halo", "conv_halo2", "conv_dma", "dma_var",
+ * "pyr_build_chunk", "ba_strict" (dh_ba synchronises and returns DH_ERR_ARG when an edge index lies outside the frame
+ * buffer or eta does not have one row per depth block; off by default -- such calls then apply NO update, silently,
+ * where the reference would read out of bounds / fail its broadcast, src/droid_kernels.cu:1407).
+ * Returns DH_ERR_ARG for an unknown name. */
+int dh_set_option(const char* name, int value);
+int dh_get_option(const char* name, int* value);
+
 /* ------------------------------------------------------------------------------------------------
  * Correlation-volume lookup.  Replaces corr_index_forward / corr_index_backward
  * (reference src/droid.cpp:175-196 -> src/correlation_kernels.cu:127-186).

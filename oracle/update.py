@@ -46,7 +46,8 @@ def _conv(p, name, x):
 def _conv_gru(p, net, inp):
     hx = torch.cat([net, inp], 1)
     g = torch.sigmoid(_conv(p, "gru.w", net)) * net
-    g = g.mean(dim=(2, 3), keepdim=True)
+    b, c, h, w = net.shape
+    g = g.view(b, c, h * w).mean(-1).view(b, c, 1, 1)
     z = torch.sigmoid(_conv(p, "gru.convz", hx) + _conv(p, "gru.convz_glo", g))
     r = torch.sigmoid(_conv(p, "gru.convr", hx) + _conv(p, "gru.convr_glo", g))
     q = torch.tanh(_conv(p, "gru.convq", torch.cat([r * net, inp], 1)) + _conv(p, "gru.convq_glo", g))
@@ -66,9 +67,17 @@ def _graph_agg(p, net, ii):
     return eta, upmask
 
 
-def update_forward(p, net, inp, corr, flow, ii):
+def update_forward(p, net, inp, corr, flow, ii, autocast=False):
     """net,inp [E,128,h,w], corr [E,196,h,w], flow [E,4,h,w], ii [E] ->
-    (net' [E,128,h,w], delta [E,h,w,2], weight [E,h,w,2], eta [K,h,w], upmask [K,576,h,w])."""
+    (net' [E,128,h,w], delta [E,h,w,2], weight [E,h,w,2], eta [K,h,w], upmask [K,576,h,w]).
+
+    ``autocast=True`` evaluates the same expressions under torch.autocast(fp16) like the reference's caller does
+    (factor_graph.py:13-16,214): every convolution output and every elementwise result is stored in fp16 (fp32
+    accumulation inside a convolution); net/inp/corr should then be fp16 tensors.  Pinned by
+    tests/golden/update_autocast_python.npz (the reference's own module under autocast)."""
+    if autocast:
+        with torch.autocast("cpu", dtype=torch.float16):
+            return update_forward(p, net, inp, corr, flow, ii, autocast=False)
     c = torch.relu(_conv(p, "corr_encoder.2", torch.relu(_conv(p, "corr_encoder.0", corr))))
     f = torch.relu(_conv(p, "flow_encoder.2", torch.relu(_conv(p, "flow_encoder.0", flow))))
     net = _conv_gru(p, net, torch.cat([inp, c, f], 1))

@@ -12,7 +12,7 @@ for (E, h, w) in [(3, 48, 64), (2, 16, 32), (2, 8, 16), (256, 48, 64)]:
     f2 = torch.randn(E, 128, h, w, device="cuda").half()
     res = {}
     for mode in ("chunk", "ring"):
-        os.environ["DH_PYR_BUILD"] = mode
+        db.set_option("pyr_build_chunk", int(mode == "chunk"))
         p = db.corr_pyramid_build(f1, f2); torch.cuda.synchronize()
         ts = []
         for _ in range(3):

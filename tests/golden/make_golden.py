@@ -136,7 +136,30 @@ def golden_update():
         tuple(net1.shape), tuple(delta.shape), tuple(eta.shape), tuple(upmask.shape)))
 
 
+def golden_update_autocast():
+    """The reference's UpdateModule exactly as FactorGraph.update runs it: under torch.autocast (factor_graph.py:13-16,
+    214, 227-228) with fp16 hidden state / context / correlation features.  No GPU here, so the autocast device is the
+    CPU (same cast policy for conv2d / cat / sigmoid / tanh: fp16 storage of every layer output, fp32 accumulation
+    inside a convolution)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from golden_inputs import update_autocast_inputs, UPDATE_AUTOCAST
+    torch.manual_seed(0)
+    m = ref_net.UpdateModule()
+    fill_deterministic(m, seed=UPDATE_AUTOCAST["weight_seed"])
+    m.eval()
+    net, inp, corr, flow, ii, jj = update_autocast_inputs()
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.float16):
+        net1, delta, weight, eta, upmask = m(net[None], inp[None], corr[None], flow[None], ii, jj)
+    assert net1.dtype == torch.float16 and upmask.dtype == torch.float16
+    np.savez_compressed(
+        os.path.join(HERE, "update_autocast_python.npz"),
+        net1=net1[0].numpy(), delta=delta[0].float().numpy(), weight=weight[0].float().numpy(),
+        eta=eta[0].float().numpy(), upmask=upmask[0].numpy())
+    print("update_autocast_python: net1 %s %s delta %s eta %s upmask %s" % (
+        tuple(net1.shape), net1.dtype, tuple(delta.shape), tuple(eta.shape), tuple(upmask.shape)))
+
+
 if __name__ == "__main__":
-    golden_ba()
-    golden_corr()
-    golden_update()
+    which = sys.argv[1:] or ["ba", "corr", "update", "update_autocast"]
+    for w in which:
+        globals()["golden_" + w]()

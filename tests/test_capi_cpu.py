@@ -117,7 +117,7 @@ def test_unmodified_reference_modules_import_against_this_repo(built):
     assert r.returncode == 0 and "closure ok" in r.stdout, r.stdout[-2000:]
 
 
-def test_convolution_weight_packing_layouts(built, monkeypatch):
+def test_convolution_weight_packing_layouts(built):
     """host logic of the update operator: the kernel-ordered weight copies (`pack_conv_halo`) follow the layout rules that
     csrc/conv.hip applies on its side (halo2 / 16- and 32-channel halo slabs / opt-in LDS-DMA), checked element by element"""
     import random
@@ -126,27 +126,29 @@ def test_convolution_weight_packing_layouts(built, monkeypatch):
     rnd = random.Random(0)
     w = torch.randn(256, 448, 3, 3).half()
     # default: conv3x3_halo2_kernel, [T, chunk32, dy, dx, row, slot', 8] with slot' = slot ^ ((row >> 2) & 3)
-    monkeypatch.delenv("DH_CONV_DMA", raising=False); monkeypatch.delenv("DH_CONV_HALO2", raising=False)
+    import droid_backends as db
+    saved = {k: db.get_option(k) for k in ("conv_dma", "conv_halo2")}
+    db.set_option("conv_dma", 0); db.set_option("conv_halo2", 1)
     p = U.pack_conv_halo(w)
     assert tuple(p.shape) == (2, 14, 3, 3, 128, 4, 8)
     for _ in range(500):
         T, c, dy, dx, r, sp, e = (rnd.randrange(n) for n in (2, 14, 3, 3, 128, 4, 8))
         assert p[T, c, dy, dx, r, sp, e] == w[T * 128 + r, c * 32 + (sp ^ ((r >> 2) & 3)) * 8 + e, dy, dx]
     # first halo kernel: [T, chunk16, tap, 128, 16]
-    monkeypatch.setenv("DH_CONV_HALO2", "0")
+    db.set_option("conv_halo2", 0)
     p = U.pack_conv_halo(w)
     assert tuple(p.shape) == (2, 28, 9, 128, 16)
     for _ in range(500):
         T, c, t, r, e = (rnd.randrange(n) for n in (2, 28, 9, 128, 16))
         assert p[T, c, t, r, e] == w[T * 128 + r, c * 16 + e, t // 3, t % 3]
     # opt-in LDS-DMA kernel: [T, chunk64, tap, row, slot', 8] with slot' = slot ^ ((row >> 1) & 7)
-    monkeypatch.setenv("DH_CONV_DMA", "1")
+    db.set_option("conv_dma", 1)
     p = U.pack_conv_halo(w)
     assert tuple(p.shape) == (2, 7, 9, 128, 8, 8)
     for _ in range(500):
         T, c, t, r, sp, e = (rnd.randrange(n) for n in (2, 7, 9, 128, 8, 8))
         assert p[T, c, t, r, sp, e] == w[T * 128 + r, c * 64 + (sp ^ ((r >> 1) & 7)) * 8 + e, t // 3, t % 3]
-    monkeypatch.delenv("DH_CONV_DMA"); monkeypatch.delenv("DH_CONV_HALO2")
+    db.set_option("conv_dma", 0); db.set_option("conv_halo2", 1)
     # small cout tiles: 32-channel slabs, cout padded to the tile
     p = U.pack_conv_halo(torch.randn(4, 256, 3, 3).half())
     assert tuple(p.shape) == (1, 8, 9, 32, 32) and torch.count_nonzero(p[0, :, :, 4:]) == 0
@@ -155,3 +157,16 @@ def test_convolution_weight_packing_layouts(built, monkeypatch):
     # correlation channel map: our level-planar (yoff, xoff) order against the reference's (xoff, yoff) order
     m = U.corr_channel_map()
     assert m.numel() == 224 and (m >= 0).sum() == 196 and sorted(m[m >= 0].tolist()) == list(range(196))
+    for k, v in saved.items():
+        db.set_option(k, v)
+
+
+def test_option_store(built):
+    """dh_set_option / dh_get_option: known names round-trip, unknown names are an argument error"""
+    import droid_backends as db
+    v = db.get_option("chol_lookahead")
+    db.set_option("chol_lookahead", 0)
+    assert db.get_option("chol_lookahead") == 0
+    db.set_option("chol_lookahead", v)
+    with pytest.raises(RuntimeError):
+        db.set_option("no_such_option", 1)

@@ -25,6 +25,19 @@ def db():
     return droid_backends
 
 
+@pytest.fixture
+def option(db):
+    """set library switches for one test (droid_backends.set_option), restored afterwards"""
+    saved = {}
+
+    def set_(name, value):
+        saved.setdefault(name, db.get_option(name))
+        db.set_option(name, int(value))
+    yield set_
+    for k, v in saved.items():
+        db.set_option(k, v)
+
+
 def dev(a, dtype=None):
     t = torch.as_tensor(np.ascontiguousarray(a))
     if dtype is not None:
@@ -125,7 +138,7 @@ def test_altcorr_forward(db, dtype):
         out, = db.altcorr_forward(f1, f2, dev(coords), dev(ii), dev(jj), 3)
         assert out.shape == (B, M, 7, 7, H, W)
         ref = ocorr.altcorr_forward(f1.float().cpu().numpy(), f2.float().cpu().numpy(), coords, ii, jj, 3)
-        tol = 1e-4 if dtype == torch.float32 else 2.0 ** -8 * np.abs(ref).max()
+        tol = 1e-4 if dtype == torch.float32 else 2.0 ** -9 * np.abs(ref).max()
         assert np.abs(out.float().cpu().numpy() - ref).max() <= tol
 
 
@@ -142,7 +155,7 @@ def test_altcorr_matches_volume_lookup_at_full_size(db):
     f2 = fm[0, jj].float().reshape(3, C, H * W) / 4
     vol = torch.matmul(f1.transpose(1, 2), f2).reshape(3, H, W, H, W).contiguous()
     ref, = db.corr_index_forward(vol, coords[0].contiguous(), 3)
-    assert (alt[0].float() - ref).abs().max() <= 2.0 ** -8 * ref.abs().max()
+    assert (alt[0].float() - ref).abs().max() <= 2.0 ** -9 * ref.abs().max()
 
 
 # ------------------------------------------------------------------------------------------ BA
@@ -256,13 +269,13 @@ def test_ba_config_c2_converges_and_matches(db):
     assert costs[-1] <= costs[1] * 1.01
 
 
-def test_ba_cholesky_schedules_agree(db, monkeypatch):
+def test_ba_cholesky_schedules_agree(db, option):
     """the look-ahead schedule (one fused launch per block column, the default) and the two-launch schedule apply the
     same updates to every block in the same order: identical factors, identical BA result (6 block columns at C2)"""
     g = syn.make_graph("C2")
-    monkeypatch.setenv("DH_CHOL_LOOKAHEAD", "0")
+    option("chol_lookahead", 0)
     ref = _run_ba(db, g, 1, 64, 2, g["lm"], g["ep"])
-    monkeypatch.setenv("DH_CHOL_LOOKAHEAD", "1")
+    option("chol_lookahead", 1)
     got = _run_ba(db, g, 1, 64, 2, g["lm"], g["ep"])
     for a, b in zip(got, ref):
         assert np.allclose(a, b, rtol=0, atol=1e-7)
@@ -426,7 +439,7 @@ def test_native_corr_pyramid_vs_oracle(db, shape, kind):
     assert out.shape == (E, 196, h, w)
     pyr = ocorr.corr_pyramid(f1, f2, 4)
     ref = ocorr.corr_block_lookup(pyr, coords, 3)
-    assert np.abs(out - ref).max() <= 2.0 ** -8 * np.abs(ref).max()
+    assert np.abs(out - ref).max() <= 2.0 ** -9 * np.abs(ref).max()
 
 
 def test_native_pyramid_matches_reference_layout_path_full_size(db):
@@ -441,19 +454,19 @@ def test_native_pyramid_matches_reference_layout_path_full_size(db):
     a = CorrBlock(f1, f2)(coords).float()
     b = CorrBlockRef(f1, f2)(coords).float()
     assert a.shape == b.shape == (1, E, 196, h, w)
-    assert (a - b).abs().max() <= 2.0 ** -7 * b.abs().max()
+    assert (a - b).abs().max() <= 2.0 ** -9 * b.abs().max()
 
 
-def test_native_pyramid_build_kernels_are_bit_identical(db, monkeypatch):
-    """the row-ring build kernel (default) and the chunk kernel (DH_PYR_BUILD=chunk) accumulate every cell in the same
+def test_native_pyramid_build_kernels_are_bit_identical(db, option):
+    """the row-ring build kernel (default) and the chunk kernel (option pyr_build_chunk) accumulate every cell in the same
     order: the stored pyramids must be equal bit for bit, at all three supported widths"""
     torch.manual_seed(11)
     for (E, h, w) in [(3, 48, 64), (2, 16, 32), (2, 8, 16), (1, 24, 64)]:
         f1 = torch.randn(E, 128, h, w, device="cuda").half()
         f2 = torch.randn(E, 128, h, w, device="cuda").half()
-        monkeypatch.setenv("DH_PYR_BUILD", "chunk")
+        option("pyr_build_chunk", 1)
         a = db.corr_pyramid_build(f1, f2)
-        monkeypatch.setenv("DH_PYR_BUILD", "ring")
+        option("pyr_build_chunk", 0)
         b = db.corr_pyramid_build(f1, f2)
         assert torch.equal(a, b)
 
@@ -491,11 +504,29 @@ def _update_inputs(E, h, w, seed):
     return net.half().float(), inp.half().float(), corr.half().float(), flow.half().float()
 
 
+def _check_update(out, ref, K):
+    """HIP update operator vs a reference evaluated under fp16 autocast.  Both sides store every layer output in fp16
+    (fp32 accumulation inside a convolution); the HIP path fuses the GRU algebra into the convolution epilogue in fp32
+    and rounds once where autocast rounds after every elementwise op, so they differ by a few fp16 roundings of O(1)
+    activations: 2^-9 absolute on the tanh/sigmoid-bounded outputs, 2^-9 relative to the tensor's scale elsewhere
+    (SURVEY 8c asks 2^-9 for fp16 quantities)."""
+    n, d, wt, eta, up = out
+    rn, rd, rw, re, ru = [t.float() for t in ref]
+    cmp = lambda a, b: (a.float().cpu() - b).abs().max().item()
+    tol = 2.0 ** -9
+    assert cmp(n, rn) <= tol
+    assert cmp(d, rd) <= tol * max(1.0, rd.abs().max().item())
+    assert cmp(wt, rw) <= tol
+    assert cmp(eta, re) <= tol * re.abs().max().item() + 1e-6
+    assert cmp(up, ru) <= tol * max(1.0, ru.abs().max().item())
+
+
 @pytest.mark.parametrize("shape", [(6, 16, 16), (5, 12, 16), (3, 48, 64)])
 def test_update_operator_vs_oracle(db, shape):
-    """UpdateModule (implicit-GEMM MFMA convolutions + fused GRU epilogues) vs the fp32 oracle restatement of
-    droid_net.py:111-143 on identical weights and fp16-representable inputs.  The HIP path rounds every layer
-    output to fp16 like the reference under autocast; tolerances are for that rounding chain."""
+    """UpdateModule (implicit-GEMM MFMA convolutions + fused GRU epilogues) vs the oracle restatement of
+    droid_net.py:111-143 evaluated under fp16 autocast like the reference's caller (factor_graph.py:214), on identical
+    weights and fp16 inputs; the autocast oracle is pinned bit-exactly to the reference's own module
+    (tests/test_oracle_golden.py::test_update_autocast_oracle_equals_reference_module)."""
     from oracle import update as oupd
     from droid_amd.update import UpdateModule
     from droid_amd.weights import deterministic_state_dict
@@ -503,7 +534,8 @@ def test_update_operator_vs_oracle(db, shape):
     sd = deterministic_state_dict(_SD(oupd.empty_state_dict()), seed=7)
     net, inp, corr, flow = _update_inputs(E, h, w, seed=E + h)
     ii = torch.tensor(([0, 0, 1, 2, 2, 2] * 3)[:E], dtype=torch.int64)
-    rn, rd, rw, re, ru = oupd.update_forward(sd, net, inp, corr, flow, ii)
+    with torch.no_grad():
+        ref = oupd.update_forward(sd, net.half(), inp.half(), corr.half(), flow, ii, autocast=True)
     mod = UpdateModule().load_state_dict(sd)
     n, d, wt, eta, up = mod(net[None].cuda().half(), inp[None].cuda().half(), corr[None].cuda().half(),
                             flow[None].cuda(), ii.cuda(), None)
@@ -511,20 +543,32 @@ def test_update_operator_vs_oracle(db, shape):
     assert n.shape == (1, E, 128, h, w) and d.shape == (1, E, h, w, 2) and wt.shape == (1, E, h, w, 2)
     K = len(torch.unique(ii))
     assert eta.shape == (1, K, h, w) and up.shape == (1, K, 576, h, w)
-    cmp = lambda a, b: (a.float().cpu() - b).abs().max().item()
-    assert cmp(n[0], rn) <= 2e-2
-    assert cmp(d[0], rd) <= 3e-2 * max(1.0, rd.abs().max().item())
-    assert cmp(wt[0], rw) <= 2e-2
-    assert cmp(eta[0], re) <= 2e-2 * re.abs().max().item() + 1e-5
-    assert cmp(up[0], ru) <= 3e-2 * max(1.0, ru.abs().max().item())
+    _check_update((n[0], d[0], wt[0], eta[0], up[0]), ref, K)
+
+
+def test_update_operator_vs_reference_module_under_autocast(db, golden_dir):
+    """the same operator against vectors written by the REFERENCE's own UpdateModule under torch.autocast(fp16)
+    (tests/golden/make_golden.py update_autocast; W = 64: the production convolution kernels)"""
+    from oracle import update as oupd
+    from droid_amd.update import UpdateModule
+    from droid_amd.weights import deterministic_state_dict
+    from golden_inputs import update_autocast_inputs, UPDATE_AUTOCAST
+    G = np.load(os.path.join(golden_dir, "update_autocast_python.npz"))
+    sd = deterministic_state_dict(_SD(oupd.empty_state_dict()), seed=UPDATE_AUTOCAST["weight_seed"])
+    net, inp, corr, flow, ii, jj = update_autocast_inputs()
+    mod = UpdateModule().load_state_dict(sd)
+    n, d, wt, eta, up = mod(net[None].cuda(), inp[None].cuda(), corr[None].cuda(), flow[None].cuda(), ii.cuda(), jj.cuda())
+    torch.cuda.synchronize()
+    ref = [torch.as_tensor(G[k].astype(np.float32)) for k in ("net1", "delta", "weight", "eta", "upmask")]
+    _check_update((n[0], d[0], wt[0], eta[0], up[0]), ref, 2)
 
 
 @pytest.mark.parametrize("halo,dma,halo2", [("1", "0", "1"), ("1", "0", "0"), ("1", "1", "1"), ("0", "0", "1")])
-def test_conv2d_nhwc_matches_torch_conv(db, monkeypatch, halo, dma, halo2):
+def test_conv2d_nhwc_matches_torch_conv(db, option, halo, dma, halo2):
     # all four main loops: halo2 (DMA weights, the default for 128-cout tiles), halo-tile, opt-in LDS-DMA, generic (fallback)
-    monkeypatch.setenv("DH_CONV_HALO", halo)
-    monkeypatch.setenv("DH_CONV_DMA", dma)
-    monkeypatch.setenv("DH_CONV_HALO2", halo2)
+    option("conv_halo", halo)
+    option("conv_dma", dma)
+    option("conv_halo2", halo2)
     """the raw convolution entry point against torch's fp32 conv2d: 1x1 / 3x3 / 7x7, multi-segment input, all tile configs"""
     from droid_amd.update import pack_conv, pack_conv_halo, EPI_LINEAR, EPI_RELU
     torch.manual_seed(0)
@@ -626,10 +670,10 @@ def test_altcorr_mfma_block_vs_oracle_and_reference_layout_path(db, kind):
     out = blk(dev(c)[None], dev(ii), dev(jj))[0].float().cpu().numpy()               # [M,196,H,W]
     ref = ocorr.alt_block_lookup(fm.astype(np.float32), c[None], ii, jj, 3, 4, pool_dtype=np.float16)[0]
     assert out.shape == ref.shape == (M, 196, H, W)
-    assert np.abs(out - ref).max() <= 2.0 ** -7 * np.abs(ref).max()
+    assert np.abs(out - ref).max() <= 2.0 ** -9 * np.abs(ref).max()
     blk.mfma = False                                                                  # reference-layout kernel
     out2 = blk(dev(c)[None], dev(ii), dev(jj))[0].float().cpu().numpy()
-    assert np.abs(out - out2).max() <= 2.0 ** -7 * np.abs(ref).max()
+    assert np.abs(out - out2).max() <= 2.0 ** -9 * np.abs(ref).max()
 
 
 # ------------------------------------------------------------------------------------------ full-size BA properties

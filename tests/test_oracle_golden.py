@@ -150,3 +150,23 @@ class _Named:
 
     def state_dict(self):
         return self._sd
+
+
+def test_update_autocast_oracle_equals_reference_module(golden_dir):
+    """oracle.update.update_forward(autocast=True) == the reference's UpdateModule under torch.autocast(fp16)
+    (tests/golden/update_autocast_python.npz): same rounding points, so equal to the last fp16 bit."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from golden_inputs import update_autocast_inputs, UPDATE_AUTOCAST
+    G = _load(golden_dir, "update_autocast_python.npz")
+
+    class _SD:
+        def state_dict(self):
+            return oupd.empty_state_dict()
+    sd = deterministic_state_dict(_SD(), seed=UPDATE_AUTOCAST["weight_seed"])
+    net, inp, corr, flow, ii, jj = update_autocast_inputs()
+    with torch.no_grad():
+        out = oupd.update_forward(sd, net, inp, corr, flow, ii, autocast=True)
+    for name, t in zip(("net1", "delta", "weight", "eta", "upmask"), out):
+        ref = G[name].astype(np.float32)
+        assert np.abs(t.float().numpy() - ref).max() <= 2.0 ** -11 * max(1e-6, np.abs(ref).max()), name

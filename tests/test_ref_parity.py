@@ -115,6 +115,39 @@ def test_ba_cholesky_failure_vs_reference(db, ref):
     assert np.all(a[2] == 0) and np.all(b[2] == 0) and np.array_equal(a[0], b[0])
 
 
+def test_ba_failure_in_the_first_iteration_only_vs_reference(db, ref):
+    """SparseBlock::solve judges every iteration on its own (droid_kernels.cu:1201-1221).  With ep = -0.14 the damped
+    system of iteration 1 is indefinite (lambda_min = 0.091 - 0.14) -> dx = 0 but dz = Q w is still applied, which lifts
+    lambda_min to 0.194: iteration 2 factorises and moves the poses.  A failure flag that sticks across iterations
+    would return dx = 0 from the two-iteration call."""
+    g = syn.small_graph(n_frames=6, seed=21, ht=12, wd=16)
+    one = _ba(db, g, g["poses"], g["disps"], g["eta"], 1, 6, 1, 1e-4, -0.14, False)
+    one_ref = _ba(ref[0], g, g["poses"], g["disps"], g["eta"], 1, 6, 1, 1e-4, -0.14, False)
+    assert np.all(one[2] == 0) and np.all(one_ref[2] == 0) and np.array_equal(one[0], g["poses"])
+    assert np.abs(one[1] - one_ref[1]).max() <= 1e-4 * np.abs(one_ref[1]).max()          # depth step applied by both
+    two = _ba(db, g, g["poses"], g["disps"], g["eta"], 1, 6, 2, 1e-4, -0.14, False)
+    two_ref = _ba(ref[0], g, g["poses"], g["disps"], g["eta"], 1, 6, 2, 1e-4, -0.14, False)
+    assert np.abs(two_ref[2]).max() > 0 and np.abs(two[2]).max() > 0
+    _check(two, two_ref)
+
+
+def test_ba_bad_indices_and_eta_rows_apply_no_update(db):
+    """an edge index outside the frame buffer / an eta without one row per depth block: the reference reads out of bounds
+    resp. fails its broadcast (droid_kernels.cu:1407); here the call is a no-op update, and an error in strict mode"""
+    g = syn.small_graph(n_frames=6, seed=21, ht=12, wd=16)
+    bad = dict(g); bad["jj"] = g["jj"].copy(); bad["jj"][3] = 77
+    out = _ba(db, bad, g["poses"], g["disps"], g["eta"], 1, 6, 2, 1e-4, 0.1, False)
+    assert np.array_equal(out[0], g["poses"]) and np.array_equal(out[1], g["disps"]) and np.all(out[2] == 0)
+    out = _ba(db, g, g["poses"], g["disps"], g["eta"][:-1], 1, 6, 1, 1e-4, 0.1, False)
+    assert np.array_equal(out[0], g["poses"]) and np.array_equal(out[1], g["disps"])
+    db.set_option("ba_strict", 1)
+    try:
+        with pytest.raises(RuntimeError):
+            _ba(db, bad, g["poses"], g["disps"], g["eta"], 1, 6, 1, 1e-4, 0.1, False)
+    finally:
+        db.set_option("ba_strict", 0)
+
+
 @pytest.mark.parametrize("cfg", ["C1", "C2", "C3"])
 def test_ba_baseline_configs_vs_reference(db, ref, cfg):
     """BASELINE configs[0..2] at full size (C3 = the headline: 512 keyframes / 4096 edges / 48x64, lm=1e-5, ep=1e-2),
