@@ -45,7 +45,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-update-op", action="store_true", help="skip the ConvGRU block (diagnostics only)")
     ap.add_argument("--no-lookup", action="store_true", help="skip the correlation pyramid (BA-only diagnostics)")
-    ap.add_argument("--edge-chunk", type=int, default=512, help="edges per update-operator chunk")
+    ap.add_argument("--per-edge-inp", action="store_true", help="context features gathered per edge and convolved with the "
+                    "other 320 gate inputs (the reference's data flow) instead of once per source frame (A/B)")
     return ap.parse_args()
 
 
@@ -175,7 +176,12 @@ def main():
                 return empty_state_dict()
         upd = UpdateModule(dev).load_state_dict(deterministic_state_dict(_SD(), seed=1234))
         net = d(g["nets"])[ii].permute(0, 2, 3, 1).contiguous()        # hidden state per edge, NHWC fp16
-        inp = d(g["inps"])[ii].permute(0, 2, 3, 1).contiguous()
+        # context features: frame-level table of this rank's source frames (the reference gathers video.inps[ii] per edge,
+        # factor_graph.py:135; every edge of a source frame carries the same 128 channels)
+        f_lo, f_hi = int(bounds[rank]), int(min(bounds[rank + 1], N))
+        inps_frames = d(g["inps"])[f_lo:f_hi].permute(0, 2, 3, 1).contiguous()       # [frames,h,w,128] f16
+        inp_index = (ii - f_lo).contiguous()
+        inp_edges = inps_frames[inp_index].contiguous() if args.per_edge_inp else None
     yy, xx = torch.meshgrid(torch.arange(ht, device=dev, dtype=torch.float32),
                             torch.arange(wd, device=dev, dtype=torch.float32), indexing="ij")
     coords0 = torch.stack([xx, yy], -1)[None]                             # [1,h,w,2]
@@ -203,7 +209,10 @@ def main():
         if upd is not None and feats is not None:
             motn = torch.cat([coords1 - coords0, target_prev - coords1], -1).clamp(-64.0, 64.0)
             flow = torch.nn.functional.pad(motn, (0, 4)).half()
-            _, delta, weight, damping, upmask = upd.forward_nhwc(net, inp, feats, flow, ii)
+            if inp_edges is not None:
+                _, delta, weight, damping, upmask = upd.forward_nhwc(net, inp_edges, feats, flow, ii)
+            else:
+                _, delta, weight, damping, upmask = upd.forward_nhwc(net, None, feats, flow, ii, inp_frames=inps_frames, inp_index=inp_index)
             tgt = (coords1 + delta).permute(0, 3, 1, 2).contiguous()
             wgt = weight.permute(0, 3, 1, 2).contiguous()
             damping_buf[uniq_ii] = damping                                   # factor_graph.py:238

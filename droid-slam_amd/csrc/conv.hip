@@ -51,7 +51,27 @@ struct ConvParams {
   int N, H, W, KH, KW, Cout, CoutPad, Kreal, Kpad, epi;
   void* out; int out_f32; int out_stride;
   const float* gterm; const __half* aux0; int aux0_stride; const __half* aux1; int aux1_stride; float* red;
+  // accumulator start values: acc(image n, pixel r, cout) = cinit[(cinit_idx[n] * H*W + r) * cinit_stride + cinit_off + cout]
+  // -- the contribution of input channels that are shared by all images of a group (the ConvGRU's per-source-frame
+  // context features), computed once per group by another convolution and kept in fp32
+  const float* cinit; const int64_t* cinit_idx; int cinit_stride; int cinit_off;
+  int xcd_tiles;          // > 0: 1-D grid, workgroup id -> (pixel tile, cout tile) through xcd_decode(); = pixel tiles per XCD
+  int ny;                 // cout tiles
 };
+
+// XCD-aware workgroup order (the dispatcher places workgroup b on XCD b % 8, each XCD has its own L2): XCD x walks the
+// contiguous run of pixel tiles [x * T, (x + 1) * T) and visits the cout tiles of a pixel tile back to back, so the halo
+// rows shared by vertically adjacent tiles, the second cout tile's re-read of the same activations and the accumulator
+// start values of a source frame's edges are L2 hits instead of trips to the other side of the fabric.
+__device__ __forceinline__ void xcd_decode(const ConvParams& P, long& m0, int& n0, int bn) {
+  if (P.xcd_tiles > 0) {
+    const unsigned id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const unsigned y = slot % (unsigned)P.ny, t = slot / (unsigned)P.ny;
+    m0 = ((long)xcd * P.xcd_tiles + t) * BM; n0 = (int)y * bn;
+  } else {
+    m0 = (long)blockIdx.x * BM; n0 = blockIdx.y * bn;
+  }
+}
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) { const float e = __expf(-2.f * fabsf(x)); const float t = (1.f - e) / (1.f + e); return x < 0 ? -t : t; }
@@ -61,6 +81,36 @@ __device__ __forceinline__ float round_h(float v) { return __half2float(__float2
 __device__ __forceinline__ uint4 keep_if(bool ok, const uint4& v) {
   const uint32_t m = ok ? 0xffffffffu : 0u;
   return uint4{v.x & m, v.y & m, v.z & m, v.w & m};
+}
+
+// accumulators start from zero or from P.cinit (see ConvParams); same element mapping as conv_epilogue.  one_img: the
+// tile lies inside one image (always true for the halo kernels), so the image index is formed once
+// start values for a tile that lies inside ONE image (the halo kernels): no per-element image index
+template <int TM, int TN>
+__device__ __forceinline__ void init_acc_tile(const ConvParams& P, f32x16 (&acc)[TM][TN], long m0, int n0, int wm0, int wn0,
+                                              int lane, int HW) {
+  const int img0 = (int)(m0 / HW);
+  const float* base = P.cinit + ((long)P.cinit_idx[img0] * HW + (m0 - (long)img0 * HW) + wm0 + 4 * (lane >> 5)) * P.cinit_stride
+                      + P.cinit_off + n0 + wn0 + (lane & 31);
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const bool co_ok = n0 + wn0 + b * 32 + (lane & 31) < P.Cout;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int q = 0; q < 16; ++q)            // 32 lanes read one 128-byte run of a pixel's couts
+        acc[a][b][q] = co_ok ? base[(long)(a * 32 + (q & 3) + 8 * (q >> 2)) * P.cinit_stride + b * 32] : 0.f;
+  }
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[TM][TN]) {
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
 }
 
 // ---- epilogue shared by both main loops: lane holds cout = n0 + wn0 + b*32 + (lane&31) and the 16 pixels
@@ -110,7 +160,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& P, f32x16 (&acc)
           default: break;
         }
         if (EPI == EPI_GLO) continue;
-        if (P.out_f32) reinterpret_cast<float*>(P.out)[pix * P.out_stride + co] = round_h(v);
+        if (P.out_f32 == 2) reinterpret_cast<float*>(P.out)[pix * P.out_stride + co] = v;        // raw fp32 (accumulator start values of another convolution)
+        else if (P.out_f32) reinterpret_cast<float*>(P.out)[pix * P.out_stride + co] = round_h(v);
         else reinterpret_cast<__half*>(P.out)[pix * P.out_stride + co] = __float2half(v);
       }
     if (EPI == EPI_GLO && glo_img >= 0) {
@@ -339,12 +390,7 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_kernel(ConvParams P) {
   };
 
   f32x16 acc[TM][TN];
-#pragma unroll
-  for (int a = 0; a < TM; ++a)
-#pragma unroll
-    for (int b = 0; b < TN; ++b)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+  zero_acc<TM, TN>(acc);                   // (start values: halo2 kernel only; the dispatcher refuses them here)
 
   fetch(0);
   for (int chunk = 0; chunk < nchunks; ++chunk) {
@@ -473,12 +519,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo_kernel(ConvParams P) {
   }
 
   f32x16 acc[TM][TN];
-#pragma unroll
-  for (int a = 0; a < TM; ++a)
-#pragma unroll
-    for (int b = 0; b < TN; ++b)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+  zero_acc<TM, TN>(acc);                  // (start values are not supported by this kernel: the dispatcher routes them elsewhere)
 
   HALO_FETCH_A(0)
   HALO_FETCH_B(0)
@@ -741,7 +782,7 @@ constexpr int H2A_BYTES = HPIX * H2CK * 2;               // 25,344: halo [396 px
 constexpr int H2B_BYTES = 3 * 128 * H2CK * 2;            // 24,576: one (chunk, dy) weight group
 constexpr int H2_LDS_BYTES = H2A_BYTES + 2 * H2B_BYTES;  // 74,496 (the staged epilogue tile needs 69,632)
 
-template <int EPI>
+template <int EPI, bool STAGED = true, bool CINIT = false>
 __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
   extern __shared__ __half s_conv[];
   char* const lds = reinterpret_cast<char*>(s_conv);
@@ -749,8 +790,8 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wrow = wave & 3, wn0 = (wave >> 2) * 64, wm0 = wrow * 64;
-  const long m0 = (long)blockIdx.x * BM;
-  const int n0 = blockIdx.y * 128;
+  long m0; int n0;
+  xcd_decode(P, m0, n0, 128);
   const int HW = P.H * P.W;
   const int img = (int)(m0 / HW), y0 = (int)((m0 - (long)img * HW) / 64);
   const int nchunks = P.Ctot / H2CK, nsteps = nchunks * 3;
@@ -769,7 +810,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
   }
   // weight DMA: per-lane offset (one register for every piece) + wave-uniform base pointer in SGPRs
   const int b_voff = lane * 16;
-  const char* const bsrc = reinterpret_cast<const char*>(P.wt_halo) + (long)blockIdx.y * nsteps * H2B_BYTES;
+  const char* const bsrc = reinterpret_cast<const char*>(P.wt_halo) + (long)(n0 >> 7) * nsteps * H2B_BYTES;
 
   // fragment addressing: 16-byte slot s of row r sits at r*64 + ((s ^ ((r >> 2) & 3)) << 4)
   const int pl = wrow * HCOLS + (lane & 31), kh = lane >> 5;
@@ -781,12 +822,8 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
   }
 
   f32x16 acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+  if constexpr (CINIT) init_acc_tile<2, 2>(P, acc, m0, n0, wm0, wn0, lane, HW);
+  else zero_acc<2, 2>(acc);
 
   u32x4 ra[A_PIECES];
 #define H2_FETCH_A(chunk_)                                                                                           \
@@ -874,7 +911,8 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
 #undef H2_FETCH_A
 #undef H2_DMA_B
 #undef GLDS16S
-  staged_epilogue<EPI, 2, 128>(P, acc, s_conv, m0, n0, wm0, wn0, tid, HW);
+  if constexpr (STAGED) staged_epilogue<EPI, 2, 128>(P, acc, s_conv, m0, n0, wm0, wn0, tid, HW);
+  else conv_epilogue<EPI, 2, 2>(P, acc, (long)P.N * HW, m0, n0, wm0, wn0, lane, HW);
 }
 
 // mean over the rows of each segment (GraphAgg's scatter_mean over the edges of a source frame, reference
@@ -964,9 +1002,28 @@ int launch_dma(const ConvParams& P, hipStream_t st) {
 }
 
 template <int EPI>
-int launch_halo2(const ConvParams& P, hipStream_t st) {
+int launch_halo2(const ConvParams& P0, hipStream_t st) {
+  ConvParams P = P0;
   const long M = (long)P.N * P.H * P.W;
-  const dim3 grid((unsigned)(M / BM), (unsigned)(P.CoutPad / 128));
+  dim3 grid((unsigned)(M / BM), (unsigned)(P.CoutPad / 128));
+  P.ny = (int)grid.y;
+  if (opts().conv_xcd && grid.x % 8 == 0) { P.xcd_tiles = (int)(grid.x / 8); grid = dim3(grid.x * grid.y, 1); }
+  if constexpr (EPI == EPI_LINEAR) {
+    if (P.out_f32) {                                      // fp32 output: 32 lanes already store one full 128-byte run per pixel
+      DH_LDS_OPTIN((&conv3x3_halo2_kernel<EPI, false>), 80 * 1024);
+      hipLaunchKernelGGL((conv3x3_halo2_kernel<EPI, false>), grid, dim3(512), H2_LDS_BYTES, st, P);
+      DH_LAUNCH_CHECK();
+      return DH_OK;
+    }
+  }
+  if constexpr (EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q) {
+    if (P.cinit) {
+      DH_LDS_OPTIN((&conv3x3_halo2_kernel<EPI, true, true>), 80 * 1024);
+      hipLaunchKernelGGL((conv3x3_halo2_kernel<EPI, true, true>), grid, dim3(512), H2_LDS_BYTES, st, P);
+      DH_LAUNCH_CHECK();
+      return DH_OK;
+    }
+  }
   DH_LDS_OPTIN((&conv3x3_halo2_kernel<EPI>), 80 * 1024);
   hipLaunchKernelGGL((conv3x3_halo2_kernel<EPI>), grid, dim3(512), H2_LDS_BYTES, st, P);
   DH_LAUNCH_CHECK();
@@ -987,6 +1044,8 @@ bool halo2_ok(const ConvParams& P) {
   if (!halo2_layout(P.CoutPad, P.Ctot)) return false;
   if (!P.wt_halo || P.KH != 3 || P.KW != 3 || P.W != 64 || P.H % 4) return false;
   for (int i = 0; i < P.nseg; ++i) if (P.segC[i] % H2CK) return false;
+  if (P.cinit && EPI != EPI_GRU_ZR && EPI != EPI_GRU_Q) return false;
+  if (EPI == EPI_LINEAR && P.out_f32) return true;          // per-element fp32 stores (launch_halo2)
   return staged_epilogue_ok<EPI>(P);
 }
 
@@ -1000,7 +1059,7 @@ bool dma_layout(int CoutPad, int Ctot) {
 }
 
 bool dma_ok(const ConvParams& P) {
-  if (!opts().conv_halo) return false;                      // 0: generic loop only
+  if (!opts().conv_halo || P.cinit) return false;           // 0: generic loop only
   if (!dma_layout(P.CoutPad, P.Ctot)) return false;
   if (!P.wt_halo || P.KH != 3 || P.KW != 3 || P.W != 64 || P.H % 4) return false;
   for (int i = 0; i < P.nseg; ++i) if (P.segC[i] % DCK || P.segS[i] % 8) return false;
@@ -1009,6 +1068,7 @@ bool dma_ok(const ConvParams& P) {
 
 // small-Cout convolutions (CoutPad == 32 or 64): bound by re-reading the activations in the generic loop
 bool halo_small_ok(const ConvParams& P, int bn) {
+  if (P.cinit) return false;
   if (!P.wt_halo || P.KH != 3 || P.KW != 3 || P.W != 64 || P.H % 4 || P.CoutPad != bn) return false;
   for (int i = 0; i < P.nseg; ++i) if (P.segC[i] % (halo_afc(bn) * halo_ck(bn))) return false;
   return true;
@@ -1019,7 +1079,7 @@ bool halo_ok(const ConvParams& P) {
   // update iteration: 91.9 vs 104.1 ms for the update operator (step 100.8 vs 113.1 ms); in isolation at 1024 edges
   // 448->256: 7.3 vs 8.7 ms, 448->128: 3.7 vs 4.3 ms, 128->128: 1.37 vs 1.45 ms.  (A first version with 32-channel
   // chunks -- one workgroup per CU -- and strided weight reads was slower than the generic loop inside the iteration.)
-  if (!opts().conv_halo) return false;
+  if (!opts().conv_halo || P.cinit) return false;
   if (dma_layout(P.CoutPad, P.Ctot) || halo2_layout(P.CoutPad, P.Ctot)) return false;     // weights_halo holds another layout
   if (!P.wt_halo || P.KH != 3 || P.KW != 3 || P.W != 64 || P.H % 4 || P.CoutPad % 128 || P.Ctot < 128) return false;
   for (int i = 0; i < P.nseg; ++i) if (P.segC[i] % halo_ck(128)) return false;
@@ -1043,12 +1103,13 @@ int launch(const ConvParams& P, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int dh_conv2d_nhwc_f16(const void* const* inputs, const int* in_channels, const int* in_strides, int n_inputs,
-                                  const void* weights, const void* weights_halo, const float* bias,
-                                  int N, int H, int W, int KH, int KW, int Cout, int CoutPad, int Kpad, int epilogue,
-                                  void* out, int out_is_f32, int out_stride,
-                                  const float* gterm, const void* aux0, int aux0_stride, const void* aux1, int aux1_stride,
-                                  float* red, dh_stream_t stream) {
+extern "C" int dh_conv2d_nhwc_f16_ex(const void* const* inputs, const int* in_channels, const int* in_strides, int n_inputs,
+                                     const void* weights, const void* weights_halo, const float* bias,
+                                     int N, int H, int W, int KH, int KW, int Cout, int CoutPad, int Kpad, int epilogue,
+                                     void* out, int out_is_f32, int out_stride,
+                                     const float* gterm, const void* aux0, int aux0_stride, const void* aux1, int aux1_stride,
+                                     float* red, const float* cinit, const int64_t* cinit_idx, int cinit_stride, int cinit_off,
+                                     dh_stream_t stream) {
   if (n_inputs < 1 || n_inputs > MAXSEG || !inputs || !in_channels || !weights || !bias) return DH_ERR_ARG;
   if (N < 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0 || !(KH & 1) || !(KW & 1)) return DH_ERR_ARG;
   if (Cout <= 0 || CoutPad < Cout || CoutPad % 32 || Kpad <= 0 || Kpad % BK) return DH_ERR_ARG;
@@ -1069,7 +1130,10 @@ extern "C" int dh_conv2d_nhwc_f16(const void* const* inputs, const int* in_chann
   if (epilogue == EPI_GRU_ZR && !aux0) return DH_ERR_ARG;
   if (epilogue == EPI_GRU_Q && (!aux0 || !aux1)) return DH_ERR_ARG;
   if (epilogue != EPI_GLO && !out) return DH_ERR_ARG;
+  if (out_is_f32 < 0 || out_is_f32 > 2) return DH_ERR_ARG;
+  if (cinit && (!cinit_idx || cinit_stride < cinit_off + Cout || cinit_off < 0)) return DH_ERR_ARG;
   if (N == 0) return DH_OK;
+  P.cinit = cinit; P.cinit_idx = cinit_idx; P.cinit_stride = cinit_stride; P.cinit_off = cinit_off;
   P.wt = (const __half*)weights; P.wt_halo = (const __half*)weights_halo; P.bias = bias;
   P.N = N; P.H = H; P.W = W; P.KH = KH; P.KW = KW; P.Cout = Cout; P.CoutPad = CoutPad; P.Kpad = Kpad; P.epi = epilogue;
   P.out = out; P.out_f32 = out_is_f32; P.out_stride = out_stride;
@@ -1119,9 +1183,21 @@ extern "C" int dh_conv2d_nhwc_f16(const void* const* inputs, const int* in_chann
       default: break;
     }
   }
+  if (P.cinit) return DH_ERR_UNSUPPORTED;                    // accumulator start values: 3x3, W == 64, H % 4 == 0, gate epilogues only
   if (CoutPad >= 128) return launch<64, 64, 128>(P, st);
   if (CoutPad >= 64) return launch<64, 32, 64>(P, st);
   return launch<32, 32, 32>(P, st);
+}
+
+extern "C" int dh_conv2d_nhwc_f16(const void* const* inputs, const int* in_channels, const int* in_strides, int n_inputs,
+                                  const void* weights, const void* weights_halo, const float* bias,
+                                  int N, int H, int W, int KH, int KW, int Cout, int CoutPad, int Kpad, int epilogue,
+                                  void* out, int out_is_f32, int out_stride,
+                                  const float* gterm, const void* aux0, int aux0_stride, const void* aux1, int aux1_stride,
+                                  float* red, dh_stream_t stream) {
+  return dh_conv2d_nhwc_f16_ex(inputs, in_channels, in_strides, n_inputs, weights, weights_halo, bias, N, H, W, KH, KW, Cout,
+                               CoutPad, Kpad, epilogue, out, out_is_f32, out_stride, gterm, aux0, aux0_stride, aux1, aux1_stride,
+                               red, nullptr, nullptr, 0, 0, stream);
 }
 
 extern "C" int dh_segment_mean_f16(const void* x, const int64_t* order, const int64_t* seg_off, void* out,

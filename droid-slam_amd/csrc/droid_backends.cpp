@@ -313,7 +313,8 @@ void conv2d_nhwc(std::vector<torch::Tensor> inputs, torch::Tensor weight, c10::o
                  torch::Tensor bias, int64_t KH, int64_t KW,
                  int64_t Cout, int64_t epilogue, c10::optional<torch::Tensor> out, int64_t out_stride,
                  c10::optional<torch::Tensor> gterm, c10::optional<torch::Tensor> aux0, c10::optional<torch::Tensor> aux1,
-                 c10::optional<torch::Tensor> red) {
+                 c10::optional<torch::Tensor> red, c10::optional<torch::Tensor> cinit, c10::optional<torch::Tensor> cinit_idx,
+                 int64_t cinit_off, bool out_raw_f32) {
   TORCH_CHECK(!inputs.empty() && inputs.size() <= 4, "conv2d_nhwc: 1..4 inputs");
   const void* ptrs[4]; int chans[4], strides[4];
   const int64_t N = inputs[0].size(0), H = inputs[0].size(1), W = inputs[0].size(2);
@@ -332,12 +333,23 @@ void conv2d_nhwc(std::vector<torch::Tensor> inputs, torch::Tensor weight, c10::o
   const bool out_f32 = out.has_value() && out->scalar_type() == torch::kFloat32;
   if (gterm.has_value()) { const torch::Tensor& gt = *gterm; CHECK_INPUT(gt); CHECK_F32(gt); }
   if (red.has_value()) { const torch::Tensor& rt = *red; CHECK_INPUT(rt); CHECK_F32(rt); }
-  check_status(dh_conv2d_nhwc_f16(ptrs, chans, strides, (int)inputs.size(), weight.data_ptr(), opt_ptr(weight_halo), bias.data_ptr<float>(),
-                                  (int)N, (int)H, (int)W, (int)KH, (int)KW, (int)Cout, (int)weight.size(0), (int)weight.size(1),
-                                  (int)epilogue, opt_ptr(out), out_f32 ? 1 : 0, (int)out_stride,
-                                  gterm.has_value() ? gterm->data_ptr<float>() : nullptr,
-                                  opt_ptr(aux0), last(aux0), opt_ptr(aux1), last(aux1),
-                                  red.has_value() ? red->data_ptr<float>() : nullptr, cur_stream()),
+  const float* ci = nullptr; const int64_t* cidx = nullptr; int cstride = 0;
+  if (cinit.has_value()) {
+    const torch::Tensor& ct = *cinit;
+    TORCH_CHECK(cinit_idx.has_value(), "conv2d_nhwc: cinit needs cinit_idx");
+    const torch::Tensor& it = *cinit_idx;
+    CHECK_INPUT(ct); CHECK_F32(ct); CHECK_INPUT(it); CHECK_I64(it);
+    TORCH_CHECK(ct.dim() == 4 && ct.size(1) == H && ct.size(2) == W && it.numel() == N, "conv2d_nhwc: cinit [K,H,W,C] f32, cinit_idx [N] i64");
+    ci = ct.data_ptr<float>(); cidx = it.data_ptr<int64_t>(); cstride = (int)ct.size(3);
+  }
+  TORCH_CHECK(!out_raw_f32 || out_f32, "conv2d_nhwc: out_raw_f32 needs a float32 output");
+  check_status(dh_conv2d_nhwc_f16_ex(ptrs, chans, strides, (int)inputs.size(), weight.data_ptr(), opt_ptr(weight_halo), bias.data_ptr<float>(),
+                                     (int)N, (int)H, (int)W, (int)KH, (int)KW, (int)Cout, (int)weight.size(0), (int)weight.size(1),
+                                     (int)epilogue, opt_ptr(out), out_f32 ? (out_raw_f32 ? 2 : 1) : 0, (int)out_stride,
+                                     gterm.has_value() ? gterm->data_ptr<float>() : nullptr,
+                                     opt_ptr(aux0), last(aux0), opt_ptr(aux1), last(aux1),
+                                     red.has_value() ? red->data_ptr<float>() : nullptr, ci, cidx, cstride, (int)cinit_off,
+                                     cur_stream()),
                "conv2d_nhwc");
 }
 
@@ -410,7 +422,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("corr_pyramid_lookup", &corr_pyramid_lookup, "fused 4-level lookup on the MI355X pyramid");
   m.def("corr_pyramid_lookup_nhwc", &corr_pyramid_lookup_nhwc, "fused 4-level lookup, channel-last output for the update operator");
   m.def("segment_mean", &segment_mean, "mean over row segments (GraphAgg scatter_mean)");
-  m.def("conv2d_nhwc", &conv2d_nhwc, "implicit-GEMM NHWC convolution on the fp16 MFMA with fused epilogues");
+  m.def("conv2d_nhwc", &conv2d_nhwc, "implicit-GEMM NHWC convolution on the fp16 MFMA with fused epilogues",
+        py::arg("inputs"), py::arg("weight"), py::arg("weight_halo"), py::arg("bias"), py::arg("KH"), py::arg("KW"), py::arg("Cout"),
+        py::arg("epilogue"), py::arg("out"), py::arg("out_stride"), py::arg("gterm"), py::arg("aux0"), py::arg("aux1"), py::arg("red"),
+        py::arg("cinit") = py::none(), py::arg("cinit_idx") = py::none(), py::arg("cinit_off") = 0, py::arg("out_raw_f32") = false);
   m.def("reproject", &reproject, "fused reprojection (Python thresholds)");
   m.def("se3_op", &se3_op, "SE3 inv/mul/exp/retr");
   m.def("se3_map", &se3_map, "SE3 act4/adjT");

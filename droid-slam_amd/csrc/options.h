@@ -11,6 +11,7 @@ struct Options {
   int conv_halo;        // DH_CONV_HALO (1): 3x3 halo-tile kernels; 0 = generic loop only
   int conv_halo2;       // DH_CONV_HALO2 (1): weights by LDS-DMA for 128-cout tiles; 0 = first halo kernel
   int conv_dma;         // DH_CONV_DMA (0): opt-in one-workgroup-per-CU LDS-DMA experiment
+  int conv_xcd;         // DH_CONV_XCD (1): XCD-aware workgroup order of the 3x3 halo2 kernel (conv.hip xcd_decode)
   int dma_var;          // DH_DMA_VAR (0): timing ablations of that experiment
   int pyr_build_chunk;  // DH_PYR_BUILD=chunk (0): first form of the pyramid build kernel
   int ba_strict;        // DH_BA_STRICT (0): dh_ba synchronises and returns DH_ERR_ARG on bad indices / eta rows

@@ -19,6 +19,7 @@ Options& opts() {
     v.conv_halo = env_int("DH_CONV_HALO", 1);
     v.conv_halo2 = env_int("DH_CONV_HALO2", 1);
     v.conv_dma = env_int("DH_CONV_DMA", 0);
+    v.conv_xcd = env_int("DH_CONV_XCD", 1);
     v.dma_var = env_int("DH_DMA_VAR", 0);
     const char* pb = getenv("DH_PYR_BUILD");
     v.pyr_build_chunk = (pb && !strcmp(pb, "chunk")) ? 1 : 0;
@@ -37,6 +38,7 @@ static int* slot(const char* name) {
   if (!strcmp(name, "conv_halo")) return &o.conv_halo;
   if (!strcmp(name, "conv_halo2")) return &o.conv_halo2;
   if (!strcmp(name, "conv_dma")) return &o.conv_dma;
+  if (!strcmp(name, "conv_xcd")) return &o.conv_xcd;
   if (!strcmp(name, "dma_var")) return &o.dma_var;
   if (!strcmp(name, "pyr_build_chunk")) return &o.pyr_build_chunk;
   if (!strcmp(name, "ba_strict")) return &o.ba_strict;

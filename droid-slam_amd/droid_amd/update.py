@@ -129,22 +129,26 @@ class _Conv:
     def __init__(self, wp, bp, k, cout, wh=None):
         self.w, self.b, self.k, self.cout, self.wh = wp, bp, k, cout, wh
 
-    def __call__(self, inputs, epi, out=None, out_stride=None, gterm=None, aux0=None, aux1=None, red=None):
+    def __call__(self, inputs, epi, out=None, out_stride=None, gterm=None, aux0=None, aux1=None, red=None,
+                 cinit=None, cinit_idx=None, cinit_off=0, out_raw_f32=False):
         x0 = inputs[0]
         if out is None and epi != EPI_GLO:
-            out = torch.empty(x0.shape[0], x0.shape[1], x0.shape[2], self.cout, dtype=torch.float16, device=x0.device)
+            out = torch.empty(x0.shape[0], x0.shape[1], x0.shape[2], self.cout,
+                              dtype=torch.float32 if out_raw_f32 else torch.float16, device=x0.device)
         stride = 0 if out is None else (out.shape[-1] if out_stride is None else out_stride)
         droid_backends.conv2d_nhwc(list(inputs), self.w, self.wh, self.b, self.k, self.k, self.cout, epi, out, stride,
-                                   gterm, aux0, aux1, red)
+                                   gterm, aux0, aux1, red, cinit, cinit_idx, cinit_off, out_raw_f32)
         return out
 
 
 class UpdateModule:
     """Weight-compatible, inference-only replacement of droid_net.UpdateModule."""
 
-    def __init__(self, device="cuda"):
+    def __init__(self, device="cuda", share_inp_by_source_frame=False):
         self.device = torch.device(device)
         self.params = None
+        # forward() (the reference's interface, per-edge `inp`): treat edges with equal ii as sharing their context features
+        self.share_inp_by_source_frame = share_inp_by_source_frame
 
     # ---- parameters ----------------------------------------------------------------------------
     def load_state_dict(self, sd, prefix=""):
@@ -169,6 +173,18 @@ class UpdateModule:
         P["zr"] = _Conv(*pack_conv(torch.cat([wz, wr], 0), torch.cat([g("gru.convz.bias"), g("gru.convr.bias")], 0)), 3, 256,
                         pack_conv_halo(torch.cat([wz, wr], 0)))
         P["q"] = conv("gru.convq")
+        # The context features `inp` are the same for every edge of a source frame (reference factor_graph.py:135,299:
+        # video.inps[ii]).  Split the 448 input channels of the gate convolutions into (net | c, f) = 320 per-edge channels
+        # and the 128 channels of inp: the latter's contribution to z | r | q is ONE convolution per FRAME
+        # (`ctx`: 128 -> 384, fp32, no bias) that the per-edge convolutions (`zr_e`, `q_e`) start their accumulators from.
+        wq = g("gru.convq.weight")
+        edge_ch = torch.cat([torch.arange(0, 128), torch.arange(256, 448)]).to(self.device)
+        wzr_e = torch.cat([wz, wr], 0)[:, edge_ch].contiguous()
+        P["zr_e"] = _Conv(*pack_conv(wzr_e, torch.cat([g("gru.convz.bias"), g("gru.convr.bias")], 0)), 3, 256, pack_conv_halo(wzr_e))
+        wq_e = wq[:, edge_ch].contiguous()
+        P["q_e"] = _Conv(*pack_conv(wq_e, g("gru.convq.bias")), 3, 128, pack_conv_halo(wq_e))
+        wctx = torch.cat([wz, wr, wq], 0)[:, 128:256].contiguous()
+        P["ctx"] = _Conv(*pack_conv(wctx, torch.zeros(384, device=self.device)), 3, 384, pack_conv_halo(wctx))
         for n in ("z", "r", "q"):
             P["glo_" + n] = (g("gru.conv%s_glo.weight" % n).float().reshape(128, 128), g("gru.conv%s_glo.bias" % n).float())
         # the two head stems (delta.0 | weight.0) share their input: one convolution with 256 outputs;
@@ -196,10 +212,21 @@ class UpdateModule:
         return x.to(torch.float16).contiguous()
 
     # ---- the operator ----------------------------------------------------------------------------
-    def forward_nhwc(self, net, inp, corr, flow, ii):
-        """net, inp [E,h,w,128] f16 (net is updated IN PLACE), corr [4,E,h,w,56] f16 = the level-planar channel-last
-        output of droid_backends.corr_pyramid_lookup_nhwc (channel order: corr_channel_map), flow [E,h,w,8] f16 (4 + zero pad), ii [E] int64 ->
-        (net, delta [E,h,w,2] f32, weight [E,h,w,2] f32, eta [K,h,w] f32, upmask [K,h,w,576] f16)."""
+    def context_term(self, inp_frames):
+        """inp_frames [K,h,w,128] f16 -> [K,h,w,384] f32: the context features' share of the z | r | q pre-activations
+        (no bias).  Depends only on the frames' context features, i.e. it can be kept for as long as the keyframes live;
+        forward_nhwc recomputes it on every call unless the caller passes it in."""
+        return self.params["ctx"]([inp_frames], EPI_LINEAR, out_raw_f32=True)
+
+    def forward_nhwc(self, net, inp, corr, flow, ii, inp_frames=None, inp_index=None, ctx=None):
+        """net [E,h,w,128] f16 (updated IN PLACE), corr [4,E,h,w,56] f16 = the level-planar channel-last output of
+        droid_backends.corr_pyramid_lookup_nhwc (channel order: corr_channel_map), flow [E,h,w,8] f16 (4 + zero pad),
+        ii [E] int64.  Context features, one of
+          * inp [E,h,w,128] f16 per edge (the reference's calling convention: any values), or
+          * inp = None, inp_frames [K',h,w,128] f16 + inp_index [E] int64: edge e uses row inp_index[e] (what the reference's
+            callers pass in effect: video.inps[ii]); the gate convolutions then run over 320 instead of 448 channels on top
+            of one per-frame convolution (`context_term`, passed in as `ctx` [K',h,w,384] f32 if the caller keeps it).
+        -> (net, delta [E,h,w,2] f32, weight [E,h,w,2] f32, eta [K,h,w] f32, upmask [K,h,w,576] f16)."""
         P = self.params
         E, h, w, _ = net.shape
         c = P["corr2"]([P["corr0"]([corr[0], corr[1], corr[2], corr[3]], EPI_RELU)], EPI_RELU)
@@ -210,8 +237,17 @@ class UpdateModule:
         glo = (red / float(h * w)).half().float()
         gz, gr, gq = (torch.addmm(P["glo_" + n][1], glo, P["glo_" + n][0].t()).half().float() for n in ("z", "r", "q"))
         gzr = torch.cat([gz, gr], 1).contiguous()
-        zr = P["zr"]([net, inp, c, f], EPI_GRU_ZR, gterm=gzr, aux0=net)             # [E,h,w,256] = z | r*net
-        P["q"]([zr[..., 128:], inp, c, f], EPI_GRU_Q, out=net, gterm=gq.contiguous(), aux0=net, aux1=zr)
+        if inp is None and not (w == 64 and h % 4 == 0):
+            inp = inp_frames[inp_index]        # image shape outside the production kernel: the reference's data flow
+        if inp is not None:
+            zr = P["zr"]([net, inp, c, f], EPI_GRU_ZR, gterm=gzr, aux0=net)             # [E,h,w,256] = z | r*net
+            P["q"]([zr[..., 128:], inp, c, f], EPI_GRU_Q, out=net, gterm=gq.contiguous(), aux0=net, aux1=zr)
+        else:
+            if ctx is None:
+                ctx = self.context_term(inp_frames)
+            zr = P["zr_e"]([net, c, f], EPI_GRU_ZR, gterm=gzr, aux0=net, cinit=ctx, cinit_idx=inp_index, cinit_off=0)
+            P["q_e"]([zr[..., 128:], c, f], EPI_GRU_Q, out=net, gterm=gq.contiguous(), aux0=net, aux1=zr,
+                     cinit=ctx, cinit_idx=inp_index, cinit_off=256)
         hd = P["heads0"]([net], EPI_RELU)
         dw = torch.empty(E, h, w, 4, dtype=torch.float32, device=net.device)
         P["heads2"]([hd], EPI_HEADS, out=dw)
@@ -243,7 +279,16 @@ class UpdateModule:
         c = self.to_nhwc(cpad[:, torch.where(self.cmap >= 0, self.cmap, torch.full_like(self.cmap, COR_PLANES))])
         c = c.view(c.shape[0], ht, wd, 4, 56).permute(3, 0, 1, 2, 4).contiguous()
         f = self.to_nhwc(flow[0], 8)
-        n, delta, weight, eta, upmask = self.forward_nhwc(n, i, c, f, ii.to(net.device))
+        ii = ii.to(net.device)
+        if self.share_inp_by_source_frame:
+            # edges with equal ii carry the same context features (true for every call site of the reference:
+            # factor_graph.py:135,299, motion_filter.py): convolve them once per source frame
+            uniq, ix = torch.unique(ii, return_inverse=True)
+            first = torch.full((uniq.numel(),), ii.numel(), dtype=torch.long, device=ii.device)
+            first.scatter_reduce_(0, ix, torch.arange(ii.numel(), device=ii.device), reduce="amin")
+            n, delta, weight, eta, upmask = self.forward_nhwc(n, None, c, f, ii, inp_frames=i[first].contiguous(), inp_index=ix.contiguous())
+        else:
+            n, delta, weight, eta, upmask = self.forward_nhwc(n, i, c, f, ii)
         net_out = n.permute(0, 3, 1, 2)[None].to(net.dtype)
         return net_out, delta[None], weight[None], eta[None], upmask.permute(0, 3, 1, 2)[None]
 

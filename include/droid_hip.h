@@ -178,6 +178,22 @@ int dh_conv2d_nhwc_f16(const void* const* inputs, const int* in_channels, const 
                        void* out, int out_is_f32, int out_stride,
                        const float* gterm, const void* aux0, int aux0_stride, const void* aux1, int aux1_stride,
                        float* red, dh_stream_t stream);
+/* The same convolution with accumulator start values:  acc(image n, pixel r, cout) starts from
+ *   cinit[(cinit_idx[n] * H*W + r) * cinit_stride + cinit_off + cout]   (fp32; cinit_idx [N] i64)
+ * instead of zero, and out_is_f32 == 2 stores unrounded fp32.  This is how the per-source-frame context features of the
+ * ConvGRU (reference `inp`, droid_slam/factor_graph.py:135: video.inps[ii], identical for all edges of a source frame)
+ * leave the per-edge convolutions: their contribution to the z, r, q gates is one convolution per FRAME
+ * (out_is_f32 = 2), and the per-edge gate convolutions run over 320 instead of 448 input channels starting from it --
+ * the same sum, associated differently.  Supported where the gate convolutions take their production kernel (3x3, W == 64,
+ * H % 4 == 0, every in_channels[i] % 32 == 0, epilogue 3 or 4); DH_ERR_UNSUPPORTED otherwise (the caller then gathers the
+ * context features per edge and uses dh_conv2d_nhwc_f16 on all 448 channels). */
+int dh_conv2d_nhwc_f16_ex(const void* const* inputs, const int* in_channels, const int* in_strides, int n_inputs,
+                          const void* weights, const void* weights_halo, const float* bias,
+                          int N, int H, int W, int KH, int KW, int Cout, int CoutPad, int Kpad, int epilogue,
+                          void* out, int out_is_f32, int out_stride,
+                          const float* gterm, const void* aux0, int aux0_stride, const void* aux1, int aux1_stride,
+                          float* red, const float* cinit, const int64_t* cinit_idx, int cinit_stride, int cinit_off,
+                          dh_stream_t stream);
 
 /* GraphAgg's scatter_mean (reference droid_net.py:67, torch_scatter): out[k,:] = mean of the rows x[order[i],:],
  * i in [seg_off[k], seg_off[k+1]); x [E,row_elems] f16, out [K,row_elems] f16, row_elems % 8 == 0. */

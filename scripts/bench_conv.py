@@ -9,11 +9,15 @@ from droid_amd.update import pack_conv, pack_conv_halo, EPI_RELU, EPI_LINEAR
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 h, w = 48, 64
 torch.manual_seed(0)
-shapes = [("gru z|r 3x3 448->256", (128, 128, 128, 64), 256, 3), ("gru q 3x3 448->128", (128, 128, 128, 64), 128, 3),
+shapes = [("gru z|r 3x3 448->256", (128, 128, 128, 64), 256, 3), ("gates z|r 3x3 320->256", (128, 128, 64), 256, 3), ("gru q 3x3 448->128", (128, 128, 128, 64), 128, 3),
           ("3x3 128->128", (128,), 128, 3), ("heads0 3x3 128->256", (128,), 256, 3), ("heads2 3x3 256->4", (256,), 4, 3),
           ("corr0 1x1 200->128", (200,), 128, 1), ("flow0 7x7 8->128", (8,), 128, 7), ("flow2 3x3 128->64", (128,), 64, 3),
           ("upmask 1x1 128->576 (K=512 frames)", (128,), 576, 1)]
+only = os.environ.get("DH_SHAPE")        # substring filter (profiling one shape)
+reps = int(os.environ.get("DH_REPS", "3"))
 for name, cins, cout, k in shapes:
+    if only and only not in name:
+        continue
     n = E // 8 if "upmask" in name else E
     xs = [torch.randn(n, h, w, c, device="cuda").half() for c in cins]
     wgt = torch.randn(cout, sum(cins), k, k, device="cuda") / (sum(cins) * k * k) ** 0.5
@@ -29,7 +33,7 @@ for name, cins, cout, k in shapes:
         ref = ref if epi == EPI_LINEAR else ref.clamp_min(0)
         print("   max |err| = %.4f (ref max %.2f)" % ((out[:2].float() - ref).abs().max().item(), ref.abs().max().item()))
     ts = []
-    for _ in range(3):
+    for _ in range(reps):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(); run(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
     ms = min(ts); fl = 2.0 * n * h * w * sum(cins) * k * k * cout

@@ -1,23 +1,27 @@
 #!/bin/bash
+# SQ / LDS / TA counters of one convolution shape (default: the 320->256 gate convolution, 1024 edges) in separate
+# rocprofv3 --pmc passes (kernel-trace only, as the pool requires).  usage: scripts/pmc_conv.sh [shape-substring] [outdir]
 export TMPDIR=/tmp
-OUT=gpurun_out/pmc_conv2; mkdir -p $OUT
+SHAPE=${1:-"gates z|r"}; OUT=${2:-gpurun_out/pmc_conv}; mkdir -p $OUT
+rocprofv3 -L > $OUT/counters_available.txt 2>&1
+DH_SHAPE="$SHAPE" python scripts/bench_conv.py 1024 | tee $OUT/timing.txt
 i=0
-while read -r pmc; do
-  [ -z "$pmc" ] && continue
+for pmc in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_LDS" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES" \
+           "SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_WAIT_INST_VMEM" \
+           "TA_TA_BUSY_sum TA_BUSY_avr GRBM_GUI_ACTIVE" "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" \
+           "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum"; do
   i=$((i+1))
-  timeout 120 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $OUT/pass$i -o run -- python scripts/bench_conv.py 512 > $OUT/pass$i.log 2>&1 || echo "pass $i failed: $pmc"
-done <<'LIST'
-SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU
-SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD
-TA_BUSY_avr TA_BUSY_max GRBM_GUI_ACTIVE
-LIST
+  DH_SHAPE="$SHAPE" DH_REPS=1 timeout 300 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $OUT/p$i -o run -- python scripts/bench_conv.py 1024 > $OUT/p$i.log 2>&1 || echo "pass $i failed: $pmc"
+done
 python - <<PY
-import csv, glob, collections
-for f in sorted(glob.glob("$OUT/pass*/run_counter_collection.csv")):
-    agg = collections.defaultdict(lambda: [0, 0.0])
+import csv, glob, collections, json
+agg = collections.defaultdict(lambda: [0, 0.0])
+for f in sorted(glob.glob("$OUT/p*/run_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        if "conv3x3_halo_kernel<1, 128>" in r["Kernel_Name"] and r.get("Grid_Size","") == "6291456":
-            agg[r["Counter_Name"]][0] += 1; agg[r["Counter_Name"]][1] += float(r["Counter_Value"])
-    for k, (n, v) in sorted(agg.items()):
-        print("%s %s %.5g (n=%d)" % (f.split("/")[-2], k, v / n, n))
+        if "conv" in r["Kernel_Name"]:
+            k = r["Counter_Name"]; agg[k][0] += 1; agg[k][1] += float(r["Counter_Value"])
+res = {k: v / n for k, (n, v) in agg.items()}
+print(json.dumps(res, indent=1))
+json.dump(res, open("$OUT/summary.json", "w"), indent=1)
 PY

@@ -521,8 +521,9 @@ def _check_update(out, ref, K):
     assert cmp(up, ru) <= tol * max(1.0, ru.abs().max().item())
 
 
+@pytest.mark.parametrize("share", [False, True])
 @pytest.mark.parametrize("shape", [(6, 16, 16), (5, 12, 16), (3, 48, 64)])
-def test_update_operator_vs_oracle(db, shape):
+def test_update_operator_vs_oracle(db, shape, share):
     """UpdateModule (implicit-GEMM MFMA convolutions + fused GRU epilogues) vs the oracle restatement of
     droid_net.py:111-143 evaluated under fp16 autocast like the reference's caller (factor_graph.py:214), on identical
     weights and fp16 inputs; the autocast oracle is pinned bit-exactly to the reference's own module
@@ -534,9 +535,11 @@ def test_update_operator_vs_oracle(db, shape):
     sd = deterministic_state_dict(_SD(oupd.empty_state_dict()), seed=7)
     net, inp, corr, flow = _update_inputs(E, h, w, seed=E + h)
     ii = torch.tensor(([0, 0, 1, 2, 2, 2] * 3)[:E], dtype=torch.int64)
+    if share:      # context features per source frame (what the reference's callers pass): one convolution per frame
+        inp = inp[[int(torch.nonzero(ii == f)[0]) for f in ii.tolist()]]
     with torch.no_grad():
         ref = oupd.update_forward(sd, net.half(), inp.half(), corr.half(), flow, ii, autocast=True)
-    mod = UpdateModule().load_state_dict(sd)
+    mod = UpdateModule(share_inp_by_source_frame=share).load_state_dict(sd)
     n, d, wt, eta, up = mod(net[None].cuda().half(), inp[None].cuda().half(), corr[None].cuda().half(),
                             flow[None].cuda(), ii.cuda(), None)
     torch.cuda.synchronize()
@@ -546,7 +549,8 @@ def test_update_operator_vs_oracle(db, shape):
     _check_update((n[0], d[0], wt[0], eta[0], up[0]), ref, K)
 
 
-def test_update_operator_vs_reference_module_under_autocast(db, golden_dir):
+@pytest.mark.parametrize("share", [False, True])
+def test_update_operator_vs_reference_module_under_autocast(db, golden_dir, share):
     """the same operator against vectors written by the REFERENCE's own UpdateModule under torch.autocast(fp16)
     (tests/golden/make_golden.py update_autocast; W = 64: the production convolution kernels)"""
     from oracle import update as oupd
@@ -557,7 +561,20 @@ def test_update_operator_vs_reference_module_under_autocast(db, golden_dir):
     sd = deterministic_state_dict(_SD(oupd.empty_state_dict()), seed=UPDATE_AUTOCAST["weight_seed"])
     net, inp, corr, flow, ii, jj = update_autocast_inputs()
     mod = UpdateModule().load_state_dict(sd)
-    n, d, wt, eta, up = mod(net[None].cuda(), inp[None].cuda(), corr[None].cuda(), flow[None].cuda(), ii.cuda(), jj.cuda())
+    if share:
+        # the golden inputs carry DIFFERENT context features on the two edges of frame 0, so the frame-level path is fed
+        # through its explicit interface: one "frame" per edge (exercises the accumulator start values, index = identity)
+        E = net.shape[0]
+        nh = lambda t: mod.to_nhwc(t.cuda())
+        cpad = torch.cat([corr.cuda(), torch.zeros_like(corr[:, :1]).cuda()], 1)
+        c = nh(cpad[:, torch.where(mod.cmap >= 0, mod.cmap, torch.full_like(mod.cmap, 196))])
+        c = c.view(E, net.shape[2], net.shape[3], 4, 56).permute(3, 0, 1, 2, 4).contiguous()
+        n, d, wt, eta, up = mod.forward_nhwc(nh(net), None, c, mod.to_nhwc(flow.cuda(), 8), ii.cuda(),
+                                             inp_frames=nh(inp), inp_index=torch.arange(E, device="cuda"))
+        n, up = n.permute(0, 3, 1, 2)[None], up.permute(0, 3, 1, 2)[None]
+        d, wt, eta = d[None], wt[None], eta[None]
+    else:
+        n, d, wt, eta, up = mod(net[None].cuda(), inp[None].cuda(), corr[None].cuda(), flow[None].cuda(), ii.cuda(), jj.cuda())
     torch.cuda.synchronize()
     ref = [torch.as_tensor(G[k].astype(np.float32)) for k in ("net1", "delta", "weight", "eta", "upmask")]
     _check_update((n[0], d[0], wt[0], eta[0], up[0]), ref, 2)
