@@ -915,6 +915,154 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
   else conv_epilogue<EPI, 2, 2>(P, acc, (long)P.N * HW, m0, n0, wm0, wn0, lane, HW);
 }
 
+// ---- 7x7 on 4 input channels (the flow encoder's first layer: motion features -> 128) -----------------------------------
+// In the generic loop this layer costs as much as a 128 -> 64 3x3 convolution: its K = 49 taps x 8 (4 real + 4 padded)
+// channels is walked in 64-wide chunks of gathered 16-byte pieces.  Here the whole problem sits in LDS: the 10 x 72 pixel
+// halo of a 4-row tile with its 4 real channels (5.6 KB) and ALL weights [128 cout][7 dy][8 dx (7 + one zero tap)][4 ch]
+// (57 KB, row stride 464 B: conflict-free ds_read_b128).  A k-step of 16 = four x-adjacent taps of one kernel row, which are
+// 16 contiguous bytes of the halo per lane pair: K = 7 x 32 = 224 -> 14 k-steps instead of 25, no staging inside the loop.
+constexpr int C7_COLS = 72, C7_ROWS = 10, C7_K = 224, C7_WLD = C7_K + 8;
+constexpr int C7_A_BYTES = C7_ROWS * C7_COLS * 8, C7_W_BYTES = 128 * C7_WLD * 2;
+constexpr int C7_LDS_BYTES = (C7_A_BYTES + C7_W_BYTES) > BM * (128 + 8) * 2 ? (C7_A_BYTES + C7_W_BYTES) : BM * (128 + 8) * 2;
+
+template <int EPI>
+__global__ __launch_bounds__(512, 4) void conv7x7_c4_kernel(ConvParams P) {
+  extern __shared__ __half s_conv[];
+  char* const lds = reinterpret_cast<char*>(s_conv);
+  char* const sW = lds + C7_A_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wrow = wave & 3, wn0 = (wave >> 2) * 64, wm0 = wrow * 64;
+  const long m0 = (long)blockIdx.x * BM;
+  const int HW = P.H * P.W;
+  const int img = (int)(m0 / HW), y0 = (int)((m0 - (long)img * HW) / 64);
+  // halo: column c holds image column c - 4, row r holds image row y0 - 3 + r; 8 bytes (4 channels) per pixel
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int id = tid + 512 * i;
+    if (id < C7_ROWS * C7_COLS) {
+      const int r = id / C7_COLS, c = id - r * C7_COLS;
+      const int y = y0 - 3 + r, x = c - 4;
+      uint2 v{0u, 0u};
+      if ((unsigned)y < (unsigned)P.H && (unsigned)x < 64u)
+        v = *reinterpret_cast<const uint2*>(P.in[0] + ((long)(img * P.H + y) * 64 + x) * P.segS[0]);
+      *reinterpret_cast<uint2*>(lds + id * 8) = v;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {                            // 128 rows x 28 pieces of 16 bytes
+    const int id = tid + 512 * i, row = id / 28, pc = id - row * 28;
+    *reinterpret_cast<uint4*>(sW + row * (C7_WLD * 2) + pc * 16) = *reinterpret_cast<const uint4*>(P.wt_halo + (long)row * C7_K + pc * 8);
+  }
+  f32x16 acc[2][2];
+  zero_acc<2, 2>(acc);
+  __syncthreads();
+  const int p = lane & 31, kh = lane >> 5;
+#pragma unroll
+  for (int dy = 0; dy < 7; ++dy) {
+#pragma unroll
+    for (int hx = 0; hx < 2; ++hx) {                       // taps dx = hx*4 + kh*2 + {0, 1}
+      const int ks = dy * 2 + hx;
+      half8 af[2], bf[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const char* src = lds + ((wrow + dy) * C7_COLS + a * 32 + p + hx * 4 + kh * 2 + 1) * 8;      // 8-byte aligned
+        const uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 8);
+        const uint4 v{lo.x, lo.y, hi.x, hi.y};
+        af[a] = *reinterpret_cast<const half8*>(&v);
+      }
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+        bf[b] = *reinterpret_cast<const half8*>(sW + (wn0 + b * 32 + p) * (C7_WLD * 2) + ks * 32 + kh * 16);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+    }
+  }
+  staged_epilogue<EPI, 2, 128>(P, acc, s_conv, m0, 0, wm0, wn0, tid, HW);
+}
+
+// ---- global-context reduction of the ConvGRU as its own kernel: red[n][c] += sum_px sigmoid(W net + b)[c] * net[c] --------
+// (reference gru.py:23-24).  A 128 x 128 1x1 convolution is a streaming problem (3.2 GB of hidden state at 4096 edges
+// against 0.4 TFLOP), and in the generic loop a workgroup never has more than one 32 KB chunk in flight and re-reads the
+// hidden state for the gate product: 1.86 ms = 1.7 TB/s.  Here a workgroup requests its whole 256 px x 128 ch tile at once
+// (8 x 16 bytes per thread: 128 KB in flight per CU with two workgroups), the tile stays in LDS as MFMA operand AND as the
+// gate's second factor, and the weights come from L2 straight into B fragments (two halves of K).
+constexpr int GLD = 128 + 8;                          // LDS row stride (halves)
+__global__ __launch_bounds__(512, 4) void glo_reduce_kernel(ConvParams P) {
+  extern __shared__ __half s_conv[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wrow = wave & 3, wn0 = (wave >> 2) * 64, wm0 = wrow * 64;
+  const long m0 = (long)blockIdx.x * BM;
+  const int HW = P.H * P.W;
+  const int img = (int)(m0 / HW);
+  uint4 ra[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int id = tid + 512 * i;
+    ra[i] = *reinterpret_cast<const uint4*>(P.in[0] + (m0 + (id >> 4)) * P.segS[0] + (id & 15) * 8);
+  }
+  const int p = lane & 31, kh = lane >> 5;
+  half8 bf[2][4];
+  auto load_b = [&](int half) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        bf[b][ks] = *reinterpret_cast<const half8*>(P.wt + (long)(wn0 + b * 32 + p) * P.Kpad + (half * 4 + ks) * 16 + kh * 8);
+  };
+  load_b(0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int id = tid + 512 * i;
+    *reinterpret_cast<uint4*>(s_conv + (id >> 4) * GLD + (id & 15) * 8) = ra[i];
+  }
+  f32x16 acc[2][2];
+  zero_acc<2, 2>(acc);
+  __syncthreads();
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      half8 af[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+        af[a] = *reinterpret_cast<const half8*>(s_conv + (wm0 + a * 32 + p) * GLD + (half * 4 + ks) * 16 + kh * 8);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b][ks], acc[a][b], 0, 0, 0);
+    }
+    if (half == 0) load_b(1);
+  }
+  // gate * feature, summed over the wave's 64 pixels per cout (same roundings as conv_epilogue's EPI_GLO)
+  float sum[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int co = wn0 + b * 32 + p;
+    const float bias = P.bias[co];
+    float t = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = wm0 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh;
+        const float g = round_h(sigmoidf_(acc[a][b][q] + bias));
+        t += round_h(g * __half2float(s_conv[row * GLD + co]));
+      }
+    sum[b] = t + __shfl_xor(t, 32, 64);
+  }
+  __syncthreads();                                    // the tile is dead: its head becomes [8 waves][64] partial sums
+  float* sR = reinterpret_cast<float*>(s_conv);
+  if (lane < 32) { sR[wave * 64 + p] = sum[0]; sR[wave * 64 + 32 + p] = sum[1]; }
+  __syncthreads();
+  if (tid < 128) {
+    const int hb = tid >> 6, c = tid & 63;            // cout half -> waves 4*hb .. 4*hb+3
+    const float t = (sR[(hb * 4 + 0) * 64 + c] + sR[(hb * 4 + 1) * 64 + c]) + (sR[(hb * 4 + 2) * 64 + c] + sR[(hb * 4 + 3) * 64 + c]);
+    atomicAdd(&P.red[(long)img * P.Cout + tid], t);
+  }
+}
+
 // mean over the rows of each segment (GraphAgg's scatter_mean over the edges of a source frame, reference
 // droid_net.py:67): out[k] = mean_{e in order[seg_off[k] .. seg_off[k+1])} x[e]; one thread = 8 channels (16 B),
 // fp32 accumulation in a fixed order, one rounding to fp16.
@@ -1066,6 +1214,20 @@ bool dma_ok(const ConvParams& P) {
   return true;
 }
 
+// 7x7 on 4 real input channels: weights_halo = [128][7][8][4] (droid_amd.update.pack_conv_7x7_c4)
+bool c7_ok(const ConvParams& P) {
+  if (!opts().conv_halo || P.cinit || !P.wt_halo || P.KH != 7 || P.KW != 7 || P.nseg != 1 || P.segC[0] != 8) return false;
+  if (P.W != 64 || P.H % 4 || P.CoutPad != 128 || P.Cout != 128 || P.epi != EPI_RELU) return false;
+  return staged_epilogue_ok<EPI_RELU>(P);
+}
+
+bool glo_ok(const ConvParams& P) {
+  if (!opts().conv_halo || P.epi != EPI_GLO || P.KH != 1 || P.KW != 1 || P.nseg != 1 || P.segC[0] != 128) return false;
+  if (P.Cout != 128 || P.CoutPad != 128 || P.Kpad != 128 || P.cinit) return false;
+  if (P.aux0 != P.in[0] || P.aux0_stride != P.segS[0]) return false;        // the gate multiplies the convolution's own input
+  return ((long)P.H * P.W) % BM == 0;                                       // whole tiles inside one image
+}
+
 // small-Cout convolutions (CoutPad == 32 or 64): bound by re-reading the activations in the generic loop
 bool halo_small_ok(const ConvParams& P, int bn) {
   if (P.cinit) return false;
@@ -1167,6 +1329,18 @@ extern "C" int dh_conv2d_nhwc_f16_ex(const void* const* inputs, const int* in_ch
       case EPI_GRU_Q: return launch_halo<EPI_GRU_Q, 128>(P, st);
       default: break;
     }
+  }
+  if (glo_ok(P)) {
+    DH_LDS_OPTIN(&glo_reduce_kernel, 80 * 1024);
+    hipLaunchKernelGGL(glo_reduce_kernel, dim3((unsigned)((long)P.N * P.H * P.W / BM)), dim3(512), BM * GLD * 2, st, P);
+    DH_LAUNCH_CHECK();
+    return DH_OK;
+  }
+  if (c7_ok(P)) {
+    DH_LDS_OPTIN((&conv7x7_c4_kernel<EPI_RELU>), 80 * 1024);
+    hipLaunchKernelGGL((conv7x7_c4_kernel<EPI_RELU>), dim3((unsigned)((long)P.N * P.H * P.W / BM)), dim3(512), C7_LDS_BYTES, st, P);
+    DH_LAUNCH_CHECK();
+    return DH_OK;
   }
   if (halo_small_ok(P, 64)) {
     switch (P.epi) {

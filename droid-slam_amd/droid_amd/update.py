@@ -125,6 +125,17 @@ def pack_conv_halo(weight):
     return w.half().contiguous()
 
 
+def pack_conv_7x7_c4(weight):
+    """[128,4,7,7] -> [128, 7 dy, 8 dx (7 + one zero tap), 4 ch] f16: the kernel-ordered copy for conv7x7_c4_kernel
+    (csrc/conv.hip): a k-step of 16 is four x-adjacent taps of one kernel row."""
+    cout, cin, kh, kw = weight.shape
+    if (cout, cin, kh, kw) != (128, 4, 7, 7):
+        return None
+    w = torch.zeros(128, 7, 8, 4, dtype=torch.float32, device=weight.device)
+    w[:, :, :7, :] = weight.float().permute(0, 2, 3, 1)
+    return w.reshape(128, 224).half().contiguous()
+
+
 class _Conv:
     def __init__(self, wp, bp, k, cout, wh=None):
         self.w, self.b, self.k, self.cout, self.wh = wp, bp, k, cout, wh
@@ -166,6 +177,7 @@ class UpdateModule:
         self.cmap = cmap
         P["corr2"] = conv("corr_encoder.2")
         P["flow0"] = conv("flow_encoder.0", 8)
+        P["flow0"].wh = pack_conv_7x7_c4(g("flow_encoder.0.weight"))
         P["flow2"] = conv("flow_encoder.2")
         P["gru_w"] = conv("gru.w")
         # z | r as one convolution with 256 outputs

@@ -608,6 +608,43 @@ def test_conv2d_nhwc_matches_torch_conv(db, option, halo, dma, halo2):
         assert (out.float() - ref).abs().max() <= 1e-2 * max(1.0, ref.abs().max().item())
 
 
+def test_conv7x7_on_four_channels_and_global_context_kernels(db):
+    """the two single-purpose kernels of the update operator against torch: flow_encoder.0 (7x7 on the 4 motion
+    channels, droid_net.py:89) and the ConvGRU's global-context reduction mean(sigmoid(w(net)) * net) (gru.py:23-24)"""
+    from droid_amd.update import pack_conv, pack_conv_7x7_c4, EPI_RELU, EPI_GLO
+    torch.manual_seed(3)
+    N, H, W = 3, 8, 64
+    x = torch.zeros(N, H, W, 8, device="cuda", dtype=torch.float16)
+    x[..., :4] = (4 * torch.randn(N, H, W, 4, device="cuda")).half()
+    wgt = torch.randn(128, 4, 7, 7, device="cuda") / 14.0
+    bias = torch.randn(128, device="cuda")
+    wp, bp = pack_conv(wgt, bias, 8)
+    out = torch.empty(N, H, W, 128, device="cuda", dtype=torch.float16)
+    db.conv2d_nhwc([x], wp, pack_conv_7x7_c4(wgt), bp, 7, 7, 128, EPI_RELU, out, 128, None, None, None, None)
+    ref = torch.relu(torch.nn.functional.conv2d(x[..., :4].float().permute(0, 3, 1, 2), wgt.half().float(), bias, padding=3)).permute(0, 2, 3, 1)
+    assert (out.float() - ref).abs().max() <= 2.0 ** -9 * max(1.0, ref.abs().max().item())
+    gen = torch.empty_like(out)                          # generic loop on the same inputs
+    db.conv2d_nhwc([x], wp, None, bp, 7, 7, 128, EPI_RELU, gen, 128, None, None, None, None)
+    assert (out.float() - gen.float()).abs().max() <= 2.0 ** -9 * max(1.0, ref.abs().max().item())
+    # global context
+    net = torch.tanh(torch.randn(N, H, W, 128, device="cuda")).half()
+    w1 = torch.randn(128, 128, 1, 1, device="cuda") / 11.0
+    b1 = torch.randn(128, device="cuda")
+    wp, bp = pack_conv(w1, b1)
+    red = torch.zeros(N, 128, device="cuda")
+    db.conv2d_nhwc([net], wp, None, bp, 1, 1, 128, EPI_GLO, None, 0, None, net, None, red)
+    g = torch.sigmoid(torch.nn.functional.conv2d(net.float().permute(0, 3, 1, 2), w1.half().float(), b1)).half().float()
+    ref = (g * net.float().permute(0, 3, 1, 2)).half().float().sum((2, 3))
+    assert (red - ref).abs().max() <= 2e-3 * max(1.0, ref.abs().max().item())
+    db.set_option("conv_halo", 0)                        # the generic loop's epilogue on the same inputs
+    try:
+        red2 = torch.zeros(N, 128, device="cuda")
+        db.conv2d_nhwc([net], wp, None, bp, 1, 1, 128, EPI_GLO, None, 0, None, net, None, red2)
+    finally:
+        db.set_option("conv_halo", 1)
+    assert (red - red2).abs().max() <= 2e-3 * max(1.0, ref.abs().max().item())
+
+
 def test_native_pyramid_channel_last_lookup_equals_reference_layout(db):
     """corr_pyramid_lookup_nhwc == corr_pyramid_lookup up to the documented channel permutation (bit-exact)"""
     from droid_amd.corr import CorrBlock
