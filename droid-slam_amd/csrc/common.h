@@ -149,6 +149,27 @@ __device__ __forceinline__ SE3f se3_exp(const float* xi) {
   return r;
 }
 
+// log: (t, q) -> (tau, phi).  phi = log of the unit quaternion (lietorch SO3::Log: 2 atan(|v| / w) / |v| * v, series near
+// the identity), tau = V(phi)^-1 t with V^-1 = I - 1/2 [phi]x + c [phi]x^2, c = (1 - theta cos(theta/2) / (2 sin(theta/2))) / theta^2
+// (1/12 near the identity): the inverse of se3_exp above.  Needed by the callers of the path: the frontend's motion model
+// (droid_frontend.py:59-63) and the trajectory filler's pose interpolation (trajectory_filler.py:55-65).
+__device__ __forceinline__ void se3_log(const SE3f& T, float* xi) {
+  const float vx = T.q.x, vy = T.q.y, vz = T.q.z, w = T.q.w;
+  const float n2 = vx * vx + vy * vy + vz * vz, n = sqrtf(n2);
+  float k;                                              // phi = k * v
+  if (n2 < 1e-10f) k = 2.f / w - (2.f / 3.f) * n2 / (w * w * w);
+  else if (fabsf(w) < 1e-10f) k = (w >= 0.f ? 3.14159265358979f : -3.14159265358979f) / n;
+  else k = 2.f * atanf(n / w) / n;
+  const Vec3 phi{k * vx, k * vy, k * vz};
+  const float th2 = phi.x * phi.x + phi.y * phi.y + phi.z * phi.z, th = sqrtf(th2);
+  float c;
+  if (th < 1e-3f) c = 1.f / 12.f + th2 / 720.f;
+  else { const float h = 0.5f * th; c = (1.f - h * cosf(h) / sinf(h)) / th2; }
+  const Vec3 c1 = cross(phi, T.t), c2 = cross(phi, c1);
+  xi[0] = T.t.x - 0.5f * c1.x + c * c2.x; xi[1] = T.t.y - 0.5f * c1.y + c * c2.y; xi[2] = T.t.z - 0.5f * c1.z + c * c2.z;
+  xi[3] = phi.x; xi[4] = phi.y; xi[5] = phi.z;
+}
+
 // exp(xi) * T
 __device__ __forceinline__ SE3f retr(const float* xi, const SE3f& T) { return mul(se3_exp(xi), T); }
 

@@ -155,12 +155,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& P, f32x16 (&acc)
             if (glo_img >= 0 && glo_img != img) { atomicAdd(&P.red[glo_img * P.Cout + co], glo_sum); glo_sum = 0.f; }
             glo_img = img; glo_sum += v;
           } break;
-          case EPI_SOFTPLUS_001: { const float hv = round_h(v); v = 0.01f * round_h(hv > 20.f ? hv : log1pf(__expf(hv))); } break;
+          case EPI_SOFTPLUS_001: { const float hv = round_h(v); v = 0.01f * (hv > 20.f ? hv : log1pf(__expf(hv))); } break;   // fp32 softplus of the fp16 conv output (autocast's fp32 list)
           case EPI_HEADS: if (co >= 2) v = sigmoidf_(round_h(v)); break;          // (delta_x, delta_y, w_x, w_y)
           default: break;
         }
         if (EPI == EPI_GLO) continue;
-        if (P.out_f32 == 2) reinterpret_cast<float*>(P.out)[pix * P.out_stride + co] = v;        // raw fp32 (accumulator start values of another convolution)
+        if (P.out_f32 == 2 || (P.out_f32 && EPI == EPI_SOFTPLUS_001)) reinterpret_cast<float*>(P.out)[pix * P.out_stride + co] = v;   // raw fp32
         else if (P.out_f32) reinterpret_cast<float*>(P.out)[pix * P.out_stride + co] = round_h(v);
         else reinterpret_cast<__half*>(P.out)[pix * P.out_stride + co] = __float2half(v);
       }

@@ -353,6 +353,58 @@ void conv2d_nhwc(std::vector<torch::Tensor> inputs, torch::Tensor weight, c10::o
                "conv2d_nhwc");
 }
 
+// ---- factor-graph side kernels (droid_amd.factor_graph / droid_amd.depth_video) ---------------------------------
+torch::Tensor motion_features(torch::Tensor coords1, torch::Tensor target) {
+  CHECK_INPUT(coords1); CHECK_INPUT(target); CHECK_F32(coords1); CHECK_F32(target);
+  TORCH_CHECK(coords1.dim() == 4 && coords1.size(3) == 2 && target.sizes() == coords1.sizes(), "motion_features: [E,h,w,2]");
+  const int E = (int)coords1.size(0), ht = (int)coords1.size(1), wd = (int)coords1.size(2);
+  torch::Tensor flow = torch::empty({E, ht, wd, 8}, coords1.options().dtype(torch::kFloat16));
+  check_status(dh_motion_features(coords1.data_ptr<float>(), target.data_ptr<float>(), flow.data_ptr(), E, ht, wd, cur_stream()), "motion_features");
+  return flow;
+}
+
+// -> {target [E,h,w,2], weight [E,h,w,2], target_ba [E,2,h,w], weight_ba [E,2,h,w]}
+std::vector<torch::Tensor> ba_inputs(torch::Tensor coords1, torch::Tensor dw) {
+  CHECK_INPUT(coords1); CHECK_INPUT(dw); CHECK_F32(coords1); CHECK_F32(dw);
+  TORCH_CHECK(coords1.dim() == 4 && coords1.size(3) == 2 && dw.dim() == 4 && dw.size(3) == 4 && dw.size(0) == coords1.size(0), "ba_inputs: shapes");
+  const int E = (int)coords1.size(0), ht = (int)coords1.size(1), wd = (int)coords1.size(2);
+  torch::Tensor target = torch::empty({E, ht, wd, 2}, coords1.options()), weight = torch::empty({E, ht, wd, 2}, coords1.options());
+  torch::Tensor tb = torch::empty({E, 2, ht, wd}, coords1.options()), wb = torch::empty({E, 2, ht, wd}, coords1.options());
+  check_status(dh_ba_inputs(coords1.data_ptr<float>(), dw.data_ptr<float>(), target.data_ptr<float>(), weight.data_ptr<float>(),
+                            tb.data_ptr<float>(), wb.data_ptr<float>(), E, ht, wd, cur_stream()), "ba_inputs");
+  return {target, weight, tb, wb};
+}
+
+torch::Tensor cvx_upsample(torch::Tensor disp, torch::Tensor mask) {
+  CHECK_INPUT(disp); CHECK_INPUT(mask); CHECK_F32(disp);
+  TORCH_CHECK(mask.scalar_type() == torch::kFloat16 && mask.dim() == 4 && mask.size(3) == 576 && disp.dim() == 3 &&
+              mask.size(0) == disp.size(0) && mask.size(1) == disp.size(1) && mask.size(2) == disp.size(2),
+              "cvx_upsample: disp [K,h,w] f32, mask [K,h,w,576] f16");
+  const int K = (int)disp.size(0), ht = (int)disp.size(1), wd = (int)disp.size(2);
+  torch::Tensor out = torch::empty({K, 8 * ht, 8 * wd}, disp.options());
+  check_status(dh_cvx_upsample(disp.data_ptr<float>(), mask.data_ptr(), out.data_ptr<float>(), K, ht, wd, cur_stream()), "cvx_upsample");
+  return out;
+}
+
+// dist [(t-t0)*(t-t1)] f32 (modified), edges_i/j: existing edges; returns {new_edges [2*max_new,2] i64, count [1] i32} (device)
+std::vector<torch::Tensor> proximity_nms(torch::Tensor dist, torch::Tensor edges_i, torch::Tensor edges_j, int64_t t0, int64_t t1,
+                                         int64_t t, int64_t rad, int64_t nms, double thresh, int64_t max_factors, int64_t n_es0,
+                                         bool stereo, int64_t max_new) {
+  CHECK_INPUT(dist); CHECK_F32(dist); CHECK_INPUT(edges_i); CHECK_INPUT(edges_j); CHECK_I64(edges_i); CHECK_I64(edges_j);
+  TORCH_CHECK(dist.numel() == (t - t0) * (t - t1) && edges_i.numel() == edges_j.numel(), "proximity_nms: shapes");
+  const int ne = (int)edges_i.numel();
+  check_status(dh_proximity_nms(dist.data_ptr<float>(), nullptr, edges_i.data_ptr<int64_t>(), edges_j.data_ptr<int64_t>(), ne, (int)t0,
+                                (int)t1, (int)t, (int)rad, (int)nms, (float)thresh, (int)max_factors, (int)n_es0, stereo ? 1 : 0,
+                                nullptr, 0, nullptr, 0, cur_stream()), "proximity_nms (mask)");
+  torch::Tensor order = torch::argsort(dist.view({-1})).contiguous();
+  torch::Tensor out = torch::zeros({2 * max_new, 2}, edges_i.options());
+  torch::Tensor count = torch::zeros({1}, dist.options().dtype(torch::kInt32));
+  check_status(dh_proximity_nms(dist.data_ptr<float>(), order.data_ptr<int64_t>(), nullptr, nullptr, 0, (int)t0, (int)t1, (int)t, (int)rad,
+                                (int)nms, (float)thresh, (int)max_factors, (int)n_es0, stereo ? 1 : 0, out.data_ptr<int64_t>(),
+                                (int)max_new, count.data_ptr<int>(), 1, cur_stream()), "proximity_nms (walk)");
+  return {out, count};
+}
+
 // ---- extensions beyond the reference module (used by droid_amd / lietorch compat) ----------------
 std::vector<torch::Tensor> reproject(torch::Tensor poses, torch::Tensor disps, torch::Tensor intrinsics,
                                      torch::Tensor ii, torch::Tensor jj) {
@@ -374,10 +426,11 @@ torch::Tensor se3_op(const std::string& op, torch::Tensor a, torch::Tensor b) {
   if (two) { CHECK_INPUT(b); CHECK_F32(b); }
   const int64_t n = (op == "exp" || op == "retr") ? a.numel() / 6 : a.numel() / 7;
   auto shape = a.sizes().vec();
-  shape.back() = 7;
+  shape.back() = (op == "log") ? 6 : 7;
   torch::Tensor out = torch::empty(shape, a.options());
   int rc;
-  if (op == "inv") rc = dh_se3_inv(a.data_ptr<float>(), out.data_ptr<float>(), (int)n, cur_stream());
+  if (op == "log") rc = dh_se3_log(a.data_ptr<float>(), out.data_ptr<float>(), (int)n, cur_stream());
+  else if (op == "inv") rc = dh_se3_inv(a.data_ptr<float>(), out.data_ptr<float>(), (int)n, cur_stream());
   else if (op == "mul") rc = dh_se3_mul(a.data_ptr<float>(), b.data_ptr<float>(), out.data_ptr<float>(), (int)n, cur_stream());
   else if (op == "exp") rc = dh_se3_exp(a.data_ptr<float>(), out.data_ptr<float>(), (int)n, cur_stream());
   else if (op == "retr") rc = dh_se3_retr(a.data_ptr<float>(), b.data_ptr<float>(), out.data_ptr<float>(), (int)n, cur_stream());
@@ -426,6 +479,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         py::arg("inputs"), py::arg("weight"), py::arg("weight_halo"), py::arg("bias"), py::arg("KH"), py::arg("KW"), py::arg("Cout"),
         py::arg("epilogue"), py::arg("out"), py::arg("out_stride"), py::arg("gterm"), py::arg("aux0"), py::arg("aux1"), py::arg("red"),
         py::arg("cinit") = py::none(), py::arg("cinit_idx") = py::none(), py::arg("cinit_off") = 0, py::arg("out_raw_f32") = false);
+  m.def("motion_features", &motion_features, "cat(coords1 - coords0, target - coords1).clamp(-64, 64) as fp16 NHWC");
+  m.def("ba_inputs", &ba_inputs, "target = coords1 + delta, weight; also in ba's [E,2,h,w] layout");
+  m.def("cvx_upsample", &cvx_upsample, "convex 8x upsampling of depth maps");
+  m.def("proximity_nms", &proximity_nms, "candidate masking + greedy NMS of add_proximity_factors on the device");
   m.def("reproject", &reproject, "fused reprojection (Python thresholds)");
   m.def("se3_op", &se3_op, "SE3 inv/mul/exp/retr");
   m.def("se3_map", &se3_map, "SE3 act4/adjT");

@@ -289,6 +289,24 @@ extern "C" int dh_se3_retr(const float* xi, const float* a, float* out, int n, d
   DH_SE3_LAUNCH(OP_RETR, xi, a)
 }
 
+__global__ __launch_bounds__(256) void se3_log_kernel(const float* __restrict__ a, float* __restrict__ out, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float xi[6];
+  se3_log(load_pose(a + 7 * (long)i), xi);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) out[6 * (long)i + k] = xi[k];
+}
+
+extern "C" int dh_se3_log(const float* a, float* out, int n, dh_stream_t stream) {
+  if (n < 0) return DH_ERR_ARG;
+  if (n == 0) return DH_OK;
+  if (!a || !out) return DH_ERR_ARG;
+  hipLaunchKernelGGL(se3_log_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, out, n);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
 extern "C" int dh_se3_act4(const float* a, const float* X, float* Y, int n, int npts, dh_stream_t stream) {
   if (n < 0 || npts < 0) return DH_ERR_ARG;
   const long tot = (long)n * npts;

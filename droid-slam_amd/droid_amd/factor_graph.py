@@ -1,0 +1,228 @@
+"""FactorGraph on MI355X: edge bookkeeping + the update iteration that drives the hot path.
+
+Host-side mirror of the reference class (droid_slam/factor_graph.py:19-412) with the same constructor, attributes
+(`ii, jj, age, corr, net, target [1,E,h,w,2], weight, damping, ii_inac/jj_inac/target_inac/weight_inac, ii_bad/jj_bad`)
+and methods (`add_factors, rm_factors, rm_keyframe, filter_edges, clear_edges, update, update_lowmem,
+add_neighborhood_factors, add_proximity_factors`).  MI355X-first underneath:
+
+  * one update iteration = reproject (1 fused kernel) -> motion features (1 kernel) -> 4-level pyramid lookup (1 kernel,
+    channel-last) -> ConvGRU update operator (droid_amd.update.UpdateModule.forward_nhwc: hidden state kept channel-last
+    fp16, context features convolved once per source frame) -> BA inputs (1 kernel) -> droid_backends.ba (all on device);
+  * `update_lowmem` runs the on-the-fly correlation on the fp16 MFMA (droid_amd.corr.AltCorrBlock) in source-frame chunks
+    (`chunk_frames`, default 8 like the reference; with 288 GB of HBM much larger chunks fit) and ONE BA over all edges;
+  * `add_proximity_factors` keeps the t x t distance matrix on the device: masking, suppression around existing edges and
+    the greedy NMS walk are kernels (droid_backends.proximity_nms), one 4-byte read-back tells how many edges were chosen.
+The reference copies the matrix to the CPU and loops over it in Python (factor_graph.py:363-409).
+"""
+import torch
+
+import droid_backends as db
+from .corr import CorrBlock, CorrBlockRef, AltCorrBlock
+
+
+class FactorGraph:
+    def __init__(self, video, update_op, device="cuda", corr_impl="volume", max_factors=-1, upsample=False, chunk_frames=8):
+        self.video = video
+        self.update_op = update_op
+        self.device = video.device if hasattr(video, "device") else torch.device(device)
+        self.max_factors = max_factors
+        self.corr_impl = corr_impl
+        self.upsample = upsample
+        self.chunk_frames = chunk_frames
+        self.ht = ht = video.ht // 8
+        self.wd = wd = video.wd // 8
+        lt = dict(dtype=torch.long, device=self.device)
+        self.ii = torch.zeros(0, **lt); self.jj = torch.zeros(0, **lt); self.age = torch.zeros(0, **lt)
+        self.corr = None
+        self._net = None                                              # [E,h,w,128] fp16, channel-last
+        self.damping = 1e-6 * torch.ones_like(self.video.disps)
+        self.target = torch.zeros(1, 0, ht, wd, 2, device=self.device)
+        self.weight = torch.zeros(1, 0, ht, wd, 2, device=self.device)
+        self.ii_inac = torch.zeros(0, **lt); self.jj_inac = torch.zeros(0, **lt)
+        self.ii_bad = torch.zeros(0, **lt); self.jj_bad = torch.zeros(0, **lt)
+        self.target_inac = torch.zeros(1, 0, ht, wd, 2, device=self.device)
+        self.weight_inac = torch.zeros(1, 0, ht, wd, 2, device=self.device)
+        self._native_corr = CorrBlock.supported(ht, wd)
+
+    # ---- reference-shaped views of the channel-last state ---------------------------------------------------------
+    @property
+    def net(self):
+        return None if self._net is None else self._net.permute(0, 3, 1, 2)[None]        # [1,E,128,h,w]
+
+    @property
+    def inp(self):
+        return self.video.inps[self.ii][None]                                                # factor_graph.py:135
+
+    # ---- edge bookkeeping (factor_graph.py:52-212) ------------------------------------------------------------------
+    def _filter_repeated_edges(self, ii, jj):
+        for a, b in ((self.ii, self.jj), (self.ii_inac, self.jj_inac)):
+            if len(a) > 0 and len(ii) > 0:
+                m = ((ii[:, None] == a) & (jj[:, None] == b)).any(dim=-1)
+                ii, jj = ii[~m], jj[~m]
+        return ii, jj
+
+    def filter_edges(self):
+        conf = torch.mean(self.weight, dim=[0, 2, 3, 4])
+        mask = (torch.abs(self.ii - self.jj) > 2) & (conf < 0.001)
+        self.ii_bad = torch.cat([self.ii_bad, self.ii[mask]])
+        self.jj_bad = torch.cat([self.jj_bad, self.jj[mask]])
+        self.rm_factors(mask, store=False)
+
+    def clear_edges(self):
+        self.rm_factors(self.ii >= 0)
+        self._net = None
+
+    def add_factors(self, ii, jj, remove=False):
+        as_t = lambda x: x.to(self.device, torch.long) if isinstance(x, torch.Tensor) else torch.as_tensor(x, dtype=torch.long, device=self.device)
+        ii, jj = self._filter_repeated_edges(as_t(ii).reshape(-1), as_t(jj).reshape(-1))
+        if ii.shape[0] == 0:
+            return
+        if self.max_factors > 0 and self.ii.shape[0] + ii.shape[0] > self.max_factors and self.corr is not None and remove:
+            ix = torch.argsort(self.age, stable=True)                 # factor_graph.py:121-122 (mask indexed by edge position)
+            self.rm_factors(ix >= self.max_factors - ii.shape[0], store=True)
+        net = self.video.nets[ii].permute(0, 2, 3, 1).contiguous()
+        if self.corr_impl == "volume":
+            c = (ii == jj).long()
+            f1 = self.video.fmaps[ii, 0][None]; f2 = self.video.fmaps[jj, c][None]
+            corr = CorrBlock(f1, f2) if self._native_corr else CorrBlockRef(f1, f2)
+            self.corr = corr if self.corr is None else self.corr.cat(corr)
+        target, _ = self.video.reproject(ii, jj)
+        self.ii = torch.cat([self.ii, ii]); self.jj = torch.cat([self.jj, jj]); self.age = torch.cat([self.age, torch.zeros_like(ii)])
+        self._net = net if self._net is None else torch.cat([self._net, net], 0)
+        self.target = torch.cat([self.target, target], 1)
+        self.weight = torch.cat([self.weight, torch.zeros_like(target)], 1)
+
+    def rm_factors(self, mask, store=False):
+        if store:
+            self.ii_inac = torch.cat([self.ii_inac, self.ii[mask]]); self.jj_inac = torch.cat([self.jj_inac, self.jj[mask]])
+            self.target_inac = torch.cat([self.target_inac, self.target[:, mask]], 1)
+            self.weight_inac = torch.cat([self.weight_inac, self.weight[:, mask]], 1)
+        self.ii = self.ii[~mask]; self.jj = self.jj[~mask]; self.age = self.age[~mask]
+        if self.corr_impl == "volume" and self.corr is not None:
+            self.corr = self.corr[~mask]
+        if self._net is not None:
+            self._net = self._net[~mask]
+        self.target = self.target[:, ~mask]; self.weight = self.weight[:, ~mask]
+
+    def rm_keyframe(self, ix):
+        """drop keyframe ix: shift the video buffers down and re-index the edges (factor_graph.py:182-212)"""
+        v = self.video
+        t = v.counter.value
+        for name in ("images", "poses", "disps", "disps_sens", "intrinsics", "nets", "inps", "fmaps", "tstamp"):
+            buf = getattr(v, name)
+            buf[ix:t - 1] = buf[ix + 1:t].clone()
+        m = (self.ii_inac == ix) | (self.jj_inac == ix)
+        self.ii_inac[self.ii_inac >= ix] -= 1; self.jj_inac[self.jj_inac >= ix] -= 1
+        if torch.any(m):
+            self.ii_inac = self.ii_inac[~m]; self.jj_inac = self.jj_inac[~m]
+            self.target_inac = self.target_inac[:, ~m]; self.weight_inac = self.weight_inac[:, ~m]
+        m = (self.ii == ix) | (self.jj == ix)
+        self.ii[self.ii >= ix] -= 1; self.jj[self.jj >= ix] -= 1
+        self.rm_factors(m, store=False)
+
+    # ---- the update iteration (factor_graph.py:214-263) ------------------------------------------------------------
+    def _operator(self, net, coords1, target_prev, feats, ii):
+        """motion features + update operator on a set of edges -> (dw [E,h,w,4], damping [K,h,w], upmask, uniq)"""
+        flow = db.motion_features(coords1, target_prev)
+        uniq, ix = torch.unique(ii, return_inverse=True)
+        inp_frames = self.video.inps[uniq].permute(0, 2, 3, 1).contiguous()
+        _, _, _, damping, upmask = self.update_op.forward_nhwc(net, None, feats, flow, ii, inp_frames=inp_frames, inp_index=ix.contiguous())
+        return self.update_op.last_dw, damping, upmask, uniq
+
+    def update(self, t0=None, t1=None, itrs=2, use_inactive=False, EP=1e-7, motion_only=False):
+        ii, jj = self.ii, self.jj
+        coords1 = self.video.reproject(ii, jj)[0][0]                                          # [E,h,w,2]
+        if self.corr_impl != "volume":
+            raise RuntimeError("update() needs corr_impl='volume' (use update_lowmem for 'alt')")
+        if self._native_corr:
+            feats = self.corr.lookup_nhwc(coords1[None])
+        else:
+            feats = self.update_op.corr_to_nhwc(self.corr(coords1[None])[0])
+        dw, damping, upmask, uniq = self._operator(self._net, coords1, self.target[0].contiguous(), feats, ii)
+        if t0 is None:
+            t0 = max(1, ii.min().item() + 1)
+        target, weight, tb, wb = db.ba_inputs(coords1, dw)
+        self.target, self.weight = target[None], weight[None]
+        self.damping[uniq] = damping
+        if use_inactive:
+            m = (self.ii_inac >= t0 - 3) & (self.jj_inac >= t0 - 3)
+            ii = torch.cat([self.ii_inac[m], ii]); jj = torch.cat([self.jj_inac[m], jj])
+            tb = torch.cat([self.target_inac[0, m].permute(0, 3, 1, 2), tb]).contiguous()
+            wb = torch.cat([self.weight_inac[0, m].permute(0, 3, 1, 2), wb]).contiguous()
+        eta = (.2 * self.damping[torch.unique(ii)] + EP).contiguous()
+        self.video.ba(tb, wb, eta, ii, jj, t0, t1, itrs=itrs, lm=1e-4, ep=0.1, motion_only=motion_only)
+        if self.upsample:
+            self.video.upsample(uniq, upmask)
+        self.age += 1
+
+    # ---- global BA (factor_graph.py:266-330) --------------------------------------------------------------------------
+    def update_lowmem(self, t0=None, t1=None, itrs=2, use_inactive=False, EP=1e-7, steps=8):
+        v = self.video
+        t = v.counter.value
+        num, rig, ch, ht, wd = v.fmaps.shape
+        corr_op = AltCorrBlock(v.fmaps.view(1, num * rig, ch, ht, wd))
+        s = self.chunk_frames
+        for _ in range(steps):
+            coords1 = v.reproject(self.ii, self.jj)[0][0]
+            target_prev = self.target[0].contiguous()
+            target = torch.empty_like(target_prev); weight = torch.empty_like(target_prev)
+            tb = torch.empty(len(self.ii), 2, ht, wd, device=self.device); wb = torch.empty_like(tb)
+            lo, hi = int(self.ii.min().item()), int(self.jj.max().item()) + 1
+            for i in range(lo, hi, s):
+                vmask = (self.ii >= i) & (self.ii < i + s)
+                e = torch.nonzero(vmask)[:, 0]
+                if e.numel() == 0:
+                    continue
+                iis, jjs = self.ii[e], self.jj[e]
+                c1 = coords1[e].contiguous()
+                corr1 = corr_op(c1[None], rig * iis, rig * jjs + (iis == jjs).long())         # [1,M,196,h,w]
+                feats = self.update_op.corr_to_nhwc(corr1[0])
+                net = self._net[e].contiguous()
+                dw, damping, upmask, uniq = self._operator(net, c1, target_prev[e].contiguous(), feats, iis)
+                if self.upsample:
+                    v.upsample(uniq, upmask)
+                self._net[e] = net
+                tg, wg, tbe, wbe = db.ba_inputs(c1, dw)
+                target[e] = tg; weight[e] = wg; tb[e] = tbe; wb[e] = wbe
+                self.damping[uniq] = damping
+            self.target, self.weight = target[None], weight[None]
+            ii, jj = self.ii, self.jj
+            if use_inactive:
+                ii = torch.cat([self.ii_inac, ii]); jj = torch.cat([self.jj_inac, jj])
+                tb = torch.cat([self.target_inac[0].permute(0, 3, 1, 2), tb]).contiguous()
+                wb = torch.cat([self.weight_inac[0].permute(0, 3, 1, 2), wb]).contiguous()
+            eta = (.2 * self.damping[torch.unique(ii)] + EP).contiguous()
+            self.age += 1
+            v.ba(tb, wb, eta, ii, jj, 1, t, itrs=itrs, lm=1e-5, ep=1e-2, motion_only=False)
+            v.dirty[:t] = True
+
+    # ---- edge creation policies (factor_graph.py:332-412) ---------------------------------------------------------------
+    def add_neighborhood_factors(self, t0, t1, r=3):
+        ii, jj = torch.meshgrid(torch.arange(t0, t1, device=self.device), torch.arange(t0, t1, device=self.device), indexing="ij")
+        c = 1 if self.video.stereo else 0
+        keep = ((ii - jj).abs() > c) & ((ii - jj).abs() <= r)
+        self.add_factors(ii[keep], jj[keep])
+
+    def add_proximity_factors(self, t0=0, t1=0, rad=2, nms=2, beta=0.25, thresh=16.0, remove=False):
+        v = self.video
+        t = v.counter.value
+        ix = torch.arange(t0, t, device=self.device); jx = torch.arange(t1, t, device=self.device)
+        ii, jj = torch.meshgrid(ix, jx, indexing="ij")
+        d = v.distance(ii.reshape(-1), jj.reshape(-1), beta=beta).contiguous()
+        # edges that are always added (known without looking at the distances): stereo self edges + temporal neighbours
+        es = []
+        for i in range(t0, t):
+            if v.stereo:
+                es.append((i, i))
+            for j in range(max(i - rad - 1, 0), i):
+                es.append((i, j)); es.append((j, i))
+        ei = torch.cat([self.ii, self.ii_bad, self.ii_inac]).contiguous(); ej = torch.cat([self.jj, self.jj_bad, self.jj_inac]).contiguous()
+        n_cand = d.numel()
+        max_new = max(1, min(n_cand, 1 << 16))
+        new_edges, count = db.proximity_nms(d, ei, ej, t0, t1, t, rad, nms, float(thresh), int(self.max_factors), len(es),
+                                            bool(v.stereo), max_new)
+        n = int(count.item())                                         # the one read-back: how many edges were chosen
+        fixed = torch.as_tensor(es, dtype=torch.long, device=self.device).reshape(-1, 2)
+        edges = torch.cat([fixed, new_edges[:2 * n]], 0)
+        if edges.shape[0] > 0:
+            self.add_factors(edges[:, 0], edges[:, 1], remove)

@@ -158,6 +158,7 @@ class UpdateModule:
     def __init__(self, device="cuda", share_inp_by_source_frame=False):
         self.device = torch.device(device)
         self.params = None
+        self.last_dw = None
         # forward() (the reference's interface, per-edge `inp`): treat edges with equal ii as sharing their context features
         self.share_inp_by_source_frame = share_inp_by_source_frame
 
@@ -263,6 +264,7 @@ class UpdateModule:
         hd = P["heads0"]([net], EPI_RELU)
         dw = torch.empty(E, h, w, 4, dtype=torch.float32, device=net.device)
         P["heads2"]([hd], EPI_HEADS, out=dw)
+        self.last_dw = dw                        # (delta_x, delta_y, w_x, w_y) as one tensor for droid_backends.ba_inputs
         # GraphAgg: conv -> mean over the edges of each source frame -> conv -> eta / upmask
         x = P["agg1"]([net], EPI_RELU)
         _, ix, cnt = torch.unique(ii, return_inverse=True, return_counts=True)
@@ -277,6 +279,14 @@ class UpdateModule:
         upmask = P["upmask"]([x2], EPI_LINEAR)
         return net, dw[..., :2], dw[..., 2:], eta[..., 0], upmask
 
+    def corr_to_nhwc(self, corr):
+        """[E,196,h,w] correlation features in the reference's channel order (level*49 + xoff*7 + yoff) -> the level-planar
+        channel-last [4,E,h,w,56] tensor that forward_nhwc consumes (what corr_pyramid_lookup_nhwc writes directly)"""
+        E, _, ht, wd = corr.shape
+        cpad = torch.cat([corr, torch.zeros_like(corr[:, :1])], 1)              # channel 196 = zeros for the pads
+        c = self.to_nhwc(cpad[:, torch.where(self.cmap >= 0, self.cmap, torch.full_like(self.cmap, COR_PLANES))])
+        return c.view(E, ht, wd, 4, 56).permute(3, 0, 1, 2, 4).contiguous()
+
     def forward(self, net, inp, corr, flow=None, ii=None, jj=None):
         """Reference interface (droid_net.py:111-143): net, inp [1,E,128,h,w], corr [1,E,196,h,w],
         flow [1,E,4,h,w] -> net [1,E,128,h,w], delta, weight [1,E,h,w,2], eta [1,K,h,w], upmask [1,K,576,h,w]."""
@@ -287,9 +297,7 @@ class UpdateModule:
         if ii is None:
             ii = torch.arange(num, device=net.device)
         n = self.to_nhwc(net[0]); i = self.to_nhwc(inp[0])
-        cpad = torch.cat([corr[0], torch.zeros_like(corr[0][:, :1])], 1)          # channel 196 = zeros for the pads
-        c = self.to_nhwc(cpad[:, torch.where(self.cmap >= 0, self.cmap, torch.full_like(self.cmap, COR_PLANES))])
-        c = c.view(c.shape[0], ht, wd, 4, 56).permute(3, 0, 1, 2, 4).contiguous()
+        c = self.corr_to_nhwc(corr[0])
         f = self.to_nhwc(flow[0], 8)
         ii = ii.to(net.device)
         if self.share_inp_by_source_frame:

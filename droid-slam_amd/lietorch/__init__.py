@@ -6,7 +6,8 @@ inv(), group product, action on homogeneous 4-vectors, adjT(), retr()/exp().  Th
 surface on top of the HIP kernels of libdroid_hip (dh_se3_inv/mul/exp/retr/act4/adjT, semantics of the reference's
 device helpers src/droid_kernels.cu:67-184,886-904); operands are broadcast to a common batch shape and sent to the
 kernels as flat [n,7] arrays.  Inference only (no autograd); tensors must live on the ROCm device.
-Sim3 / SO3 / log / matrix are outside the path and raise NotImplementedError.
+log / matrix serve the callers of the path (frontend motion model, trajectory filler, viewers); Sim3 / SO3 are used by
+training and trajectory alignment only and raise NotImplementedError.
 """
 import torch
 
@@ -110,10 +111,25 @@ class SE3(_Group):
         return SE3(_db.se3_op("retr", a, b).view(shape + (7,)).to(self.data.dtype))
 
     def log(self):
-        raise NotImplementedError("SE3.log is not on the BA update path (SURVEY.md Appendix C)")
+        """[...,7] -> tangent vectors [...,6] = (tau, phi) (droid_frontend.py:61, trajectory_filler.py:63)"""
+        out = _db.se3_op("log", _flat(self.data, 7), _flat(self.data, 7))
+        return out.view(self.data.shape[:-1] + (6,)).to(self.data.dtype)
 
     def matrix(self):
-        raise NotImplementedError("SE3.matrix is not on the BA update path (SURVEY.md Appendix C)")
+        """[...,7] -> homogeneous 4x4 matrices (viewers, visualization.py:86); plain tensor arithmetic, not on the hot path"""
+        t, q = self.data[..., :3], self.data[..., 3:]
+        x, y, z, w = q.unbind(-1)
+        R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                         2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                         2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1).view(q.shape[:-1] + (3, 3))
+        M = torch.zeros(q.shape[:-1] + (4, 4), dtype=self.data.dtype, device=self.data.device)
+        M[..., :3, :3] = R; M[..., :3, 3] = t; M[..., 3, 3] = 1.0
+        return M
+
+    def scale(self, s):
+        """translation scaled by s (DepthVideo.normalize-style rescaling of a trajectory)"""
+        s = torch.as_tensor(s, dtype=self.data.dtype, device=self.data.device)
+        return SE3(torch.cat([self.data[..., :3] * s[..., None] if s.dim() else self.data[..., :3] * s, self.data[..., 3:]], -1))
 
 
 class Sim3(_Group):

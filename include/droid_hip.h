@@ -154,6 +154,30 @@ int dh_ba_finish(float* poses, float* disps, const int64_t* jj,
                  void* workspace, size_t workspace_bytes, dh_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Factor-graph side kernels (csrc/graph.hip): the glue of FactorGraph.update / add_proximity_factors and
+ * DepthVideo.upsample (reference droid_slam/factor_graph.py:214-263,346-412, depth_video.py:155-159, droid_net.py:21-35).
+ *   dh_motion_features: coords1, target [E,ht,wd,2] f32 -> flow [E,ht,wd,8] f16 =
+ *     cat(coords1 - coords0, target - coords1).clamp(-64, 64), channels 4..7 zero (factor_graph.py:221-222)
+ *   dh_ba_inputs: coords1 [E,ht,wd,2], dw [E,ht,wd,4] f32 = (delta, weight) of the update operator ->
+ *     target = coords1 + delta, weight [E,ht,wd,2] (optional, NULL to skip) and the same in ba's [E,2,ht,wd] layout
+ *     (factor_graph.py:233-234,253-254)
+ *   dh_cvx_upsample: disp [K,ht,wd] f32, mask [K,ht,wd,576] f16 channel-last (channel = (dy*3+dx)*64 + sy*8 + sx)
+ *     -> out [K,8ht,8wd] f32 (droid_net.py:21-35: softmax over the 9 neighbours, weights rounded to fp16)
+ *   dh_proximity_nms: the candidate selection of add_proximity_factors on the device.  dist [(t-t0) x (t-t1)] f32 is
+ *     MODIFIED.  stage 0: dist[i - rad < j] = dist[dist > 100] = inf, temporal neighbours / stereo self edges and the
+ *     |di|+|dj| <= max(min(|i-j|-2, nms), 0) neighbourhood of every edge in edges_i/j [n_edges] i64 = inf.
+ *     stage 1 (after the caller sorted: order [n] i64 = argsort(dist)): greedy walk in ascending distance, every accepted
+ *     (i,j) is written as (i,j),(j,i) to out_edges [2*max_new][2] i64 and suppresses its neighbourhood; stops at
+ *     dist > thresh, when n_es0 + 2*accepted > max_factors (max_factors > 0), or at max_new; out_count[0] = accepted. */
+int dh_motion_features(const float* coords1, const float* target, void* flow, int E, int ht, int wd, dh_stream_t stream);
+int dh_ba_inputs(const float* coords1, const float* dw, float* target, float* weight, float* target_ba, float* weight_ba,
+                 int E, int ht, int wd, dh_stream_t stream);
+int dh_cvx_upsample(const float* disp, const void* mask, float* out, int K, int ht, int wd, dh_stream_t stream);
+int dh_proximity_nms(float* dist, const int64_t* order, const int64_t* edges_i, const int64_t* edges_j, int n_edges,
+                     int t0, int t1, int t, int rad, int nms, float thresh, int max_factors, int n_es0, int stereo,
+                     int64_t* out_edges, int max_new, int* out_count, int stage, dh_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * ConvGRU update operator building block.  Replaces the cuDNN convolutions + elementwise GRU algebra of
  * UpdateModule / ConvGRU / GraphAgg (reference droid_slam/droid_net.py:78-143,44-75, modules/gru.py:5-33).
  * Implicit-GEMM convolution, stride 1, "same" padding, fp16 MFMA with fp32 accumulation, NHWC activations.
@@ -235,6 +259,9 @@ int dh_se3_mul(const float* a, const float* b, float* out, int n, dh_stream_t st
 int dh_se3_exp(const float* xi, float* out, int n, dh_stream_t stream);
 int dh_se3_retr(const float* xi, const float* a, float* out, int n, dh_stream_t stream);
 int dh_se3_act4(const float* a, const float* X, float* Y, int n, int npts, dh_stream_t stream);
+/* out [n,6] = log(a[i]) = (tau, phi): the inverse of dh_se3_exp (lietorch SE3.log; used by the frontend's motion model,
+ * reference droid_slam/droid_frontend.py:59-63, and the trajectory filler, trajectory_filler.py:55-65) */
+int dh_se3_log(const float* a, float* out, int n, dh_stream_t stream);
 int dh_se3_adjT(const float* a, const float* X, float* Y, int n, int npts, dh_stream_t stream);
 int dh_reproject(const float* poses, const float* disps, const float* intrinsics,
                  const int64_t* ii, const int64_t* jj, float* coords, float* valid,

@@ -111,6 +111,28 @@ def se3_exp(xi):
     return t, q
 
 
+def se3_log(t, q):
+    """log: (t, q) -> xi = (tau, phi), the inverse of se3_exp (lietorch SE3.log, un-vendored: SO3 log of the unit
+    quaternion, tau = V(phi)^-1 t).  Used by the callers of the path (droid_frontend.py:59-63, trajectory_filler.py:55-65)."""
+    v, w = q[..., :3], q[..., 3:4]
+    n2 = np.sum(v * v, -1, keepdims=True)
+    n = np.sqrt(n2)
+    small = n2 < 1e-20
+    ns = np.where(small, 1.0, n)
+    k = np.where(small, 2.0 / w - (2.0 / 3.0) * n2 / w ** 3, 2.0 * np.arctan2(ns, w) / ns)
+    k = np.where((~small) & (w < 0), 2.0 * np.arctan(ns / np.where(w == 0, 1.0, w)) / ns, k)     # atan branch of the reference (no +pi unwrap)
+    phi = k * v
+    th2 = np.sum(phi * phi, -1, keepdims=True)
+    th = np.sqrt(th2)
+    tiny = th < 1e-6
+    ths = np.where(tiny, 1.0, th)
+    c = np.where(tiny, 1.0 / 12.0 + th2 / 720.0, (1.0 - 0.5 * ths * np.cos(0.5 * ths) / np.sin(0.5 * ths)) / np.where(tiny, 1.0, th2))
+    c1 = _cross(phi, t)
+    c2 = _cross(phi, c1)
+    tau = t - 0.5 * c1 + c * c2
+    return np.concatenate([tau, phi], -1)
+
+
 def se3_retr(xi, t, q):
     """Left retraction  T <- exp(xi) * T."""
     dt, dq = se3_exp(xi)

@@ -62,7 +62,7 @@ def _graph_agg(p, net, ii):
     cnt = torch.zeros(K, dtype=x.dtype).index_add_(0, ix, torch.ones(len(ix), dtype=x.dtype))
     x = acc / cnt.view(-1, 1, 1, 1)
     x = torch.relu(_conv(p, "agg.conv2", x))
-    eta = 0.01 * F.softplus(_conv(p, "agg.eta.0", x))[:, 0]
+    eta = 0.01 * F.softplus(_conv(p, "agg.eta.0", x).float())[:, 0]      # softplus is on autocast's fp32 list on a GPU
     upmask = _conv(p, "agg.upmask.0", x)
     return eta, upmask
 

@@ -1,0 +1,36 @@
+"""Oracle-backed stand-in for the reference's CUDA extension -- GOLDEN GENERATION ONLY (tests/golden/make_graph_golden.py).
+
+Lets the reference's unmodified factor_graph.py / depth_video.py / modules/corr.py run on CPU: every entry point forwards
+to the numpy oracle (which is itself pinned to the reference's CUDA kernels by tests/golden/ref_cuda.npz).  What the
+resulting vectors pin is the reference's ORCHESTRATION: index bookkeeping, tensor views, ordering of updates, edge
+selection.  Not part of the product."""
+import numpy as np
+import torch
+
+from oracle import ba as _oba, corr as _ocorr, geom as _ogeom
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1, iterations, lm, ep, motion_only):
+    p = poses.numpy(); d = disps.numpy()                      # views: updated in place like the CUDA extension does
+    dx, dz = _oba.ba(p, d, _np(intrinsics), _np(disps_sens), _np(targets), _np(weights), _np(eta), _np(ii), _np(jj),
+                     int(t0), int(t1), int(iterations), float(lm), float(ep), bool(motion_only), dtype=np.float64)
+    return [torch.as_tensor(dx, dtype=torch.float32), torch.as_tensor(dz if dz is not None else np.zeros(0), dtype=torch.float32)]
+
+
+def corr_index_forward(volume, coords, radius):
+    out = _ocorr.corr_index_forward(_np(volume.float()), _np(coords.float()), int(radius))
+    return [torch.as_tensor(out).to(volume.dtype)]
+
+
+def altcorr_forward(fmap1, fmap2, coords, ii, jj, radius):
+    out = _ocorr.altcorr_forward(_np(fmap1.float()), _np(fmap2.float()), _np(coords.float()), _np(ii), _np(jj), int(radius))
+    return [torch.as_tensor(out).to(fmap1.dtype)]
+
+
+def frame_distance(poses, disps, intrinsics, ii, jj, beta):
+    d = _ogeom.frame_distance(_np(poses), _np(disps), _np(intrinsics), _np(ii), _np(jj), float(beta))
+    return torch.as_tensor(d, dtype=torch.float32)

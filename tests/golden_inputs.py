@@ -19,3 +19,24 @@ def update_autocast_inputs():
     flow = np.clip(4.0 * rng.standard_normal((E, 4, ht, wd)), -64, 64).astype(np.float16).astype(np.float32)
     t = lambda a: torch.as_tensor(a)
     return t(net), t(inp), t(corr), t(flow), torch.as_tensor(c["ii"]), torch.as_tensor(c["jj"])
+
+
+def graph_scenario():
+    """Six keyframes at 16 x 64 (1/8 resolution; W = 64 so the HIP path takes its production kernels): state of a
+    DepthVideo (poses, depths, features) for the factor-graph golden run (tests/golden/make_graph_golden.py)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "droid-slam_amd"))
+    from droid_amd import synthetic as syn
+    ht, wd, N = 16, 64, 6
+    rng = np.random.default_rng(77)
+    cfg = syn.GraphConfig("scn", N, 2 * (N - 1) + 2 * (N - 2), radius=2)
+    g = syn.make_graph(cfg, seed=5, ht=ht, wd=wd)
+    intr = np.array([24.0, 24.0, 32.0, 8.0], dtype=np.float32)
+    disps = (0.7 + 0.6 * g["disps_gt"] / g["disps_gt"].max()).astype(np.float32)
+    return dict(ht=ht, wd=wd, n_frames=N, weight_seed=1234,
+                poses=g["poses"].astype(np.float32), disps=disps, intrinsics=np.tile(intr, (N, 1)),
+                fmaps=rng.standard_normal((N, 128, ht, wd)).astype(np.float16),
+                nets=np.tanh(rng.standard_normal((N, 128, ht, wd))).astype(np.float16),
+                inps=np.maximum(rng.standard_normal((N, 128, ht, wd)), 0).astype(np.float16),
+                prox_rad=1, prox_nms=1, prox_thresh=1e3, prox_beta=0.25)
