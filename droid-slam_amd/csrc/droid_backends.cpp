@@ -393,13 +393,14 @@ std::vector<torch::Tensor> proximity_nms(torch::Tensor dist, torch::Tensor edges
   CHECK_INPUT(dist); CHECK_F32(dist); CHECK_INPUT(edges_i); CHECK_INPUT(edges_j); CHECK_I64(edges_i); CHECK_I64(edges_j);
   TORCH_CHECK(dist.numel() == (t - t0) * (t - t1) && edges_i.numel() == edges_j.numel(), "proximity_nms: shapes");
   const int ne = (int)edges_i.numel();
-  check_status(dh_proximity_nms(dist.data_ptr<float>(), nullptr, edges_i.data_ptr<int64_t>(), edges_j.data_ptr<int64_t>(), ne, (int)t0,
+  check_status(dh_proximity_nms(dist.data_ptr<float>(), nullptr, nullptr, edges_i.data_ptr<int64_t>(), edges_j.data_ptr<int64_t>(), ne, (int)t0,
                                 (int)t1, (int)t, (int)rad, (int)nms, (float)thresh, (int)max_factors, (int)n_es0, stereo ? 1 : 0,
                                 nullptr, 0, nullptr, 0, cur_stream()), "proximity_nms (mask)");
-  torch::Tensor order = torch::argsort(dist.view({-1})).contiguous();
+  auto srt = torch::sort(dist.view({-1}), /*stable=*/true, 0, false);
+  torch::Tensor sorted = std::get<0>(srt).contiguous(), order = std::get<1>(srt).contiguous();
   torch::Tensor out = torch::zeros({2 * max_new, 2}, edges_i.options());
   torch::Tensor count = torch::zeros({1}, dist.options().dtype(torch::kInt32));
-  check_status(dh_proximity_nms(dist.data_ptr<float>(), order.data_ptr<int64_t>(), nullptr, nullptr, 0, (int)t0, (int)t1, (int)t, (int)rad,
+  check_status(dh_proximity_nms(dist.data_ptr<float>(), sorted.data_ptr<float>(), order.data_ptr<int64_t>(), nullptr, nullptr, 0, (int)t0, (int)t1, (int)t, (int)rad,
                                 (int)nms, (float)thresh, (int)max_factors, (int)n_es0, stereo ? 1 : 0, out.data_ptr<int64_t>(),
                                 (int)max_new, count.data_ptr<int>(), 1, cur_stream()), "proximity_nms (walk)");
   return {out, count};

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void prox_suppress_kernel(float* __restrict__ 
 // (j,i), suppress its neighbourhood.  ONE workgroup: the walk is a dependent chain, the suppression of an accepted edge is
 // done by the threads in parallel.  `order` = argsort(d); out_edges [2 * max_new][2] i64; out_count[0] = accepted pairs.
 // The reference stops when len(es) > max_factors (checked before each accepted pair; es already holds n_es0 edges).
-__global__ __launch_bounds__(256) void prox_nms_kernel(float* __restrict__ d, const int64_t* __restrict__ order, long n, int t0, int t1, int t,
+__global__ __launch_bounds__(256) void prox_nms_kernel(float* __restrict__ d, const float* __restrict__ sorted, const int64_t* __restrict__ order, long n, int t0, int t1, int t,
                                                        int nms, float thresh, int max_factors, int n_es0,
                                                        int64_t* __restrict__ out_edges, int max_new, int* __restrict__ out_count) {
   __shared__ int s_i, s_j, s_take, s_stop;
@@ -122,7 +122,8 @@ __global__ __launch_bounds__(256) void prox_nms_kernel(float* __restrict__ d, co
       const long k = order[q];
       const float v = d[k];                           // plain loads: this workgroup is the only writer, barriers order them
       s_stop = 0; s_take = 0;
-      if (!(v <= thresh)) s_stop = 1;                 // sorted ascending: nothing further can pass (inf / nan included)
+      if (!(sorted[q] <= thresh)) s_stop = 1;         // value at sort time: ascending, nothing further can pass (inf / nan too)
+      else if (!(v <= thresh)) { }                    // suppressed since the sort: skipped, the walk goes on (:389-390 `continue`)
       else if (max_factors > 0 && n_es0 + 2 * count > max_factors) s_stop = 1;
       else if (count >= max_new) s_stop = 1;
       else { s_take = 1; s_i = t0 + (int)(k / nj); s_j = t1 + (int)(k % nj); }
@@ -185,7 +186,7 @@ extern "C" int dh_cvx_upsample(const float* disp, const void* mask, float* out, 
   return DH_OK;
 }
 
-extern "C" int dh_proximity_nms(float* dist, const int64_t* order, const int64_t* edges_i, const int64_t* edges_j, int n_edges,
+extern "C" int dh_proximity_nms(float* dist, const float* sorted, const int64_t* order, const int64_t* edges_i, const int64_t* edges_j, int n_edges,
                                 int t0, int t1, int t, int rad, int nms, float thresh, int max_factors, int n_es0, int stereo,
                                 int64_t* out_edges, int max_new, int* out_count, int stage, dh_stream_t stream) {
   if (t0 < 0 || t1 < 0 || t <= t0 || t <= t1 || nms < 0 || nms > 7 || rad < 0) return DH_ERR_ARG;
@@ -203,8 +204,8 @@ extern "C" int dh_proximity_nms(float* dist, const int64_t* order, const int64_t
     }
     return DH_OK;
   }
-  if (!order || !out_edges || !out_count || max_new < 0) return DH_ERR_ARG;
-  hipLaunchKernelGGL(prox_nms_kernel, dim3(1), dim3(256), 0, st, dist, order, n, t0, t1, t, nms, thresh, max_factors, n_es0, out_edges,
+  if (!order || !sorted || !out_edges || !out_count || max_new < 0) return DH_ERR_ARG;
+  hipLaunchKernelGGL(prox_nms_kernel, dim3(1), dim3(256), 0, st, dist, sorted, order, n, t0, t1, t, nms, thresh, max_factors, n_es0, out_edges,
                      max_new, out_count);
   DH_LAUNCH_CHECK();
   return DH_OK;

@@ -151,7 +151,7 @@ def fill_poses(update_op, video, tstamps, fmaps, intrinsics=None, iters=6):
     video.tstamp[idx] = tt
     video.poses[idx] = Gs.data
     video.disps[idx] = 1.0
-    video.intrinsics[idx] = video.intrinsics[0] if intrinsics is None else intrinsics
+    video.intrinsics[idx] = video.intrinsics[0].clone() if intrinsics is None else intrinsics
     video.fmaps[idx] = fmaps
     graph = FactorGraph(video, update_op)
     graph.add_factors(t0, idx)

@@ -166,14 +166,15 @@ int dh_ba_finish(float* poses, float* disps, const int64_t* jj,
  *   dh_proximity_nms: the candidate selection of add_proximity_factors on the device.  dist [(t-t0) x (t-t1)] f32 is
  *     MODIFIED.  stage 0: dist[i - rad < j] = dist[dist > 100] = inf, temporal neighbours / stereo self edges and the
  *     |di|+|dj| <= max(min(|i-j|-2, nms), 0) neighbourhood of every edge in edges_i/j [n_edges] i64 = inf.
- *     stage 1 (after the caller sorted: order [n] i64 = argsort(dist)): greedy walk in ascending distance, every accepted
+ *     stage 1 (after the caller sorted the masked matrix: sorted [n] f32 values, order [n] i64 indices): greedy walk in
+ *     ascending distance (entries suppressed since the sort are skipped), every accepted
  *     (i,j) is written as (i,j),(j,i) to out_edges [2*max_new][2] i64 and suppresses its neighbourhood; stops at
  *     dist > thresh, when n_es0 + 2*accepted > max_factors (max_factors > 0), or at max_new; out_count[0] = accepted. */
 int dh_motion_features(const float* coords1, const float* target, void* flow, int E, int ht, int wd, dh_stream_t stream);
 int dh_ba_inputs(const float* coords1, const float* dw, float* target, float* weight, float* target_ba, float* weight_ba,
                  int E, int ht, int wd, dh_stream_t stream);
 int dh_cvx_upsample(const float* disp, const void* mask, float* out, int K, int ht, int wd, dh_stream_t stream);
-int dh_proximity_nms(float* dist, const int64_t* order, const int64_t* edges_i, const int64_t* edges_j, int n_edges,
+int dh_proximity_nms(float* dist, const float* sorted, const int64_t* order, const int64_t* edges_i, const int64_t* edges_j, int n_edges,
                      int t0, int t1, int t, int rad, int nms, float thresh, int max_factors, int n_es0, int stereo,
                      int64_t* out_edges, int max_new, int* out_count, int stage, dh_stream_t stream);
 

@@ -21,14 +21,14 @@ def update_autocast_inputs():
     return t(net), t(inp), t(corr), t(flow), torch.as_tensor(c["ii"]), torch.as_tensor(c["jj"])
 
 
-def graph_scenario():
+def graph_scenario(n_frames=6):
     """Six keyframes at 16 x 64 (1/8 resolution; W = 64 so the HIP path takes its production kernels): state of a
     DepthVideo (poses, depths, features) for the factor-graph golden run (tests/golden/make_graph_golden.py)."""
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "droid-slam_amd"))
     from droid_amd import synthetic as syn
-    ht, wd, N = 16, 64, 6
+    ht, wd, N = 16, 64, n_frames
     rng = np.random.default_rng(77)
     cfg = syn.GraphConfig("scn", N, 2 * (N - 1) + 2 * (N - 2), radius=2)
     g = syn.make_graph(cfg, seed=5, ht=ht, wd=wd)

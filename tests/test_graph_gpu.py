@@ -203,3 +203,37 @@ def test_pose_filler_recovers_interpolated_poses(db):
     # frames stamped exactly at a keyframe start from that keyframe's pose and stay close to it
     kp = poses0[[1, 4]].cpu().numpy()
     assert np.abs(got[[0, 2], :3] - kp[:, :3]).max() < 0.1
+
+
+def test_frontend_and_backend_policies_run_on_a_short_sequence(db):
+    """DroidFrontend (initialisation with 8 + 8 update iterations, then per-keyframe updates incl. the keyframe-removal
+    branch) and DroidBackend (proximity edges + update_lowmem) on a synthetic 10-keyframe sequence: the policies of
+    droid_frontend.py:65-164 / droid_backend.py:25-43 execute end to end on the device and keep the state sane"""
+    from types import SimpleNamespace
+    from droid_amd.policies import DroidFrontend, DroidBackend
+    S = graph_scenario(n_frames=10)
+    N = S["n_frames"]
+    video, upd = _setup(S, buffer_extra=4)
+    args = SimpleNamespace(upsample=True, warmup=8, beta=0.3, frontend_nms=1, keyframe_thresh=0.5, frontend_window=20,
+                           frontend_thresh=16.0, frontend_radius=2, backend_thresh=22.0, backend_radius=2, backend_nms=3)
+    video.counter.value = 8                                   # the first `warmup` keyframes have arrived
+    fe = DroidFrontend(upd, video, args)
+    fe()
+    assert fe.is_initialized and fe.t1 == 8
+    for k in (9, 10):                                         # two more keyframes
+        video.counter.value = k
+        fe()
+    torch.cuda.synchronize()
+    t = video.counter.value
+    assert 8 <= t <= 10 and fe.t1 == t
+    p = video.poses[:t].cpu().numpy(); dd = video.disps[:t].cpu().numpy()
+    assert np.isfinite(p).all() and np.isfinite(dd).all() and dd.min() >= 0.001
+    assert np.abs(np.linalg.norm(p[:, 3:], axis=-1) - 1).max() < 1e-4 and np.array_equal(p[0], S["poses"][0])
+    assert len(fe.graph.ii) <= 48 + 2 * 5 * (args.frontend_radius + 1) and int(fe.graph.age.max()) <= fe.max_age + 1
+    be = DroidBackend(upd, video, args, chunk_frames=64)
+    g = be(steps=2)
+    torch.cuda.synchronize()
+    assert len(g.ii) == 0                                     # clear_edges
+    p2 = video.poses[:t].cpu().numpy()
+    assert np.isfinite(p2).all() and np.abs(np.linalg.norm(p2[:, 3:], axis=-1) - 1).max() < 1e-4
+    assert abs(float(video.disps[:t].mean()) - 1.0) < 0.5     # normalised to unit mean disparity before the global BA
