@@ -13,8 +13,8 @@ N > 1: one process per GPU (torch.distributed, RCCL); edges are sharded by sourc
 exchange is the all-reduce of the reduced camera system inside the BA ("multi-GPU").
 
 The JSON line also carries `roofline` (correlation-lookup kernel, HBM bound, algorithmic bytes from
-SURVEY.md 8d: 880 B per edge-pixel for fp16) and `cpu_baseline` (the numpy/C oracle timed on a bounded
-sample of the same graph on this host's cores).
+SURVEY.md 8d: 880 B per edge-pixel for fp16) and `cpu_baseline` (the numpy / torch-CPU oracle timed on all of this
+host's cores: BA on the whole graph, lookup and update operator on bounded samples).
 """
 import argparse
 import json
@@ -50,72 +50,96 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(g, n_frames_sample=128, n_lookup_edges=32, n_update_edges=32):
-    """Oracle (numpy / torch-CPU restatement of the reference kernels, kind "port") on a bounded sample of the same
-    workload, single-threaded (threadpoolctl + torch.set_num_threads(1)): one update iteration = lookup + update
-    operator + ba(itrs) per edge-pixel, each leg timed on its own sample and summed per edge-pixel.  The samples are sized
-    for about 10 s of timed work on the bench host and to fall out of its caches like the full workload does (with an
-    8-edge lookup sample the per-edge-pixel cost came out 4x lower than with 32 edges)."""
+def cpu_baseline(g, n_lookup_edges=64, n_update_edges=128, repeats=3):
+    """Oracle (numpy / torch-CPU restatement of the reference kernels, kind "port") on this host's cores, on a bounded
+    sample of the same workload; each leg of one update iteration (lookup, update operator, ba) is timed on its own sample
+    and the legs are summed per edge-pixel.  ALL host cores: the per-edge and per-depth-block stages of oracle.ba run on a
+    thread pool (numpy releases the GIL), the lookup goes through torch's multi-threaded grid_sample, the update operator
+    through torch's CPU convolutions, the solve through LAPACK; one warm-up run, then the median of `repeats`.
+    BA sample = the WHOLE C3 graph (512 keyframes / 4096 edges, itrs = 2).  The single-core figure of the same legs is
+    kept as `value_1core` (BA on the 128-frame sub-graph)."""
     from oracle import ba as oba, corr as ocorr, update as oupd
     from droid_amd.weights import deterministic_state_dict
+    import statistics
     import threadpoolctl
-    # untimed setup (host pyramid for the lookup sample) with all host threads
-    rng = np.random.default_rng(0)
+    ncores = os.cpu_count() or 1
     ht, wd = g["ht"], g["wd"]
-    f1 = rng.standard_normal((n_lookup_edges, 128, ht, wd)).astype(np.float32)
-    f2 = rng.standard_normal((n_lookup_edges, 128, ht, wd)).astype(np.float32)
-    a_ = torch.from_numpy(f1).reshape(n_lookup_edges, 128, ht * wd) / 4.0
-    b_ = torch.from_numpy(f2).reshape(n_lookup_edges, 128, ht * wd) / 4.0
-    vol = torch.matmul(a_.transpose(1, 2), b_).reshape(n_lookup_edges * ht * wd, 1, ht, wd)
+    rng = np.random.default_rng(0)
+
+    def timed(fn, reps):
+        fn()                                             # warm-up
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+        return statistics.median(ts)
+
+    # ---- samples
+    f1 = torch.from_numpy(rng.standard_normal((n_lookup_edges, 128, ht * wd)).astype(np.float32)) / 4.0
+    f2 = torch.from_numpy(rng.standard_normal((n_lookup_edges, 128, ht * wd)).astype(np.float32)) / 4.0
+    vol = torch.matmul(f1.transpose(1, 2), f2).reshape(n_lookup_edges * ht * wd, 1, ht, wd)
     pyr = []
     for _ in range(4):
-        pyr.append(vol.reshape(n_lookup_edges, ht, wd, vol.shape[-2], vol.shape[-1]).numpy())
+        pyr.append(vol.reshape(n_lookup_edges, ht, wd, vol.shape[-2], vol.shape[-1]))
         vol = torch.nn.functional.avg_pool2d(vol, 2, stride=2)
-    coords = np.stack([rng.uniform(0, wd, (n_lookup_edges, ht, wd)), rng.uniform(0, ht, (n_lookup_edges, ht, wd))], -1)
-    nthreads = torch.get_num_threads()
+    coords = torch.from_numpy(np.stack([rng.uniform(0, wd, (n_lookup_edges, ht, wd)), rng.uniform(0, ht, (n_lookup_edges, ht, wd))], -1).astype(np.float32))
+
+    class _SD:
+        def state_dict(self):
+            return oupd.empty_state_dict()
+    sd = deterministic_state_dict(_SD(), seed=1234)
+    tg = torch.Generator().manual_seed(0)
+    E1 = n_update_edges
+    uargs = (torch.randn(E1, 128, ht, wd, generator=tg), torch.randn(E1, 128, ht, wd, generator=tg),
+             torch.randn(E1, 196, ht, wd, generator=tg), torch.randn(E1, 4, ht, wd, generator=tg), torch.arange(E1) // 8)
+
+    def run_ba(sub, N, threads):
+        poses = g["poses"][:N].astype(np.float32).copy(); disps = np.array(g["disps"][:N], dtype=np.float32, order="C")
+        oba.ba(poses, disps, g["intrinsics"], g["disps_sens"][:N], sub["targets"], sub["weights"], sub["eta"], sub["ii"], sub["jj"],
+               1, N, g["itrs"], g["lm"], g["ep"], False, dtype=np.float32, threads=threads, chunk=None if threads > 1 else 64)
+
+    def subgraph(N):
+        ii, jj = g["ii"], g["jj"]
+        keep = (ii < N) & (jj < N)
+        kx_full = np.unique(np.concatenate([np.arange(1, g["n_frames"]), ii]))
+        kx = np.unique(np.concatenate([np.arange(1, N), ii[keep]]))
+        return dict(ii=ii[keep], jj=jj[keep], targets=g["targets"][keep], weights=g["weights"][keep], eta=g["eta"][np.searchsorted(kx_full, kx)])
+
+    def lookup():
+        ocorr.corr_block_lookup_torch(pyr, coords, 3)
+
+    def update():
+        with torch.no_grad():
+            oupd.update_forward(sd, *uargs)
+
+    # ---- all cores
+    nthreads0 = torch.get_num_threads()
+    torch.set_num_threads(ncores)
+    full = subgraph(g["n_frames"])
+    t_ba = timed(lambda: run_ba(full, g["n_frames"], min(ncores, 64)), max(1, repeats - 1))
+    t_lk = timed(lookup, repeats)
+    t_up = timed(update, repeats)
+    ep_ba, ep_lk, ep_up = len(full["ii"]) * ht * wd, n_lookup_edges * ht * wd, E1 * ht * wd
+    per_ep = t_ba / ep_ba + t_lk / ep_lk + t_up / ep_up
+    # ---- one core (the figure of round 1): BA on the 128-frame sub-graph, 16-edge lookup / update samples
     torch.set_num_threads(1)
     with threadpoolctl.threadpool_limits(limits=1):
-        ii, jj = g["ii"], g["jj"]
-        keep = (ii < n_frames_sample) & (jj < n_frames_sample)
-        sub = dict(g)
-        for k in ("ii", "jj", "targets", "weights"):
-            sub[k] = g[k][keep]
-        N = n_frames_sample
-        kx_full = np.unique(np.concatenate([np.arange(1, g["n_frames"]), ii]))
-        kx = np.unique(np.concatenate([np.arange(1, N), sub["ii"]]))
-        eta = g["eta"][np.searchsorted(kx_full, kx)]
-        poses = g["poses"][:N].astype(np.float32).copy(); disps = g["disps"][:N].astype(np.float32).copy()
-        t0 = time.perf_counter()
-        oba.ba(poses, disps, g["intrinsics"], g["disps_sens"][:N], sub["targets"], sub["weights"], eta,
-               sub["ii"], sub["jj"], 1, N, g["itrs"], g["lm"], g["ep"], False, dtype=np.float32)
-        t_ba = time.perf_counter() - t0
-        ep_ba = int(keep.sum()) * g["ht"] * g["wd"]
-        t0 = time.perf_counter()
-        ocorr.corr_block_lookup(pyr, coords.astype(np.float32), 3)
-        t_lk = time.perf_counter() - t0
-        ep_lk = n_lookup_edges * ht * wd
-        # update operator (fp32 torch-CPU restatement of droid_net.py:111-143)
-
-        class _SD:
-            def state_dict(self):
-                return oupd.empty_state_dict()
-        sd = deterministic_state_dict(_SD(), seed=1234)
-        tg = torch.Generator().manual_seed(0)
-        E1 = n_update_edges
-        args = (torch.randn(E1, 128, ht, wd, generator=tg), torch.randn(E1, 128, ht, wd, generator=tg),
-                torch.randn(E1, 196, ht, wd, generator=tg), torch.randn(E1, 4, ht, wd, generator=tg), torch.zeros(E1, dtype=torch.int64))
+        sub = subgraph(128)
+        t0 = time.perf_counter(); run_ba(sub, 128, 1); t_ba1 = time.perf_counter() - t0
+        small_pyr = [v[:16] for v in pyr]; small_c = coords[:16]
+        t0 = time.perf_counter(); ocorr.corr_block_lookup_torch(small_pyr, small_c, 3); t_lk1 = time.perf_counter() - t0
+        u16 = tuple(a[:16] for a in uargs)
         t0 = time.perf_counter()
         with torch.no_grad():
-            oupd.update_forward(sd, *args)
-        t_up = time.perf_counter() - t0
-        ep_up = E1 * ht * wd
-    torch.set_num_threads(nthreads)
-    per_ep = t_ba / ep_ba + t_lk / ep_lk + t_up / ep_up
-    return {"value": 1.0 / per_ep, "unit": "edge-pixels/s", "cores": 1, "kind": "port",
-            "sample": "single-threaded numpy/torch-CPU oracle (fp32): ba itrs=%d on the %d-frame / %d-edge sub-graph (%.2fs) + "
-                      "4-level lookup of %d edges (%.2fs) + update operator on %d edge(s) (%.2fs); host has %d cores" % (
-                          g["itrs"], N, int(keep.sum()), t_ba, n_lookup_edges, t_lk, E1, t_up, os.cpu_count()),
-            "ba_s": t_ba, "lookup_s": t_lk, "update_s": t_up}
+            oupd.update_forward(sd, *u16)
+        t_up1 = time.perf_counter() - t0
+    per_ep1 = t_ba1 / (len(sub["ii"]) * ht * wd) + t_lk1 / (16 * ht * wd) + t_up1 / (16 * ht * wd)
+    torch.set_num_threads(nthreads0)
+    return {"value": 1.0 / per_ep, "unit": "edge-pixels/s", "cores": ncores, "kind": "port",
+            "sample": "oracle (numpy/torch-CPU, fp32) on all %d host cores, 1 warm-up + median of %d: ba itrs=%d on the whole %d-keyframe / "
+                      "%d-edge graph (%.2fs, thread pool of %d + LAPACK) + 4-level lookup of %d edges (%.3fs) + update operator on %d edges (%.3fs)" % (
+                          ncores, repeats, g["itrs"], g["n_frames"], len(full["ii"]), t_ba, min(ncores, 64), n_lookup_edges, t_lk, E1, t_up),
+            "ba_s": t_ba, "lookup_s": t_lk, "update_s": t_up, "ms_per_global_ba_cpu": 1e3 * t_ba,
+            "value_1core": 1.0 / per_ep1}
 
 
 def main():
@@ -207,14 +231,12 @@ def main():
         feats = (corr.lookup_nhwc(coords1[None]) if fused else corr(coords1[None])[0]) if corr is not None else None
         e1.record()
         if upd is not None and feats is not None:
-            motn = torch.cat([coords1 - coords0, target_prev - coords1], -1).clamp(-64.0, 64.0)
-            flow = torch.nn.functional.pad(motn, (0, 4)).half()
+            flow = db.motion_features(coords1, target_prev)                   # factor_graph.py:221-222
             if inp_edges is not None:
-                _, delta, weight, damping, upmask = upd.forward_nhwc(net, inp_edges, feats, flow, ii)
+                _, _, _, damping, upmask = upd.forward_nhwc(net, inp_edges, feats, flow, ii)
             else:
-                _, delta, weight, damping, upmask = upd.forward_nhwc(net, None, feats, flow, ii, inp_frames=inps_frames, inp_index=inp_index)
-            tgt = (coords1 + delta).permute(0, 3, 1, 2).contiguous()
-            wgt = weight.permute(0, 3, 1, 2).contiguous()
+                _, _, _, damping, upmask = upd.forward_nhwc(net, None, feats, flow, ii, inp_frames=inps_frames, inp_index=inp_index)
+            _, _, tgt, wgt = db.ba_inputs(coords1, upd.last_dw)               # target = coords1 + delta, [E,2,h,w] for ba (:233,253-254)
             damping_buf[uniq_ii] = damping                                   # factor_graph.py:238
             eta_ba = (0.2 * damping_buf[kx_t] + 1e-7).contiguous()            # factor_graph.py:251 (rows = depth blocks)
         else:
@@ -265,7 +287,8 @@ def main():
         # FETCH_SIZE correction; scripts/pmc_bench_lookup.sh), scaled to this rank's edge-pixels; None if not measured
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_lookup_pmc.json")))
+            cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_lookup_pmc.json"))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))             # the latest round's passes
             variant = "nhwc" if (upd is not None and corr is not None) else "nchw"
             traffic = pmc[variant]["hbm_bytes_per_edge_pixel"] * E * HW
         except (OSError, KeyError, ValueError):

@@ -404,7 +404,8 @@ constexpr int BATCH = HALF_ROWS * NPAIR;           // loads per batch (20)
 constexpr int MIN_STORES = (NCH_OUT * 8) / 64;     // output-store instructions every wave issues per level (>= 6)
 
 struct LevelGeom {                                  // per-lane addressing / weights of one level
-  const __half* base;                               // wave-uniform: this source block of this level
+  const __half* base;                               // wave-uniform: source block 0 of this level (this edge)
+  int sboff;                                        // wave-uniform byte offset of this wave's source block
   int coloff[NPAIR];                                // byte offsets of the 5 cell pairs (lane included)
   uint32_t cmask[WIN / 2];                          // column validity of the aligned tap pairs (0xffff per tap)
   int Y0, y1l, par16;                               // first window row, own row at this level, 16 * (u0 & 1)
@@ -448,7 +449,11 @@ __global__ __launch_bounds__(NHWC ? 64 : W * 8, NHWC ? 3 : 4) void pyr_lookup_ke
     const int X0 = (int)fxf - RAD;
     G.Y0 = (int)fyf - RAD;
     G.y1l = y1 >> l;
-    G.base = ebase + D.lev_off[l] + (long)sb * D.blk_elems[l];
+    // Out-of-image window rows read zeros.  Every source block has its own all-zero row, but pointing all blocks at
+    // block 0's makes those reads L2 hits instead of HBM lines nobody else will ever touch (8 % of the lookup's reads at
+    // 48x64: two of the eight window rows at level 3, one to two at level 2): addresses are formed against block 0's base.
+    G.base = ebase + D.lev_off[l];
+    G.sboff = (int)((long)sb * D.blk_elems[l] * 2);
     const int u0 = (X0 - (x1 >> l)) & (w2 - 1);              // two's complement: correct for any X0
     G.par16 = (u0 & 1) * 16;
     const int k0 = u0 >> 1;
@@ -471,8 +476,8 @@ __global__ __launch_bounds__(NHWC ? 64 : W * 8, NHWC ? 3 : 4) void pyr_lookup_ke
 #pragma unroll
     for (int jj = 0; jj < HALF_ROWS; ++jj) {
       const int y2 = G.Y0 + half * HALF_ROWS + jj;
-      const int v = (unsigned)y2 < (unsigned)h2 ? wrap(y2 - G.y1l, h2) : h2;      // h2 = the all-zero row
-      const int rowoff = v * (w2 * 128);
+      const bool inside = (unsigned)y2 < (unsigned)h2;
+      const int rowoff = inside ? wrap(y2 - G.y1l, h2) * (w2 * 128) + G.sboff : h2 * (w2 * 128);      // else block 0's all-zero row
 #pragma unroll
       for (int m = 0; m < NPAIR; ++m)
         asm volatile("global_load_dword %0, %1, %2" : "=v"(T.raw[jj][m]) : "v"(rowoff + G.coloff[m]), "s"(G.base));

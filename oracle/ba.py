@@ -95,6 +95,19 @@ def edge_blocks(T):
     return np.stack([Hii, Hij, Hji, Hjj]), np.stack([vi, vj]), Eii, Eij, Cii, bz
 
 
+def edge_stage(poses, disps, intrinsics, targets, weights, ii, jj, dtype=np.float64, chunk=None, pool=None):
+    """edge_blocks(edge_terms(...)) evaluated in chunks of edges (bounded temporaries: the [E,2,6,HW] Jacobians of 4096
+    edges would be 1.2 GB each) and, with a thread pool, on several host cores (numpy releases the GIL inside its
+    kernels).  Per-edge arithmetic is untouched, so the result does not depend on `chunk` / `pool`."""
+    E = len(ii)
+    if chunk is None or chunk >= E:
+        return edge_blocks(edge_terms(poses, disps, intrinsics, targets, weights, ii, jj, dtype=dtype))
+    slices = [slice(a, min(E, a + chunk)) for a in range(0, E, chunk)]
+    work = lambda sl: edge_blocks(edge_terms(poses, disps, intrinsics, targets[sl], weights[sl], ii[sl], jj[sl], dtype=dtype))
+    parts = list(pool.map(work, slices)) if pool is not None else [work(sl) for sl in slices]
+    return tuple(np.concatenate([p[k] for p in parts], axis=1 if k < 2 else 0) for k in range(6))
+
+
 def _segsum(data, ix, jx):
     """accum_cuda: out[j] = sum_{i: ix[i]==jx[j]} data[i]   (:957-1007)."""
     out = np.zeros((len(jx),) + data.shape[1:], dtype=data.dtype)
@@ -127,13 +140,14 @@ def solve_damped(H, b, lm, ep):
 
 def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj,
        t0, t1, iterations, lm, ep, motion_only, dtype=np.float64, strict_q6=True,
-       return_system=False):
+       return_system=False, chunk=None, threads=1):
     """In-place Gauss-Newton on ``poses`` [buf,7] and ``disps`` [buf,ht,wd]  (ba_cuda :1323-1443).
 
     ``eta`` has one row per entry of ``unique(cat(arange(t0,t1), ii))``.
     Returns ``(dx [P,6], dz [K,HW])`` of the last iteration (``dz`` None when
     ``motion_only``), computed in ``dtype`` and stored back into the callers'
-    arrays in their own dtype.  ``strict_q6`` reproduces EvT6x1_kernel's skip of
+    arrays in their own dtype.  ``chunk`` / ``threads``: evaluate the per-edge stage in chunks of edges and the per-edge /
+    per-depth-block stages on a thread pool (the multi-core CPU baseline of bench.py); results do not depend on them.  ``strict_q6`` reproduces EvT6x1_kernel's skip of
     rows whose relative pose index is <= 0 (:1114).
     """
     E, _, ht, wd = targets.shape
@@ -148,9 +162,14 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj,
     K = len(kx)
     dx = dz = None
     info = {}
+    pool = None
+    if threads and threads > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=threads)
+        if chunk is None:
+            chunk = max(8, -(-E // (4 * threads)))
     for _ in range(iterations):
-        T = edge_terms(poses, disps, intrinsics, targets, weights, ii, jj, dtype=dtype)
-        Hs, vs, Eii, Eij, Cii, bz = edge_blocks(T)
+        Hs, vs, Eii, Eij, Cii, bz = edge_stage(poses, disps, intrinsics, targets, weights, ii, jj, dtype=dtype, chunk=chunk, pool=pool)
 
         # pose x pose block A, rhs (update_lhs / update_rhs :1140-1182, called at :1385-1392)
         A = np.zeros((P, 6, P, 6), dtype=np.float64)
@@ -193,12 +212,18 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj,
         for n in range(len(jj_exp)):
             if t0 <= jj_exp[n] <= t1:                              # :1257 (j==t1 never occurs)
                 rows_of[kk_exp[n]].append(n)
+        def gram(k):
+            rows = rows_of[k]
+            if not rows:
+                return None
+            M = Erow[rows]                                         # [r,6,HW]
+            return np.einsum("aip,p,bjp->aibj", M, Q[k], M)
+        grams = list(pool.map(gram, range(K))) if pool is not None else [gram(k) for k in range(K)]
         for k in range(K):
             rows = rows_of[k]
             if not rows:
                 continue
-            M = Erow[rows]                                         # [r,6,HW]
-            G = np.einsum("aip,p,bjp->aibj", M, Q[k], M)
+            G = grams[k]
             pk = jj_exp[rows] - t0
             for a in range(len(rows)):
                 for b_ in range(len(rows)):
@@ -230,6 +255,8 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj,
             disps[...] = dflat.reshape(disps.shape)
         info = dict(ok=ok, H=Hsys, b=bsys, C=C, w=w, kx=kx, A=A, S=S, bA=bA, bS=bS,
                     Hs=Hs, vs=vs, Erow=Erow, Q=Q, ii_exp=ii_exp, jj_exp=jj_exp, kk_exp=kk_exp) if return_system else dict(ok=ok)
+    if pool is not None:
+        pool.shutdown()
     if return_system:
         return dx, dz, info
     return dx, dz

@@ -119,6 +119,28 @@ def corr_block_lookup(pyramid, coords, radius=3):
     return np.concatenate(outs, axis=1)
 
 
+def corr_block_lookup_torch(pyramid, coords, radius=3):
+    """The same lookup through torch's multi-threaded grid_sample (the kernel is equivalent to
+    F.grid_sample(align_corners=True, padding_mode="zeros") on each pixel's own slice): the
+    multi-core form used by bench.py's cpu_baseline.  pyramid: list of torch tensors [E,h,w,h2,w2]; coords [E,h,w,2]."""
+    import torch
+    import torch.nn.functional as F
+    E, h, w, _ = coords.shape
+    r = radius
+    dd = torch.arange(-r, r + 1, dtype=torch.float32)
+    outs = []
+    for l, vol in enumerate(pyramid):
+        h2, w2 = vol.shape[-2:]
+        c = coords.reshape(E * h * w, 1, 1, 2) / float(2 ** l)
+        gx = c[..., 0] + dd.view(1, -1, 1)                     # [N, a (x offset), 1]
+        gy = c[..., 1] + dd.view(1, 1, -1)                     # [N, 1, b (y offset)]
+        gx, gy = torch.broadcast_tensors(gx, gy)               # [N, a, b]
+        grid = torch.stack([2 * gx / max(w2 - 1, 1) - 1, 2 * gy / max(h2 - 1, 1) - 1], -1)
+        o = F.grid_sample(vol.reshape(E * h * w, 1, h2, w2).float(), grid, mode="bilinear", padding_mode="zeros", align_corners=True)
+        outs.append(o.view(E, h, w, (2 * r + 1) ** 2).permute(0, 3, 1, 2))    # channel = a*7 + b
+    return torch.cat(outs, 1)
+
+
 def altcorr_forward(fmap1, fmap2, coords, ii, jj, radius):
     """fmap1 [B,N,C,H,W], fmap2 [B,N,C,H2,W2], coords [B,M,2,H,W] -> [B,M,2r+1,2r+1,H,W] (x-offset outer).
 

@@ -22,6 +22,18 @@ for f in sorted(glob.glob("$OUT/*/run_counter_collection.csv")):
             agg[r["Counter_Name"]][0] += 1; agg[r["Counter_Name"]][1] += float(r["Counter_Value"])
     for k, (n, v) in agg.items():
         res.setdefault(tag, {})[k] = v / n
-print(json.dumps(res, indent=1))
-json.dump(res, open("$OUT/summary.json", "w"), indent=1)
+EP = 4096 * 48 * 64
+out = {"note": "rocprofv3 --kernel-trace --pmc <one group per pass> -- python scripts/bench_lookup.py --edges 4096 --flow reproj [--nhwc]; "
+               "per-dispatch averages of pyr_lookup_kernel on one MI355X (scripts/pmc_bench_lookup.sh). hbm_read_bytes = "
+               "TCC_EA0_RDREQ_128B*128 (+64 B for the rest); FETCH_SIZE (KB) reads exactly half of it on gfx950, as MI355X_MICROARCH.md "
+               "says; hbm_write_bytes = TCC_EA0_WRREQ_64B*64 = WRITE_SIZE*1024.",
+       "edge_pixels": EP, "algorithmic_bytes_per_edge_pixel": 880}
+for tag, c in res.items():
+    rd = c.get("TCC_EA0_RDREQ_128B_sum", 0) * 128 + (c.get("TCC_EA0_RDREQ_sum", 0) - c.get("TCC_EA0_RDREQ_128B_sum", 0)) * 64
+    wr = c.get("TCC_EA0_WRREQ_64B_sum", 0) * 64
+    out[tag] = {"counters": c, "hbm_read_bytes": rd, "hbm_write_bytes": wr, "hbm_bytes": rd + wr,
+                "hbm_bytes_per_edge_pixel": (rd + wr) / EP,
+                "fetch_size_x2_plus_write_size_bytes": (2 * c.get("FETCH_SIZE", 0) + c.get("WRITE_SIZE", 0)) * 1024}
+print(json.dumps({k: (v if not isinstance(v, dict) else {a: b for a, b in v.items() if a != "counters"}) for k, v in out.items() if k != "note"}, indent=1))
+json.dump(out, open("$OUT/lookup_pmc.json", "w"), indent=1)
 PY

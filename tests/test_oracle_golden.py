@@ -170,3 +170,23 @@ def test_update_autocast_oracle_equals_reference_module(golden_dir):
     for name, t in zip(("net1", "delta", "weight", "eta", "upmask"), out):
         ref = G[name].astype(np.float32)
         assert np.abs(t.float().numpy() - ref).max() <= 2.0 ** -11 * max(1e-6, np.abs(ref).max()), name
+
+
+def test_threaded_forms_of_the_oracle_equal_the_plain_ones():
+    """bench.py's multi-core cpu_baseline uses oracle.ba(threads=..) and corr_block_lookup_torch: same numbers"""
+    from droid_amd import synthetic as syn
+    g = syn.small_graph(n_frames=6, seed=21, ht=12, wd=16)
+    outs = []
+    for kw in (dict(), dict(chunk=5), dict(threads=3)):
+        p = g["poses"].astype(np.float64); d = np.array(g["disps"], dtype=np.float64, order="C")
+        dx, dz = oba.ba(p, d, g["intrinsics"], g["disps_sens"], g["targets"], g["weights"], g["eta"], g["ii"], g["jj"], 1, 6, 2, 1e-4, 0.1, False, **kw)
+        outs.append((p, d, dx, dz))
+    for o in outs[1:]:
+        assert all(np.array_equal(a, b) for a, b in zip(outs[0], o))
+    rng = np.random.default_rng(2)
+    f1 = rng.standard_normal((2, 16, 8, 8)).astype(np.float32); f2 = rng.standard_normal((2, 16, 8, 8)).astype(np.float32)
+    pyr = ocorr.corr_pyramid(f1, f2, 3)
+    coords = np.stack([rng.uniform(-3, 10, (2, 8, 8)), rng.uniform(-3, 10, (2, 8, 8))], -1).astype(np.float32)
+    a = ocorr.corr_block_lookup(pyr, coords, 3)
+    b = ocorr.corr_block_lookup_torch([torch.as_tensor(v, dtype=torch.float32) for v in pyr], torch.as_tensor(coords), 3).numpy()
+    assert np.abs(a - b).max() < 1e-4 * np.abs(a).max()
