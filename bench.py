@@ -241,6 +241,7 @@ def main():
     solver = DistBA(world) if world > 1 else None
     if solver is not None:
         solver.set_owned_frames(bounds[rank], bounds[rank + 1])
+        solver.set_graph(ii_all, jj_all, 1, N)              # all-reduce of the co-visible 6x6 blocks only (~6 MB instead of 77 MB)
     uniq_ii = torch.unique(ii)
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
@@ -303,6 +304,13 @@ def main():
     up = float(np.mean([a.elapsed_time(b) for a, b in up_ms])) if up_ms else 0.0
     ba = float(np.mean([a.elapsed_time(b) for a, b in ba_ms])) if ba_ms else 0.0
 
+    dist_info = None
+    if world > 1:                                               # auditable record of the process group behind a multi-GPU line
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {"rank": rank, "device": torch.cuda.get_device_name(local), "local_rank": local,
+                                          "edges": int(E), "frames": [int(bounds[rank]), int(min(bounds[rank + 1], N))]})
+        dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": per_rank,
+                     "allreduce_bytes_per_gn_iteration": int(solver.last_exchange_bytes)}
     if rank == 0:
         ms = 1000.0 * elapsed / max(1, args.steps)
         ep_total = E_all * HW
@@ -337,6 +345,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch_group": lookup_bytes},
         }
+        if dist_info is not None:
+            out["dist"] = dist_info
         if upd is not None and up > 0:
             # secondary roofline (the contract's `roofline` object stays the HBM-bound lookup named by north_star): the
             # update operator is where the step time goes; algorithmic flops of this rank's convolutions (edge-level ones

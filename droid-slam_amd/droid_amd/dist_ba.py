@@ -8,7 +8,9 @@ depths of its frames; poses are replicated (28 B per frame).
 
 Per Gauss-Newton iteration:
     build    every rank reduces ITS edges to a partial reduced camera system  (droid_backends.ba_build)
-    exchange ONE all-reduce (sum, fp64) of [A - S | v - b_S] over RCCL/xGMI   (torch.distributed)
+    exchange ONE all-reduce (sum, fp64) of [A - S | v - b_S] over RCCL/xGMI   (torch.distributed) -- of its NON-ZERO
+             6x6 blocks only: after `set_graph` the co-visible lower-triangular blocks + the rhs are packed into one
+             contiguous buffer (512 keyframes / 4096 edges: 6 MB instead of the dense 77 MB; xGMI rings are per-link bound)
     finish   every rank damps + solves redundantly (no broadcast), back-substitutes the depths of its own
              frames and retracts the replicated poses                         (droid_backends.ba_finish)
 At the end the owned depth maps are exchanged with one all-reduce of the depth increments so that every
@@ -58,6 +60,35 @@ def local_eta_rows(ii_all, ii_local, t0, t1):
     return np.searchsorted(kx_g, kx_l), kx_l
 
 
+def reduced_system_pattern(ii_all, jj_all, t0, t1):
+    """Block pairs (p >= q) of the reduced camera system that any rank can touch: for every source frame k the clique
+    over {k} U {j : (k, j) is an edge}, restricted to the free poses [t0, t1) -- the pose blocks of k's edges
+    (src/droid_kernels.cu:1385-1389) and the Schur blocks of depth block k (:1253-1281).  Depends only on the global
+    edge list, so every rank computes the same pattern.  Returns int64 arrays (p, q)."""
+    ii_all = np.asarray(ii_all); jj_all = np.asarray(jj_all)
+    P = t1 - t0
+    order = np.argsort(ii_all, kind="stable")
+    pairs = set()
+    s = 0
+    E = len(ii_all)
+    while s < E:
+        k = ii_all[order[s]]
+        e = s
+        while e < E and ii_all[order[e]] == k:
+            e += 1
+        members = np.unique(np.concatenate([[k], jj_all[order[s:e]]])) - t0
+        members = members[(members >= 0) & (members < P)]
+        for a in members:
+            for b in members:
+                if a >= b:
+                    pairs.add((int(a), int(b)))
+        s = e
+    for p in range(P):
+        pairs.add((p, p))                                   # damping touches every diagonal block
+    pq = np.array(sorted(pairs), dtype=np.int64).reshape(-1, 2)
+    return pq[:, 0], pq[:, 1]
+
+
 class DistBA:
     """ba() with the droid_backends.ba contract, applied to this rank's edge shard."""
 
@@ -68,6 +99,25 @@ class DistBA:
         if backend is None:
             import droid_backends as backend          # HIP path; fails loudly without the extension
         self.be = backend
+        self._pattern = None            # (t0, t1, p, q) after set_graph
+        self._flat = None
+        self.last_exchange_bytes = 0
+
+    def set_graph(self, ii_all, jj_all, t0, t1):
+        """global edge list -> the all-reduce moves only the co-visible blocks (see reduced_system_pattern).  Without it
+        the whole dense system is reduced."""
+        p, q = reduced_system_pattern(ii_all, jj_all, t0, t1)
+        self._pattern = (int(t0), int(t1), p, q)
+        self._flat = None
+
+    def _flat_index(self, system, t0, t1):
+        ld = system.shape[1]
+        if self._flat is None or self._flat[0] != (ld, system.device):
+            _, _, p, q = self._pattern
+            r = np.arange(6)
+            off = ((6 * p[:, None, None] + r[None, :, None]) * ld + 6 * q[:, None, None] + r[None, None, :]).reshape(-1)
+            self._flat = ((ld, system.device), torch.as_tensor(off, dtype=torch.long, device=system.device))
+        return self._flat[1]
 
     def set_owned_frames(self, lo, hi):
         self.frame_lo, self.frame_hi = int(lo), int(hi)
@@ -86,7 +136,20 @@ class DistBA:
             before = disps.clone() if not motion_only else None
             ws, system = self.be.ba_build(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj,
                                           t0, t1, motion_only)
-            self._allreduce(system)
+            if self.world > 1 and self._pattern is not None and self._pattern[:2] == (int(t0), int(t1)):
+                # packed exchange: lower-triangular 6x6 blocks + rhs row (the factorisation reads the lower triangle only)
+                n = 6 * (t1 - t0)
+                idx = self._flat_index(system, t0, t1)
+                flat = system.view(-1)
+                rhs_row = system.shape[1]                                    # the rhs is row npad of [npad + NB, npad]
+                buf = torch.cat([flat[idx], system[rhs_row, :n]])
+                self._allreduce(buf)
+                flat[idx] = buf[:idx.numel()]
+                system[rhs_row, :n] = buf[idx.numel():]
+                self.last_exchange_bytes = buf.numel() * buf.element_size()
+            else:
+                self._allreduce(system)
+                self.last_exchange_bytes = system.numel() * system.element_size()
             dx, dz = self.be.ba_finish(poses, disps, jj, ws, eta.shape[0], t0, t1, lm, ep, motion_only)
             if not motion_only:
                 # only the owner of a frame updates its depth map

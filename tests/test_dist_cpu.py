@@ -54,7 +54,7 @@ class OracleBackend:
         return torch.from_numpy(dx), torch.from_numpy(dz)
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, packed=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -69,10 +69,12 @@ def _worker(rank, world, port, out):
         poses, disps = T(g["poses"]), T(g["disps"])
         solver = DistBA(world, backend=OracleBackend())
         solver.set_owned_frames(bounds[rank], bounds[rank + 1])
+        if packed:
+            solver.set_graph(g["ii"], g["jj"], t0, t1)          # all-reduce of the co-visible 6x6 blocks only
         solver.ba(poses, disps, T(g["intrinsics"]), T(g["disps_sens"]), T(g["targets"][mine]), T(g["weights"][mine]),
                   T(g["eta"][rows]), T(g["ii"][mine], torch.int64), T(g["jj"][mine], torch.int64), t0, t1, 2, 1e-4, 0.1)
         if rank == 0:
-            np.savez(out, poses=poses.numpy(), disps=disps.numpy())
+            np.savez(out, poses=poses.numpy(), disps=disps.numpy(), exchange_bytes=solver.last_exchange_bytes)
         # every rank ends with the same state
         chk = torch.cat([poses.flatten(), disps.flatten()])
         ref = chk.clone(); dist.broadcast(ref, 0)
@@ -81,13 +83,16 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_sharded_ba_two_ranks_gloo(tmp_path):
+@pytest.mark.parametrize("packed", [False, True])
+def test_sharded_ba_two_ranks_gloo(tmp_path, packed):
     from droid_amd import synthetic as syn
     from oracle import ba as oba
     out = str(tmp_path / "rank0.npz")
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    port = 29500 + (os.getpid() % 2000) + (7 if packed else 0)
+    mp.spawn(_worker, args=(2, port, out, packed), nprocs=2, join=True)
     got = np.load(out)
+    n = 6 * 6
+    assert int(got["exchange_bytes"]) == ((n + 1) * n * 8 if not packed else int(got["exchange_bytes"])) and (not packed or int(got["exchange_bytes"]) < (n + 1) * n * 8)
     g = syn.small_graph(n_frames=7, seed=11, ht=8, wd=12, radius=3)
     p = g["poses"].astype(np.float64).copy(); d = g["disps"].astype(np.float64).copy()
     oba.ba(p, d, g["intrinsics"], g["disps_sens"], g["targets"], g["weights"], g["eta"], g["ii"], g["jj"],
@@ -109,3 +114,22 @@ def test_partition_covers_every_edge_once_and_keeps_source_frames_together():
             for f in np.unique(ii[s]):
                 assert owners.setdefault(int(f), r) == r
                 assert bounds[r] <= f < bounds[r + 1]
+
+
+def test_reduced_system_pattern_covers_the_nonzero_blocks():
+    """every 6x6 block of the oracle's reduced camera system that is not identically zero lies in the pattern"""
+    from droid_amd import synthetic as syn
+    from droid_amd.dist_ba import reduced_system_pattern
+    from oracle import ba as oba
+    g = syn.small_graph(n_frames=9, seed=3, ht=8, wd=12, radius=2)
+    t0, t1 = 2, 9
+    p = g["poses"].astype(np.float64); d = np.array(g["disps"], dtype=np.float64, order="C")
+    kx = np.unique(np.concatenate([np.arange(t0, t1), g["ii"]]))
+    eta = np.full((len(kx),) + g["disps"].shape[1:], 1e-4, dtype=np.float32)
+    _, _, info = oba.ba(p, d, g["intrinsics"], g["disps_sens"], g["targets"], g["weights"], eta, g["ii"], g["jj"], t0, t1, 1, 1e-4, 0.1, False, return_system=True)
+    P = t1 - t0
+    nz = np.abs(info["H"].reshape(P, 6, P, 6)).max(axis=(1, 3)) > 0
+    pp, qq = reduced_system_pattern(g["ii"], g["jj"], t0, t1)
+    pat = np.zeros((P, P), bool); pat[pp, qq] = True
+    assert np.all(pp >= qq) and not np.any(np.tril(nz) & ~pat)
+    assert pat.sum() < P * (P + 1) // 2                       # and it is sparse: not every pair is co-visible
