@@ -197,7 +197,7 @@ template <bool MOTION_ONLY>
 __global__ __launch_bounds__(256) void ba_build_kernel(
     const float* __restrict__ poses, const float* __restrict__ disps, const float* __restrict__ intr,
     const float* __restrict__ disps_sens, const float* __restrict__ targets, const float* __restrict__ weights,
-    const float* __restrict__ eta, int n_eta_rows, const int64_t* __restrict__ jj,
+    const float* __restrict__ eta, int n_eta_rows, const float* __restrict__ alpha, const int64_t* __restrict__ jj,
     const int* __restrict__ kx, const int* __restrict__ eoff, const int* __restrict__ eidx,
     const int* __restrict__ meta, int HW, int wd, int NS,
     float* __restrict__ Q, float* __restrict__ W, float* __restrict__ Ei, float* __restrict__ Ej,
@@ -292,8 +292,10 @@ __global__ __launch_bounds__(256) void ba_build_kernel(
       const int p = px[q];
       const float ds = disps_sens[(long)f * HW + p];
       const bool m = ds > 0.f;
-      const float C = Cs[q] + (m ? ALPHA_PRIOR : (eta_ok ? eta[(long)k * HW + p] : 1.f));
-      const float w = Ws[q] - (m ? ALPHA_PRIOR * (h[q] - ds) : 0.f);
+      // depth prior: the reference's constant alpha = 0.05 (:1405), or per pixel (dh_ba_ex: confidence of the sensor depth)
+      const float al = alpha ? alpha[(long)f * HW + p] : ALPHA_PRIOR;
+      const float C = Cs[q] + (m ? al : (eta_ok ? eta[(long)k * HW + p] : 1.f));
+      const float w = Ws[q] - (m ? al * (h[q] - ds) : 0.f);
       Q[(long)k * HW + p] = 1.f / C;
       W[(long)k * HW + p] = w;
 #pragma unroll
@@ -1044,7 +1046,7 @@ int run_prep(const BaLayout& L, char* ws, const int64_t* ii, const int64_t* jj, 
 
 int run_build(const BaLayout& L, char* ws, const float* poses, const float* disps, const float* intr,
               const float* disps_sens, const float* targets, const float* weights, const float* eta,
-              int n_eta_rows, const int64_t* ii, const int64_t* jj, int F, int E, int HW, int wd,
+              int n_eta_rows, const float* alpha, const int64_t* ii, const int64_t* jj, int F, int E, int HW, int wd,
               int t0, int motion_only, hipStream_t st) {
   double* H = (double*)(ws + L.H);
   if (hipMemsetAsync(H, 0, sizeof(double) * (size_t)(L.npad + NB) * L.ld, st) != hipSuccess) return DH_ERR_LAUNCH;
@@ -1053,11 +1055,11 @@ int run_build(const BaLayout& L, char* ws, const float* poses, const float* disp
   dim3 grid(F, L.NS);
   if (motion_only)
     hipLaunchKernelGGL(ba_build_kernel<true>, grid, dim3(256), 0, st, poses, disps, intr, disps_sens, targets,
-                       weights, eta, n_eta_rows, jj, kx, eoff, eidx, meta, HW, wd, L.NS,
+                       weights, eta, n_eta_rows, alpha, jj, kx, eoff, eidx, meta, HW, wd, L.NS,
                        (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)(ws + L.Hpart));
   else
     hipLaunchKernelGGL(ba_build_kernel<false>, grid, dim3(256), 0, st, poses, disps, intr, disps_sens, targets,
-                       weights, eta, n_eta_rows, jj, kx, eoff, eidx, meta, HW, wd, L.NS,
+                       weights, eta, n_eta_rows, alpha, jj, kx, eoff, eidx, meta, HW, wd, L.NS,
                        (float*)(ws + L.Q), (float*)(ws + L.W), (float*)(ws + L.Ei), (float*)(ws + L.Ej),
                        (float*)(ws + L.Hpart));
   DH_LAUNCH_CHECK();
@@ -1172,7 +1174,7 @@ extern "C" int dh_ba_build(const float* poses, const float* disps, const float* 
   hipStream_t st = (hipStream_t)stream;
   rc = run_prep(L, ws, ii, jj, n_edges, num_frames, t0, t1, motion_only ? -1 : n_eta_rows, st);
   if (rc != DH_OK) return rc;
-  rc = run_build(L, ws, poses, disps, intrinsics, disps_sens, targets, weights, eta, n_eta_rows, ii, jj,
+  rc = run_build(L, ws, poses, disps, intrinsics, disps_sens, targets, weights, eta, n_eta_rows, nullptr, ii, jj,
                  num_frames, n_edges, ht * wd, wd, t0, motion_only, st);
   if (Hsys_out) *Hsys_out = (double*)(ws + L.H);
   if (bsys_out) *bsys_out = (double*)(ws + L.H) + (size_t)L.npad * L.ld;
@@ -1193,12 +1195,12 @@ extern "C" int dh_ba_finish(float* poses, float* disps, const int64_t* jj,
                     dx_out, dz_out, num_frames, (hipStream_t)stream);
 }
 
-extern "C" int dh_ba(float* poses, float* disps, const float* intrinsics, const float* disps_sens,
-                     const float* targets, const float* weights, const float* eta,
-                     const int64_t* ii, const int64_t* jj,
-                     int num_frames, int n_edges, int n_eta_rows, int ht, int wd,
-                     int t0, int t1, int iterations, float lm, float ep, int motion_only,
-                     float* dx_out, float* dz_out, void* workspace, size_t workspace_bytes, dh_stream_t stream) {
+extern "C" int dh_ba_ex(float* poses, float* disps, const float* intrinsics, const float* disps_sens, const float* alpha,
+                        const float* targets, const float* weights, const float* eta,
+                        const int64_t* ii, const int64_t* jj,
+                        int num_frames, int n_edges, int n_eta_rows, int ht, int wd,
+                        int t0, int t1, int iterations, float lm, float ep, int motion_only,
+                        float* dx_out, float* dz_out, void* workspace, size_t workspace_bytes, dh_stream_t stream) {
   int rc = check_args(num_frames, n_edges, ht, wd, t0, t1);
   if (rc != DH_OK) return rc;
   if (iterations < 0) return DH_ERR_ARG;
@@ -1213,7 +1215,7 @@ extern "C" int dh_ba(float* poses, float* disps, const float* intrinsics, const 
   rc = run_prep(L, ws, ii, jj, n_edges, num_frames, t0, t1, motion_only ? -1 : n_eta_rows, st);
   if (rc != DH_OK) return rc;
   for (int it = 0; it < iterations; ++it) {
-    rc = run_build(L, ws, poses, disps, intrinsics, disps_sens, targets, weights, eta, n_eta_rows, ii, jj,
+    rc = run_build(L, ws, poses, disps, intrinsics, disps_sens, targets, weights, eta, n_eta_rows, alpha, ii, jj,
                    num_frames, n_edges, HW, wd, t0, motion_only, st);
     if (rc != DH_OK) return rc;
     const bool last = it == iterations - 1;
@@ -1228,4 +1230,14 @@ extern "C" int dh_ba(float* poses, float* disps, const float* intrinsics, const 
     if (flags[2]) return DH_ERR_ARG;
   }
   return DH_OK;
+}
+
+extern "C" int dh_ba(float* poses, float* disps, const float* intrinsics, const float* disps_sens,
+                     const float* targets, const float* weights, const float* eta,
+                     const int64_t* ii, const int64_t* jj,
+                     int num_frames, int n_edges, int n_eta_rows, int ht, int wd,
+                     int t0, int t1, int iterations, float lm, float ep, int motion_only,
+                     float* dx_out, float* dz_out, void* workspace, size_t workspace_bytes, dh_stream_t stream) {
+  return dh_ba_ex(poses, disps, intrinsics, disps_sens, nullptr, targets, weights, eta, ii, jj, num_frames, n_edges, n_eta_rows, ht, wd,
+                  t0, t1, iterations, lm, ep, motion_only, dx_out, dz_out, workspace, workspace_bytes, stream);
 }

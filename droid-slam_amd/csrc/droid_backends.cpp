@@ -37,10 +37,10 @@ int dtype_code(const torch::Tensor& t, const char* name) {
 }
 
 // ---- ba (droid.cpp:93-122) --------------------------------------------------------------------
-std::vector<torch::Tensor> ba(torch::Tensor poses, torch::Tensor disps, torch::Tensor intrinsics,
-                              torch::Tensor disps_sens, torch::Tensor targets, torch::Tensor weights,
-                              torch::Tensor eta, torch::Tensor ii, torch::Tensor jj, const int t0, const int t1,
-                              const int iterations, const float lm, const float ep, const bool motion_only) {
+std::vector<torch::Tensor> ba_impl(torch::Tensor poses, torch::Tensor disps, torch::Tensor intrinsics,
+                                   torch::Tensor disps_sens, c10::optional<torch::Tensor> alpha, torch::Tensor targets,
+                                   torch::Tensor weights, torch::Tensor eta, torch::Tensor ii, torch::Tensor jj, const int t0,
+                                   const int t1, const int iterations, const float lm, const float ep, const bool motion_only) {
   CHECK_INPUT(targets); CHECK_INPUT(weights); CHECK_INPUT(poses); CHECK_INPUT(disps);
   CHECK_INPUT(intrinsics); CHECK_INPUT(disps_sens); CHECK_INPUT(ii); CHECK_INPUT(jj);
   CHECK_DEVICE(eta);
@@ -60,14 +60,37 @@ std::vector<torch::Tensor> ba(torch::Tensor poses, torch::Tensor disps, torch::T
   const size_t wsb = dh_ba_workspace_bytes(F, E, ht, wd, t0, t1, motion_only ? 1 : 0);
   TORCH_CHECK(wsb > 0, "ba: invalid arguments (t0/t1/buffer sizes)");
   torch::Tensor ws = torch::empty({(int64_t)wsb}, poses.options().dtype(torch::kUInt8));
-  const int rc = dh_ba(poses.data_ptr<float>(), disps.data_ptr<float>(), intrinsics.data_ptr<float>(),
-                       disps_sens.data_ptr<float>(), targets.data_ptr<float>(), weights.data_ptr<float>(),
+  const float* al = nullptr;
+  if (alpha.has_value()) {
+    const torch::Tensor& a = *alpha;
+    CHECK_INPUT(a); CHECK_F32(a);
+    TORCH_CHECK(a.numel() == disps.numel(), "ba_ex: alpha must have the shape of disps");
+    al = a.data_ptr<float>();
+  }
+  const int rc = dh_ba_ex(poses.data_ptr<float>(), disps.data_ptr<float>(), intrinsics.data_ptr<float>(),
+                       disps_sens.data_ptr<float>(), al, targets.data_ptr<float>(), weights.data_ptr<float>(),
                        eta.data_ptr<float>(), ii.data_ptr<int64_t>(), jj.data_ptr<int64_t>(),
                        F, E, K, ht, wd, t0, t1, iterations, lm, ep, motion_only ? 1 : 0,
                        dx.data_ptr<float>(), motion_only ? nullptr : dz.data_ptr<float>(),
                        ws.data_ptr(), wsb, cur_stream());
   check_status(rc, "ba");
   return {dx, dz};
+}
+
+
+std::vector<torch::Tensor> ba(torch::Tensor poses, torch::Tensor disps, torch::Tensor intrinsics,
+                              torch::Tensor disps_sens, torch::Tensor targets, torch::Tensor weights,
+                              torch::Tensor eta, torch::Tensor ii, torch::Tensor jj, const int t0, const int t1,
+                              const int iterations, const float lm, const float ep, const bool motion_only) {
+  return ba_impl(poses, disps, intrinsics, disps_sens, c10::nullopt, targets, weights, eta, ii, jj, t0, t1, iterations, lm, ep, motion_only);
+}
+
+// ba with a per-pixel depth-prior weight alpha [buf,ht,wd] (MI355X extension, include/droid_hip.h dh_ba_ex)
+std::vector<torch::Tensor> ba_ex(torch::Tensor poses, torch::Tensor disps, torch::Tensor intrinsics,
+                                 torch::Tensor disps_sens, torch::Tensor alpha, torch::Tensor targets, torch::Tensor weights,
+                                 torch::Tensor eta, torch::Tensor ii, torch::Tensor jj, const int t0, const int t1,
+                                 const int iterations, const float lm, const float ep, const bool motion_only) {
+  return ba_impl(poses, disps, intrinsics, disps_sens, alpha, targets, weights, eta, ii, jj, t0, t1, iterations, lm, ep, motion_only);
 }
 
 
@@ -469,6 +492,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("corr_index_forward", &corr_index_forward, "INDEX forward");
   m.def("corr_index_backward", &corr_index_backward, "INDEX backward");
   // MI355X extensions (not in the reference module)
+  m.def("ba_ex", &ba_ex, "bundle adjustment with a per-pixel depth-prior weight");
   m.def("ba_build", &ba_build, "per-rank reduced camera system (split BA)");
   m.def("ba_finish", &ba_finish, "damp + solve + back-substitute + retract (split BA)");
   m.def("altcorr_forward_nhwc", &altcorr_forward_nhwc, "on-the-fly correlation on the fp16 MFMA, channel-last features");

@@ -139,6 +139,18 @@ int dh_ba(float* poses, float* disps, const float* intrinsics, const float* disp
  *   Hsys [6P,6P] f64 (row-major, lower+upper), bsys [6P] f64, and keeps per-frame depth terms in the
  *   workspace; dh_ba_finish damps, solves, back-substitutes the depths of the frames this rank owns
  *   and retracts.  dh_ba() == dh_ba_build + dh_ba_finish per iteration. */
+/* dh_ba with a PER-PIXEL weight of the sensor-depth prior (BASELINE.json configs[4], "per-pixel depth-confidence weights";
+ * SURVEY.md Q10b): alpha [num_frames,ht,wd] f32 replaces the reference's constant 0.05 (src/droid_kernels.cu:1405-1408) where
+ * disps_sens > 0:  C = sum Cii + alpha,  w = sum bz - alpha * (disps - disps_sens).  alpha == NULL or alpha == 0.05
+ * everywhere is exactly dh_ba.  The positional signature of the reference's `ba` is fixed (src/droid.cpp:93-108), hence a
+ * new entry point (droid_backends.ba_ex). */
+int dh_ba_ex(float* poses, float* disps, const float* intrinsics, const float* disps_sens, const float* alpha,
+             const float* targets, const float* weights, const float* eta,
+             const int64_t* ii, const int64_t* jj,
+             int num_frames, int n_edges, int n_eta_rows, int ht, int wd,
+             int t0, int t1, int iterations, float lm, float ep, int motion_only,
+             float* dx_out, float* dz_out, void* workspace, size_t workspace_bytes, dh_stream_t stream);
+
 /* shape of the system buffer behind Hsys_out: [rows, cols] f64, row-major; rows [0, 6P) x cols [0, 6P) = Hsys,
  * row `cols` = bsys (the right-hand side travels as an extra block row), everything else padding. */
 int dh_ba_system_shape(int t0, int t1, int* rows, int* cols);

@@ -140,7 +140,7 @@ def solve_damped(H, b, lm, ep):
 
 def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj,
        t0, t1, iterations, lm, ep, motion_only, dtype=np.float64, strict_q6=True,
-       return_system=False, chunk=None, threads=1):
+       return_system=False, chunk=None, threads=1, alpha_map=None):
     """In-place Gauss-Newton on ``poses`` [buf,7] and ``disps`` [buf,ht,wd]  (ba_cuda :1323-1443).
 
     ``eta`` has one row per entry of ``unique(cat(arange(t0,t1), ii))``.
@@ -197,7 +197,8 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj,
         dsens = disps_sens.reshape(disps_sens.shape[0], HW).astype(dtype)[kx]
         dcur = disps.reshape(disps.shape[0], HW).astype(dtype)[kx]
         m = (dsens > 0).astype(dtype)
-        alpha = dtype(ALPHA_DEPTH_PRIOR)
+        # the reference's constant 0.05 (:1405); alpha_map [buf,ht,wd] = the per-pixel extension (dh_ba_ex)
+        alpha = dtype(ALPHA_DEPTH_PRIOR) if alpha_map is None else alpha_map.reshape(alpha_map.shape[0], HW).astype(dtype)[kx]
         C = _segsum(Cii, ii, kx) + m * alpha + (1 - m) * eta.reshape(-1, HW).astype(dtype)
         w = _segsum(bz, ii, kx) - m * alpha * (dcur - dsens)
         Q = dtype(1) / C

@@ -237,3 +237,28 @@ def test_frontend_and_backend_policies_run_on_a_short_sequence(db):
     p2 = video.poses[:t].cpu().numpy()
     assert np.isfinite(p2).all() and np.abs(np.linalg.norm(p2[:, 3:], axis=-1) - 1).max() < 1e-4
     assert abs(float(video.disps[:t].mean()) - 1.0) < 0.5     # normalised to unit mean disparity before the global BA
+
+
+def test_reconstruction_dump_and_point_cloud(db, tmp_path):
+    """demo.py:60-76 dump format (keys, shapes, dtypes, round trip) and the viewers' point-cloud extraction
+    (view_reconstruction.py:15-38): points of a consistent synthetic scene survive the multi-view filter"""
+    from droid_amd.reconstruction import save_reconstruction, load_reconstruction, point_cloud
+    from droid_amd import synthetic as syn
+    S = graph_scenario()
+    N = S["n_frames"]
+    video, upd = _setup(S)
+    g = syn.small_graph(n_frames=N, seed=13, ht=S["ht"], wd=S["wd"])
+    video.poses[:N] = torch.as_tensor(g["poses_gt"]).cuda(); video.disps[:N] = torch.as_tensor(g["disps_gt"]).cuda()
+    video.intrinsics[:N] = torch.as_tensor(g["intrinsics"]).cuda()
+    video.disps_up[:N] = torch.nn.functional.interpolate(video.disps[:N][None], scale_factor=8, mode="nearest")[0]
+    video.images[:N] = torch.randint(0, 255, (N, 3, 8 * S["ht"], 8 * S["wd"]), dtype=torch.uint8, device="cuda")
+    path = str(tmp_path / "rec.pth")
+    save_reconstruction(video, path)
+    blob = load_reconstruction(path)
+    assert set(blob) == {"tstamps", "images", "disps", "poses", "intrinsics"}
+    assert blob["disps"].shape == (N, 8 * S["ht"], 8 * S["wd"]) and blob["images"].dtype == torch.uint8
+    assert torch.equal(blob["poses"], video.poses[:N]) and torch.equal(blob["disps"], video.disps_up[:N])
+    pts, cols, mask = point_cloud(video.poses[:N], video.disps[:N], video.intrinsics[0], video.images[:N, :, 3::8, 3::8],
+                                  filter_thresh=0.05)
+    assert mask.shape == (N, S["ht"], S["wd"]) and pts.shape[1] == 3 and cols.shape == pts.shape
+    assert mask.float().mean() > 0.3 and torch.isfinite(pts).all()

@@ -164,6 +164,38 @@ def test_ba_c5_shape_stereo_sensor_vs_reference(db, ref):
     _per_iteration(db, ref, g, g["eta"], 1, 64, 2, g["lm"], g["ep"])
 
 
+def test_ba_ex_per_pixel_depth_prior(db, ref):
+    """dh_ba_ex (BASELINE configs[4] "per-pixel depth-confidence weights"): with alpha == 0.05 everywhere it
+    IS the reference's ba (vs oracle/_ref); with a per-pixel map it matches the oracle's restatement with that map"""
+    from oracle import ba as oba
+    g = syn.small_graph(n_frames=6, seed=3, ht=12, wd=16, stereo=True, sensor_depth=True)
+    eta = _eta_for(g, 1, 6)
+    want = _ba(ref[0], g, g["poses"], g["disps"], eta, 1, 6, 1, 1e-5, 1e-2, False)
+    p, d = dev(g["poses"]), dev(g["disps"])
+    alpha = torch.full_like(d, 0.05)
+    r = db.ba_ex(p, d, dev(g["intrinsics"]), dev(g["disps_sens"]), alpha, dev(g["targets"]), dev(g["weights"]), dev(eta),
+                 dev(g["ii"]), dev(g["jj"]), 1, 6, 1, 1e-5, 1e-2, False)
+    _check((p.cpu().numpy(), d.cpu().numpy(), r[0].cpu().numpy(), r[1].cpu().numpy()), want)
+    amap = np.random.default_rng(1).uniform(0.0, 0.3, g["disps"].shape).astype(np.float32)
+    p, d = dev(g["poses"]), dev(g["disps"])
+    r = db.ba_ex(p, d, dev(g["intrinsics"]), dev(g["disps_sens"]), dev(amap), dev(g["targets"]), dev(g["weights"]), dev(eta),
+                 dev(g["ii"]), dev(g["jj"]), 1, 6, 1, 1e-5, 1e-2, False)
+    op = g["poses"].astype(np.float64); od = np.array(g["disps"], dtype=np.float64, order="C")
+    odx, odz = oba.ba(op, od, g["intrinsics"], g["disps_sens"], g["targets"], g["weights"], eta, g["ii"], g["jj"], 1, 6, 1, 1e-5, 1e-2,
+                      False, alpha_map=amap)
+    _check((p.cpu().numpy(), d.cpu().numpy(), r[0].cpu().numpy(), r[1].cpu().numpy()), (op, od, odx, odz))
+
+
+def test_ba_config_c5_size_vs_reference(db, ref):
+    """BASELINE configs[4] at full size on ONE GPU: 1024 keyframes / 8192 edges (stereo self-edges + temporal + closures),
+    sensor depth with holes, global-BA damping; one Gauss-Newton iteration against the reference's ba (its host-side
+    Schur pair search and the dense fp64 LLT of the 6138-unknown system take about a minute)"""
+    g = syn.make_graph("C5")
+    got = _ba(db, g, g["poses"], g["disps"], g["eta"], 1, g["n_frames"], 1, g["lm"], g["ep"], False)
+    want = _ba(ref[0], g, g["poses"], g["disps"], g["eta"], 1, g["n_frames"], 1, g["lm"], g["ep"], False)
+    _check(got, want)
+
+
 # ------------------------------------------------------------------------------------------ assembled system
 @pytest.mark.parametrize("cfg", ["small", "small_stereo_sensor", "C1", "C2"])
 def test_reduced_camera_system_vs_reference(db, ref, cfg):
