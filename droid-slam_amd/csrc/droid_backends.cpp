@@ -429,6 +429,24 @@ std::vector<torch::Tensor> proximity_nms(torch::Tensor dist, torch::Tensor edges
   return {out, count};
 }
 
+// ---- encoder glue (droid_amd.encoder) ---------------------------------------------------------------------------------
+torch::Tensor norm_act(torch::Tensor x, c10::optional<torch::Tensor> residual, bool normalize, bool relu) {
+  CHECK_INPUT(x);
+  TORCH_CHECK(x.scalar_type() == torch::kFloat16 && x.dim() == 4, "norm_act: x [N,H,W,C] float16");
+  const int N = (int)x.size(0), HW = (int)(x.size(1) * x.size(2)), C = (int)x.size(3);
+  const void* r = nullptr;
+  if (residual.has_value()) {
+    const torch::Tensor& rt = *residual; CHECK_INPUT(rt);
+    TORCH_CHECK(rt.scalar_type() == torch::kFloat16 && rt.sizes() == x.sizes(), "norm_act: residual must match x");
+    r = rt.data_ptr();
+  }
+  torch::Tensor y = torch::empty_like(x);
+  torch::Tensor ws = torch::empty({normalize ? (int64_t)N * C * 2 : 1}, x.options().dtype(torch::kFloat32));
+  check_status(dh_norm_act_nhwc_f16(x.data_ptr(), r, y.data_ptr(), ws.data_ptr<float>(), N, HW, C, normalize ? 1 : 0, relu ? 1 : 0,
+                                    cur_stream()), "norm_act");
+  return y;
+}
+
 // ---- extensions beyond the reference module (used by droid_amd / lietorch compat) ----------------
 std::vector<torch::Tensor> reproject(torch::Tensor poses, torch::Tensor disps, torch::Tensor intrinsics,
                                      torch::Tensor ii, torch::Tensor jj) {
@@ -508,6 +526,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("ba_inputs", &ba_inputs, "target = coords1 + delta, weight; also in ba's [E,2,h,w] layout");
   m.def("cvx_upsample", &cvx_upsample, "convex 8x upsampling of depth maps");
   m.def("proximity_nms", &proximity_nms, "candidate masking + greedy NMS of add_proximity_factors on the device");
+  m.def("norm_act", &norm_act, "instance norm / residual add + activation on channel-last fp16 (encoders)");
   m.def("reproject", &reproject, "fused reprojection (Python thresholds)");
   m.def("se3_op", &se3_op, "SE3 inv/mul/exp/retr");
   m.def("se3_map", &se3_map, "SE3 act4/adjT");

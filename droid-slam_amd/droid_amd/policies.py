@@ -129,6 +129,55 @@ class DroidBackend:
         return graph
 
 
+class MotionFilter:
+    """keyframe selection (motion_filter.py:20-91): encode every incoming frame, estimate the flow to the last keyframe
+    with ONE update iteration (no BA) on a single self-built correlation volume, append the frame to the video if the mean
+    flow magnitude exceeds `thresh`."""
+
+    def __init__(self, nets, update_op, video, thresh=2.5):
+        self.nets, self.update, self.video, self.thresh = nets, update_op, video, thresh
+        self.count = 0
+        self.last_delta = float("nan")
+
+    @torch.no_grad()
+    def track(self, tstamp, image, depth=None, intrinsics=None):
+        """image [1,3,H,W] uint8 BGR (one camera) or [2,3,H,W] (stereo pair)"""
+        from .corr import CorrBlock, CorrBlockRef
+        v = self.video
+        dev = v.device
+        ht, wd = image.shape[-2] // 8, image.shape[-1] // 8
+        image = image.to(dev)
+        x = image[None]
+        from .encoder import normalize_images
+        xn = normalize_images(x)
+        gmap = self.nets.fnet(xn)[0]                                          # [rig,128,h,w]
+        Id = torch.tensor([0, 0, 0, 0, 0, 0, 1.0], device=dev)
+        intr8 = None if intrinsics is None else intrinsics.to(dev) / 8.0
+
+        def context():
+            net, inp = self.nets.cnet(xn[:, [0]])[0].split([128, 128], dim=1)
+            return torch.tanh(net.float()).half(), torch.relu(inp)
+        if v.counter.value == 0:
+            self.net, self.inp = context()
+            self.fmap = gmap
+            v.append(tstamp, image[0], Id, 1.0, depth, intr8, gmap, self.net[0], self.inp[0])
+            return
+        yy, xx = torch.meshgrid(torch.arange(ht, device=dev, dtype=torch.float32), torch.arange(wd, device=dev, dtype=torch.float32), indexing="ij")
+        coords0 = torch.stack([xx, yy], -1)[None, None]
+        f1, f2 = self.fmap[None, [0]], gmap[None, [0]]
+        blk = CorrBlock(f1, f2) if CorrBlock.supported(ht, wd) else CorrBlockRef(f1, f2)
+        corr = blk(coords0)
+        _, delta, weight = self.update(self.net[None], self.inp[None], corr)[:3]
+        self.last_delta = delta.norm(dim=-1).mean().item()
+        if self.last_delta > self.thresh:
+            self.count = 0
+            self.net, self.inp = context()
+            self.fmap = gmap
+            v.append(tstamp, image[0], None, None, depth, intr8, gmap, self.net[0], self.inp[0])
+        else:
+            self.count += 1
+
+
 @torch.no_grad()
 def fill_poses(update_op, video, tstamps, fmaps, intrinsics=None, iters=6):
     """Poses of M non-keyframes from their feature maps (trajectory_filler.py:42-84 without the image encoder): linear

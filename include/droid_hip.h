@@ -166,6 +166,15 @@ int dh_ba_finish(float* poses, float* disps, const int64_t* jj,
                  void* workspace, size_t workspace_bytes, dh_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Encoder glue (csrc/norm.hip): the normalisation / residual steps of the feature and context encoders
+ * (reference droid_slam/modules/extractor.py:6-50,120-198), whose convolutions go through dh_conv2d_nhwc_f16.
+ *   y = act( instance_norm(x) )   (normalize = 1: per image and channel over the H*W pixels, eps 1e-5, fp32 statistics)
+ *   y = act( x + residual )       (normalize = 0; residual may be NULL: plain activation)
+ * x, residual, y [N,H,W,C] f16 channel-last, C % 8 == 0; stats_ws [N*C*2] f32 scratch; relu = 0 / 1. */
+int dh_norm_act_nhwc_f16(const void* x, const void* residual, void* y, float* stats_ws, int N, int HW, int C,
+                         int normalize, int relu, dh_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Factor-graph side kernels (csrc/graph.hip): the glue of FactorGraph.update / add_proximity_factors and
  * DepthVideo.upsample (reference droid_slam/factor_graph.py:214-263,346-412, depth_video.py:155-159, droid_net.py:21-35).
  *   dh_motion_features: coords1, target [E,ht,wd,2] f32 -> flow [E,ht,wd,8] f16 =

@@ -169,7 +169,28 @@ def golden_update_autocast():
         tuple(net1.shape), net1.dtype, tuple(delta.shape), tuple(eta.shape), tuple(upmask.shape)))
 
 
+def golden_encoder():
+    """The reference's BasicEncoder (modules/extractor.py) as DroidNet instantiates it (droid_net.py:149-150), under fp16
+    autocast like MotionFilter runs it (motion_filter.py:38-49), on two seeded 64x128 images."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from golden_inputs import encoder_inputs
+    from modules.extractor import BasicEncoder
+    out = {}
+    x = encoder_inputs()
+    for tag, dim, norm in (("fnet", 128, "instance"), ("cnet", 256, "none")):
+        torch.manual_seed(0)
+        m = BasicEncoder(output_dim=dim, norm_fn=norm)
+        fill_deterministic(m, seed=4321 if tag == "fnet" else 8765)
+        m.eval()
+        with torch.no_grad(), torch.autocast("cpu", dtype=torch.float16):
+            y = m(x[None])
+        assert y.dtype == torch.float16
+        out[tag] = y[0].numpy()
+    np.savez_compressed(os.path.join(HERE, "encoder_python.npz"), **out)
+    print("encoder_python:", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ba", "corr", "update", "update_autocast"]
+    which = sys.argv[1:] or ["ba", "corr", "update", "update_autocast", "encoder"]
     for w in which:
         globals()["golden_" + w]()

@@ -40,3 +40,12 @@ def graph_scenario(n_frames=6):
                 nets=np.tanh(rng.standard_normal((N, 128, ht, wd))).astype(np.float16),
                 inps=np.maximum(rng.standard_normal((N, 128, ht, wd)), 0).astype(np.float16),
                 prox_rad=1, prox_nms=1, prox_thresh=1e3, prox_beta=0.25)
+
+
+def encoder_inputs():
+    """two normalised 64 x 128 images [2,3,64,128] float32 (seeded)"""
+    rng = np.random.default_rng(123)
+    img = rng.integers(0, 256, (2, 3, 64, 128)).astype(np.float32) / 255.0
+    mean = np.array([0.485, 0.456, 0.406], dtype=np.float32)[:, None, None]
+    std = np.array([0.229, 0.224, 0.225], dtype=np.float32)[:, None, None]
+    return torch.as_tensor((img - mean) / std)

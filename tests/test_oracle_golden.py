@@ -190,3 +190,23 @@ def test_threaded_forms_of_the_oracle_equal_the_plain_ones():
     a = ocorr.corr_block_lookup(pyr, coords, 3)
     b = ocorr.corr_block_lookup_torch([torch.as_tensor(v, dtype=torch.float32) for v in pyr], torch.as_tensor(coords), 3).numpy()
     assert np.abs(a - b).max() < 1e-4 * np.abs(a).max()
+
+
+def test_encoder_oracle_equals_reference_module(golden_dir):
+    """oracle.encoder.basic_encoder(autocast=True) == the reference's BasicEncoder under autocast (fnet 'instance', cnet 'none')"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from golden_inputs import encoder_inputs
+    from oracle import encoder as oenc
+    from droid_amd.encoder import empty_state_dict
+    G = _load(golden_dir, "encoder_python.npz")
+    x = encoder_inputs()
+    for tag, dim, inst, seed in (("fnet", 128, True, 4321), ("cnet", 256, False, 8765)):
+        class _SD:
+            def state_dict(self):
+                return empty_state_dict(dim)
+        sd = deterministic_state_dict(_SD(), seed=seed)
+        with torch.no_grad():
+            y = oenc.basic_encoder(sd, x, inst, autocast=True)
+        ref = G[tag].astype(np.float32)
+        assert np.abs(y.float().numpy() - ref).max() <= 2.0 ** -10 * np.abs(ref).max(), tag
