@@ -346,7 +346,9 @@ void conv2d_nhwc(std::vector<torch::Tensor> inputs, torch::Tensor weight, c10::o
     TORCH_CHECK(t.is_cuda() && t.scalar_type() == torch::kFloat16 && t.dim() == 4, "conv2d_nhwc: inputs [N,H,W,C] float16 device tensors");
     TORCH_CHECK(t.size(0) == N && t.size(1) == H && t.size(2) == W, "conv2d_nhwc: input shapes differ");
     // dense NHWC or a channel slice of one: stride(3) == 1, pixels equally spaced
-    TORCH_CHECK(t.stride(3) == 1 && t.stride(1) == t.stride(2) * W && t.stride(0) == t.stride(1) * H, "conv2d_nhwc: input must be NHWC (channel slices allowed)");
+    // (the stride of a size-1 dimension is arbitrary in torch: only dimensions that are actually stepped through count)
+    TORCH_CHECK(t.stride(3) == 1 && (H == 1 || t.stride(1) == t.stride(2) * W) && (N == 1 || t.stride(0) == t.stride(2) * W * H),
+                "conv2d_nhwc: input must be NHWC (channel slices allowed)");
     ptrs[i] = t.data_ptr(); chans[i] = (int)t.size(3); strides[i] = (int)t.stride(2);
   }
   CHECK_INPUT(weight); CHECK_INPUT(bias); CHECK_F32(bias);
