@@ -43,7 +43,7 @@ constexpr int LDT = BK + 8;        // LDS row stride (halves)
 constexpr int MAXSEG = 4;
 
 enum Epi { EPI_LINEAR = 0, EPI_RELU = 1, EPI_SIGMOID = 2, EPI_GRU_ZR = 3, EPI_GRU_Q = 4, EPI_GLO = 5,
-           EPI_SOFTPLUS_001 = 6, EPI_HEADS = 7 };
+           EPI_SOFTPLUS_001 = 6, EPI_HEADS = 7, EPI_HEADS0 = 8 };
 
 struct ConvParams {
   const __half* in[MAXSEG]; int segC[MAXSEG]; int segS[MAXSEG]; int nseg; int Ctot;   // segS = pixel stride (elements)
@@ -185,6 +185,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& P, f32x16 (&acc)
 template <int EPI>
 inline bool staged_epilogue_ok(const ConvParams& P) {
   if (!opts().conv_epi_staged) return false;                // 0: per-element epilogue everywhere (A/B runs)
+  if (EPI == EPI_HEADS0) return P.aux1 && P.red && P.Cout == P.CoutPad && P.CoutPad % 128 == 0 && ((uintptr_t)P.aux1) % 16 == 0;
   if (EPI == EPI_GLO) return P.Cout % 8 == 0 && P.aux0_stride % 8 == 0 && ((uintptr_t)P.aux0) % 16 == 0;
   if (P.out_f32 || P.Cout % 8 || P.out_stride % 8 || ((uintptr_t)P.out) % 16) return false;
   if (EPI == EPI_GRU_ZR && (P.aux0_stride % 8 || ((uintptr_t)P.aux0) % 16)) return false;
@@ -256,6 +257,85 @@ __device__ __forceinline__ void staged_epilogue(const ConvParams& P, f32x16 (&ac
     }
     *reinterpret_cast<uint4*>(reinterpret_cast<__half*>(P.out) + pix * P.out_stride + co) = v;
   }
+}
+
+// EPI_HEADS0: first layer of the delta | weight heads (3x3, 128 -> 256, relu) FUSED with the second layer's channel
+// contraction.  The second layer is a 3x3 convolution 256 -> 4: o(p) = sum_t W2_t . hd(p + t).  Its per-pixel part
+// P_t(q) = W2_t . hd(q) (9 taps x 4 outputs = 36 dot products over the channels) only needs the pixel's own hidden
+// vector, which this workgroup has just computed: the relu'd fp16 tile is parked in LDS as for the other staged epilogues,
+// multiplied on the MFMA with the 36 (padded to 64) x 128 weight slice of this cout tile, and the fp32 partial products
+// [cout tile][pixel][36] are all that leaves the kernel -- the 256-channel head activations (6.4 GB at 4096 edges) are
+// never written nor re-read with a halo by a second convolution; heads_gather_kernel sums the 9 shifted partials.
+// P.aux1 = W2 packed [CoutPad/128][64][128] f16 (n = tap*4 + output), P.red = partials [CoutPad/128][M][36] f32.
+__device__ __forceinline__ void staged_heads0_epilogue(const ConvParams& P, f32x16 (&acc)[2][2], __half* __restrict__ sT, long m0, int n0,
+                                                       int wm0, int wn0, int tid) {
+  constexpr int ELD = 128 + 8;
+  const int lane = tid & 63, wave = tid >> 6;
+  __syncthreads();
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int cl = wn0 + b * 32 + (lane & 31), co = n0 + cl;
+    const float add = co < P.CoutPad ? P.bias[co] : 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = wm0 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        sT[row * ELD + cl] = __float2half(fmaxf(acc[a][b][q] + add, 0.f));
+      }
+  }
+  __syncthreads();
+  const int mrow = (wave & 3) * 64, nh = (wave >> 2) * 32, p = lane & 31, kh = lane >> 5;
+  const int tile = n0 >> 7;
+  const __half* wsrc = P.aux1 + ((long)tile * 64 + nh + p) * 128 + kh * 8;
+  f32x16 d[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) d[a][q] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    const half8 bf = *reinterpret_cast<const half8*>(wsrc + ks * 16);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const half8 af = *reinterpret_cast<const half8*>(sT + (mrow + a * 32 + p) * ELD + ks * 16 + kh * 8);
+      d[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, d[a], 0, 0, 0);
+    }
+  }
+  const int n = nh + p;
+  if (n < 36) {
+    const long M = (long)P.N * P.H * P.W;
+    float* dst = P.red + ((long)tile * M + m0 + mrow + 4 * kh) * 36 + n;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) dst[(long)(a * 32 + (q & 3) + 8 * (q >> 2)) * 36] = d[a][q];
+  }
+}
+
+// o(p) = bias + sum over cout tiles and taps of P_t(p + t - 1) (zero outside the image), then the heads' activation
+// (delta_x, delta_y raw; sigmoid on the two confidence outputs), values rounded to fp16 like the convolution it replaces
+__global__ __launch_bounds__(256) void heads_gather_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ dw,
+                                                           long M, int ntiles, int H, int W) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= M) return;
+  const int HW = H * W;
+  const int r = (int)(i % HW), y = r / W, x = r - y * W;
+  float o[4] = {bias[0], bias[1], bias[2], bias[3]};
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+    if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) continue;
+    const long q = i + (long)(t / 3 - 1) * W + (t % 3 - 1);
+    for (int tl = 0; tl < ntiles; ++tl) {
+      const float4 v = *reinterpret_cast<const float4*>(part + ((long)tl * M + q) * 36 + t * 4);
+      o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w;
+    }
+  }
+  float4 res;
+  res.x = round_h(o[0]); res.y = round_h(o[1]);
+  res.z = round_h(sigmoidf_(round_h(o[2]))); res.w = round_h(sigmoidf_(round_h(o[3])));
+  reinterpret_cast<float4*>(dw)[i] = res;
 }
 
 // EPI_GLO through the same staged tile: sigmoid gate -> LDS, gate * feature with 16-byte operand loads, per-cout sum
@@ -911,7 +991,8 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
 #undef H2_FETCH_A
 #undef H2_DMA_B
 #undef GLDS16S
-  if constexpr (STAGED) staged_epilogue<EPI, 2, 128>(P, acc, s_conv, m0, n0, wm0, wn0, tid, HW);
+  if constexpr (EPI == EPI_HEADS0) staged_heads0_epilogue(P, acc, s_conv, m0, n0, wm0, wn0, tid);
+  else if constexpr (STAGED) staged_epilogue<EPI, 2, 128>(P, acc, s_conv, m0, n0, wm0, wn0, tid, HW);
   else conv_epilogue<EPI, 2, 2>(P, acc, (long)P.N * HW, m0, n0, wm0, wn0, lane, HW);
 }
 
@@ -1259,6 +1340,7 @@ int launch(const ConvParams& P, hipStream_t st) {
     case EPI_GLO: return launch_epi<WM, WN, BN, EPI_GLO>(P, st);
     case EPI_SOFTPLUS_001: return launch_epi<WM, WN, BN, EPI_SOFTPLUS_001>(P, st);
     case EPI_HEADS: return launch_epi<WM, WN, BN, EPI_HEADS>(P, st);
+    default: break;
   }
   return DH_ERR_ARG;
 }
@@ -1275,7 +1357,7 @@ extern "C" int dh_conv2d_nhwc_f16_ex(const void* const* inputs, const int* in_ch
   if (n_inputs < 1 || n_inputs > MAXSEG || !inputs || !in_channels || !weights || !bias) return DH_ERR_ARG;
   if (N < 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0 || !(KH & 1) || !(KW & 1)) return DH_ERR_ARG;
   if (Cout <= 0 || CoutPad < Cout || CoutPad % 32 || Kpad <= 0 || Kpad % BK) return DH_ERR_ARG;
-  if (epilogue < 0 || epilogue > EPI_HEADS) return DH_ERR_ARG;
+  if (epilogue < 0 || epilogue > EPI_HEADS0) return DH_ERR_ARG;
   ConvParams P{};
   int ctot = 0;
   for (int i = 0; i < n_inputs; ++i) {
@@ -1291,7 +1373,8 @@ extern "C" int dh_conv2d_nhwc_f16_ex(const void* const* inputs, const int* in_ch
   if (epilogue == EPI_GLO && (!red || !aux0)) return DH_ERR_ARG;
   if (epilogue == EPI_GRU_ZR && !aux0) return DH_ERR_ARG;
   if (epilogue == EPI_GRU_Q && (!aux0 || !aux1)) return DH_ERR_ARG;
-  if (epilogue != EPI_GLO && !out) return DH_ERR_ARG;
+  if (epilogue == EPI_HEADS0 && (!red || !aux1)) return DH_ERR_ARG;
+  if (epilogue != EPI_GLO && epilogue != EPI_HEADS0 && !out) return DH_ERR_ARG;
   if (out_is_f32 < 0 || out_is_f32 > 2) return DH_ERR_ARG;
   if (cinit && (!cinit_idx || cinit_stride < cinit_off + Cout || cinit_off < 0)) return DH_ERR_ARG;
   if (N == 0) return DH_OK;
@@ -1318,6 +1401,7 @@ extern "C" int dh_conv2d_nhwc_f16_ex(const void* const* inputs, const int* in_ch
     case EPI_SIGMOID: if (halo2_ok<EPI_SIGMOID>(P)) return launch_halo2<EPI_SIGMOID>(P, st); break;
     case EPI_GRU_ZR: if (halo2_ok<EPI_GRU_ZR>(P)) return launch_halo2<EPI_GRU_ZR>(P, st); break;
     case EPI_GRU_Q: if (halo2_ok<EPI_GRU_Q>(P)) return launch_halo2<EPI_GRU_Q>(P, st); break;
+    case EPI_HEADS0: if (halo2_ok<EPI_HEADS0>(P)) return launch_halo2<EPI_HEADS0>(P, st); return DH_ERR_UNSUPPORTED;
     default: break;
   }
   if (halo_ok(P)) {
@@ -1372,6 +1456,16 @@ extern "C" int dh_conv2d_nhwc_f16(const void* const* inputs, const int* in_chann
   return dh_conv2d_nhwc_f16_ex(inputs, in_channels, in_strides, n_inputs, weights, weights_halo, bias, N, H, W, KH, KW, Cout,
                                CoutPad, Kpad, epilogue, out, out_is_f32, out_stride, gterm, aux0, aux0_stride, aux1, aux1_stride,
                                red, nullptr, nullptr, 0, 0, stream);
+}
+
+extern "C" int dh_heads_gather(const float* partials, const float* bias4, float* dw, int N, int H, int W, int n_cout_tiles, dh_stream_t stream) {
+  if (N < 0 || H <= 0 || W <= 0 || n_cout_tiles < 1) return DH_ERR_ARG;
+  if (N == 0) return DH_OK;
+  if (!partials || !bias4 || !dw) return DH_ERR_ARG;
+  const long M = (long)N * H * W;
+  hipLaunchKernelGGL(heads_gather_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partials, bias4, dw, M, n_cout_tiles, H, W);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
 }
 
 extern "C" int dh_segment_mean_f16(const void* x, const int64_t* order, const int64_t* seg_off, void* out,

@@ -431,6 +431,16 @@ std::vector<torch::Tensor> proximity_nms(torch::Tensor dist, torch::Tensor edges
   return {out, count};
 }
 
+torch::Tensor heads_gather(torch::Tensor partials, torch::Tensor bias4, int64_t H, int64_t W) {
+  CHECK_INPUT(partials); CHECK_INPUT(bias4); CHECK_F32(partials); CHECK_F32(bias4);
+  TORCH_CHECK(partials.dim() == 3 && partials.size(2) == 36 && bias4.numel() >= 4 && partials.size(1) % (H * W) == 0, "heads_gather: partials [tiles,N*H*W,36]");
+  const int N = (int)(partials.size(1) / (H * W));
+  torch::Tensor dw = torch::empty({N, H, W, 4}, partials.options());
+  check_status(dh_heads_gather(partials.data_ptr<float>(), bias4.data_ptr<float>(), dw.data_ptr<float>(), N, (int)H, (int)W,
+                               (int)partials.size(0), cur_stream()), "heads_gather");
+  return dw;
+}
+
 // ---- encoder glue (droid_amd.encoder) ---------------------------------------------------------------------------------
 torch::Tensor norm_act(torch::Tensor x, c10::optional<torch::Tensor> residual, bool normalize, bool relu) {
   CHECK_INPUT(x);
@@ -528,6 +538,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("ba_inputs", &ba_inputs, "target = coords1 + delta, weight; also in ba's [E,2,h,w] layout");
   m.def("cvx_upsample", &cvx_upsample, "convex 8x upsampling of depth maps");
   m.def("proximity_nms", &proximity_nms, "candidate masking + greedy NMS of add_proximity_factors on the device");
+  m.def("heads_gather", &heads_gather, "second head layer from the fused first layer's partial products");
   m.def("norm_act", &norm_act, "instance norm / residual add + activation on channel-last fp16 (encoders)");
   m.def("reproject", &reproject, "fused reprojection (Python thresholds)");
   m.def("se3_op", &se3_op, "SE3 inv/mul/exp/retr");

@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 import droid_backends
 
-EPI_LINEAR, EPI_RELU, EPI_SIGMOID, EPI_GRU_ZR, EPI_GRU_Q, EPI_GLO, EPI_SOFTPLUS_001, EPI_HEADS = range(8)
+EPI_LINEAR, EPI_RELU, EPI_SIGMOID, EPI_GRU_ZR, EPI_GRU_Q, EPI_GLO, EPI_SOFTPLUS_001, EPI_HEADS, EPI_HEADS0 = range(9)
 COR_PLANES = 4 * 49
 COR_NHWC = 224           # channel-last correlation features: 4 levels x (49 + 7 zero channels)
 
@@ -143,7 +143,7 @@ class _Conv:
     def __call__(self, inputs, epi, out=None, out_stride=None, gterm=None, aux0=None, aux1=None, red=None,
                  cinit=None, cinit_idx=None, cinit_off=0, out_raw_f32=False):
         x0 = inputs[0]
-        if out is None and epi != EPI_GLO:
+        if out is None and epi not in (EPI_GLO, EPI_HEADS0):
             out = torch.empty(x0.shape[0], x0.shape[1], x0.shape[2], self.cout,
                               dtype=torch.float32 if out_raw_f32 else torch.float16, device=x0.device)
         stride = 0 if out is None else (out.shape[-1] if out_stride is None else out_stride)
@@ -208,6 +208,10 @@ class UpdateModule:
         w2[0:2, 0:128] = g("delta.2.weight").float()
         w2[2:4, 128:256] = g("weight.2.weight").float()
         P["heads2"] = _Conv(*pack_conv(w2, torch.cat([g("delta.2.bias"), g("weight.2.bias")], 0)), 3, 4, pack_conv_halo(w2))
+        # fused form (csrc/conv.hip EPI_HEADS0): second-layer weights as [cout tile][tap*4 + output (36 of 64)][128 channels]
+        w2p = torch.zeros(2, 64, 128, device=self.device)
+        w2p[:, :36] = w2.reshape(4, 2, 128, 9).permute(1, 3, 0, 2).reshape(2, 36, 128)
+        P["heads2_fused"] = (w2p.half().contiguous(), torch.cat([g("delta.2.bias"), g("weight.2.bias")], 0).float().contiguous())
         P["agg1"] = conv("agg.conv1")
         P["agg2"] = conv("agg.conv2")
         P["eta"] = conv("agg.eta.0")
@@ -261,9 +265,16 @@ class UpdateModule:
             zr = P["zr_e"]([net, c, f], EPI_GRU_ZR, gterm=gzr, aux0=net, cinit=ctx, cinit_idx=inp_index, cinit_off=0)
             P["q_e"]([zr[..., 128:], c, f], EPI_GRU_Q, out=net, gterm=gq.contiguous(), aux0=net, aux1=zr,
                      cinit=ctx, cinit_idx=inp_index, cinit_off=256)
-        hd = P["heads0"]([net], EPI_RELU)
-        dw = torch.empty(E, h, w, 4, dtype=torch.float32, device=net.device)
-        P["heads2"]([hd], EPI_HEADS, out=dw)
+        if w == 64 and h % 4 == 0 and droid_backends.get_option("conv_halo") and droid_backends.get_option("conv_halo2"):
+            # heads: the 256-channel activations never leave the first layer's kernel (see csrc/conv.hip EPI_HEADS0)
+            w2p, b4 = P["heads2_fused"]
+            part = torch.empty(2, E * h * w, 36, dtype=torch.float32, device=net.device)
+            P["heads0"]([net], EPI_HEADS0, aux1=w2p, red=part)
+            dw = droid_backends.heads_gather(part, b4, h, w)
+        else:
+            hd = P["heads0"]([net], EPI_RELU)
+            dw = torch.empty(E, h, w, 4, dtype=torch.float32, device=net.device)
+            P["heads2"]([hd], EPI_HEADS, out=dw)
         self.last_dw = dw                        # (delta_x, delta_y, w_x, w_y) as one tensor for droid_backends.ba_inputs
         # GraphAgg: conv -> mean over the edges of each source frame -> conv -> eta / upmask
         x = P["agg1"]([net], EPI_RELU)
