@@ -266,7 +266,7 @@ __device__ __forceinline__ void staged_epilogue(const ConvParams& P, f32x16 (&ac
 // multiplied on the MFMA with the 36 (padded to 64) x 128 weight slice of this cout tile, and the fp32 partial products
 // [cout tile][pixel][36] are all that leaves the kernel -- the 256-channel head activations (6.4 GB at 4096 edges) are
 // never written nor re-read with a halo by a second convolution; heads_gather_kernel sums the 9 shifted partials.
-// P.aux1 = W2 packed [CoutPad/128][64][128] f16 (n = tap*4 + output), P.red = partials [CoutPad/128][M][36] f32.
+// P.aux1 = W2 packed [CoutPad/128][64][128] f16 (n = tap*4 + output), P.red = partials [CoutPad/128][9 taps][M][4] f32.
 __device__ __forceinline__ void staged_heads0_epilogue(const ConvParams& P, f32x16 (&acc)[2][2], __half* __restrict__ sT, long m0, int n0,
                                                        int wm0, int wn0, int tid) {
   constexpr int ELD = 128 + 8;
@@ -302,14 +302,31 @@ __device__ __forceinline__ void staged_heads0_epilogue(const ConvParams& P, f32x
       d[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, d[a], 0, 0, 0);
     }
   }
+  // transpose through LDS so that the partials leave as [tap][pixel][4 outputs] planes in full lines (and the gather
+  // reads them coalesced): plane stride 1024 + 4 floats = conflict-free scatter of the MFMA layout
+  constexpr int PLD = 256 * 4 + 4;
+  float* sD = reinterpret_cast<float*>(sT);
+  __syncthreads();                                  // every wave has read its A fragments: the tile may be overwritten
   const int n = nh + p;
   if (n < 36) {
-    const long M = (long)P.N * P.H * P.W;
-    float* dst = P.red + ((long)tile * M + m0 + mrow + 4 * kh) * 36 + n;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) dst[(long)(a * 32 + (q & 3) + 8 * (q >> 2)) * 36] = d[a][q];
+      for (int q = 0; q < 16; ++q) {
+        const int row = mrow + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh;
+        sD[(n >> 2) * PLD + row * 4 + (n & 3)] = d[a][q];
+      }
+  }
+  __syncthreads();
+  const long M = (long)P.N * P.H * P.W;
+#pragma unroll
+  for (int it = 0; it < 5; ++it) {
+    const int piece = tid + 512 * it;               // 9 taps x 256 pixels
+    if (piece < 9 * 256) {
+      const int t = piece >> 8, px = piece & 255;
+      const float4 v = *reinterpret_cast<const float4*>(sD + t * PLD + px * 4);
+      *reinterpret_cast<float4*>(P.red + (((long)tile * 9 + t) * M + m0 + px) * 4) = v;
+    }
   }
 }
 
@@ -328,7 +345,7 @@ __global__ __launch_bounds__(256) void heads_gather_kernel(const float* __restri
     if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) continue;
     const long q = i + (long)(t / 3 - 1) * W + (t % 3 - 1);
     for (int tl = 0; tl < ntiles; ++tl) {
-      const float4 v = *reinterpret_cast<const float4*>(part + ((long)tl * M + q) * 36 + t * 4);
+      const float4 v = *reinterpret_cast<const float4*>(part + (((long)tl * 9 + t) * M + q) * 4);
       o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w;
     }
   }
