@@ -19,8 +19,9 @@ for name, cins, cout, k in shapes:
     if only and only not in name:
         continue
     n = E // 8 if "upmask" in name else E
-    xs = [torch.randn(n, h, w, c, device="cuda").half() for c in cins]
-    wgt = torch.randn(cout, sum(cins), k, k, device="cuda") / (sum(cins) * k * k) ** 0.5
+    fill = os.environ.get("DH_FILL", "randn")       # "zero": operands of zeros (DVFS headroom check, MI355X_MICROARCH.md)
+    xs = [(torch.zeros if fill == "zero" else torch.randn)(n, h, w, c, device="cuda").half() for c in cins]
+    wgt = (torch.zeros if fill == "zero" else torch.randn)(cout, sum(cins), k, k, device="cuda") / (sum(cins) * k * k) ** 0.5
     wp, bp = pack_conv(wgt, torch.zeros(cout, device="cuda"))
     wh = pack_conv_halo(wgt) if not os.environ.get("DH_CONV_NO_HALO") else None
     out = torch.empty(n, h, w, cout, device="cuda", dtype=torch.float16)
