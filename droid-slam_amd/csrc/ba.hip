@@ -537,6 +537,12 @@ __global__ void ba_damp_kernel(double* __restrict__ H, int ld, int n, int npad, 
 // Inside a 64x64 block the factorisation is blocked again by 16: the 16x16 diagonal sub-block is factorised
 // by ONE wave with row r in the registers of lane r (cross-lane traffic = v_readlane broadcasts, no barriers),
 // the panel below it by row-wise substitution, the trailing update by all 4 waves.
+#ifdef DH_CHOL_TS                  // scripts/ubench/chol_ts.hip: phase timestamps of workgroup 0 (never defined in the library build)
+__device__ unsigned long long g_chol_ts[128];
+#define DH_TS(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { g_chol_ts[i] = __builtin_readcyclecounter(); g_chol_ts[64 + (i)] = wall_clock64(); } } while (0)
+#else
+#define DH_TS(i) do { } while (0)
+#endif
 constexpr int SB = 16;            // sub-block
 constexpr int LDB = NB + 2;       // LDS leading dimension (doubles): 16 rows x {k, k+1} hit 32 distinct bank pairs
 
@@ -658,6 +664,142 @@ __device__ bool chol_panel128_lds(double* __restrict__ P, int tid) {
     }
     __syncthreads();
   }
+  return ok;
+}
+
+// 1/sqrt(a) for the pivot chain of the register panel: hardware estimate + ONE third-order step
+// y (1 + e/2 + 3 e^2 / 8), e = 1 - a y^2 -- 5 dependent operations after the estimate instead of 7
+__device__ __forceinline__ double pivot_rsqrt(double a) {
+  const double y = __builtin_amdgcn_rsq(a);
+  const double t = a * y;
+  const double e = __builtin_fma(-t, y, 1.0);
+  const double p = __builtin_fma(e, 0.375, 0.5);
+  return __builtin_fma(y, p * e, y);
+}
+
+// The same stacked-panel factorisation with the UNFINISHED part of the panel held in registers as fp64-MFMA accumulator
+// tiles: wave w owns rows 16w..16w+15 of A_jj (`top`) and of A_rj (`bot`), all four 16-column tiles (the layout
+// mfma_abt_64 leaves the updated blocks in, so the look-ahead step never stages them).  P only carries what has to cross
+// lanes: per 8-column step the owners drop the 8 current columns into P, every thread factors the 8x8 diagonal
+// sub-block in its own registers, one thread per row (the 8 rows of the sub-block included: their substitution IS the
+// row of L_kk) substitutes and writes the row of L back, and the trailing tiles take their rank-8 update straight from
+// P into the accumulators -- first the tile that holds the NEXT 8 columns, whose columns go to P at once; the other
+// tiles are updated after the barrier, interleaved with the next pivot chain (the fp64 MFMA of gfx950 takes 64 cycles;
+// the chain leaves the issue slots for it).  Straight-line code: every wave issues the same MFMAs (a `top` tile above
+// the diagonal gets a zero operand or is never read), so the accumulators never move between register files.
+// Two barriers per step, no accumulator round trips through LDS.  On return P = [L_jj (zeros above the diagonal); L_rj].
+__device__ __forceinline__ bool chol_panel128_regs(double* __restrict__ P, f64x4 (&top)[4], f64x4 (&bot)[4], int tid) {
+  constexpr int PB = 8;
+  const int lane = tid & 63, wave = tid >> 6, lr = lane >> 4, lc = lane & 15;
+  bool ok = true;
+  double aT[2] = {0.0, 0.0}, aB[2] = {0.0, 0.0}, bq[4][2] = {};
+  if ((lc >> 3) == 0) {                                  // columns 0..7 of the panel
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = 16 * wave + lr + 4 * q;
+      P[row * LDB + lc] = top[0][q];
+      P[(NB + row) * LDB + lc] = bot[0][q];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NB / PB; ++k) {
+    const int o = k * PB, first = o + PB;
+    const int nsub = 2 * NB - o;                         // rows o .. 127 are substituted (thread t <-> row o + t)
+    __syncthreads();                                     // the step's 8 columns are in P
+    DH_TS(8 + 4 * k);
+    double L[PB][PB], dinv[PB], x[PB];
+#pragma unroll
+    for (int r = 0; r < PB; ++r)
+#pragma unroll
+      for (int c = 0; c <= r; ++c) L[r][c] = P[(o + r) * LDB + o + c];       // same address in every lane: broadcast
+    double* prow = P + (o + (tid < nsub ? tid : 0)) * LDB + o;
+#pragma unroll
+    for (int c = 0; c < PB; ++c) x[c] = prow[c];
+    // rest of the previous step's rank-8 update (column tiles after the one that holds this step's columns)
+    if (k > 0) {
+#pragma unroll
+      for (int nt = (k >> 1) + 1; nt < 4; ++nt)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          bot[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(aB[kk], bq[nt][kk], bot[nt], 0, 0, 0);
+          top[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(aT[kk], bq[nt][kk], top[nt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < PB; ++c) {
+      const double piv = L[c][c];
+      ok = ok & (piv > 0.0) & (piv < 1e300);               // off the dependent chain: a bad pivot only has to be reported
+      const double rs = pivot_rsqrt(piv);
+      dinv[c] = rs;
+#pragma unroll
+      for (int r = c + 1; r < PB; ++r) L[r][c] *= rs;
+#pragma unroll
+      for (int c2 = c + 1; c2 < PB; ++c2)
+#pragma unroll
+        for (int r = c2; r < PB; ++r) L[r][c2] = __builtin_fma(-L[r][c], L[c2][c], L[r][c2]);
+    }
+    // x <- x L_kk^-T (right-looking: one fma + one mul per column on the chain); for a row of the sub-block itself the
+    // result is its row of L_kk, with zeros forced above the diagonal
+#pragma unroll
+    for (int c = 0; c < PB; ++c) {
+      x[c] *= dinv[c];
+#pragma unroll
+      for (int m = c + 1; m < PB; ++m) x[m] = __builtin_fma(-x[c], L[m][c], x[m]);
+    }
+#pragma unroll
+    for (int c = 1; c < PB; ++c) x[c] = tid < c ? 0.0 : x[c];
+    if (k > 0) {                                         // one MFMA per ~14 chain operations
+#pragma unroll
+      for (int i = 0; i < 4 * (3 - (k >> 1)); ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 14, 0);
+      }
+    }
+    DH_TS(9 + 4 * k);
+    if (tid >= PB && tid < nsub) {
+#pragma unroll
+      for (int c = 0; c < PB; ++c) prow[c] = x[c];
+    }
+    __syncthreads();                                     // rows of L for this step are in P
+    DH_TS(10 + 4 * k);
+    if (tid < PB) {                                      // L_kk after the barrier: the others were still reading the sub-block
+#pragma unroll
+      for (int c = 0; c < PB; ++c) prow[c] = x[c];
+    }
+    if (k + 1 < NB / PB) {
+      // operands of the rank-8 update: rows/columns before `first` are finished -> 0
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int rt = 16 * wave + lc;
+        const double vt = P[rt * LDB + o + kk * 4 + lr];
+        aT[kk] = rt >= first ? -vt : 0.0;
+        aB[kk] = -P[(NB + rt) * LDB + o + kk * 4 + lr];
+#pragma unroll
+        for (int nt = first / SB; nt < 4; ++nt) {
+          const int rb = 16 * nt + lc;
+          const double vb = P[rb * LDB + o + kk * 4 + lr];
+          bq[nt][kk] = rb >= first ? vb : 0.0;
+        }
+      }
+      // the tile with the next 8 columns first; its columns go to P for the next step
+      const int nu = first / SB, half = (first / PB) & 1;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bot[nu] = __builtin_amdgcn_mfma_f64_16x16x4f64(aB[kk], bq[nu][kk], bot[nu], 0, 0, 0);
+        top[nu] = __builtin_amdgcn_mfma_f64_16x16x4f64(aT[kk], bq[nu][kk], top[nu], 0, 0, 0);
+      }
+      if ((lc >> 3) == half) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = 16 * wave + lr + 4 * q;
+          P[row * LDB + first + (lc & 7)] = row >= first ? top[nu][q] : 0.0;
+          P[(NB + row) * LDB + first + (lc & 7)] = bot[nu][q];
+        }
+      }
+    }
+    DH_TS(11 + 4 * k);
+  }
+  __syncthreads();
   return ok;
 }
 
@@ -833,6 +975,7 @@ __global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ H
 //       A_{r,j+1} -= L_{r,j} L_{j+1,j}^T on the fp64 MFMA, written straight into the stacked LDS panel, then the
 //       same stacked factorisation as chol_panel_kernel -> L_{r,j+1} (workgroup 0 also stores L_{j+1,j+1});
 //   the others: A_rc -= L_rj L_cj^T for j+2 <= c <= r (chol_update_kernel's work minus block column j+1).
+template <bool REGP>
 __global__ __launch_bounds__(256, 1) void chol_step_kernel(double* __restrict__ H, int ld, int j, int nbk, int nP,
                                                            int* __restrict__ meta, double* __restrict__ Ldiag) {
   extern __shared__ double s_chol[];
@@ -840,6 +983,7 @@ __global__ __launch_bounds__(256, 1) void chol_step_kernel(double* __restrict__ 
   double* sB = sA + NB * LDB;             // L_cj
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool panel = (int)blockIdx.x < nP;
+  DH_TS(0);
   int r, c;
   if (panel) { r = j + 2 + blockIdx.x; c = j + 1; }
   else {
@@ -870,6 +1014,7 @@ __global__ __launch_bounds__(256, 1) void chol_step_kernel(double* __restrict__ 
     *reinterpret_cast<double2*>(sB + (o >> 5) * LDB + (o & 31) * 2) = vb[q];
   }
   __syncthreads();
+  DH_TS(1);
   f64x4 acc[4];
   mfma_abt_64<false>(sA, sB, wave, lane, acc);
   if (!panel) {
@@ -883,18 +1028,29 @@ __global__ __launch_bounds__(256, 1) void chol_step_kernel(double* __restrict__ 
   f64x4 accd[4];
   mfma_abt_64<false>(sB, sB, wave, lane, accd);
   __syncthreads();                          // every wave has read both operand blocks: the panel may overwrite them
+  DH_TS(2);
   double* P = s_chol;                       // [128][LDB]: updated A_cc over updated A_rc
+  bool ok;
+  if (REGP) {
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt)
+    for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int row = wave * 16 + (lane >> 4) + 4 * q, col = nt * 16 + (lane & 15);
-      P[row * LDB + col] = curd[nt][q] - accd[nt][q];
-      P[(NB + row) * LDB + col] = cur[nt][q] - acc[nt][q];
-    }
-  __syncthreads();
-  const bool ok = chol_panel128_lds(P, tid);
+      for (int q = 0; q < 4; ++q) { accd[nt][q] = curd[nt][q] - accd[nt][q]; acc[nt][q] = cur[nt][q] - acc[nt][q]; }
+    ok = chol_panel128_regs(P, accd, acc, tid);
+  } else {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = wave * 16 + (lane >> 4) + 4 * q, col = nt * 16 + (lane & 15);
+        P[row * LDB + col] = curd[nt][q] - accd[nt][q];
+        P[(NB + row) * LDB + col] = cur[nt][q] - acc[nt][q];
+      }
+    __syncthreads();
+    ok = chol_panel128_lds(P, tid);
+  }
   if (!ok && tid == 0) meta[1] = 1;
+  DH_TS(3);
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const int o = tid + 256 * q;
@@ -907,6 +1063,7 @@ __global__ __launch_bounds__(256, 1) void chol_step_kernel(double* __restrict__ 
       *reinterpret_cast<double2*>(Ldiag + (long)c * NB * NB + (o >> 5) * NB + (o & 31) * 2) = *reinterpret_cast<const double2*>(P + (o >> 5) * LDB + (o & 31) * 2);
     }
   }
+  DH_TS(4);
 }
 
 // back substitution of L^T x = y (y = row `brow` of H) in groups of BG block rows per launch:
@@ -1096,7 +1253,8 @@ int run_finish(const BaLayout& L, char* ws, float* poses, float* disps, const in
     DH_LDS_OPTIN(&chol_panel_kernel, 72 * 1024);
     DH_LDS_OPTIN(&chol_inverse_kernel, 80 * 1024);
     DH_LDS_OPTIN(&chol_update_kernel, 72 * 1024);
-    DH_LDS_OPTIN(&chol_step_kernel, 72 * 1024);
+    DH_LDS_OPTIN(&chol_step_kernel<true>, 72 * 1024);
+    DH_LDS_OPTIN(&chol_step_kernel<false>, 72 * 1024);
     DH_LDS_OPTIN(&chol_backsub_kernel, 112 * 1024);
     const size_t lds_panel = sizeof(double) * 2 * NB * LDB;
     const size_t lds_inv = sizeof(double) * (2 * NB * LDB + 3 * SB * (SB + 1) + NB);
@@ -1116,7 +1274,10 @@ int run_finish(const BaLayout& L, char* ws, float* poses, float* disps, const in
       DH_LAUNCH_CHECK();
       for (int j = 0; j + 1 < L.nbk; ++j) {
         const int nP = nbrows - j - 2;                   // block rows below the diagonal block of column j+1
-        hipLaunchKernelGGL(chol_step_kernel, dim3(nP + nP * nP), dim3(256), lds_panel, st, H, L.ld, j, L.nbk, nP, meta, Ldiag);
+        if (opts().chol_regpanel)
+          hipLaunchKernelGGL(chol_step_kernel<true>, dim3(nP + nP * nP), dim3(256), lds_panel, st, H, L.ld, j, L.nbk, nP, meta, Ldiag);
+        else
+          hipLaunchKernelGGL(chol_step_kernel<false>, dim3(nP + nP * nP), dim3(256), lds_panel, st, H, L.ld, j, L.nbk, nP, meta, Ldiag);
         DH_LAUNCH_CHECK();
       }
     }
