@@ -36,7 +36,6 @@ constexpr int STRIP = 256 * PPT;  // pixels per strip
 constexpr int HP_STRIDE = 28;     // per (edge, strip) partial: 21 Hjj + 6 vj (+1 pad)
 constexpr int GS = 10;            // slots per Gram chunk: 10*6 + 1 (w) = 61 <= 64 MFMA columns
 constexpr int GCOLS = 64;
-constexpr int GLD = 65;           // LDS leading dimension of the M tile (floats)
 constexpr float ALPHA_PRIOR = 0.05f;   // src/droid_kernels.cu:1405
 
 struct BaLayout {
@@ -368,16 +367,121 @@ __global__ __launch_bounds__(64) void ba_pose_blocks_kernel(
 }
 
 // ---- Schur complement blocks of one depth block: Gram matrix on the fp32 MFMA -------------------
+// G = M^T diag(Q) M over the pixels of depth block k, M = [E_i | E_ij of the block's edges | w] (61 of 64 columns per
+// chunk of GS slots).  The pixel sum is order-free, so the MFMA operands come STRAIGHT from global memory: lane
+// (c = lane & 15, g = lane >> 4) reads four consecutive pixels of column 16 t + c as one 16-byte load and feeds element e
+// to k-step e -- A and B see the same pixel for the same (k-step, lane group), which is all the contraction needs.  No LDS
+// staging, no barrier in the pixel loop; the waves of a workgroup take interleaved 16-pixel groups and meet once, in the
+// cross-wave reduction of the finished 64x64 Gram.  Q scales the A side only.
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-__global__ __launch_bounds__(256) void ba_gram_kernel(
+struct GramCols { const float* p[4]; unsigned valid; };      // lane's column of each 16-column tile; bit t = column exists
+
+// the column pointers travel through LDS, which costs them their address space: without the cast the loads become FLAT
+// loads, which the compiler has to drain with vmcnt(0) before anything else -- no prefetch would survive that
+typedef const float __attribute__((address_space(1)))* gram_gptr;
+typedef const f32x4 __attribute__((address_space(1)))* gram_gptr4;    // (a native vector: HIP's float4 class would copy through a generic reference)
+
+template <bool VEC4>
+__device__ __forceinline__ f32x4 gram_ld(const float* col, int pix, int p_end) {
+  if (VEC4) return *(gram_gptr4)(col + pix);
+  gram_gptr c = (gram_gptr)col;
+  return f32x4{c[pix], c[min(pix + 1, p_end - 1)], c[min(pix + 2, p_end - 1)], c[min(pix + 3, p_end - 1)]};
+}
+
+// One 16-pixel group of a wave: NA column tiles on the A side (first tile TA0), NBT on the B side (0: B = A, a chunk
+// against itself) and Q.
+template <int NA, int NBT> struct GramTile { f32x4 a[NA], b[NBT ? NBT : 1], q; };
+
+template <bool VEC4, int NA, int NBT, int TA0>
+__device__ __forceinline__ void gram_fetch(const GramCols& CA, const GramCols& CB, const float* __restrict__ Qk, int p0, int g,
+                                           int p_end, GramTile<NA, NBT>& T) {
+  const int pix = min(p0 + 4 * g, p_end - 1) & (VEC4 ? ~3 : ~0);       // clamped: every lane loads from inside the strip
+#pragma unroll
+  for (int t = 0; t < NA; ++t) T.a[t] = gram_ld<VEC4>(CA.p[TA0 + t], pix, p_end);
+#pragma unroll
+  for (int t = 0; t < NBT; ++t) T.b[t] = gram_ld<VEC4>(CB.p[t], pix, p_end);
+  T.q = gram_ld<VEC4>(Qk, pix, p_end);
+}
+
+// acc[ti * 4 + tj] += (Q A_ti)^T B_tj; pixels past the end of the strip (ragged last group) and columns that do not exist
+// contribute 0.  NBT == 0: upper tiles of the symmetric product only.
+template <int NA, int NBT, int TA0>
+__device__ __forceinline__ void gram_mfma(const GramCols& CA, const GramCols& CB, const GramTile<NA, NBT>& T, int pix, int p_end,
+                                          f32x4 (&acc)[NA * 4]) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float qe = (pix + e < p_end) ? T.q[e] : 0.f;
+    float a[NA], bb[4];
+#pragma unroll
+    for (int t = 0; t < NA; ++t) {
+      const float x = ((CA.valid >> (TA0 + t)) & 1) ? T.a[t][e] : 0.f;
+      a[t] = x * qe;
+      if (NBT == 0) bb[t] = x;
+    }
+#pragma unroll
+    for (int t = 0; t < NBT; ++t) bb[t] = ((CB.valid >> t) & 1) ? T.b[t][e] : 0.f;
+#pragma unroll
+    for (int ti = 0; ti < NA; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj)
+        if (NBT != 0 || tj >= ti)
+          acc[ti * 4 + tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ti], bb[tj], acc[ti * 4 + tj], 0, 0, 0);
+  }
+}
+
+// two groups in flight, ping-pong (no register copies), every fetch unconditional -- addresses are clamped into the strip
+// and a group past its end has all its pixels masked -- so that the compiler can wait for exactly the older group's loads
+template <bool VEC4, int NA, int NBT, int TA0>
+__device__ __forceinline__ void gram_accumulate(const GramCols& CA, const GramCols& CB, const float* __restrict__ Qk,
+                                                int p_begin, int p_end, int wave, int g, f32x4 (&acc)[NA * 4]) {
+  GramTile<NA, NBT> T0, T1;
+  int p0 = p_begin + 16 * wave;
+  gram_fetch<VEC4, NA, NBT, TA0>(CA, CB, Qk, p0, g, p_end, T0);
+  for (; p0 < p_end; p0 += 128) {
+    gram_fetch<VEC4, NA, NBT, TA0>(CA, CB, Qk, p0 + 64, g, p_end, T1);
+    __builtin_amdgcn_sched_barrier(0);                   // the loads stay ahead of the other group's MFMAs
+    gram_mfma<NA, NBT, TA0>(CA, CB, T0, p0 + 4 * g, p_end, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    gram_fetch<VEC4, NA, NBT, TA0>(CA, CB, Qk, p0 + 128, g, p_end, T0);
+    __builtin_amdgcn_sched_barrier(0);
+    gram_mfma<NA, NBT, TA0>(CA, CB, T1, p0 + 64 + 4 * g, p_end, acc);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// the waves' partial Grams (tiles ti0 .. ti0 + NA - 1 of the rows) summed into s_out in a fixed order
+template <int NA>
+__device__ __forceinline__ void gram_reduce(float* __restrict__ s_out, const f32x4 (&acc)[NA * 4], int ti0, bool upper_only,
+                                            int wave, int lane) {
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int ti = 0; ti < NA; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) {
+          if (upper_only && tj < ti0 + ti) continue;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = (ti0 + ti) * 16 + (lane >> 4) * 4 + r, col = tj * 16 + (lane & 15);
+            if (w == 0) s_out[row * GCOLS + col] = acc[ti * 4 + tj][r];
+            else s_out[row * GCOLS + col] += acc[ti * 4 + tj][r];
+          }
+        }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void ba_gram_kernel(
     const float* __restrict__ Q, const float* __restrict__ W, const float* __restrict__ Ei,
     const float* __restrict__ Ej, const int64_t* __restrict__ jj, const int* __restrict__ kx,
     const int* __restrict__ eoff, const int* __restrict__ eidx, const int* __restrict__ meta,
     int HW, int NSG, int t0, int P, double* __restrict__ H, int ld, int brow) {
   const int k = blockIdx.x;
   if (k >= meta[0]) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // scalar: the pixel loop below branches uniformly
   const int f = kx[k];
   const int e0 = eoff[k];
   const int nslots = 1 + (eoff[k + 1] - e0);
@@ -385,18 +489,16 @@ __global__ __launch_bounds__(256) void ba_gram_kernel(
   const int per = ((HW + NSG - 1) / NSG + 63) / 64 * 64;
   const int p_begin = blockIdx.y * per, p_end = min(HW, p_begin + per);
   if (p_begin >= p_end) return;
+  const bool vec4 = (HW & 3) == 0;              // 16-byte loads need every column (a multiple of HW floats) aligned
 
-  __shared__ float s_M[2][64 * GLD];            // [chunk a / chunk b][px][col], already scaled by sqrt(Q)
   __shared__ float s_out[GCOLS * GCOLS];        // cross-wave reduction
   __shared__ int s_pose[2][GS];
   __shared__ const float* s_col[2][GCOLS];      // per-column source rows (nullptr = zero column)
-
-  const int pl = tid & 63, cg = tid >> 6;       // staging role: pixel within the tile, column group
+  const float* Qk = Q + (long)k * HW;
 
   for (int ca = 0; ca < nchunks; ++ca) {
     for (int cb = ca; cb < nchunks; ++cb) {
       const bool same = ca == cb;
-      const int nw = same ? 1 : 2;
       __syncthreads();
       if (tid < 2 * GCOLS) {
         const int which = tid / GCOLS, col = tid % GCOLS, c = which ? cb : ca;
@@ -422,77 +524,38 @@ __global__ __launch_bounds__(256) void ba_gram_kernel(
       }
       __syncthreads();
 
-      f32x4 acc[16];
+      GramCols CA, CB;
+      CA.valid = CB.valid = 0;
 #pragma unroll
-      for (int t = 0; t < 16; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-      // software pipeline: the next tile's 16(+16) values travel from HBM while this tile is on the MFMA
-      float pre[2][16], preq;
-      auto issue = [&](int pb) {
-        const int p = pb + pl;
-        const bool pok = p < p_end;
-        preq = pok ? Q[(long)k * HW + p] : 0.f;
-#pragma unroll
-        for (int which = 0; which < 2; ++which) {
-          if (which < nw) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-              const float* ptr = s_col[which][cg + 4 * i];
-              pre[which][i] = (pok && ptr) ? ptr[p] : 0.f;
-            }
-          }
-        }
-      };
-      issue(p_begin);
-      for (int pb = p_begin; pb < p_end; pb += 64) {
-        __syncthreads();
-        {
-          const float sq = sqrtf(preq);
-#pragma unroll
-          for (int which = 0; which < 2; ++which)
-            if (which < nw) {
-#pragma unroll
-              for (int i = 0; i < 16; ++i) s_M[which][pl * GLD + cg + 4 * i] = pre[which][i] * sq;
-            }
-        }
-        __syncthreads();
-        if (pb + 64 < p_end) issue(pb + 64);
-        const float* MA = s_M[0];
-        const float* MB = s_M[same ? 0 : 1];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const int prow = wave * 16 + kk * 4 + (lane >> 4);
-          float a[4], b[4];
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            a[t] = MA[prow * GLD + t * 16 + (lane & 15)];
-            b[t] = MB[prow * GLD + t * 16 + (lane & 15)];
-          }
-#pragma unroll
-          for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-            for (int tj = 0; tj < 4; ++tj)
-              if (!same || tj >= ti)          // a chunk against itself is symmetric: upper tiles only
-                acc[ti * 4 + tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ti], b[tj], acc[ti * 4 + tj], 0, 0, 0);
-        }
+      for (int t = 0; t < 4; ++t) {
+        const float* pa = s_col[0][t * 16 + (lane & 15)];
+        const float* pb = s_col[same ? 0 : 1][t * 16 + (lane & 15)];
+        CA.valid |= (pa != nullptr) << t; CB.valid |= (pb != nullptr) << t;
+        CA.p[t] = pa ? pa : Qk;                 // a column that does not exist reads Q (in bounds) and is masked to 0
+        CB.p[t] = pb ? pb : Qk;
       }
-      // reduce the 4 waves' partial Grams in LDS (fixed order), then add into the fp64 system
-      for (int w = 0; w < 4; ++w) {
-        __syncthreads();
-        if (wave == w) {
+      const int g = lane >> 4;
+      if (same) {
+        f32x4 acc[16];
 #pragma unroll
-          for (int ti = 0; ti < 4; ++ti)
+        for (int t = 0; t < 16; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (vec4) gram_accumulate<true, 4, 0, 0>(CA, CB, Qk, p_begin, p_end, wave, g, acc);
+        else gram_accumulate<false, 4, 0, 0>(CA, CB, Qk, p_begin, p_end, wave, g, acc);
+        gram_reduce<4>(s_out, acc, 0, true, wave, lane);
+      } else {
+        // two chunks against each other (a depth block with more than GS - 1 edges): all 16 tiles are needed; two passes of
+        // 8 keep the register budget -- and with it the occupancy -- of the common single-chunk case
+        f32x4 acc[8];
 #pragma unroll
-            for (int tj = 0; tj < 4; ++tj) {
-              if (same && tj < ti) continue;
+        for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (vec4) gram_accumulate<true, 2, 4, 0>(CA, CB, Qk, p_begin, p_end, wave, g, acc);
+        else gram_accumulate<false, 2, 4, 0>(CA, CB, Qk, p_begin, p_end, wave, g, acc);
+        gram_reduce<2>(s_out, acc, 0, false, wave, lane);
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const int row = ti * 16 + (lane >> 4) * 4 + r, col = tj * 16 + (lane & 15);
-                if (w == 0) s_out[row * GCOLS + col] = acc[ti * 4 + tj][r];
-                else s_out[row * GCOLS + col] += acc[ti * 4 + tj][r];
-              }
-            }
-        }
+        for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (vec4) gram_accumulate<true, 2, 4, 2>(CA, CB, Qk, p_begin, p_end, wave, g, acc);
+        else gram_accumulate<false, 2, 4, 2>(CA, CB, Qk, p_begin, p_end, wave, g, acc);
+        gram_reduce<2>(s_out, acc, 2, false, wave, lane);
       }
       __syncthreads();
       // G[row=(slot a, r)][col=(slot b, c)] -> S block (pose_a, pose_b); column 6*GS = E Q w
@@ -1227,9 +1290,9 @@ int run_build(const BaLayout& L, char* ws, const float* poses, const float* disp
   }
   if (!motion_only && L.P > 0) {
     const int kest = std::max(1, std::min(F, L.P + E));
-    // one MFMA pass over a whole 48x64 frame is ~26 us on one CU: split frames into pixel strips only
-    // while there are fewer frames than CUs (every extra strip multiplies the fp64 atomics)
-    const int NSG = std::max(1, std::min((256 + kest - 1) / kest, std::max(1, HW / 256)));
+    // ~4 workgroups per CU hide the HBM latency of the operand loads; every extra strip multiplies the fp64 atomics
+    int NSG = std::max(1, std::min((1024 + kest - 1) / kest, std::max(1, HW / 256)));
+    if (opts().gram_strips > 0) NSG = std::min(opts().gram_strips, std::max(1, HW / 64));
     hipLaunchKernelGGL(ba_gram_kernel, dim3(F, NSG), dim3(256), 0, st, (const float*)(ws + L.Q),
                        (const float*)(ws + L.W), (const float*)(ws + L.Ei), (const float*)(ws + L.Ej), jj, kx,
                        eoff, eidx, meta, HW, NSG, t0, L.P, H, L.ld, L.npad);

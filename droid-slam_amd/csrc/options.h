@@ -6,6 +6,7 @@ namespace dh {
 
 struct Options {
   int debug;            // DH_DEBUG=1: print HIP errors to stderr
+  int gram_strips;      // DH_GRAM_STRIPS (0 = automatic): pixel strips per depth block in the Schur-complement kernel
   int chol_regpanel;    // DH_CHOL_REGPANEL (1): look-ahead step keeps the unfinished panel in MFMA accumulator registers; 0 = LDS panel
   int chol_lookahead;   // DH_CHOL_LOOKAHEAD (1): one fused launch per block column of the Cholesky; 0 = two launches
   int conv_epi_staged;  // DH_CONV_EPI_STAGED (1): LDS-staged convolution epilogues

@@ -16,6 +16,7 @@ Options& opts() {
     v.debug = env_int("DH_DEBUG", 0);
     v.chol_lookahead = env_int("DH_CHOL_LOOKAHEAD", 1);
     v.chol_regpanel = env_int("DH_CHOL_REGPANEL", 1);
+    v.gram_strips = env_int("DH_GRAM_STRIPS", 0);
     v.conv_epi_staged = env_int("DH_CONV_EPI_STAGED", 1);
     v.conv_halo = env_int("DH_CONV_HALO", 1);
     v.conv_halo2 = env_int("DH_CONV_HALO2", 1);
@@ -36,6 +37,7 @@ static int* slot(const char* name) {
   if (!strcmp(name, "debug")) return &o.debug;
   if (!strcmp(name, "chol_lookahead")) return &o.chol_lookahead;
   if (!strcmp(name, "chol_regpanel")) return &o.chol_regpanel;
+  if (!strcmp(name, "gram_strips")) return &o.gram_strips;
   if (!strcmp(name, "conv_epi_staged")) return &o.conv_epi_staged;
   if (!strcmp(name, "conv_halo")) return &o.conv_halo;
   if (!strcmp(name, "conv_halo2")) return &o.conv_halo2;
