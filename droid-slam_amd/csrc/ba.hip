@@ -226,8 +226,24 @@ __global__ __launch_bounds__(256) void ba_build_kernel(
   }
 
   const int e0 = eoff[k], e1 = eoff[k + 1];
+  // targets / weights of the NEXT edge travel from HBM while this edge is being reduced
+  float tw[PPT][4];
+  auto fetch_tw = [&](int e, float (&o)[PPT][4]) {
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+      const int p = ok[q] ? px[q] : 0;
+      o[q][0] = targets[((long)e * 2 + 0) * HW + p];
+      o[q][1] = targets[((long)e * 2 + 1) * HW + p];
+      o[q][2] = weights[((long)e * 2 + 0) * HW + p];
+      o[q][3] = weights[((long)e * 2 + 1) * HW + p];
+    }
+  };
+  int e = e0 < e1 ? eidx[e0] : 0;
+  if (e0 < e1) fetch_tw(e, tw);
   for (int ei = e0; ei < e1; ++ei) {
-    const int e = eidx[ei];
+    const int e_next = eidx[min(ei + 1, e1 - 1)];
+    float ntw[PPT][4];
+    fetch_tw(e_next, ntw);
     const int j = (int)jj[e];
     const EdgeGeom g = edge_geom(poses, f, j);
     float hj[21], vj[6];
@@ -238,9 +254,9 @@ __global__ __launch_bounds__(256) void ba_build_kernel(
 #pragma unroll
     for (int q = 0; q < PPT; ++q) {
       const int p = ok[q] ? px[q] : 0;
-      const float tu = targets[((long)e * 2 + 0) * HW + p], tv = targets[((long)e * 2 + 1) * HW + p];
-      const float wu0 = ok[q] ? weights[((long)e * 2 + 0) * HW + p] : 0.f;
-      const float wv0 = ok[q] ? weights[((long)e * 2 + 1) * HW + p] : 0.f;
+      const float tu = tw[q][0], tv = tw[q][1];
+      const float wu0 = ok[q] ? tw[q][2] : 0.f;
+      const float wv0 = ok[q] ? tw[q][3] : 0.f;
       PixTerms t = pix_terms(g.T, Xn[q], Yn[q], h[q], tu, tv, wu0, wv0, fx, fy, cx, cy);
       if (!MOTION_ONLY) {
         Cs[q] += t.wu * t.Jzu * t.Jzu + t.wv * t.Jzv * t.Jzv;
@@ -266,21 +282,27 @@ __global__ __launch_bounds__(256) void ba_build_kernel(
         }
       }
     }
-    // block reduction of the 27 per-edge sums: wave shuffles, then 4 waves through LDS
+    // block reduction of the 27 per-edge sums: seven 4-way wave reductions (rows of the result register hold the
+    // totals of values 4i, 4i+2, 4i+1, 4i+3), then the 4 waves through LDS
+    float r4[7];
 #pragma unroll
-    for (int l = 0; l < 21; ++l) hj[l] = wave_sum(hj[l]);
-#pragma unroll
-    for (int n = 0; n < 6; ++n) vj[n] = wave_sum(vj[n]);
+    for (int i = 0; i < 5; ++i) r4[i] = wave_sum4(hj[4 * i], hj[4 * i + 1], hj[4 * i + 2], hj[4 * i + 3]);
+    r4[5] = wave_sum4(hj[20], vj[0], vj[1], vj[2]);
+    r4[6] = wave_sum4(vj[3], vj[4], vj[5], 0.f);
     __syncthreads();
-    if (lane == 0) {
+    if ((lane & 15) == 0) {
+      const int row = lane >> 4, sub = ((row & 1) << 1) | (row >> 1);       // row 0,1,2,3 -> value 0,2,1,3 of the group
 #pragma unroll
-      for (int l = 0; l < 21; ++l) s_red[wave][l] = hj[l];
-#pragma unroll
-      for (int n = 0; n < 6; ++n) s_red[wave][21 + n] = vj[n];
+      for (int i = 0; i < 7; ++i) s_red[wave][4 * i + sub] = r4[i];
     }
     __syncthreads();
     if (tid < 27)
       Hpart[((long)e * NS + strip) * HP_STRIDE + tid] = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
+    e = e_next;
+#pragma unroll
+    for (int q = 0; q < PPT; ++q)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) tw[q][c] = ntw[q][c];
   }
 
   if (!MOTION_ONLY) {

@@ -173,7 +173,28 @@ __device__ __forceinline__ void se3_log(const SE3f& T, float* xi) {
 // exp(xi) * T
 __device__ __forceinline__ SE3f retr(const float* xi, const SE3f& T) { return mul(se3_exp(xi), T); }
 
-// ---- wave64 reductions (DPP-backed shuffles) -------------------------------------------------
+// ---- wave64 reductions -------------------------------------------------------------------------
+// sum over the 16 lanes of a DPP row, left in every lane of the row (4 VALU adds with DPP operands, no LDS crossbar)
+__device__ __forceinline__ float row_sum16(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, true));   // row_ror:4
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, true));   // row_ror:8
+  return v;
+}
+
+// Four wave sums for the price of (almost) one: v_permlane32_swap / v_permlane16_swap (gfx950) pair the values up so
+// that each halving step also halves the number of registers.  Returns a register whose DPP rows 0..3 hold, in every
+// lane of the row, the wave totals of a, c, b, d (in that order).
+__device__ __forceinline__ float wave_sum4(float a, float b, float c, float d) {
+  auto x = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  auto y = __builtin_amdgcn_permlane32_swap(__float_as_uint(c), __float_as_uint(d), false, false);
+  const float xs = __uint_as_float(x[0]) + __uint_as_float(x[1]);      // lanes 0..31: a, lanes 32..63: b
+  const float ys = __uint_as_float(y[0]) + __uint_as_float(y[1]);      //              c                d
+  auto z = __builtin_amdgcn_permlane16_swap(__float_as_uint(xs), __float_as_uint(ys), false, false);
+  return row_sum16(__uint_as_float(z[0]) + __uint_as_float(z[1]));     // rows: a, c, b, d
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
