@@ -25,6 +25,7 @@
 // level); everything else is deterministic.
 #include "common.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace {
 
@@ -446,7 +447,7 @@ __device__ __forceinline__ void gram_mfma(const GramCols& CA, const GramCols& CB
 #pragma unroll
     for (int ti = 0; ti < NA; ++ti)
 #pragma unroll
-      for (int tj = 0; tj < 4; ++tj)
+      for (int tj = 0; tj < (NBT ? NBT : NA); ++tj)
         if (NBT != 0 || tj >= ti)
           acc[ti * 4 + tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ti], bb[tj], acc[ti * 4 + tj], 0, 0, 0);
   }
@@ -473,7 +474,7 @@ __device__ __forceinline__ void gram_accumulate(const GramCols& CA, const GramCo
 }
 
 // the waves' partial Grams (tiles ti0 .. ti0 + NA - 1 of the rows) summed into s_out in a fixed order
-template <int NA>
+template <int NA, int NTJ>
 __device__ __forceinline__ void gram_reduce(float* __restrict__ s_out, const f32x4 (&acc)[NA * 4], int ti0, bool upper_only,
                                             int wave, int lane) {
   for (int w = 0; w < 4; ++w) {
@@ -482,7 +483,7 @@ __device__ __forceinline__ void gram_reduce(float* __restrict__ s_out, const f32
 #pragma unroll
       for (int ti = 0; ti < NA; ++ti)
 #pragma unroll
-        for (int tj = 0; tj < 4; ++tj) {
+        for (int tj = 0; tj < NTJ; ++tj) {
           if (upper_only && tj < ti0 + ti) continue;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -495,7 +496,11 @@ __device__ __forceinline__ void gram_reduce(float* __restrict__ s_out, const f32
   }
 }
 
-__global__ __launch_bounds__(256, 2) void ba_gram_kernel(
+// DIAG: the products of every chunk with itself (all there is for a depth block with at most GS - 1 edges); !DIAG: the
+// chunk pairs of the larger blocks.  Two kernels so that the common one is compiled for its own, smaller register budget
+// (4 waves per SIMD: the pixel loop lives on memory-level parallelism).
+template <bool DIAG>
+__global__ __launch_bounds__(256, DIAG ? 4 : 2) void ba_gram_kernel(
     const float* __restrict__ Q, const float* __restrict__ W, const float* __restrict__ Ei,
     const float* __restrict__ Ej, const int64_t* __restrict__ jj, const int* __restrict__ kx,
     const int* __restrict__ eoff, const int* __restrict__ eidx, const int* __restrict__ meta,
@@ -518,18 +523,23 @@ __global__ __launch_bounds__(256, 2) void ba_gram_kernel(
   __shared__ const float* s_col[2][GCOLS];      // per-column source rows (nullptr = zero column)
   const float* Qk = Q + (long)k * HW;
 
+  if (!DIAG && nchunks < 2) return;
+  const int g = lane >> 4;
   for (int ca = 0; ca < nchunks; ++ca) {
-    for (int cb = ca; cb < nchunks; ++cb) {
-      const bool same = ca == cb;
+    for (int cb = DIAG ? ca : ca + 1; cb < (DIAG ? ca + 1 : nchunks); ++cb) {
+      constexpr bool same = DIAG;
+      // slots of the two chunks; the w column (DIAG only) sits right behind the last real column, so a short chunk is a
+      // short product: only the 16-column tiles that hold something are multiplied
+      const int nsa = min(GS, nslots - ca * GS), nsb = min(GS, nslots - cb * GS);
+      const int nta = (6 * nsa + (DIAG ? 1 : 0) + 15) / 16, ntb = (6 * nsb + 15) / 16;
       __syncthreads();
       if (tid < 2 * GCOLS) {
-        const int which = tid / GCOLS, col = tid % GCOLS, c = which ? cb : ca;
+        const int which = tid / GCOLS, col = tid % GCOLS, c = which ? cb : ca, ns = which ? nsb : nsa;
         const float* ptr = nullptr;
-        if (col < 6 * GS) {
+        if (col < 6 * ns) {
           const int sl = c * GS + col / 6, a = col % 6;
-          if (sl < nslots)
-            ptr = (sl == 0) ? Ei + ((long)k * 6 + a) * HW : Ej + ((long)eidx[e0 + sl - 1] * 6 + a) * HW;
-        } else if (col == 6 * GS) {
+          ptr = (sl == 0) ? Ei + ((long)k * 6 + a) * HW : Ej + ((long)eidx[e0 + sl - 1] * 6 + a) * HW;
+        } else if (DIAG && col == 6 * ns) {
           ptr = W + (long)k * HW;
         }
         s_col[which][col] = ptr;
@@ -556,33 +566,59 @@ __global__ __launch_bounds__(256, 2) void ba_gram_kernel(
         CA.p[t] = pa ? pa : Qk;                 // a column that does not exist reads Q (in bounds) and is masked to 0
         CB.p[t] = pb ? pb : Qk;
       }
-      const int g = lane >> 4;
       if (same) {
-        f32x4 acc[16];
+        auto diag = [&](auto nt_c) {
+          constexpr int NT = decltype(nt_c)::value;
+          f32x4 acc[NT * 4];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (vec4) gram_accumulate<true, 4, 0, 0>(CA, CB, Qk, p_begin, p_end, wave, g, acc);
-        else gram_accumulate<false, 4, 0, 0>(CA, CB, Qk, p_begin, p_end, wave, g, acc);
-        gram_reduce<4>(s_out, acc, 0, true, wave, lane);
+          for (int t = 0; t < NT * 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+          gram_accumulate<true, NT, 0, 0>(CA, CB, Qk, p_begin, p_end, wave, g, acc);
+          gram_reduce<NT, NT>(s_out, acc, 0, true, wave, lane);
+        };
+        if (!vec4) {
+          f32x4 acc[16];
+#pragma unroll
+          for (int t = 0; t < 16; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+          gram_accumulate<false, 4, 0, 0>(CA, CB, Qk, p_begin, p_end, wave, g, acc);
+          gram_reduce<4, 4>(s_out, acc, 0, true, wave, lane);
+        } else if (nta == 1) diag(std::integral_constant<int, 1>{});
+        else if (nta == 2) diag(std::integral_constant<int, 2>{});
+        else if (nta == 3) diag(std::integral_constant<int, 3>{});
+        else diag(std::integral_constant<int, 4>{});
       } else {
-        // two chunks against each other (a depth block with more than GS - 1 edges): all 16 tiles are needed; two passes of
-        // 8 keep the register budget -- and with it the occupancy -- of the common single-chunk case
-        f32x4 acc[8];
+        // two chunks against each other (a depth block with more than GS - 1 edges): passes of two A tiles keep the register
+        // budget low; the second pass shifts A tiles 2, 3 into the places of 0, 1
+        for (int pass = 0; pass < 2 && 2 * pass < nta; ++pass) {
+          if (pass == 1) { CA.p[0] = CA.p[2]; CA.p[1] = CA.p[3]; CA.valid >>= 2; }
+          const int na = min(2, nta - 2 * pass);
+          auto off = [&](auto na_c, auto nb_c) {
+            constexpr int NA = decltype(na_c)::value, NBT = decltype(nb_c)::value;
+            f32x4 acc[NA * 4];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (vec4) gram_accumulate<true, 2, 4, 0>(CA, CB, Qk, p_begin, p_end, wave, g, acc);
-        else gram_accumulate<false, 2, 4, 0>(CA, CB, Qk, p_begin, p_end, wave, g, acc);
-        gram_reduce<2>(s_out, acc, 0, false, wave, lane);
+            for (int t = 0; t < NA * 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            gram_accumulate<true, NA, NBT, 0>(CA, CB, Qk, p_begin, p_end, wave, g, acc);
+            gram_reduce<NA, NBT>(s_out, acc, 2 * pass, false, wave, lane);
+          };
+          using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+          using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>;
+          if (!vec4) {
+            f32x4 acc[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (vec4) gram_accumulate<true, 2, 4, 2>(CA, CB, Qk, p_begin, p_end, wave, g, acc);
-        else gram_accumulate<false, 2, 4, 2>(CA, CB, Qk, p_begin, p_end, wave, g, acc);
-        gram_reduce<2>(s_out, acc, 2, false, wave, lane);
+            for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            gram_accumulate<false, 2, 4, 0>(CA, CB, Qk, p_begin, p_end, wave, g, acc);
+            gram_reduce<2, 4>(s_out, acc, 2 * pass, false, wave, lane);
+          } else if (na == 1) {
+            if (ntb == 1) off(I1{}, I1{}); else if (ntb == 2) off(I1{}, I2{}); else if (ntb == 3) off(I1{}, I3{}); else off(I1{}, I4{});
+          } else {
+            if (ntb == 1) off(I2{}, I1{}); else if (ntb == 2) off(I2{}, I2{}); else if (ntb == 3) off(I2{}, I3{}); else off(I2{}, I4{});
+          }
+        }
       }
       __syncthreads();
-      // G[row=(slot a, r)][col=(slot b, c)] -> S block (pose_a, pose_b); column 6*GS = E Q w
-      for (int o = tid; o < 6 * GS * 6 * GS; o += 256) {
-        const int row = o / (6 * GS), col = o % (6 * GS);
+      // G[row=(slot a, r)][col=(slot b, c)] -> S block (pose_a, pose_b); column 6 nsa = E Q w
+      for (int o = tid; o < 6 * nsa * 6 * (same ? nsa : nsb); o += 256) {
+        const int ncol = 6 * (same ? nsa : nsb);
+        const int row = o / ncol, col = o % ncol;
         const int pa = s_pose[0][row / 6], pbq = s_pose[same ? 0 : 1][col / 6];
         if (pa < 0 || pbq < 0) continue;
         const bool lower = same && (col >> 4) < (row >> 4);
@@ -591,9 +627,9 @@ __global__ __launch_bounds__(256, 2) void ba_gram_kernel(
         if (!same) atomicAdd(&H[(long)(6 * pbq + col % 6) * ld + 6 * pa + row % 6], -v);
       }
       if (same) {
-        for (int o = tid; o < 6 * GS; o += 256) {
+        for (int o = tid; o < 6 * nsa; o += 256) {
           const int pa = s_pose[0][o / 6];
-          if (pa >= 0) atomicAdd(&H[(long)brow * ld + 6 * pa + o % 6], -(double)s_out[o * GCOLS + 6 * GS]);
+          if (pa >= 0) atomicAdd(&H[(long)brow * ld + 6 * pa + o % 6], -(double)s_out[o * GCOLS + 6 * nsa]);
         }
       }
     }
@@ -1312,13 +1348,19 @@ int run_build(const BaLayout& L, char* ws, const float* poses, const float* disp
   }
   if (!motion_only && L.P > 0) {
     const int kest = std::max(1, std::min(F, L.P + E));
-    // ~4 workgroups per CU hide the HBM latency of the operand loads; every extra strip multiplies the fp64 atomics
-    int NSG = std::max(1, std::min((1024 + kest - 1) / kest, std::max(1, HW / 256)));
+    // ~8 workgroups per CU (4 resident) hide the HBM latency of the operand loads; every extra strip multiplies the fp64 atomics
+    int NSG = std::max(1, std::min((2048 + kest - 1) / kest, std::max(1, HW / 256)));
     if (opts().gram_strips > 0) NSG = std::min(opts().gram_strips, std::max(1, HW / 64));
-    hipLaunchKernelGGL(ba_gram_kernel, dim3(F, NSG), dim3(256), 0, st, (const float*)(ws + L.Q),
+    hipLaunchKernelGGL(ba_gram_kernel<true>, dim3(F, NSG), dim3(256), 0, st, (const float*)(ws + L.Q),
                        (const float*)(ws + L.W), (const float*)(ws + L.Ei), (const float*)(ws + L.Ej), jj, kx,
                        eoff, eidx, meta, HW, NSG, t0, L.P, H, L.ld, L.npad);
     DH_LAUNCH_CHECK();
+    if (E + F > GS - 1) {                                  // a depth block can only have a second chunk with GS or more slots
+      hipLaunchKernelGGL(ba_gram_kernel<false>, dim3(F, NSG), dim3(256), 0, st, (const float*)(ws + L.Q),
+                         (const float*)(ws + L.W), (const float*)(ws + L.Ei), (const float*)(ws + L.Ej), jj, kx,
+                         eoff, eidx, meta, HW, NSG, t0, L.P, H, L.ld, L.npad);
+      DH_LAUNCH_CHECK();
+    }
   }
   return DH_OK;
 }
