@@ -1362,6 +1362,36 @@ int launch(const ConvParams& P, hipStream_t st) {
   return DH_ERR_ARG;
 }
 
+// ---- global-context terms of the gates: the three 1x1 convolutions on the pixel mean (gru.py:21-27) as one GEMV -------
+// out[e][n] = fp16( bias[n] + sum_k fp16(red[e][k] * scale) * wt[k][n] ),  n < N = 384 (z | r | q), k < 128; wt is k-major
+// so that thread n reads it coalesced.  16 edges per workgroup share the weight reads.
+constexpr int GV_EDGES = 16;
+__global__ __launch_bounds__(384) void glo_gemv_kernel(const float* __restrict__ red, const float* __restrict__ wt,
+                                                       const float* __restrict__ bias, float* __restrict__ out,
+                                                       int E, int N, float scale) {
+  __shared__ float s_g[GV_EDGES][128];
+  const int e0 = blockIdx.x * GV_EDGES, n = threadIdx.x;
+  for (int o = threadIdx.x; o < GV_EDGES * 128; o += blockDim.x) {
+    const int e = e0 + (o >> 7);
+    s_g[o >> 7][o & 127] = e < E ? __half2float(__float2half(red[(long)e * 128 + (o & 127)] * scale)) : 0.f;
+  }
+  __syncthreads();
+  if (n >= N) return;
+  float acc[GV_EDGES];
+  const float b = bias[n];
+#pragma unroll
+  for (int i = 0; i < GV_EDGES; ++i) acc[i] = b;
+#pragma unroll 4
+  for (int k = 0; k < 128; ++k) {
+    const float wv = wt[(long)k * N + n];
+#pragma unroll
+    for (int i = 0; i < GV_EDGES; ++i) acc[i] = fmaf(s_g[i][k], wv, acc[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < GV_EDGES; ++i)
+    if (e0 + i < E) out[(long)(e0 + i) * N + n] = __half2float(__float2half(acc[i]));
+}
+
 }  // namespace
 
 extern "C" int dh_conv2d_nhwc_f16_ex(const void* const* inputs, const int* in_channels, const int* in_strides, int n_inputs,
@@ -1473,6 +1503,17 @@ extern "C" int dh_conv2d_nhwc_f16(const void* const* inputs, const int* in_chann
   return dh_conv2d_nhwc_f16_ex(inputs, in_channels, in_strides, n_inputs, weights, weights_halo, bias, N, H, W, KH, KW, Cout,
                                CoutPad, Kpad, epilogue, out, out_is_f32, out_stride, gterm, aux0, aux0_stride, aux1, aux1_stride,
                                red, nullptr, nullptr, 0, 0, stream);
+}
+
+extern "C" int dh_glo_gemv(const float* red, const float* wt, const float* bias, float* out, int E, int N, float scale,
+                           dh_stream_t stream) {
+  if (E < 0 || N <= 0 || N > 384) return DH_ERR_ARG;
+  if (E == 0) return DH_OK;
+  if (!red || !wt || !bias || !out) return DH_ERR_ARG;
+  hipLaunchKernelGGL(glo_gemv_kernel, dim3((unsigned)((E + GV_EDGES - 1) / GV_EDGES)), dim3(384), 0, (hipStream_t)stream, red, wt,
+                     bias, out, E, N, scale);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
 }
 
 extern "C" int dh_heads_gather(const float* partials, const float* bias4, float* dw, int N, int H, int W, int n_cout_tiles, dh_stream_t stream) {

@@ -318,6 +318,18 @@ torch::Tensor corr_pyramid_lookup_nhwc(torch::Tensor pyramid, torch::Tensor coor
   return out;
 }
 
+torch::Tensor glo_gemv(torch::Tensor red, torch::Tensor wt, torch::Tensor bias, double scale) {
+  CHECK_INPUT(red); CHECK_INPUT(wt); CHECK_INPUT(bias);
+  TORCH_CHECK(red.scalar_type() == torch::kFloat32 && red.dim() == 2 && red.size(1) == 128, "glo_gemv: red [E,128] float32");
+  TORCH_CHECK(wt.scalar_type() == torch::kFloat32 && wt.dim() == 2 && wt.size(0) == 128, "glo_gemv: wt [128,N] float32");
+  const int64_t E = red.size(0), N = wt.size(1);
+  TORCH_CHECK(bias.scalar_type() == torch::kFloat32 && bias.numel() == N && N <= 384, "glo_gemv: bias [N], N <= 384");
+  torch::Tensor out = torch::empty({E, N}, red.options());
+  check_status(dh_glo_gemv(red.data_ptr<float>(), wt.data_ptr<float>(), bias.data_ptr<float>(), out.data_ptr<float>(), (int)E, (int)N,
+                           (float)scale, cur_stream()), "glo_gemv");
+  return out;
+}
+
 torch::Tensor segment_mean(torch::Tensor x, torch::Tensor order, torch::Tensor seg_off) {
   CHECK_INPUT(x); CHECK_INPUT(order); CHECK_INPUT(seg_off); CHECK_I64(order); CHECK_I64(seg_off);
   TORCH_CHECK(x.scalar_type() == torch::kFloat16 && x.dim() >= 2, "segment_mean: x [E,...] float16");
@@ -530,6 +542,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("corr_pyramid_build", &corr_pyramid_build, "all-pairs correlation pyramid, MI355X layout");
   m.def("corr_pyramid_lookup", &corr_pyramid_lookup, "fused 4-level lookup on the MI355X pyramid");
   m.def("corr_pyramid_lookup_nhwc", &corr_pyramid_lookup_nhwc, "fused 4-level lookup, channel-last output for the update operator");
+  m.def("glo_gemv", &glo_gemv, "global-context GEMV of the ConvGRU gates: fp16(bias + fp16(red * scale) wt)");
   m.def("segment_mean", &segment_mean, "mean over row segments (GraphAgg scatter_mean)");
   m.def("conv2d_nhwc", &conv2d_nhwc, "implicit-GEMM NHWC convolution on the fp16 MFMA with fused epilogues",
         py::arg("inputs"), py::arg("weight"), py::arg("weight_halo"), py::arg("bias"), py::arg("KH"), py::arg("KW"), py::arg("Cout"),

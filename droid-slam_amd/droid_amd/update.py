@@ -200,6 +200,9 @@ class UpdateModule:
         P["ctx"] = _Conv(*pack_conv(wctx, torch.zeros(384, device=self.device)), 3, 384, pack_conv_halo(wctx))
         for n in ("z", "r", "q"):
             P["glo_" + n] = (g("gru.conv%s_glo.weight" % n).float().reshape(128, 128), g("gru.conv%s_glo.bias" % n).float())
+        # k-major weights of the global-context GEMVs (droid_backends.glo_gemv): z | r together, q on its own
+        P["glo_zr_t"] = (torch.cat([P["glo_z"][0], P["glo_r"][0]], 0).t().contiguous(), torch.cat([P["glo_z"][1], P["glo_r"][1]]).contiguous())
+        P["glo_q_t"] = (P["glo_q"][0].t().contiguous(), P["glo_q"][1].contiguous())
         # the two head stems (delta.0 | weight.0) share their input: one convolution with 256 outputs;
         # the two 2-channel heads become one block-diagonal convolution on those 256 channels
         wh0 = torch.cat([g("delta.0.weight"), g("weight.0.weight")], 0)
@@ -235,6 +238,18 @@ class UpdateModule:
         forward_nhwc recomputes it on every call unless the caller passes it in."""
         return self.params["ctx"]([inp_frames], EPI_LINEAR, out_raw_f32=True)
 
+    def segments(self, ii):
+        """edges grouped by source frame for GraphAgg's mean (droid_net.py:66-67): (order [E], seg_off [K+1]).  Depends on the
+        edge list only, so it is kept until `ii` changes (torch.unique has to synchronise to size its result)."""
+        key = (ii.data_ptr(), ii._version, ii.numel(), ii.device)
+        if getattr(self, "_seg_key", None) != key:
+            _, ix, cnt = torch.unique(ii, return_inverse=True, return_counts=True)
+            order = torch.argsort(ix, stable=True)
+            seg_off = torch.zeros(cnt.numel() + 1, dtype=torch.int64, device=ii.device)
+            seg_off[1:] = torch.cumsum(cnt, 0)
+            self._seg_key, self._seg = key, (order, seg_off, ii)       # (ii kept alive: its address is part of the key)
+        return self._seg[0], self._seg[1]
+
     def forward_nhwc(self, net, inp, corr, flow, ii, inp_frames=None, inp_index=None, ctx=None):
         """net [E,h,w,128] f16 (updated IN PLACE), corr [4,E,h,w,56] f16 = the level-planar channel-last output of
         droid_backends.corr_pyramid_lookup_nhwc (channel order: corr_channel_map), flow [E,h,w,8] f16 (4 + zero pad),
@@ -251,19 +266,18 @@ class UpdateModule:
         # global context: mean over pixels of sigmoid(w(net)) * net, then three 128x128 GEMVs per edge
         red = torch.zeros(E, 128, dtype=torch.float32, device=net.device)
         P["gru_w"]([net], EPI_GLO, aux0=net, red=red)
-        glo = (red / float(h * w)).half().float()
-        gz, gr, gq = (torch.addmm(P["glo_" + n][1], glo, P["glo_" + n][0].t()).half().float() for n in ("z", "r", "q"))
-        gzr = torch.cat([gz, gr], 1).contiguous()
+        gzr = droid_backends.glo_gemv(red, P["glo_zr_t"][0], P["glo_zr_t"][1], 1.0 / float(h * w))     # [E,256] z | r
+        gq = droid_backends.glo_gemv(red, P["glo_q_t"][0], P["glo_q_t"][1], 1.0 / float(h * w))        # [E,128]
         if inp is None and not (w == 64 and h % 4 == 0):
             inp = inp_frames[inp_index]        # image shape outside the production kernel: the reference's data flow
         if inp is not None:
             zr = P["zr"]([net, inp, c, f], EPI_GRU_ZR, gterm=gzr, aux0=net)             # [E,h,w,256] = z | r*net
-            P["q"]([zr[..., 128:], inp, c, f], EPI_GRU_Q, out=net, gterm=gq.contiguous(), aux0=net, aux1=zr)
+            P["q"]([zr[..., 128:], inp, c, f], EPI_GRU_Q, out=net, gterm=gq, aux0=net, aux1=zr)
         else:
             if ctx is None:
                 ctx = self.context_term(inp_frames)
             zr = P["zr_e"]([net, c, f], EPI_GRU_ZR, gterm=gzr, aux0=net, cinit=ctx, cinit_idx=inp_index, cinit_off=0)
-            P["q_e"]([zr[..., 128:], c, f], EPI_GRU_Q, out=net, gterm=gq.contiguous(), aux0=net, aux1=zr,
+            P["q_e"]([zr[..., 128:], c, f], EPI_GRU_Q, out=net, gterm=gq, aux0=net, aux1=zr,
                      cinit=ctx, cinit_idx=inp_index, cinit_off=256)
         if w == 64 and h % 4 == 0 and droid_backends.get_option("conv_halo") and droid_backends.get_option("conv_halo2"):
             # heads: the 256-channel activations never leave the first layer's kernel (see csrc/conv.hip EPI_HEADS0)
@@ -278,10 +292,7 @@ class UpdateModule:
         self.last_dw = dw                        # (delta_x, delta_y, w_x, w_y) as one tensor for droid_backends.ba_inputs
         # GraphAgg: conv -> mean over the edges of each source frame -> conv -> eta / upmask
         x = P["agg1"]([net], EPI_RELU)
-        _, ix, cnt = torch.unique(ii, return_inverse=True, return_counts=True)
-        order = torch.argsort(ix, stable=True)
-        seg_off = torch.zeros(cnt.numel() + 1, dtype=torch.int64, device=net.device)
-        seg_off[1:] = torch.cumsum(cnt, 0)
+        order, seg_off = self.segments(ii)
         xm = droid_backends.segment_mean(x, order, seg_off)
         x2 = P["agg2"]([xm], EPI_RELU)
         K = xm.shape[0]

@@ -249,6 +249,12 @@ int dh_conv2d_nhwc_f16_ex(const void* const* inputs, const int* in_channels, con
                           float* red, const float* cinit, const int64_t* cinit_idx, int cinit_stride, int cinit_off,
                           dh_stream_t stream);
 
+/* Global-context terms of the ConvGRU gates (reference modules/gru.py:21-27: three 1x1 convolutions on the pixel mean of
+ * sigmoid(w(net)) * net) as one GEMV: out [E,N] f32 = fp16(bias + fp16(red * scale) wt), red [E,128] f32 (pixel SUMS, scale =
+ * 1 / pixels), wt [128,N] f32 k-major, N <= 384 (z | r | q).  Values are rounded to fp16 where autocast rounds them. */
+int dh_glo_gemv(const float* red, const float* wt, const float* bias, float* out, int E, int N, float scale,
+                dh_stream_t stream);
+
 /* GraphAgg's scatter_mean (reference droid_net.py:67, torch_scatter): out[k,:] = mean of the rows x[order[i],:],
  * i in [seg_off[k], seg_off[k+1]); x [E,row_elems] f16, out [K,row_elems] f16, row_elems % 8 == 0. */
 int dh_segment_mean_f16(const void* x, const int64_t* order, const int64_t* seg_off, void* out,

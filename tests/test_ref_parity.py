@@ -89,7 +89,8 @@ def _per_iteration(db, ref, g, eta, t0, t1, iters, lm, ep, mo=False):
 
 
 # ------------------------------------------------------------------------------------------ ba (droid_kernels.cu:1323-1443)
-@pytest.mark.parametrize("case", ["mono", "stereo", "sensor", "t0_3", "many_edges"])
+@pytest.mark.parametrize("case", ["mono", "stereo", "sensor", "t0_3", "many_edges", "three_chunks", "short_second_chunk",
+                                  "odd_hw", "odd_hw_many_edges"])
 def test_ba_small_graphs_vs_reference(db, ref, case):
     kw = dict(n_frames=6, seed=21, ht=12, wd=16)
     t0 = 3 if case == "t0_3" else 1
@@ -97,8 +98,16 @@ def test_ba_small_graphs_vs_reference(db, ref, case):
         kw.update(stereo=True)
     if case == "sensor":
         kw.update(sensor_depth=True)
-    if case == "many_edges":
+    if case == "many_edges":                   # 14 slots per depth block: Gram chunks of 10 + 4 slots
         kw.update(n_frames=14, radius=13)
+    if case == "three_chunks":                 # 24 slots: 10 + 10 + 4, every chunk pair
+        kw.update(n_frames=24, radius=23)
+    if case == "short_second_chunk":           # 12 slots: the second chunk is a single 16-column tile
+        kw.update(n_frames=12, radius=11)
+    if case == "odd_hw":                       # 143 pixels: no 16-byte operand loads, ragged last pixel group
+        kw.update(ht=11, wd=13)
+    if case == "odd_hw_many_edges":
+        kw.update(n_frames=13, radius=12, ht=11, wd=13)
     g = syn.small_graph(**kw)
     _per_iteration(db, ref, g, _eta_for(g, t0, g["n_frames"]), t0, g["n_frames"], 3, 1e-4, 0.1)
 
