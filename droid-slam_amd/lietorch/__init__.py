@@ -6,8 +6,9 @@ inv(), group product, action on homogeneous 4-vectors, adjT(), retr()/exp().  Th
 surface on top of the HIP kernels of libdroid_hip (dh_se3_inv/mul/exp/retr/act4/adjT, semantics of the reference's
 device helpers src/droid_kernels.cu:67-184,886-904); operands are broadcast to a common batch shape and sent to the
 kernels as flat [n,7] arrays.  Inference only (no autograd); tensors must live on the ROCm device.
-log / matrix serve the callers of the path (frontend motion model, trajectory filler, viewers); Sim3 / SO3 are used by
-training and trajectory alignment only and raise NotImplementedError.
+log / matrix serve the callers of the path (frontend motion model, trajectory filler, viewers).  Sim3 (training and trajectory
+alignment only) has its group algebra -- product, inverse, action, matrix -- as plain tensor arithmetic; Sim3.exp / log and
+SO3 raise NotImplementedError.
 """
 import torch
 
@@ -132,15 +133,64 @@ class SE3(_Group):
         return SE3(torch.cat([self.data[..., :3] * s[..., None] if s.dim() else self.data[..., :3] * s, self.data[..., 3:]], -1))
 
 
+def _qmul(a, b):
+    ax, ay, az, aw = a.unbind(-1); bx, by, bz, bw = b.unbind(-1)
+    return torch.stack([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                        aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz], -1)
+
+
+def _qrot(q, v):
+    u, w = q[..., :3], q[..., 3:]
+    t = 2.0 * torch.cross(u, v, dim=-1)
+    return v + w * t + torch.cross(u, t, dim=-1)
+
+
 class Sim3(_Group):
+    """similarity transforms x -> s R(q) x + t, data [...,8] = (t, q = xyzw, s).  Not on the BA update path (the reference
+    constructs Sim3 only in training, geom/losses.py / train.py, and in the Sim3 branch of projective_ops.actp): the group
+    algebra below is plain tensor arithmetic; exp / log (training only) are not provided."""
     manifold_dim = 7
     embedded_dim = 8
 
     def __init__(self, data):
-        super().__init__(data)
+        super().__init__(data.data if isinstance(data, _Group) and data.data.shape[-1] == 8 else
+                         (torch.cat([data.data, torch.ones_like(data.data[..., :1])], -1) if isinstance(data, _Group) else data))
+
+    @staticmethod
+    def Identity(*shape, device="cuda", dtype=torch.float32):
+        d = torch.zeros(*shape, 8, device=device, dtype=dtype)
+        d[..., 6] = 1.0; d[..., 7] = 1.0
+        return Sim3(d)
+
+    def inv(self):
+        t, q, s = self.data[..., :3], self.data[..., 3:7], self.data[..., 7:]
+        qi = torch.cat([-q[..., :3], q[..., 3:]], -1)
+        return Sim3(torch.cat([-_qrot(qi, t) / s, qi, 1.0 / s], -1))
 
     def __mul__(self, other):
-        raise NotImplementedError("Sim3 is used by training / evaluation only (SURVEY.md Appendix C)")
+        a, b = torch.broadcast_tensors(self.data, other.data)
+        t = a[..., 7:] * _qrot(a[..., 3:7], b[..., :3]) + a[..., :3]
+        return Sim3(torch.cat([t, _qmul(a[..., 3:7], b[..., 3:7]), a[..., 7:] * b[..., 7:]], -1))
+
+    def act(self, X):
+        """homogeneous points [...,4] (projective_ops.py:94 convention: translation scaled by the 4th coordinate)"""
+        d = self.data
+        while d.dim() < X.dim():
+            d = d[..., None, :]
+        p = d[..., 7:] * _qrot(d[..., 3:7].expand(X.shape[:-1] + (4,)), X[..., :3]) + d[..., :3] * X[..., 3:]
+        return torch.cat([p, X[..., 3:]], -1)
+
+    def matrix(self):
+        M = SE3(self.data[..., :7]).matrix()
+        M[..., :3, :3] = M[..., :3, :3] * self.data[..., 7:, None]
+        return M
+
+    @staticmethod
+    def exp(xi):
+        raise NotImplementedError("Sim3.exp is used by training only (SURVEY.md Appendix C)")
+
+    def log(self):
+        raise NotImplementedError("Sim3.log is used by training / evaluation only (SURVEY.md Appendix C)")
 
 
 class SO3(_Group):

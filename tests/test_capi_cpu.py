@@ -97,6 +97,26 @@ def test_dropin_packages_import_and_torch_scatter_semantics(built):
     assert torch.allclose(torch_scatter.scatter_mean(x, ix, dim=0), torch.stack([x[[0, 2]].mean(0), x[1], x[3:].mean(0)]))
 
 
+def test_sim3_group_algebra(built):
+    """Sim3 (training / trajectory alignment only; plain tensor arithmetic): product, inverse and action against 4x4 matrices"""
+    import lietorch
+    torch.manual_seed(0)
+
+    def rnd(n):
+        d = torch.randn(n, 8, dtype=torch.float64)
+        d[:, 3:7] /= d[:, 3:7].norm(dim=-1, keepdim=True); d[:, 7] = d[:, 7].abs() + 0.5
+        return lietorch.Sim3(d)
+    a, b = rnd(5), rnd(5)
+    Ma, Mb = a.matrix(), b.matrix()
+    assert (Ma @ Mb - (a * b).matrix()).abs().max() < 1e-12
+    assert (torch.linalg.inv(Ma) - a.inv().matrix()).abs().max() < 1e-12
+    X = torch.randn(5, 7, 4, dtype=torch.float64)
+    assert ((Ma[:, None] @ X[..., None])[..., 0] - a.act(X)).abs().max() < 1e-12
+    assert torch.equal(lietorch.Sim3.Identity(2, device="cpu").data[0], torch.tensor([0, 0, 0, 0, 0, 0, 1.0, 1.0]))
+    with pytest.raises(NotImplementedError):
+        a.log()
+
+
 def test_unmodified_reference_modules_import_against_this_repo(built):
     """factor_graph.py / depth_video.py / droid_net.py of the reference checkout resolve their whole import closure
     (droid_backends, lietorch, torch_scatter) inside droid-slam_amd/ -- in a subprocess, reference untouched.
