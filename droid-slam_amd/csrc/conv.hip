@@ -1369,11 +1369,11 @@ constexpr int GV_EDGES = 16;
 __global__ __launch_bounds__(384) void glo_gemv_kernel(const float* __restrict__ red, const float* __restrict__ wt,
                                                        const float* __restrict__ bias, float* __restrict__ out,
                                                        int E, int N, float scale) {
-  __shared__ float s_g[GV_EDGES][128];
+  __shared__ float4 s_g[128][GV_EDGES / 4];            // [k][edge]: one k-step reads its 16 edge values as four 16-byte broadcasts
   const int e0 = blockIdx.x * GV_EDGES, n = threadIdx.x;
   for (int o = threadIdx.x; o < GV_EDGES * 128; o += blockDim.x) {
-    const int e = e0 + (o >> 7);
-    s_g[o >> 7][o & 127] = e < E ? __half2float(__float2half(red[(long)e * 128 + (o & 127)] * scale)) : 0.f;
+    const int i = o >> 7, k = o & 127, e = e0 + i;
+    reinterpret_cast<float*>(&s_g[k][0])[i] = e < E ? __half2float(__float2half(red[(long)e * 128 + k] * scale)) : 0.f;
   }
   __syncthreads();
   if (n >= N) return;
@@ -1385,7 +1385,11 @@ __global__ __launch_bounds__(384) void glo_gemv_kernel(const float* __restrict__
   for (int k = 0; k < 128; ++k) {
     const float wv = wt[(long)k * N + n];
 #pragma unroll
-    for (int i = 0; i < GV_EDGES; ++i) acc[i] = fmaf(s_g[i][k], wv, acc[i]);
+    for (int i4 = 0; i4 < GV_EDGES / 4; ++i4) {
+      const float4 gk = s_g[k][i4];
+      acc[4 * i4 + 0] = fmaf(gk.x, wv, acc[4 * i4 + 0]); acc[4 * i4 + 1] = fmaf(gk.y, wv, acc[4 * i4 + 1]);
+      acc[4 * i4 + 2] = fmaf(gk.z, wv, acc[4 * i4 + 2]); acc[4 * i4 + 3] = fmaf(gk.w, wv, acc[4 * i4 + 3]);
+    }
   }
 #pragma unroll
   for (int i = 0; i < GV_EDGES; ++i)
