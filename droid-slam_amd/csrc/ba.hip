@@ -34,7 +34,7 @@ using namespace dh;
 constexpr int NB = 64;            // Cholesky block
 constexpr int PPT = 3;            // pixels per thread in build/backsub strips
 constexpr int STRIP = 256 * PPT;  // pixels per strip
-constexpr int HP_STRIDE = 28;     // per (edge, strip) partial: 21 Hjj + 6 vj (+1 pad)
+constexpr int HP_STRIDE = 28;     // per (edge, strip, wave) partial: 21 Hjj + 6 vj (+1 pad)
 constexpr int GS = 10;            // slots per Gram chunk: 10*6 + 1 (w) = 61 <= 64 MFMA columns
 constexpr int GCOLS = 64;
 constexpr float ALPHA_PRIOR = 0.05f;   // src/droid_kernels.cu:1405
@@ -67,7 +67,7 @@ BaLayout make_layout(int F, int E, int HW, int t0, int t1, int motion_only) {
   L.cursor = take(sizeof(int) * (size_t)F);
   L.eidx = take(sizeof(int) * (size_t)(E > 0 ? E : 1));
   L.meta = take(sizeof(int) * 16);
-  L.Hpart = take(sizeof(float) * (size_t)(E > 0 ? E : 1) * L.NS * HP_STRIDE);
+  L.Hpart = take(sizeof(float) * (size_t)(E > 0 ? E : 1) * L.NS * 4 * HP_STRIDE);
   if (!motion_only) {
     L.Q = take(sizeof(float) * (size_t)F * HW);
     L.W = take(sizeof(float) * (size_t)F * HW);
@@ -208,7 +208,6 @@ __global__ __launch_bounds__(256) void ba_build_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int f = kx[k];
   const float fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
-  __shared__ float s_red[4][HP_STRIDE];
 
   int px[PPT]; bool ok[PPT]; float Xn[PPT], Yn[PPT], h[PPT];
   float Cs[PPT], Ws[PPT], Eacc[PPT][6];
@@ -290,15 +289,14 @@ __global__ __launch_bounds__(256) void ba_build_kernel(
     for (int i = 0; i < 5; ++i) r4[i] = wave_sum4(hj[4 * i], hj[4 * i + 1], hj[4 * i + 2], hj[4 * i + 3]);
     r4[5] = wave_sum4(hj[20], vj[0], vj[1], vj[2]);
     r4[6] = wave_sum4(vj[3], vj[4], vj[5], 0.f);
-    __syncthreads();
+    // every wave leaves its own partial (ba_pose_blocks_kernel sums the NS * 4 of an edge in a fixed order): no LDS, no
+    // barrier -- the waves of a workgroup never wait for each other
     if ((lane & 15) == 0) {
       const int row = lane >> 4, sub = ((row & 1) << 1) | (row >> 1);       // row 0,1,2,3 -> value 0,2,1,3 of the group
+      float* hp = Hpart + (((long)e * NS + strip) * 4 + wave) * HP_STRIDE;
 #pragma unroll
-      for (int i = 0; i < 7; ++i) s_red[wave][4 * i + sub] = r4[i];
+      for (int i = 0; i < 7; ++i) hp[4 * i + sub] = r4[i];
     }
-    __syncthreads();
-    if (tid < 27)
-      Hpart[((long)e * NS + strip) * HP_STRIDE + tid] = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
     e = e_next;
 #pragma unroll
     for (int q = 0; q < PPT; ++q)
@@ -341,7 +339,7 @@ __global__ __launch_bounds__(64) void ba_pose_blocks_kernel(
   if (!vi_ok && !vj_ok) return;
   if (tid < 27) {
     double s = 0;
-    for (int st = 0; st < NS; ++st) s += (double)Hpart[((long)e * NS + st) * HP_STRIDE + tid];
+    for (int st = 0; st < NS * 4; ++st) s += (double)Hpart[((long)e * NS * 4 + st) * HP_STRIDE + tid];       // strips x waves
     if (tid < 21) {
       int a = 0, rem = tid;
       while (rem > a) { rem -= a + 1; ++a; }
@@ -1457,7 +1455,7 @@ extern "C" int dh_ba_build(const float* poses, const float* disps, const float* 
   if (n_edges > 0 && (!targets || !weights || !ii || !jj)) return DH_ERR_ARG;
   if (!motion_only && (!disps_sens || (n_eta_rows > 0 && !eta))) return DH_ERR_ARG;
   const BaLayout L = make_layout(num_frames, n_edges, ht * wd, t0, t1, motion_only);
-  if (workspace_bytes < L.total) return DH_ERR_WORKSPACE;
+  if (workspace_bytes < L.total || ((uintptr_t)workspace & 255)) return DH_ERR_WORKSPACE;   // 16-byte operand loads, fp64 blocks
   char* ws = (char*)workspace;
   hipStream_t st = (hipStream_t)stream;
   rc = run_prep(L, ws, ii, jj, n_edges, num_frames, t0, t1, motion_only ? -1 : n_eta_rows, st);
@@ -1477,7 +1475,7 @@ extern "C" int dh_ba_finish(float* poses, float* disps, const int64_t* jj,
   if (rc != DH_OK) return rc;
   if (!poses || !disps || !workspace) return DH_ERR_ARG;
   const BaLayout L = make_layout(num_frames, n_edges, ht * wd, t0, t1, motion_only);
-  if (workspace_bytes < L.total) return DH_ERR_WORKSPACE;
+  if (workspace_bytes < L.total || ((uintptr_t)workspace & 255)) return DH_ERR_WORKSPACE;   // 16-byte operand loads, fp64 blocks
   if (n_edges > 0 && !jj) return DH_ERR_ARG;
   return run_finish(L, (char*)workspace, poses, disps, jj, num_frames, ht * wd, t0, lm, ep, motion_only,
                     dx_out, dz_out, num_frames, (hipStream_t)stream);
@@ -1497,7 +1495,7 @@ extern "C" int dh_ba_ex(float* poses, float* disps, const float* intrinsics, con
   if (!motion_only && (!disps_sens || (n_eta_rows > 0 && !eta))) return DH_ERR_ARG;
   const int HW = ht * wd;
   const BaLayout L = make_layout(num_frames, n_edges, HW, t0, t1, motion_only);
-  if (workspace_bytes < L.total) return DH_ERR_WORKSPACE;
+  if (workspace_bytes < L.total || ((uintptr_t)workspace & 255)) return DH_ERR_WORKSPACE;   // 16-byte operand loads, fp64 blocks
   char* ws = (char*)workspace;
   hipStream_t st = (hipStream_t)stream;
   rc = run_prep(L, ws, ii, jj, n_edges, num_frames, t0, t1, motion_only ? -1 : n_eta_rows, st);

@@ -124,7 +124,8 @@ int dh_corr_pyramid_lookup_nhwc(const void* pyramid, const float* coords, void* 
  *   ii, jj [E] i64
  *   dx_out [t1-t0,6] f32, dz_out [K,ht*wd] f32 (may be NULL): updates of the LAST iteration
  * Everything (index building, Schur complement, fp64 Cholesky, back-substitution, retraction) runs
- * on the device with no host round trip.  `workspace` must hold dh_ba_workspace_bytes(...) bytes.
+ * on the device with no host round trip.  `workspace` must hold dh_ba_workspace_bytes(...) bytes and be 256-byte aligned
+ * (DH_ERR_WORKSPACE otherwise).
  */
 size_t dh_ba_workspace_bytes(int num_frames, int n_edges, int ht, int wd, int t0, int t1, int motion_only);
 int dh_ba(float* poses, float* disps, const float* intrinsics, const float* disps_sens,
