@@ -1353,7 +1353,7 @@ int run_build(const BaLayout& L, char* ws, const float* poses, const float* disp
                        (const float*)(ws + L.W), (const float*)(ws + L.Ei), (const float*)(ws + L.Ej), jj, kx,
                        eoff, eidx, meta, HW, NSG, t0, L.P, H, L.ld, L.npad);
     DH_LAUNCH_CHECK();
-    if (E + F > GS - 1) {                                  // a depth block can only have a second chunk with GS or more slots
+    if (E >= GS) {                                         // a second chunk takes a depth block with at least GS edges
       hipLaunchKernelGGL(ba_gram_kernel<false>, dim3(F, NSG), dim3(256), 0, st, (const float*)(ws + L.Q),
                          (const float*)(ws + L.W), (const float*)(ws + L.Ei), (const float*)(ws + L.Ej), jj, kx,
                          eoff, eidx, meta, HW, NSG, t0, L.P, H, L.ld, L.npad);
