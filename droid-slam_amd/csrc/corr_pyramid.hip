@@ -423,6 +423,7 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // NHWC workgroups are single waves (nothing is shared between the waves of a strip in that mode), which lets the
 // register allocator use 168 VGPRs at 3 waves/SIMD: the inline-asm tap loads must never be spilled or copied
 // while they are in flight (scripts/audit_asm_loads.py checks the generated ISA for exactly that at build time).
+typedef unsigned int u32x4_nt __attribute__((ext_vector_type(4)));
 template <int W, bool NHWC>
 __global__ __launch_bounds__(NHWC ? 64 : W * 8, NHWC ? 3 : 4) void pyr_lookup_kernel(const __half* __restrict__ pyr, const float* __restrict__ coords,
                                                                __half* __restrict__ out, PyrDims D) {
@@ -591,7 +592,9 @@ __global__ __launch_bounds__(NHWC ? 64 : W * 8, NHWC ? 3 : 4) void pyr_lookup_ke
         const int p = it * 64 + lane;
         const int row = p / PPR, off = p - row * PPR;
         const uint4 v = wtile[p];
-        *reinterpret_cast<uint4*>(lbase + (long)row * W * NHWC_LEVEL_CH + off * 8) = v;
+        // streaming store: the 5.6 GB of lookup output are next read by another kernel, long after they have left every cache;
+        // kept out of L2 they leave it to the pyramid lines that neighbouring blocks share (-2 % measured)
+        __builtin_nontemporal_store(__builtin_bit_cast(u32x4_nt, v), reinterpret_cast<u32x4_nt*>(lbase + (long)row * W * NHWC_LEVEL_CH + off * 8));
       }
       __builtin_amdgcn_s_waitcnt(0xc07f);                        // the tile is reused by the next level
       __builtin_amdgcn_wave_barrier();
@@ -608,7 +611,7 @@ __global__ __launch_bounds__(NHWC ? 64 : W * 8, NHWC ? 3 : 4) void pyr_lookup_ke
         if (it * NTHREADS + NTHREADS <= NPIECES || o < NPIECES) {
           const int sg = o % NBX, row = (o / NBX) % 8, ch = o / (NBX * 8);
           const uint4 val = *reinterpret_cast<const uint4*>(s_out + (ch * 8 + row) * W + (sg ^ (row & (NBX - 1))) * 8);
-          *reinterpret_cast<uint4*>(obase + (long)ch * HW + row * W + sg * 8) = val;
+          __builtin_nontemporal_store(__builtin_bit_cast(u32x4_nt, val), reinterpret_cast<u32x4_nt*>(obase + (long)ch * HW + row * W + sg * 8));
         }
       }
       lds_barrier();
