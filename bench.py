@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-update-op", action="store_true", help="skip the ConvGRU block (diagnostics only)")
     ap.add_argument("--no-lookup", action="store_true", help="skip the correlation pyramid (BA-only diagnostics)")
+    ap.add_argument("--nhwc-lookup", action="store_true", help="A/B: channel-last lookup output (7 pad channels per level) + "
+                    "implicit-GEMM first correlation layer, instead of the reference-layout output + corr0_nchw")
     ap.add_argument("--per-edge-inp", action="store_true", help="context features gathered per edge and convolved with the "
                     "other 320 gate inputs (the reference's data flow) instead of once per source frame (A/B)")
     return ap.parse_args()
@@ -247,6 +249,9 @@ def main():
     ev = lambda: torch.cuda.Event(enable_timing=True)
     lk_ms, up_ms, ba_ms = [], [], []
 
+    # the update operator takes the unpadded reference-layout features where its first layer has the kernel for them
+    ref_layout = upd is not None and upd.wants_reference_layout_corr(ht, wd) and not args.nhwc_lookup
+
     def step(timed):
         """one FactorGraph.update iteration (reference factor_graph.py:214-263)"""
         poses.copy_(poses0); disps.copy_(disps0)
@@ -255,7 +260,7 @@ def main():
         e0.record()
         fused = upd is not None and corr is not None
         # channel-last features straight into the update operator; the reference-layout [E,196,h,w] otherwise
-        feats = (corr.lookup_nhwc(coords1[None]) if fused else corr(coords1[None])[0]) if corr is not None else None
+        feats = (corr.lookup_nhwc(coords1[None]) if (fused and not ref_layout) else corr(coords1[None])[0]) if corr is not None else None
         e1.record()
         if upd is not None and feats is not None:
             flow = db.motion_features(coords1, target_prev)                   # factor_graph.py:221-222
@@ -323,7 +328,7 @@ def main():
         try:
             cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_lookup_pmc.json"))
             pmc = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))             # the latest round's passes
-            variant = "nhwc" if (upd is not None and corr is not None) else "nchw"
+            variant = "nhwc" if (upd is not None and corr is not None and not ref_layout) else "nchw"
             traffic = pmc[variant]["hbm_bytes_per_edge_pixel"] * E * HW
         except (OSError, KeyError, ValueError):
             pass
@@ -340,7 +345,7 @@ def main():
                 "parallelism": "edge-sharded x%d" % world},
             "ms_per_global_ba": ba, "ms_corr_lookup": lk, "ms_update_operator": up,
             "roofline": {"kernel": "pyr_lookup_kernel<64, %s> (1 launch = 4-level pyramid lookup of all edges)" % (
-                "channel-last" if upd is not None and corr is not None else "reference layout"), "bound": "hbm",
+                "channel-last" if (upd is not None and corr is not None and not ref_layout) else "reference layout"), "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch_group": lookup_bytes},

@@ -1396,6 +1396,119 @@ __global__ __launch_bounds__(384) void glo_gemv_kernel(const float* __restrict__
     if (e0 + i < E) out[(long)(e0 + i) * N + n] = __half2float(__float2half(acc[i]));
 }
 
+// ---- corr_encoder.0 on the REFERENCE-layout lookup output: 1x1, 196 -> 128, relu (droid_net.py:83-86) -------------------
+// The channel-last lookup pads every level from 49 to 56 channels so that this convolution can read 16-byte pieces; the
+// reference layout [E,196,h,w] has no padding (392 instead of 448 bytes per pixel leave the lookup, and are read here),
+// but its channels are HW apart.  This kernel turns the tile itself: thread (kg, pg) loads the 8 x 8 block
+// (channels 8 kg .. +7) x (pixels 8 pg .. +7) as eight 16-byte pieces -- a wave touches 4 channel rows x 256 contiguous
+// bytes per load --, transposes it in registers (32 v_perm_b32) and writes eight 16-byte pixel-major pieces to LDS, where
+// the MFMA fragments are plain ds_read_b128 (row stride 432 B: conflict-free).  out[px][co] = relu(b + sum_k x[k][px] w[co][k])
+// with i = cout, j = pixel on the 32x32x16 MFMA (K padded to 208), results staged through LDS for 16-byte stores.
+// Persistent workgroups (one per CU, the weights stay in LDS): tile = 128 pixels of one edge, the next tile's 8 pieces
+// are in flight while this one is multiplied.  HBM-bound: 392 + 256 bytes per pixel.
+constexpr int C0_K = 196, C0_KP = 208, C0_ROWB = 432;              // row stride in bytes (216 halves)
+constexpr int C0_TILE = 128;
+constexpr int C0_LDS_BYTES = 2 * 128 * C0_ROWB;                    // weights + pixel tile (the output tile aliases the pixel tile)
+constexpr int C0_OROWB = 272;                                      // output staging row: 128 couts x 2 B + 16
+
+__global__ __launch_bounds__(512, 2) void corr0_nchw_kernel(const __half* __restrict__ x, const __half* __restrict__ wp,
+                                                            const float* __restrict__ bias, __half* __restrict__ out,
+                                                            int E, int HW) {
+  extern __shared__ __half s_conv[];
+  char* const Ws = reinterpret_cast<char*>(s_conv);
+  char* const Xs = Ws + 128 * C0_ROWB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_per_edge = HW / C0_TILE;
+  const long ntiles = (long)E * tiles_per_edge;
+
+  // weights -> LDS once: [128 couts][208 halves] -> rows of 432 B
+  for (int o = tid; o < 128 * (C0_KP / 8); o += 512) {
+    const int co = o / (C0_KP / 8), pc = o - co * (C0_KP / 8);
+    *reinterpret_cast<uint4*>(Ws + co * C0_ROWB + pc * 16) = *reinterpret_cast<const uint4*>(wp + (long)co * C0_KP + pc * 8);
+  }
+  // staging role: 16 lanes of a DS pass = 4 pixel groups x 4 channel groups (2-way bank conflicts at worst; global side:
+  // 16 pixel groups of one channel row = 256 contiguous bytes)
+  const int pg = ((lane >> 4) & 3) * 4 + (lane & 3), kg = wave * 4 + ((lane >> 2) & 3);
+  const bool stager = kg * 8 < C0_K;                                // kg 0..24
+  // MFMA role: wave -> 32 couts x 64 pixels
+  const int co0 = (wave & 3) * 32, px0 = (wave >> 2) * 64;
+  float bia[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) bia[q] = bias[co0 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5)];
+
+  uint4 P[8];
+  auto fetch = [&](long tile) {
+    const int e = (int)(tile / tiles_per_edge), p0 = (int)(tile - (long)e * tiles_per_edge) * C0_TILE;
+    const __half* src = x + ((long)e * C0_K + kg * 8) * HW + p0 + pg * 8;
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+      P[r] = (stager && kg * 8 + r < C0_K) ? *reinterpret_cast<const uint4*>(src + (long)r * HW) : uint4{0u, 0u, 0u, 0u};
+  };
+  long tile = blockIdx.x;
+  if (tile < ntiles) fetch(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+    // 8 channels x 8 pixels -> 8 pixels x 8 channels
+    if (stager) {
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const uint32_t sel = (p & 1) ? 0x07060302u : 0x05040100u;
+        uint4 o;
+        const uint32_t* P32 = reinterpret_cast<const uint32_t*>(P);
+        o.x = __builtin_amdgcn_perm(P32[1 * 4 + (p >> 1)], P32[0 * 4 + (p >> 1)], sel);
+        o.y = __builtin_amdgcn_perm(P32[3 * 4 + (p >> 1)], P32[2 * 4 + (p >> 1)], sel);
+        o.z = __builtin_amdgcn_perm(P32[5 * 4 + (p >> 1)], P32[4 * 4 + (p >> 1)], sel);
+        o.w = __builtin_amdgcn_perm(P32[7 * 4 + (p >> 1)], P32[6 * 4 + (p >> 1)], sel);
+        *reinterpret_cast<uint4*>(Xs + (pg * 8 + p) * C0_ROWB + kg * 16) = o;
+        if (kg == 24) *reinterpret_cast<uint4*>(Xs + (pg * 8 + p) * C0_ROWB + 25 * 16) = uint4{0u, 0u, 0u, 0u};   // k 200..207
+      }
+    }
+    const long next = tile + gridDim.x;
+    if (next < ntiles) fetch(next);
+    __syncthreads();                                      // the pixel tile (and, first time, the weights) are in LDS
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < C0_KP / 16; ++ks) {
+      const int slot = 2 * ks + (lane >> 5);
+      const half8 wf = *reinterpret_cast<const half8*>(Ws + (co0 + (lane & 31)) * C0_ROWB + slot * 16);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const half8 xf = *reinterpret_cast<const half8*>(Xs + (px0 + t * 32 + (lane & 31)) * C0_ROWB + slot * 16);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xf, acc[t], 0, 0, 0);
+      }
+    }
+    __syncthreads();                                      // every wave has read the pixel tile: the output tile may overwrite it
+    char* const Os = Xs;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int px = px0 + t * 32 + (lane & 31);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = co0 + g * 8 + 4 * (lane >> 5);
+        __half2 h01 = __floats2half2_rn(fmaxf(acc[t][4 * g + 0] + bia[4 * g + 0], 0.f), fmaxf(acc[t][4 * g + 1] + bia[4 * g + 1], 0.f));
+        __half2 h23 = __floats2half2_rn(fmaxf(acc[t][4 * g + 2] + bia[4 * g + 2], 0.f), fmaxf(acc[t][4 * g + 3] + bia[4 * g + 3], 0.f));
+        uint2 v; v.x = __builtin_bit_cast(uint32_t, h01); v.y = __builtin_bit_cast(uint32_t, h23);
+        *reinterpret_cast<uint2*>(Os + px * C0_OROWB + co * 2) = v;
+      }
+    }
+    __syncthreads();
+    {
+      const int e = (int)(tile / tiles_per_edge), p0 = (int)(tile - (long)e * tiles_per_edge) * C0_TILE;
+      __half* dst = out + ((long)e * HW + p0) * 128;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int id = tid + 512 * i, px = id >> 4, sg = id & 15;
+        *reinterpret_cast<uint4*>(dst + (long)px * 128 + sg * 8) = *reinterpret_cast<const uint4*>(Os + px * C0_OROWB + sg * 16);
+      }
+    }
+    __syncthreads();                                      // the output tile is out: the next pixel tile may be written
+  }
+}
+
 }  // namespace
 
 extern "C" int dh_conv2d_nhwc_f16_ex(const void* const* inputs, const int* in_channels, const int* in_strides, int n_inputs,
@@ -1507,6 +1620,25 @@ extern "C" int dh_conv2d_nhwc_f16(const void* const* inputs, const int* in_chann
   return dh_conv2d_nhwc_f16_ex(inputs, in_channels, in_strides, n_inputs, weights, weights_halo, bias, N, H, W, KH, KW, Cout,
                                CoutPad, Kpad, epilogue, out, out_is_f32, out_stride, gterm, aux0, aux0_stride, aux1, aux1_stride,
                                red, nullptr, nullptr, 0, 0, stream);
+}
+
+extern "C" int dh_corr0_nchw_f16(const void* x, const void* wp, const float* bias, void* out, int E, int HW, dh_stream_t stream) {
+  if (E < 0 || HW <= 0 || HW % C0_TILE) return DH_ERR_ARG;
+  if (E == 0) return DH_OK;
+  if (!x || !wp || !bias || !out) return DH_ERR_ARG;
+  DH_LDS_OPTIN(&corr0_nchw_kernel, C0_LDS_BYTES);
+  static int cu_count[64];                                // per device, queried once (hipGetDeviceProperties takes milliseconds)
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+    if (!cu_count[dev]) { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cu_count[dev] = n; }
+    if (cu_count[dev]) cus = cu_count[dev];
+  }
+  const long ntiles = (long)E * (HW / C0_TILE);
+  const unsigned grid = (unsigned)std::min<long>(ntiles, cus);
+  hipLaunchKernelGGL(corr0_nchw_kernel, dim3(grid), dim3(512), C0_LDS_BYTES, (hipStream_t)stream, (const __half*)x, (const __half*)wp,
+                     bias, (__half*)out, E, HW);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
 }
 
 extern "C" int dh_glo_gemv(const float* red, const float* wt, const float* bias, float* out, int E, int N, float scale,

@@ -318,6 +318,18 @@ torch::Tensor corr_pyramid_lookup_nhwc(torch::Tensor pyramid, torch::Tensor coor
   return out;
 }
 
+torch::Tensor corr0_nchw(torch::Tensor x, torch::Tensor wp, torch::Tensor bias) {
+  CHECK_INPUT(x); CHECK_INPUT(wp); CHECK_INPUT(bias);
+  TORCH_CHECK(x.scalar_type() == torch::kFloat16 && x.dim() == 4 && x.size(1) == 196, "corr0_nchw: x [E,196,h,w] float16");
+  TORCH_CHECK(wp.scalar_type() == torch::kFloat16 && wp.dim() == 2 && wp.size(0) == 128 && wp.size(1) == 208, "corr0_nchw: wp [128,208] float16");
+  TORCH_CHECK(bias.scalar_type() == torch::kFloat32 && bias.numel() == 128, "corr0_nchw: bias [128] float32");
+  const int64_t E = x.size(0), h = x.size(2), w = x.size(3);
+  torch::Tensor out = torch::empty({E, h, w, 128}, x.options());
+  check_status(dh_corr0_nchw_f16(x.data_ptr(), wp.data_ptr(), bias.data_ptr<float>(), out.data_ptr(), (int)E, (int)(h * w), cur_stream()),
+               "corr0_nchw");
+  return out;
+}
+
 torch::Tensor glo_gemv(torch::Tensor red, torch::Tensor wt, torch::Tensor bias, double scale) {
   CHECK_INPUT(red); CHECK_INPUT(wt); CHECK_INPUT(bias);
   TORCH_CHECK(red.scalar_type() == torch::kFloat32 && red.dim() == 2 && red.size(1) == 128, "glo_gemv: red [E,128] float32");
@@ -542,6 +554,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("corr_pyramid_build", &corr_pyramid_build, "all-pairs correlation pyramid, MI355X layout");
   m.def("corr_pyramid_lookup", &corr_pyramid_lookup, "fused 4-level lookup on the MI355X pyramid");
   m.def("corr_pyramid_lookup_nhwc", &corr_pyramid_lookup_nhwc, "fused 4-level lookup, channel-last output for the update operator");
+  m.def("corr0_nchw", &corr0_nchw, "corr_encoder.0 (1x1, 196 -> 128, relu) on the reference-layout lookup output [E,196,h,w] -> [E,h,w,128]");
   m.def("glo_gemv", &glo_gemv, "global-context GEMV of the ConvGRU gates: fp16(bias + fp16(red * scale) wt)");
   m.def("segment_mean", &segment_mean, "mean over row segments (GraphAgg scatter_mean)");
   m.def("conv2d_nhwc", &conv2d_nhwc, "implicit-GEMM NHWC convolution on the fp16 MFMA with fused epilogues",

@@ -135,7 +135,8 @@ class FactorGraph:
         if self.corr_impl != "volume":
             raise RuntimeError("update() needs corr_impl='volume' (use update_lowmem for 'alt')")
         if self._native_corr:
-            feats = self.corr.lookup_nhwc(coords1[None])
+            feats = (self.corr(coords1[None])[0] if self.update_op.wants_reference_layout_corr(*coords1.shape[1:3])
+                     else self.corr.lookup_nhwc(coords1[None]))
         else:
             feats = self.update_op.corr_to_nhwc(self.corr(coords1[None])[0])
         dw, damping, upmask, uniq = self._operator(self._net, coords1, self.target[0].contiguous(), feats, ii)

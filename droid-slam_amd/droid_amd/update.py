@@ -175,6 +175,10 @@ class UpdateModule:
         w0p = torch.zeros(128, COR_NHWC, 1, 1, device=self.device)
         w0p[:, cmap >= 0] = w0[:, cmap[cmap >= 0]]
         P["corr0"] = _Conv(*pack_conv(w0p, g("corr_encoder.0.bias")), 1, 128)
+        # the same layer on the reference-layout lookup output [E,196,h,w] (droid_backends.corr0_nchw): [cout][208] fp16
+        w0n = torch.zeros(128, 208, device=self.device)
+        w0n[:, :COR_PLANES] = w0.reshape(128, COR_PLANES)
+        P["corr0_nchw"] = (w0n.half().contiguous(), g("corr_encoder.0.bias").float().contiguous())
         self.cmap = cmap
         P["corr2"] = conv("corr_encoder.2")
         P["flow0"] = conv("flow_encoder.0", 8)
@@ -238,6 +242,13 @@ class UpdateModule:
         forward_nhwc recomputes it on every call unless the caller passes it in."""
         return self.params["ctx"]([inp_frames], EPI_LINEAR, out_raw_f32=True)
 
+    @staticmethod
+    def wants_reference_layout_corr(h, w):
+        """True where forward_nhwc is fastest on the UNPADDED reference-layout correlation features [E,196,h,w]
+        (CorrBlock.__call__ / corr_pyramid_lookup: 392 instead of 448 bytes per pixel leave the lookup): its first layer
+        then transposes its tiles itself (droid_backends.corr0_nchw, 128-pixel tiles)"""
+        return (h * w) % 128 == 0
+
     def segments(self, ii):
         """edges grouped by source frame for GraphAgg's mean (droid_net.py:66-67): (order [E], seg_off [K+1]).  Depends on the
         edge list only, so it is kept until `ii` changes (torch.unique has to synchronise to size its result)."""
@@ -251,7 +262,8 @@ class UpdateModule:
         return self._seg[0], self._seg[1]
 
     def forward_nhwc(self, net, inp, corr, flow, ii, inp_frames=None, inp_index=None, ctx=None):
-        """net [E,h,w,128] f16 (updated IN PLACE), corr [4,E,h,w,56] f16 = the level-planar channel-last output of
+        """net [E,h,w,128] f16 (updated IN PLACE), corr = [E,196,h,w] f16 in the reference's layout (pixel counts that are a
+        multiple of 128) or [4,E,h,w,56] f16, the level-planar channel-last output of
         droid_backends.corr_pyramid_lookup_nhwc (channel order: corr_channel_map), flow [E,h,w,8] f16 (4 + zero pad),
         ii [E] int64.  Context features, one of
           * inp [E,h,w,128] f16 per edge (the reference's calling convention: any values), or
@@ -261,7 +273,11 @@ class UpdateModule:
         -> (net, delta [E,h,w,2] f32, weight [E,h,w,2] f32, eta [K,h,w] f32, upmask [K,h,w,576] f16)."""
         P = self.params
         E, h, w, _ = net.shape
-        c = P["corr2"]([P["corr0"]([corr[0], corr[1], corr[2], corr[3]], EPI_RELU)], EPI_RELU)
+        if corr.dim() == 4 and corr.shape[1] == COR_PLANES:      # reference layout [E,196,h,w] (see wants_reference_layout_corr)
+            c0 = droid_backends.corr0_nchw(corr, P["corr0_nchw"][0], P["corr0_nchw"][1])
+        else:
+            c0 = P["corr0"]([corr[0], corr[1], corr[2], corr[3]], EPI_RELU)
+        c = P["corr2"]([c0], EPI_RELU)
         f = P["flow2"]([P["flow0"]([flow], EPI_RELU)], EPI_RELU)
         # global context: mean over pixels of sigmoid(w(net)) * net, then three 128x128 GEMVs per edge
         red = torch.zeros(E, 128, dtype=torch.float32, device=net.device)
@@ -319,7 +335,7 @@ class UpdateModule:
         if ii is None:
             ii = torch.arange(num, device=net.device)
         n = self.to_nhwc(net[0]); i = self.to_nhwc(inp[0])
-        c = self.corr_to_nhwc(corr[0])
+        c = corr[0].half().contiguous() if self.wants_reference_layout_corr(ht, wd) else self.corr_to_nhwc(corr[0])
         f = self.to_nhwc(flow[0], 8)
         ii = ii.to(net.device)
         if self.share_inp_by_source_frame:

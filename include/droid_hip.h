@@ -250,6 +250,12 @@ int dh_conv2d_nhwc_f16_ex(const void* const* inputs, const int* in_channels, con
                           float* red, const float* cinit, const int64_t* cinit_idx, int cinit_stride, int cinit_off,
                           dh_stream_t stream);
 
+/* corr_encoder.0 (reference droid_net.py:83-86: 1x1 convolution 196 -> 128 + relu) on the REFERENCE-layout correlation
+ * features: x [E,196,HW] f16 (what dh_corr_pyramid_lookup / corr_index_forward produce, channel = level*49 + xoff*7 + yoff),
+ * wp [128,208] f16 = weight[cout][cin] zero-padded to 208 input channels, bias [128] f32 -> out [E,HW,128] f16 channel-last.
+ * HW % 128 == 0 (DH_ERR_ARG otherwise: use dh_conv2d_nhwc_f16 on the channel-last lookup output). */
+int dh_corr0_nchw_f16(const void* x, const void* wp, const float* bias, void* out, int E, int HW, dh_stream_t stream);
+
 /* Global-context terms of the ConvGRU gates (reference modules/gru.py:21-27: three 1x1 convolutions on the pixel mean of
  * sigmoid(w(net)) * net) as one GEMV: out [E,N] f32 = fp16(bias + fp16(red * scale) wt), red [E,128] f32 (pixel SUMS, scale =
  * 1 / pixels), wt [128,N] f32 k-major, N <= 384 (z | r | q).  Values are rounded to fp16 where autocast rounds them. */

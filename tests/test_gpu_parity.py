@@ -666,6 +666,47 @@ def test_native_pyramid_channel_last_lookup_equals_reference_layout(db):
         assert torch.count_nonzero(b[..., m < 0]) == 0
 
 
+def test_corr0_on_reference_layout_features(db):
+    """droid_backends.corr0_nchw: corr_encoder.0 (1x1, 196 -> 128, relu, droid_net.py:83-86) reading [E,196,h,w] directly
+    (in-register tile transpose) == fp32 convolution of the same fp16 operands, and == the channel-last implicit-GEMM path"""
+    torch.manual_seed(11)
+    for (E, h, w) in [(3, 16, 64), (5, 8, 16), (2, 48, 64)]:
+        x = (torch.randn(E, 196, h, w, device="cuda") * 2).half()
+        wgt = (torch.randn(128, 196, device="cuda") * 0.1).half()
+        bias = torch.randn(128, device="cuda")
+        wp = torch.zeros(128, 208, device="cuda", dtype=torch.half); wp[:, :196] = wgt
+        out = db.corr0_nchw(x, wp, bias)                                   # [E,h,w,128] f16
+        ref = torch.relu(torch.einsum("ekhw,ck->ehwc", x.float(), wgt.float()) + bias)
+        assert out.shape == (E, h, w, 128) and out.dtype == torch.half
+        assert (out.float() - ref).abs().max() <= 2.0 ** -9 * ref.abs().max()
+    with pytest.raises(RuntimeError):
+        db.corr0_nchw(torch.zeros(1, 196, 12, 16, device="cuda").half(), wp, bias)      # 192 pixels: not a multiple of 128
+
+
+def test_update_operator_same_result_from_both_correlation_layouts(db):
+    """forward_nhwc on the reference-layout features [E,196,h,w] (corr0_nchw) and on the channel-last level-planar
+    features (implicit GEMM): same operator, results within one fp16 rounding of the first layer"""
+    from droid_amd.update import UpdateModule
+    torch.manual_seed(3)
+    E, h, w = 6, 16, 64
+    from oracle import update as oupd
+    from droid_amd.weights import deterministic_state_dict
+    upd = UpdateModule().load_state_dict(deterministic_state_dict(_SD(oupd.empty_state_dict()), seed=7))
+    corr = (torch.randn(E, 196, h, w, device="cuda")).half()
+    net0 = torch.tanh(torch.randn(E, h, w, 128, device="cuda")).half()
+    inp = torch.relu(torch.randn(E, h, w, 128, device="cuda")).half()
+    flow = torch.zeros(E, h, w, 8, device="cuda").half(); flow[..., :4] = torch.randn(E, h, w, 4, device="cuda").half()
+    ii = torch.tensor([0, 0, 1, 1, 2, 2], device="cuda")
+    assert upd.wants_reference_layout_corr(h, w)
+    outs = []
+    for feats in (corr, upd.corr_to_nhwc(corr)):
+        net = net0.clone()
+        n, d, wt, eta, um = upd.forward_nhwc(net, inp, feats, flow, ii)
+        outs.append([t.float().clone() for t in (n, d, wt, eta, um)])
+    for a, b in zip(*outs):
+        assert (a - b).abs().max() <= 2.0 ** -8 * max(1.0, b.abs().max().item())
+
+
 # ------------------------------------------------------------------------------------------ lietorch / torch_scatter drop-ins
 def test_lietorch_dropin_matches_oracle_and_reference_call_pattern(db):
     """the SE3 surface the reference's projective_ops.py:165-198 uses, through the `lietorch` package of this repo"""
