@@ -10,13 +10,15 @@
 //   build     FRAME-centric: workgroup = (source frame k, pixel strip).  Loops over k's out-edges with
 //             lane = pixel, so per-frame sums (C_k, w_k, E_i[k]) are plain register accumulations in a
 //             fixed edge order -- no segment-sum kernels, no atomics.  Uses linearity Ji = -Adj^T Jj:
-//             only Hjj (21 entries) + vj are reduced per edge (wave64 shuffles + one LDS hop), the
-//             6x6 adjoint is applied once per edge in fp64 (pose_blocks) and once per pixel for E_i;
-//   gram      Schur blocks of one depth block as a TRUE contraction over pixels: G = M^T M with
-//             M = sqrt(Q) [E_slot0 .. E_slotn | w]  (HW x (6(n+1)+1)), on the exact-fp32 MFMA
-//             (v_mfma_f32_16x16x4_f32), K split over the 4 waves, reduced in LDS, accumulated into the
-//             fp64 reduced camera system;
-//   solve     hand-written blocked right-looking Cholesky in fp64 (48x48 blocks = 8 poses), the rhs is
+//             only Hjj (21 entries) + vj are reduced per edge (seven 4-way wave reductions on v_permlane32/16_swap +
+//             DPP, one partial per wave), the 6x6 adjoint is applied once per edge in fp64 (pose_blocks) and once
+//             per pixel for E_i;
+//   gram      Schur blocks of one depth block as a TRUE contraction over pixels: G = M^T diag(Q) M with
+//             M = [E_slot0 .. E_slotn | w]  (HW x (6(n+1)+1)), on the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32), operands
+//             straight from global memory (16-byte loads, no LDS staging), pixel groups interleaved over the 4 waves,
+//             reduced in LDS, accumulated into the fp64 reduced camera system;
+//   solve     hand-written blocked right-looking Cholesky in fp64 (64x64 blocks, one look-ahead launch per block
+//             column, the panel in MFMA accumulator registers), the rhs is
 //             carried as an extra block row so forward substitution is free; damping and the
 //             "failure -> zero update" semantics of SparseBlock::solve are preserved;
 //   backsub   dz = Q (w - sum_slots E^T dx) incl. the reference's row-skip quirk (EvT6x1_kernel :1114),

@@ -26,6 +26,9 @@
 //   conv3x3_halo_kernel   3x3 halo-tile loop with register staging: cout tiles of 64 and 32 (small heads), and the first
 //                         form of the 128-cout tile (DH_CONV_HALO2=0);
 //   conv_igemm_kernel     the generic loop described above: 1x1 and 7x7 convolutions, images that are not 64 wide, fallback;
+//   corr0_nchw_kernel     corr_encoder.0 (1x1, 196 -> 128) on the reference-layout lookup output: in-register tile transpose,
+//                         persistent workgroups (dh_corr0_nchw_f16); conv7x7_c4_kernel / glo_reduce_kernel / glo_gemv_kernel /
+//                         heads_gather_kernel / segment_mean_kernel: the single-purpose kernels of the update operator;
 //   staged_epilogue / staged_glo_epilogue   results parked in LDS and finished in 16-byte pieces (coalesced stores and GRU
 //                         operand loads); conv_epilogue is the per-element form for tiles that straddle images or write fp32.
 #include "common.h"
