@@ -37,7 +37,12 @@ __global__ void k(double* out, unsigned long long* t, double a0) {
   TIC(t0);
   asm volatile(".rept 32\n v_fma_f64 %0, %0, %1, %2\n v_mul_f64 %0, %0, %1\n .endr" : "+v"(a) : "v"(b), "v"(c));            // fma -> mul dependent
   TIC(t1); if (threadIdx.x == 0) t[8] = t1 - t0;
-  out[threadIdx.x] = a + x1 + x2 + x3 + f;
+  typedef double f64x4 __attribute__((ext_vector_type(4)));
+  f64x4 acc = {a, x1, x2, x3};
+  TIC(t0);
+  asm volatile(".rept 64\n v_mfma_f64_16x16x4_f64 %0, %1, %2, %0\n .endr\n s_nop 15\n s_nop 15" : "+v"(acc) : "v"(b), "v"(c));
+  TIC(t1); if (threadIdx.x == 0) t[9] = t1 - t0;
+  out[threadIdx.x] = a + x1 + x2 + x3 + f + acc[0] + acc[1] + acc[2] + acc[3];
 }
 int main() {
   double* out; unsigned long long* t;
@@ -45,7 +50,7 @@ int main() {
   for (int r = 0; r < 2; ++r) hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, out, t, 1.5);
   unsigned long long h[16]; (void)hipMemcpy(h, t, sizeof(h), hipMemcpyDeviceToHost);
   const char* names[] = {"dependent v_fma_f64 (x64)", "4 independent v_fma_f64 streams (x64 ops)", "dependent v_mul_f64 (x64)", "dependent v_rsq_f64 (x64)",
-                         "dependent v_rcp_f64 (x64)", "4 independent v_rsq_f64 streams (x64 ops)", "dependent v_fma_f32 (x64)", "fma->(mul off chain) x32 (64 ops)", "fma->mul dependent x32 (64 ops)"};
-  for (int i = 0; i < 9; ++i) printf("%-48s %6.1f ticks per op\n", names[i], h[i] / 64.0);
+                         "dependent v_rcp_f64 (x64)", "4 independent v_rsq_f64 streams (x64 ops)", "dependent v_fma_f32 (x64)", "fma->(mul off chain) x32 (64 ops)", "fma->mul dependent x32 (64 ops)", "dependent v_mfma_f64_16x16x4_f64 (x64)"};
+  for (int i = 0; i < 10; ++i) printf("%-48s %6.1f ticks per op\n", names[i], h[i] / 64.0);
   return 0;
 }
