@@ -124,10 +124,23 @@ class FactorGraph:
     def _operator(self, net, coords1, target_prev, feats, ii):
         """motion features + update operator on a set of edges -> (dw [E,h,w,4], damping [K,h,w], upmask, uniq)"""
         flow = db.motion_features(coords1, target_prev)
-        uniq, ix = torch.unique(ii, return_inverse=True)
-        inp_frames = self.video.inps[uniq].permute(0, 2, 3, 1).contiguous()
-        _, _, _, damping, upmask = self.update_op.forward_nhwc(net, None, feats, flow, ii, inp_frames=inp_frames, inp_index=ix.contiguous())
+        uniq, ix, inp_frames, ctx = self._context(ii)
+        _, _, _, damping, upmask = self.update_op.forward_nhwc(net, None, feats, flow, ii, inp_frames=inp_frames, inp_index=ix, ctx=ctx)
         return self.update_op.last_dw, damping, upmask, uniq
+
+    def _context(self, ii):
+        """source frames of the edge list, their context features channel-last and the gates' per-frame context term
+        (UpdateModule.context_term).  All three depend only on the edge list and on video.inps, which change when a keyframe is
+        added or removed, not between the update iterations in between: kept until either changes (tensor version counters)."""
+        inps = self.video.inps
+        key = (ii.data_ptr(), ii._version, ii.numel(), inps.data_ptr(), inps._version)
+        if getattr(self, "_ctx_key", None) != key:
+            uniq, ix = torch.unique(ii, return_inverse=True)
+            inp_frames = inps[uniq].permute(0, 2, 3, 1).contiguous()
+            h, w = inp_frames.shape[1:3]
+            ctx = self.update_op.context_term(inp_frames) if (w == 64 and h % 4 == 0) else None
+            self._ctx_key, self._ctx = key, (uniq, ix.contiguous(), inp_frames, ctx, ii)     # (ii kept alive: its address is in the key)
+        return self._ctx[:4]
 
     def update(self, t0=None, t1=None, itrs=2, use_inactive=False, EP=1e-7, motion_only=False):
         ii, jj = self.ii, self.jj

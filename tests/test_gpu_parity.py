@@ -666,6 +666,28 @@ def test_native_pyramid_channel_last_lookup_equals_reference_layout(db):
         assert torch.count_nonzero(b[..., m < 0]) == 0
 
 
+def test_update_operator_edge_segments_follow_the_edge_list(db):
+    """UpdateModule.segments caches GraphAgg's grouping per edge list: a new tensor, a tensor modified in place, and a
+    tensor reallocated at the same address must all be regrouped"""
+    from droid_amd.update import UpdateModule
+    upd = UpdateModule()
+    def groups(ii):
+        order, off = upd.segments(ii)
+        o, f = order.cpu().tolist(), off.cpu().tolist()
+        return sorted(sorted(o[f[k]:f[k + 1]]) for k in range(len(f) - 1))
+    expect = lambda ii: sorted(sorted(i for i, v in enumerate(ii) if v == u) for u in set(ii))
+    a = [0, 0, 1, 2, 2, 2]
+    ii = torch.tensor(a, device="cuda")
+    assert groups(ii) == expect(a)
+    assert upd.segments(ii)[0] is upd.segments(ii)[0]                      # cached
+    ii[1] = 1                                                              # in place
+    assert groups(ii) == expect([0, 1, 1, 2, 2, 2])
+    del ii
+    b = [3, 1, 1, 1, 0, 3]
+    jj = torch.tensor(b, device="cuda")                                    # may land on the freed address
+    assert groups(jj) == expect(b)
+
+
 def test_corr0_on_reference_layout_features(db):
     """droid_backends.corr0_nchw: corr_encoder.0 (1x1, 196 -> 128, relu, droid_net.py:83-86) reading [E,196,h,w] directly
     (in-register tile transpose) == fp32 convolution of the same fp16 operands, and == the channel-last implicit-GEMM path"""
