@@ -368,12 +368,13 @@ __global__ __launch_bounds__(64) void ba_pose_blocks_kernel(
   __syncthreads();
   if (tid < 36) {
     const int r = tid / 6, c = tid % 6;
-    if (vj_ok) atomicAdd(&H[(long)(6 * pj + r) * ld + 6 * pj + c], s_h[r][c]);
+    // (lower triangle only, like the Schur blocks)
+    if (vj_ok && r >= c) atomicAdd(&H[(long)(6 * pj + r) * ld + 6 * pj + c], s_h[r][c]);
     if (vi_ok && vj_ok) {
-      atomicAdd(&H[(long)(6 * pi + r) * ld + 6 * pj + c], s_AH[r][c]);     // Hij
-      atomicAdd(&H[(long)(6 * pj + r) * ld + 6 * pi + c], s_AH[c][r]);     // Hji = Hij^T
+      if (pi > pj) atomicAdd(&H[(long)(6 * pi + r) * ld + 6 * pj + c], s_AH[r][c]);     // Hij
+      else atomicAdd(&H[(long)(6 * pj + r) * ld + 6 * pi + c], s_AH[c][r]);             // Hji = Hij^T
     }
-    if (vi_ok) {
+    if (vi_ok && r >= c) {
       double s = 0;
       for (int m = 0; m < 6; ++m) s += s_AH[r][m] * s_A[c][m];              // Hii = A Hjj A^T
       atomicAdd(&H[(long)(6 * pi + r) * ld + 6 * pi + c], s);
@@ -623,8 +624,10 @@ __global__ __launch_bounds__(256, DIAG ? 4 : 2) void ba_gram_kernel(
         if (pa < 0 || pbq < 0) continue;
         const bool lower = same && (col >> 4) < (row >> 4);
         const double v = (double)(lower ? s_out[col * GCOLS + row] : s_out[row * GCOLS + col]);
-        atomicAdd(&H[(long)(6 * pa + row % 6) * ld + 6 * pbq + col % 6], -v);
-        if (!same) atomicAdd(&H[(long)(6 * pbq + col % 6) * ld + 6 * pa + row % 6], -v);
+        // only the lower triangle of the reduced camera system is ever read (Cholesky, packed exchange): half the atomics
+        const int R = 6 * pa + row % 6, C = 6 * pbq + col % 6;
+        if (R >= C) atomicAdd(&H[(long)R * ld + C], -v);
+        if (!same && C >= R) atomicAdd(&H[(long)C * ld + R], -v);
       }
       if (same) {
         for (int o = tid; o < 6 * nsa; o += 256) {

@@ -137,7 +137,8 @@ int dh_ba(float* poses, float* disps, const float* intrinsics, const float* disp
 
 /* Split form used by the edge-sharded multi-GPU solver (one RCCL all-reduce between the two calls):
  * dh_ba_build fills the reduced camera system of THIS rank's edges,
- *   Hsys [6P,6P] f64 (row-major, lower+upper), bsys [6P] f64, and keeps per-frame depth terms in the
+ *   Hsys [6P,6P] f64 (row-major, LOWER triangle -- all the factorisation reads; the strict upper triangle is not
+ *   assembled), bsys [6P] f64, and keeps per-frame depth terms in the
  *   workspace; dh_ba_finish damps, solves, back-substitutes the depths of the frames this rank owns
  *   and retracts.  dh_ba() == dh_ba_build + dh_ba_finish per iteration. */
 /* dh_ba with a PER-PIXEL weight of the sensor-depth prior (BASELINE.json configs[4], "per-pixel depth-confidence weights";
