@@ -996,6 +996,17 @@ __device__ __forceinline__ void mfma_abt_64(const double* __restrict__ A, const 
   }
 }
 
+// one 16x16 tile of A B^T: rows 16 rb .. of A against rows 16 nt .. of B (both 64 columns, LDS, leading dimension LDB)
+__device__ __forceinline__ f64x4 mfma_abt_tile(const double* __restrict__ A, const double* __restrict__ B, int rb, int nt, int lane) {
+  f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+  const int kq = lane >> 4;
+#pragma unroll
+  for (int kk = 0; kk < NB / 4; ++kk)
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[(rb * 16 + (lane & 15)) * LDB + kk * 4 + kq], B[(nt * 16 + (lane & 15)) * LDB + kk * 4 + kq],
+                                               acc, 0, 0, 0);
+  return acc;
+}
+
 __global__ __launch_bounds__(256, 1) void chol_panel_kernel(double* __restrict__ H, int ld, int j, int* __restrict__ meta,
                                                             double* __restrict__ Ldiag) {
   extern __shared__ double s_chol[];
@@ -1149,9 +1160,34 @@ __global__ __launch_bounds__(256, 1) void chol_step_kernel(double* __restrict__ 
         H[(r0 + wave * 16 + (lane >> 4) + 4 * q) * ld + c0 + nt * 16 + (lane & 15)] = cur[nt][q] - acc[nt][q];
     return;
   }
+  // A_cc -= L_cj L_cj^T: only the tiles on and below the diagonal are ever used (wave w: column tiles 0..w) and the fp64 MFMA
+  // (64 cycles) is the whole cost of this phase, so the 10 tiles are spread 2 / 2 / 3 / 3 over the waves: wave 0 also computes
+  // wave 3's tile 0 and hands it over through LDS -- 112 instead of 128 MFMAs on the longest wave
   f64x4 accd[4];
-  mfma_abt_64<false>(sB, sB, wave, lane, accd);
+  double* const xch = s_chol + 2 * NB * LDB;       // 256 doubles behind the two operand blocks
+  if (REGP) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) accd[nt] = f64x4{0.0, 0.0, 0.0, 0.0};
+    if (wave == 0) {
+      accd[0] = mfma_abt_tile(sB, sB, 0, 0, lane);
+      const f64x4 t30 = mfma_abt_tile(sB, sB, 3, 0, lane);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xch[q * 64 + lane] = t30[q];
+    } else if (wave == 1) {
+      accd[0] = mfma_abt_tile(sB, sB, 1, 0, lane); accd[1] = mfma_abt_tile(sB, sB, 1, 1, lane);
+    } else if (wave == 2) {
+      accd[0] = mfma_abt_tile(sB, sB, 2, 0, lane); accd[1] = mfma_abt_tile(sB, sB, 2, 1, lane); accd[2] = mfma_abt_tile(sB, sB, 2, 2, lane);
+    } else {
+      accd[1] = mfma_abt_tile(sB, sB, 3, 1, lane); accd[2] = mfma_abt_tile(sB, sB, 3, 2, lane); accd[3] = mfma_abt_tile(sB, sB, 3, 3, lane);
+    }
+  } else {
+    mfma_abt_64<false>(sB, sB, wave, lane, accd);
+  }
   __syncthreads();                          // every wave has read both operand blocks: the panel may overwrite them
+  if (REGP && wave == 3) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) accd[0][q] = xch[q * 64 + lane];
+  }
   DH_TS(2);
   double* P = s_chol;                       // [128][LDB]: updated A_cc over updated A_rc
   bool ok;
@@ -1405,7 +1441,7 @@ int run_finish(const BaLayout& L, char* ws, float* poses, float* disps, const in
       for (int j = 0; j + 1 < L.nbk; ++j) {
         const int nP = nbrows - j - 2;                   // block rows below the diagonal block of column j+1
         if (opts().chol_regpanel)
-          hipLaunchKernelGGL(chol_step_kernel<true>, dim3(nP + nP * nP), dim3(256), lds_panel, st, H, L.ld, j, L.nbk, nP, meta, Ldiag);
+          hipLaunchKernelGGL(chol_step_kernel<true>, dim3(nP + nP * nP), dim3(256), lds_panel + 256 * sizeof(double), st, H, L.ld, j, L.nbk, nP, meta, Ldiag);
         else
           hipLaunchKernelGGL(chol_step_kernel<false>, dim3(nP + nP * nP), dim3(256), lds_panel, st, H, L.ld, j, L.nbk, nP, meta, Ldiag);
         DH_LAUNCH_CHECK();
