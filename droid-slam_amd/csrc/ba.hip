@@ -832,13 +832,22 @@ __device__ __forceinline__ bool chol_panel128_regs(double* __restrict__ P, f64x4
     __syncthreads();                                     // the step's 8 columns are in P
     DH_TS(8 + 4 * k);
     double L[PB][PB], dinv[PB], x[PB];
+    // the sub-block as 16-byte broadcast reads at compile-time offsets (rows start 16-byte aligned: 528-byte row stride,
+    // o a multiple of 8): 20 ds_read_b128 with immediate offsets instead of 36 separately addressed 8-byte reads
 #pragma unroll
     for (int r = 0; r < PB; ++r)
 #pragma unroll
-      for (int c = 0; c <= r; ++c) L[r][c] = P[(o + r) * LDB + o + c];       // same address in every lane: broadcast
+      for (int c = 0; c <= r; c += 2) {
+        const double2 v = *reinterpret_cast<const double2*>(P + (o + r) * LDB + o + c);
+        L[r][c] = v.x;
+        if (c + 1 <= r) L[r][c + 1] = v.y;
+      }
     double* prow = P + (o + (tid < nsub ? tid : 0)) * LDB + o;
 #pragma unroll
-    for (int c = 0; c < PB; ++c) x[c] = prow[c];
+    for (int c = 0; c < PB; c += 2) {
+      const double2 v = *reinterpret_cast<const double2*>(prow + c);
+      x[c] = v.x; x[c + 1] = v.y;
+    }
     // rest of the previous step's rank-8 update (column tiles after the one that holds this step's columns)
     if (k > 0) {
 #pragma unroll
