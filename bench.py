@@ -170,9 +170,34 @@ def cpu_baseline(g, n_lookup_edges=64, n_update_edges=128, repeats=3):
             "value_1core": 1.0 / per_ep1}
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks here (one process per GPU, RCCL) by
+    re-executing this command line under torch.distributed.run, the form the round driver itself uses for N > 1."""
+    import socket
+    import subprocess
+    n = args.gpus
+    have = torch.cuda.device_count()
+    backend = os.environ.get("DH_BENCH_BACKEND", "nccl")
+    if have < n and backend != "gloo":
+        sys.exit("bench.py --gpus %d: only %d device(s) visible; RCCL needs one GPU per rank (DH_BENCH_BACKEND=gloo runs "
+                 "the multi-rank code path with several ranks per device, as a self-test)" % (n, have))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC (RCCL between processes on this driver)
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(1, args.gpus):
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a ROCm device (no CPU fallback)"

@@ -1480,6 +1480,19 @@ int run_finish(const BaLayout& L, char* ws, float* poses, float* disps, const in
 
 }  // namespace
 
+namespace {
+// default (DH_BA_STRICT=1): one stream synchronisation behind the call's last launch, flagged arguments (meta[2]: an edge
+// outside the frame buffer, eta without one row per depth block) are reported as DH_ERR_ARG.  The flagged call has
+// applied no update either way.
+int strict_check(const BaLayout& L, char* ws, hipStream_t st) {
+  if (!opts().ba_strict) return DH_OK;
+  int flags[4] = {0, 0, 0, 0};
+  if (hipMemcpyAsync(flags, ws + L.meta, sizeof(flags), hipMemcpyDeviceToHost, st) != hipSuccess) return DH_ERR_LAUNCH;
+  if (hipStreamSynchronize(st) != hipSuccess) return DH_ERR_LAUNCH;
+  return flags[2] ? DH_ERR_ARG : DH_OK;
+}
+}  // namespace
+
 extern "C" size_t dh_ba_workspace_bytes(int num_frames, int n_edges, int ht, int wd, int t0, int t1, int motion_only) {
   if (check_args(num_frames, n_edges, ht, wd, t0, t1) != DH_OK) return 0;
   return make_layout(num_frames, n_edges, ht * wd, t0, t1, motion_only).total;
@@ -1514,7 +1527,8 @@ extern "C" int dh_ba_build(const float* poses, const float* disps, const float* 
                  num_frames, n_edges, ht * wd, wd, t0, motion_only, st);
   if (Hsys_out) *Hsys_out = (double*)(ws + L.H);
   if (bsys_out) *bsys_out = (double*)(ws + L.H) + (size_t)L.npad * L.ld;
-  return rc;
+  if (rc != DH_OK) return rc;
+  return strict_check(L, ws, st);                  // (the caller's all-reduce of the system follows: a natural sync point)
 }
 
 extern "C" int dh_ba_finish(float* poses, float* disps, const int64_t* jj,
@@ -1559,13 +1573,7 @@ extern "C" int dh_ba_ex(float* poses, float* disps, const float* intrinsics, con
                     last ? dx_out : nullptr, last ? dz_out : nullptr, n_eta_rows, st);
     if (rc != DH_OK) return rc;
   }
-  if (opts().ba_strict) {                                   // opt-in: synchronise and report flagged arguments as an error
-    int flags[4] = {0, 0, 0, 0};
-    if (hipMemcpyAsync(flags, ws + L.meta, sizeof(flags), hipMemcpyDeviceToHost, st) != hipSuccess) return DH_ERR_LAUNCH;
-    if (hipStreamSynchronize(st) != hipSuccess) return DH_ERR_LAUNCH;
-    if (flags[2]) return DH_ERR_ARG;
-  }
-  return DH_OK;
+  return strict_check(L, ws, st);
 }
 
 extern "C" int dh_ba(float* poses, float* disps, const float* intrinsics, const float* disps_sens,

@@ -492,9 +492,13 @@ std::vector<torch::Tensor> reproject(torch::Tensor poses, torch::Tensor disps, t
   const int E = (int)ii.size(0), ht = (int)disps.size(1), wd = (int)disps.size(2);
   torch::Tensor coords = torch::empty({E, ht, wd, 2}, poses.options());
   torch::Tensor valid = torch::empty({E, ht, wd, 1}, poses.options());
-  check_status(dh_reproject(poses.data_ptr<float>(), disps.data_ptr<float>(), intrinsics.data_ptr<float>(),
-                            ii.data_ptr<int64_t>(), jj.data_ptr<int64_t>(), coords.data_ptr<float>(),
-                            valid.data_ptr<float>(), E, ht, wd, cur_stream()),
+  // intrinsics [4]: one camera; [frames,4]: per frame (source frame's for the back-projection, target frame's for the projection)
+  const int per_frame = intrinsics.dim() == 2 ? 1 : 0;
+  TORCH_CHECK(intrinsics.size(-1) == 4 && (!per_frame || intrinsics.size(0) >= disps.size(0)),
+              "reproject: intrinsics must be [4] or [frames,4] with one row per frame of disps");
+  check_status(dh_reproject_ex(poses.data_ptr<float>(), disps.data_ptr<float>(), intrinsics.data_ptr<float>(), per_frame,
+                               ii.data_ptr<int64_t>(), jj.data_ptr<int64_t>(), coords.data_ptr<float>(),
+                               valid.data_ptr<float>(), E, ht, wd, cur_stream()),
                "reproject");
   return {coords, valid};
 }
@@ -572,5 +576,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("se3_map", &se3_map, "SE3 act4/adjT");
   m.def("version", []() { return std::string(dh_version()); });
   m.def("set_option", [](const std::string& name, int value) { check_status(dh_set_option(name.c_str(), value), "set_option"); });
+  m.def("options_epoch", []() { return dh_options_epoch(); });
   m.def("get_option", [](const std::string& name) { int v = 0; check_status(dh_get_option(name.c_str(), &v), "get_option"); return v; });
 }

@@ -143,15 +143,19 @@ __global__ __launch_bounds__(256) void depth_filter_kernel(
 __global__ __launch_bounds__(256) void reproject_kernel(
     const float* __restrict__ poses, const float* __restrict__ disps, const float* __restrict__ intr,
     const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, float* __restrict__ coords,
-    float* __restrict__ valid, int HW, int wd) {
+    float* __restrict__ valid, int HW, int wd, int intr_stride) {
   const int e = blockIdx.x;
   const int p = blockIdx.y * 256 + threadIdx.x;
   if (p >= HW) return;
   const int i = (int)ii[e], j = (int)jj[e];
-  const float fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
+  // back-projection with the source frame's intrinsics, projection with the target frame's (projective_ops.py:180,183:
+  // intrinsics[:,ii] / intrinsics[:,jj]); intr_stride = 0: one camera for every frame
+  const float* ki = intr + (long)i * intr_stride;
+  const float* kj = intr + (long)j * intr_stride;
+  const float fx = kj[0], fy = kj[1], cx = kj[2], cy = kj[3];
   const SE3f T = (i == j) ? stereo_rel() : mul(load_pose(poses + 7 * (long)j), inv(load_pose(poses + 7 * (long)i)));
   float u, v, X, Y;
-  pixel_ray(p, wd, fx, fy, cx, cy, u, v, X, Y);
+  pixel_ray(p, wd, ki[0], ki[1], ki[2], ki[3], u, v, X, Y);
   const float h = disps[(long)i * HW + p];
   Vec3 R = rot(T.q, {X, Y, 1.f});
   const float x = R.x + h * T.t.x, y = R.y + h * T.t.y, z = R.z + h * T.t.z;
@@ -255,12 +259,18 @@ extern "C" int dh_depth_filter(const float* poses, const float* disps, const flo
 extern "C" int dh_reproject(const float* poses, const float* disps, const float* intrinsics,
                             const int64_t* ii, const int64_t* jj, float* coords, float* valid,
                             int E, int ht, int wd, dh_stream_t stream) {
+  return dh_reproject_ex(poses, disps, intrinsics, 0, ii, jj, coords, valid, E, ht, wd, stream);
+}
+
+extern "C" int dh_reproject_ex(const float* poses, const float* disps, const float* intrinsics, int per_frame_intrinsics,
+                               const int64_t* ii, const int64_t* jj, float* coords, float* valid,
+                               int E, int ht, int wd, dh_stream_t stream) {
   if (E < 0 || ht <= 0 || wd <= 0) return DH_ERR_ARG;
   if (E == 0) return DH_OK;
   if (!poses || !disps || !intrinsics || !ii || !jj || !coords) return DH_ERR_ARG;
   const int HW = ht * wd;
   hipLaunchKernelGGL(reproject_kernel, dim3(E, (HW + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                     poses, disps, intrinsics, ii, jj, coords, valid, HW, wd);
+                     poses, disps, intrinsics, ii, jj, coords, valid, HW, wd, per_frame_intrinsics ? 4 : 0);
   DH_LAUNCH_CHECK();
   return DH_OK;
 }

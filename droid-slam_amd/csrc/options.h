@@ -16,7 +16,7 @@ struct Options {
   int conv_xcd;         // DH_CONV_XCD (1): XCD-aware workgroup order of the 3x3 halo2 kernel (conv.hip xcd_decode)
   int dma_var;          // DH_DMA_VAR (0): timing ablations of that experiment
   int pyr_build_chunk;  // DH_PYR_BUILD=chunk (0): first form of the pyramid build kernel
-  int ba_strict;        // DH_BA_STRICT (0): dh_ba synchronises and returns DH_ERR_ARG on bad indices / eta rows
+  int ba_strict;        // DH_BA_STRICT (1): dh_ba / dh_ba_build synchronise and return DH_ERR_ARG on bad indices / eta rows; 0 = asynchronous, such calls apply no update
 };
 
 Options& opts();

@@ -25,7 +25,7 @@ Options& opts() {
     v.dma_var = env_int("DH_DMA_VAR", 0);
     const char* pb = getenv("DH_PYR_BUILD");
     v.pyr_build_chunk = (pb && !strcmp(pb, "chunk")) ? 1 : 0;
-    v.ba_strict = env_int("DH_BA_STRICT", 0);
+    v.ba_strict = env_int("DH_BA_STRICT", 1);
     return v;
   }();
   return o;
@@ -51,12 +51,17 @@ static int* slot(const char* name) {
 
 }  // namespace dh
 
+static int g_options_epoch = 0;
+
 extern "C" int dh_set_option(const char* name, int value) {
   int* s = dh::slot(name);
   if (!s) return DH_ERR_ARG;
+  if (*s != value) ++g_options_epoch;
   *s = value;
   return DH_OK;
 }
+
+extern "C" int dh_options_epoch(void) { return g_options_epoch; }
 
 extern "C" int dh_get_option(const char* name, int* value) {
   int* s = dh::slot(name);

@@ -112,7 +112,8 @@ class DepthVideo:
     def reproject(self, ii, jj):
         """coords [1,E,h,w,2], valid [1,E,h,w,1] of the pixels of frame ii seen from frame jj (depth_video.py:171-179)"""
         ii, jj = self.format_indicies(ii, jj)
-        coords, valid = db.reproject(self.poses, self.disps, self.intrinsics[0].contiguous(), ii, jj)
+        # per-frame intrinsics like projective_transform (projective_ops.py:180,183): the pose filler writes its own rows
+        coords, valid = db.reproject(self.poses, self.disps, self.intrinsics, ii, jj)
         return coords[None], valid[None]
 
     def distance(self, ii=None, jj=None, beta=0.3, bidirectional=True):

@@ -100,15 +100,35 @@ class DistBA:
             import droid_backends as backend          # HIP path; fails loudly without the extension
         self.be = backend
         self._pattern = None            # (t0, t1, p, q) after set_graph
+        self._pattern_keys = None
+        self._covered = None
         self._flat = None
         self.last_exchange_bytes = 0
+        self.last_exchange_packed = False
 
     def set_graph(self, ii_all, jj_all, t0, t1):
         """global edge list -> the all-reduce moves only the co-visible blocks (see reduced_system_pattern).  Without it
-        the whole dense system is reduced."""
+        the whole dense system is reduced.  Call it again whenever the global edge list changes: ba() verifies that the
+        blocks of its local edges lie inside the pattern and falls back to the dense exchange (on every rank) if not."""
         p, q = reduced_system_pattern(ii_all, jj_all, t0, t1)
         self._pattern = (int(t0), int(t1), p, q)
+        self._pattern_keys = np.unique(p * (int(t1) - int(t0)) + q)
         self._flat = None
+        self._covered = None
+
+    def _local_blocks_covered(self, ii, jj, t0, t1):
+        """True if every block this rank's edges can touch is part of the pattern of the last set_graph().  Bound to the
+        edge tensors (identity + version), so the host-side check runs once per edge list, not once per call."""
+        if self._pattern is None or self._pattern[:2] != (int(t0), int(t1)):
+            return False
+        from .update import tensor_cache_key
+        key = tensor_cache_key(ii, jj)
+        if key is not None and self._covered is not None and self._covered[0] == key:
+            return self._covered[1]
+        p, q = reduced_system_pattern(ii.cpu().numpy(), jj.cpu().numpy(), t0, t1)
+        ok = bool(np.isin(p * (int(t1) - int(t0)) + q, self._pattern_keys).all())
+        self._covered = (key, ok, ii, jj)                    # (tensors kept alive: their addresses are in the key)
+        return ok
 
     def _flat_index(self, system, t0, t1):
         ld = system.shape[1]
@@ -132,11 +152,19 @@ class DistBA:
         lo, hi = max(0, self.frame_lo), min(F, self.frame_hi)
         disps_in = disps.clone()
         dx = dz = None
+        packed = False
+        if self.world > 1 and self._pattern is not None:
+            # the packed exchange is only valid if EVERY rank's blocks lie inside the pattern (a stale pattern after the edge
+            # list changed would silently drop blocks): one 4-byte MAX-reduce per call makes the decision collective
+            bad = torch.tensor([0 if self._local_blocks_covered(ii, jj, t0, t1) else 1], dtype=torch.int32, device=disps.device)
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=self.group)
+            packed = int(bad.item()) == 0
+        self.last_exchange_packed = packed
         for _ in range(iterations):
             before = disps.clone() if not motion_only else None
             ws, system = self.be.ba_build(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj,
                                           t0, t1, motion_only)
-            if self.world > 1 and self._pattern is not None and self._pattern[:2] == (int(t0), int(t1)):
+            if packed:
                 # packed exchange: lower-triangular 6x6 blocks + rhs row (the factorisation reads the lower triangle only)
                 n = 6 * (t1 - t0)
                 idx = self._flat_index(system, t0, t1)

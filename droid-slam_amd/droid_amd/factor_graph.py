@@ -18,6 +18,7 @@ import torch
 
 import droid_backends as db
 from .corr import CorrBlock, CorrBlockRef, AltCorrBlock
+from .update import tensor_cache_key
 
 
 class FactorGraph:
@@ -133,8 +134,8 @@ class FactorGraph:
         (UpdateModule.context_term).  All three depend only on the edge list and on video.inps, which change when a keyframe is
         added or removed, not between the update iterations in between: kept until either changes (tensor version counters)."""
         inps = self.video.inps
-        key = (ii.data_ptr(), ii._version, ii.numel(), inps.data_ptr(), inps._version)
-        if getattr(self, "_ctx_key", None) != key:
+        key = tensor_cache_key(ii, inps)
+        if key is None or getattr(self, "_ctx_key", None) != key:
             uniq, ix = torch.unique(ii, return_inverse=True)
             inp_frames = inps[uniq].permute(0, 2, 3, 1).contiguous()
             h, w = inp_frames.shape[1:3]
@@ -179,9 +180,15 @@ class FactorGraph:
         for _ in range(steps):
             coords1 = v.reproject(self.ii, self.jj)[0][0]
             target_prev = self.target[0].contiguous()
-            target = torch.empty_like(target_prev); weight = torch.empty_like(target_prev)
-            tb = torch.empty(len(self.ii), 2, ht, wd, device=self.device); wb = torch.empty_like(tb)
             lo, hi = int(self.ii.min().item()), int(self.jj.max().item()) + 1
+            if int(self.ii.max().item()) >= lo + (hi - lo + s - 1) // s * s:
+                # the reference's chunk loop (factor_graph.py:284-287) stops at jj.max(): edges whose source frame lies beyond
+                # it are not visited and keep their previous target / weight
+                target = target_prev.clone(); weight = self.weight[0].clone()
+                tb = target.permute(0, 3, 1, 2).contiguous(); wb = weight.permute(0, 3, 1, 2).contiguous()
+            else:                                                       # every edge is written below
+                target = torch.empty_like(target_prev); weight = torch.empty_like(target_prev)
+                tb = torch.empty(len(self.ii), 2, ht, wd, device=self.device); wb = torch.empty_like(tb)
             for i in range(lo, hi, s):
                 vmask = (self.ii >= i) & (self.ii < i + s)
                 e = torch.nonzero(vmask)[:, 0]

@@ -55,6 +55,17 @@ def empty_state_dict(dtype=torch.float32):
     return sd
 
 
+def tensor_cache_key(*tensors):
+    """identity + version of tensors a cached derivation depends on, or None when no key can be formed (tensors created
+    under torch.inference_mode() carry no version counter: their derivations are then recomputed on every call)"""
+    key = []
+    for t in tensors:
+        if t.is_inference():
+            return None
+        key.append((t.data_ptr(), t._version, t.numel(), t.device))
+    return tuple(key)
+
+
 def _round_up(v, m):
     return (v + m - 1) // m * m
 
@@ -136,12 +147,30 @@ def pack_conv_7x7_c4(weight):
     return w.reshape(128, 224).half().contiguous()
 
 
+def _halo_layout_options():
+    """the options that decide the layout of `weights_halo` (csrc/conv.hip dma_layout / halo2_layout)"""
+    return droid_backends.get_option("conv_dma"), droid_backends.get_option("conv_halo2")
+
+
 class _Conv:
     def __init__(self, wp, bp, k, cout, wh=None):
         self.w, self.b, self.k, self.cout, self.wh = wp, bp, k, cout, wh
+        # the kernel-ordered copy `wh` was laid out for the option values of this moment; csrc/conv.hip picks its kernel from
+        # the option values at launch time -> remember them, re-check whenever any option changed (options_epoch)
+        self._epoch = droid_backends.options_epoch()
+        self._layout = _halo_layout_options()
+
+    def _check_layout(self):
+        epoch = droid_backends.options_epoch()
+        if epoch != self._epoch:
+            if self.wh is not None and _halo_layout_options() != self._layout:
+                raise RuntimeError("conv weights were packed for (conv_dma, conv_halo2) = %s, the options now say %s: "
+                                   "call load_state_dict again after changing them" % (self._layout, _halo_layout_options()))
+            self._epoch = epoch
 
     def __call__(self, inputs, epi, out=None, out_stride=None, gterm=None, aux0=None, aux1=None, red=None,
                  cinit=None, cinit_idx=None, cinit_off=0, out_raw_f32=False):
+        self._check_layout()
         x0 = inputs[0]
         if out is None and epi not in (EPI_GLO, EPI_HEADS0):
             out = torch.empty(x0.shape[0], x0.shape[1], x0.shape[2], self.cout,
@@ -252,8 +281,8 @@ class UpdateModule:
     def segments(self, ii):
         """edges grouped by source frame for GraphAgg's mean (droid_net.py:66-67): (order [E], seg_off [K+1]).  Depends on the
         edge list only, so it is kept until `ii` changes (torch.unique has to synchronise to size its result)."""
-        key = (ii.data_ptr(), ii._version, ii.numel(), ii.device)
-        if getattr(self, "_seg_key", None) != key:
+        key = tensor_cache_key(ii)
+        if key is None or getattr(self, "_seg_key", None) != key:
             _, ix, cnt = torch.unique(ii, return_inverse=True, return_counts=True)
             order = torch.argsort(ix, stable=True)
             seg_off = torch.zeros(cnt.numel() + 1, dtype=torch.int64, device=ii.device)

@@ -46,12 +46,16 @@ const char* dh_status_string(int status);
 /* Process-wide switches (A/B measurements and the fallbacks the parity tests exercise).  Initialised from the
  * environment variables DH_<NAME> once, when the library is loaded; nothing on a launch path reads the environment.
  * names: "debug", "chol_lookahead", "conv_epi_staged", "conv_halo", "conv_halo2", "conv_dma", "dma_var",
- * "pyr_build_chunk", "ba_strict" (dh_ba synchronises and returns DH_ERR_ARG when an edge index lies outside the frame
- * buffer or eta does not have one row per depth block; off by default -- such calls then apply NO update, silently,
- * where the reference would read out of bounds / fail its broadcast, src/droid_kernels.cu:1407).
+ * "pyr_build_chunk", "ba_strict" (ON by default: dh_ba / dh_ba_ex / dh_ba_build synchronise the stream once, after their
+ * last launch, and return DH_ERR_ARG when an edge index lies outside the frame buffer or eta does not have one row per
+ * depth block -- the reference would read out of bounds / fail its broadcast, src/droid_kernels.cu:1407; in either mode
+ * such a call applies NO update.  0 = fully asynchronous call, no signal to the caller).
  * Returns DH_ERR_ARG for an unknown name. */
 int dh_set_option(const char* name, int value);
 int dh_get_option(const char* name, int* value);
+/* number of dh_set_option calls that changed a value so far: lets a holder of option-dependent state (the kernel-ordered
+ * weight copies of dh_conv2d_nhwc_f16, whose layout follows "conv_dma" / "conv_halo2") notice cheaply that it must re-check */
+int dh_options_epoch(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Correlation-volume lookup.  Replaces corr_index_forward / corr_index_backward
@@ -310,6 +314,11 @@ int dh_se3_adjT(const float* a, const float* X, float* Y, int n, int npts, dh_st
 int dh_reproject(const float* poses, const float* disps, const float* intrinsics,
                  const int64_t* ii, const int64_t* jj, float* coords, float* valid,
                  int E, int ht, int wd, dh_stream_t stream);
+/* per_frame_intrinsics != 0: intrinsics is [num_frames,4]; pixels of frame ii[e] are back-projected with intrinsics[ii[e]]
+ * and projected with intrinsics[jj[e]], as projective_transform does (projective_ops.py:180,183) */
+int dh_reproject_ex(const float* poses, const float* disps, const float* intrinsics, int per_frame_intrinsics,
+                    const int64_t* ii, const int64_t* jj, float* coords, float* valid,
+                    int E, int ht, int wd, dh_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -140,21 +140,31 @@ def test_ba_failure_in_the_first_iteration_only_vs_reference(db, ref):
     _check(two, two_ref)
 
 
-def test_ba_bad_indices_and_eta_rows_apply_no_update(db):
+def test_ba_bad_indices_and_eta_rows_raise_and_apply_no_update(db):
     """an edge index outside the frame buffer / an eta without one row per depth block: the reference reads out of bounds
-    resp. fails its broadcast (droid_kernels.cu:1407); here the call is a no-op update, and an error in strict mode"""
+    resp. fails its broadcast (droid_kernels.cu:1407); here the call raises (default) and has applied no update; with
+    ba_strict = 0 (fully asynchronous calls) it is a silent no-op update"""
     g = syn.small_graph(n_frames=6, seed=21, ht=12, wd=16)
     bad = dict(g); bad["jj"] = g["jj"].copy(); bad["jj"][3] = 77
-    out = _ba(db, bad, g["poses"], g["disps"], g["eta"], 1, 6, 2, 1e-4, 0.1, False)
-    assert np.array_equal(out[0], g["poses"]) and np.array_equal(out[1], g["disps"]) and np.all(out[2] == 0)
-    out = _ba(db, g, g["poses"], g["disps"], g["eta"][:-1], 1, 6, 1, 1e-4, 0.1, False)
-    assert np.array_equal(out[0], g["poses"]) and np.array_equal(out[1], g["disps"])
-    db.set_option("ba_strict", 1)
+    assert db.get_option("ba_strict") == 1
+    p, d = dev(g["poses"]), dev(g["disps"])
+    with pytest.raises(RuntimeError):
+        db.ba(p, d, dev(g["intrinsics"]), dev(g["disps_sens"]), dev(g["targets"]), dev(g["weights"]), dev(g["eta"]),
+              dev(g["ii"]), dev(bad["jj"]), 1, 6, 2, 1e-4, 0.1, False)
+    assert np.array_equal(p.cpu().numpy(), g["poses"]) and np.array_equal(d.cpu().numpy(), g["disps"])
+    with pytest.raises(RuntimeError):
+        _ba(db, g, g["poses"], g["disps"], g["eta"][:-1], 1, 6, 1, 1e-4, 0.1, False)
+    with pytest.raises(RuntimeError):                       # the two-phase entry points of the edge-sharded BA as well
+        db.ba_build(dev(g["poses"]), dev(g["disps"]), dev(g["intrinsics"]), dev(g["disps_sens"]), dev(g["targets"]), dev(g["weights"]),
+                    dev(g["eta"]), dev(g["ii"]), dev(bad["jj"]), 1, 6, False)
+    db.set_option("ba_strict", 0)
     try:
-        with pytest.raises(RuntimeError):
-            _ba(db, bad, g["poses"], g["disps"], g["eta"], 1, 6, 1, 1e-4, 0.1, False)
+        out = _ba(db, bad, g["poses"], g["disps"], g["eta"], 1, 6, 2, 1e-4, 0.1, False)
+        assert np.array_equal(out[0], g["poses"]) and np.array_equal(out[1], g["disps"]) and np.all(out[2] == 0)
+        out = _ba(db, g, g["poses"], g["disps"], g["eta"][:-1], 1, 6, 1, 1e-4, 0.1, False)
+        assert np.array_equal(out[0], g["poses"]) and np.array_equal(out[1], g["disps"])
     finally:
-        db.set_option("ba_strict", 0)
+        db.set_option("ba_strict", 1)
 
 
 @pytest.mark.parametrize("cfg", ["C1", "C2", "C3"])
