@@ -49,6 +49,17 @@ def parse():
                     "implicit-GEMM first correlation layer, instead of the reference-layout output + corr0_nchw")
     ap.add_argument("--per-edge-inp", action="store_true", help="context features gathered per edge and convolved with the "
                     "other 320 gate inputs (the reference's data flow) instead of once per source frame (A/B)")
+    ap.add_argument("--op-chunks", type=int, default=0, help="run the update operator over this many contiguous groups of source "
+                    "frames (0 = automatic: 1, or 2 when the pyramid leaves less than 70 GB of HBM -- C5 on one GPU)")
+    ap.add_argument("--no-check", action="store_true", help="skip the untimed output check of the step (N = 1 only): the same "
+                    "iteration through the reference-layout entry points (torch.matmul volumes + corr_index_forward, the "
+                    "reference interface of the update operator with per-edge context features, ba) from the same state")
+    ap.add_argument("--no-sensitivity", action="store_true", help="skip the untimed flow-sensitivity runs of the lookup kernel")
+    ap.add_argument("--lowmem", action="store_true", help="time FactorGraph.update_lowmem steps (the global-BA iteration, "
+                    "reference factor_graph.py:266-330) instead of FactorGraph.update steps")
+    ap.add_argument("--lowmem-corr", default="auto", choices=["auto", "alt", "pyramid"], help="correlation features of the "
+                    "global-BA iteration: on-the-fly alt-correlation in source-frame chunks, or a pyramid built once per call")
+    ap.add_argument("--chunk-frames", type=int, default=64, help="source frames per chunk of the alt-correlation path")
     return ap.parse_args()
 
 
@@ -191,12 +202,132 @@ def launch_ranks(args):
     sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
+def _ev():
+    return torch.cuda.Event(enable_timing=True)
+
+
+def _lookup_rate(ms, E, HW):
+    gbs = LOOKUP_BYTES_PER_EP_F16 * E * HW / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    return {"ms": ms, "GB/s": gbs, "frac": gbs / HBM_PEAK_GBS}
+
+
+def _time_ms(fn, reps=3):
+    fn(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        a, b = _ev(), _ev()
+        a.record(); fn(); b.record(); torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    return float(np.median(ts))
+
+
+def lookup_sensitivity(db, corr, g, coords_bench, ii, jj, fmaps, dev, lk_ms):
+    """The pyramid layout coalesces when the 64 pixels of an 8x8 source block want the same displacement cells, i.e. it is
+    sensitive to the spatial coherence of the flow (the reference layout is not).  Same kernel, same pyramid, three flows:
+      bench    the step's own coords (reprojection with the bench's initial state: depth 1 everywhere)
+      planes   reprojection with the ground-truth poses and piecewise-constant depth planes (16x16-pixel patches, depth
+               jumps between them): coherent inside a patch, discontinuous across
+      random   independent uniform coordinates per pixel: no coherence at all (the worst case)
+    and the reference-layout lookup (droid_backends.corr_index_forward on [n,h,w,h2,w2] volumes, 4 levels) on the first 256
+    edges under the same three flows."""
+    from droid_amd.corr import CorrBlockRef
+    E, ht, wd = len(ii), g["ht"], g["wd"]
+    HW = ht * wd
+    rng = np.random.default_rng(11)
+    d = lambda a, **kw: torch.as_tensor(np.ascontiguousarray(a), **kw).to(dev)
+    N = g["n_frames"]
+    planes = rng.uniform(0.3, 2.0, (N, ht // 16, wd // 16)).astype(np.float32)
+    disps_planes = d(np.kron(planes, np.ones((16, 16), dtype=np.float32)))
+    coords_planes, _ = db.reproject(d(g["poses_gt"]), disps_planes, d(g["intrinsics"]), ii, jj)
+    coords_random = d(np.stack([rng.uniform(0, wd, (E, ht, wd)), rng.uniform(0, ht, (E, ht, wd))], -1).astype(np.float32))
+    flows = {"bench": coords_bench, "planes": coords_planes, "random": coords_random}
+    out = {}
+    for name, c in flows.items():
+        c = c.contiguous()
+        ms = lk_ms if name == "bench" and lk_ms > 0 else _time_ms(lambda: corr(c[None]))
+        out[name] = _lookup_rate(ms, E, HW)
+    n = min(256, E)
+    rig = fmaps.shape[1]
+    cidx = (ii[:n] == jj[:n]).long() if rig > 1 else torch.zeros_like(ii[:n])
+    ref_block = CorrBlockRef(fmaps[ii[:n], 0][None], fmaps[jj[:n], cidx][None])
+    refl = {"edges": n}
+    for name, c in flows.items():
+        cn = c[:n].contiguous()
+        refl[name] = _lookup_rate(_time_ms(lambda: ref_block(cn[None])), n, HW)
+    out["reference_layout_kernel"] = refl
+    del ref_block
+    return out
+
+
+def check_step(db, upd, g, dev, state, product_step):
+    """Untimed: the timed iteration again from a saved state, and the same iteration through the REFERENCE-LAYOUT entry points
+    -- all-pairs volumes by torch.matmul + droid_backends.corr_index_forward per level (CorrBlockRef = modules/corr.py:23-50),
+    motion features in torch (factor_graph.py:221-222), the update operator through its reference interface with per-edge
+    context features (448-channel gate convolutions), droid_backends.ba -- from the same poses / depths / hidden state."""
+    from droid_amd.corr import CorrBlockRef
+    poses0, disps0, net, ii, jj, fmaps, inps_frames, inp_index, target_prev, damping0, kx_t, uniq_ii, intr, sens = state
+    E, ht, wd, N = len(ii), g["ht"], g["wd"], g["n_frames"]
+    net_saved = net.clone()
+    pa, da = product_step()                                   # poses / disps after the product step (net updated in place)
+    net_a = net.clone()
+    net.copy_(net_saved)
+    # ---- reference-layout iteration
+    poses, disps = poses0.clone(), disps0.clone()
+    coords1, _ = db.reproject(poses, disps, intr, ii, jj)
+    rig = fmaps.shape[1]
+    feats = torch.empty(E, 196, ht, wd, device=dev, dtype=torch.float16)
+    for s in range(0, E, 128):
+        e = slice(s, min(E, s + 128))
+        cidx = (ii[e] == jj[e]).long() if rig > 1 else torch.zeros_like(ii[e])
+        blk = CorrBlockRef(fmaps[ii[e], 0][None], fmaps[jj[e], cidx][None])
+        feats[e] = blk(coords1[e][None])[0]
+        del blk
+    yy, xx = torch.meshgrid(torch.arange(ht, device=dev, dtype=torch.float32), torch.arange(wd, device=dev, dtype=torch.float32), indexing="ij")
+    coords0 = torch.stack([xx, yy], -1)
+    motn = torch.cat([coords1 - coords0, target_prev - coords1], -1).permute(0, 3, 1, 2).clamp(-64.0, 64.0)
+    damping_buf = damping0.clone()
+    delta = torch.empty(E, ht, wd, 2, device=dev); weight = torch.empty(E, ht, wd, 2, device=dev)
+    net_b = torch.empty_like(net_saved)
+    # (in groups of whole source frames: the reference interface materialises NCHW copies of everything)
+    bounds = [0]
+    iic = ii.cpu().numpy()
+    for s in range(1024, E, 1024):
+        while s < E and iic[s] == iic[s - 1]:
+            s += 1
+        if s < E and s > bounds[-1]:
+            bounds.append(s)
+    bounds.append(E)
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        e = slice(a, b)
+        n_out, dl, wt, eta_e, _ = upd.forward(net_saved[e].permute(0, 3, 1, 2)[None], inps_frames[inp_index[e]].permute(0, 3, 1, 2)[None],
+                                              feats[e][None], motn[e][None], ii[e], jj[e])
+        net_b[e] = n_out[0].permute(0, 2, 3, 1); delta[e] = dl[0]; weight[e] = wt[0]
+        damping_buf[torch.unique(ii[e])] = eta_e[0]
+    tgt = (coords1 + delta).permute(0, 3, 1, 2).contiguous(); wgt = weight.permute(0, 3, 1, 2).contiguous()
+    eta_ba = (0.2 * damping_buf[kx_t] + 1e-7).contiguous()
+    db.ba(poses, disps, intr, sens, tgt, wgt, eta_ba, ii, jj, 1, N, g["itrs"], g["lm"], g["ep"], False)
+    disps.clamp_(min=0.001)
+    torch.cuda.synchronize()
+    q, qr = pa[:, 3:].double(), poses[:, 3:].double()
+    v = q[:, 3:4] * -qr[:, :3] + qr[:, 3:4] * q[:, :3] + torch.cross(q[:, :3], -qr[:, :3], dim=-1)
+    rel = (da - disps).abs() / disps.abs().clamp(min=1.0)
+    res = {"max_dtrans": float((pa[:, :3] - poses[:, :3]).abs().max()), "max_drot_rad": float(2 * v.norm(dim=-1).max()),
+           "disps_rel_q99": float(torch.quantile(rel.flatten()[:: max(1, rel.numel() // 1000000)], 0.99)), "disps_rel_max": float(rel.max()),
+           "hidden_state_max_abs_diff": float((net_a.float() - net_b.float()).abs().max()),
+           "pose_update_norm": float((pa[:, :3] - poses0[:, :3]).abs().max()),
+           "against": "reference-layout entry points (torch.matmul volumes + corr_index_forward, UpdateModule.forward with per-edge "
+                      "context features, ba) from the same state"}
+    res["ok"] = bool(res["max_dtrans"] <= 2e-3 and res["max_drot_rad"] <= 2e-3 and res["disps_rel_q99"] <= 1e-2
+                     and res["hidden_state_max_abs_diff"] <= 2.0 ** -7 and np.isfinite(res["max_dtrans"]) and res["pose_update_norm"] > 0)
+    return res
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != max(1, args.gpus):
+    if args.gpus > 1 and world != args.gpus:
         sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -209,6 +340,8 @@ def main():
         # with a single GPU (RCCL refuses two ranks on one device)
         dist.init_process_group(os.environ.get("DH_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
     dev = torch.device("cuda", local)
+    if args.lowmem:
+        return main_lowmem(args, dev, world, rank)
 
     import droid_backends as db
     from droid_amd import synthetic as syn
@@ -218,6 +351,11 @@ def main():
     g = syn.make_graph(cfg, with_features=True)
     N, ht, wd = g["n_frames"], g["ht"], g["wd"]
     HW = ht * wd
+    # edges grouped by source frame (a permutation of the seeded edge list; FactorGraph appends edges in that order too,
+    # factor_graph.py:332-344): every rank's shard and every operator chunk is then a contiguous range of records
+    order = np.argsort(g["ii"], kind="stable")
+    for k in ("ii", "jj", "targets", "weights"):
+        g[k] = g[k][order]
     ii_all, jj_all = g["ii"], g["jj"]
     E_all = len(ii_all)
 
@@ -242,8 +380,11 @@ def main():
     # ---- correlation pyramid for this rank's edges (setup, untimed: built once per edge lifetime) ----
     c = (ii == jj).long() if rig > 1 else torch.zeros_like(ii)
     corr = None if args.no_lookup else CorrBlock(fmaps[ii, 0][None], fmaps[jj, c][None])
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()                              # (the per-edge feature gathers and the build workspace)
     # ---- ConvGRU update operator: random-init weights of the reference architecture (no droid.pth here) ----
     upd = None
+    op_chunks = 1
     if not args.no_update_op:
         from droid_amd.update import UpdateModule, empty_state_dict
         from droid_amd.weights import deterministic_state_dict
@@ -259,9 +400,23 @@ def main():
         inps_frames = d(g["inps"])[f_lo:f_hi].permute(0, 2, 3, 1).contiguous()       # [frames,h,w,128] f16
         inp_index = (ii - f_lo).contiguous()
         inp_edges = inps_frames[inp_index].contiguous() if args.per_edge_inp else None
-    yy, xx = torch.meshgrid(torch.arange(ht, device=dev, dtype=torch.float32),
-                            torch.arange(wd, device=dev, dtype=torch.float32), indexing="ij")
-    coords0 = torch.stack([xx, yy], -1)[None]                             # [1,h,w,2]
+        # the operator's activations take ~3.5 KB per edge-pixel: with the 210 GB pyramid of C5 on one GPU it runs over two
+        # groups of source frames (GraphAgg averages over the edges of a source frame: groups keep them together)
+        free_b = torch.cuda.mem_get_info(dev)[0]
+        op_chunks = args.op_chunks if args.op_chunks > 0 else (1 if free_b > 1.25 * E * HW * 3584 else max(2, int(np.ceil(1.6 * E * HW * 3584 / free_b))))
+    iic = ii_all[mine]
+    cuts = [0]
+    for k in range(1, op_chunks):
+        s = (E * k) // op_chunks
+        while s < E and iic[s] == iic[s - 1]:
+            s += 1
+        if cuts[-1] < s < E:
+            cuts.append(s)
+    cuts.append(E)
+    chunk_slices = [slice(a, b) for a, b in zip(cuts[:-1], cuts[1:])]
+    ii_chunks = [ii[s].contiguous() for s in chunk_slices]                 # (kept: the operator caches per edge-list tensor)
+    idx_chunks = [inp_index[s].contiguous() for s in chunk_slices] if upd is not None else None
+    uniq_chunks = [torch.unique(t) for t in ii_chunks]
     target_prev = targets.permute(0, 2, 3, 1).contiguous()                # [E,h,w,2]
     torch.cuda.synchronize()
 
@@ -271,7 +426,6 @@ def main():
         solver.set_graph(ii_all, jj_all, 1, N)              # all-reduce of the co-visible 6x6 blocks only (~6 MB instead of 77 MB)
     uniq_ii = torch.unique(ii)
 
-    ev = lambda: torch.cuda.Event(enable_timing=True)
     lk_ms, up_ms, ba_ms = [], [], []
 
     # the update operator takes the unpadded reference-layout features where its first layer has the kernel for them
@@ -281,7 +435,7 @@ def main():
         """one FactorGraph.update iteration (reference factor_graph.py:214-263)"""
         poses.copy_(poses0); disps.copy_(disps0)
         coords1, _ = db.reproject(poses, disps, intr, ii, jj)              # [E,h,w,2]
-        e0, e1, e2, e3 = ev(), ev(), ev(), ev()
+        e0, e1, e2, e3 = _ev(), _ev(), _ev(), _ev()
         e0.record()
         fused = upd is not None and corr is not None
         # channel-last features straight into the update operator; the reference-layout [E,196,h,w] otherwise
@@ -289,12 +443,24 @@ def main():
         e1.record()
         if upd is not None and feats is not None:
             flow = db.motion_features(coords1, target_prev)                   # factor_graph.py:221-222
-            if inp_edges is not None:
-                _, _, _, damping, upmask = upd.forward_nhwc(net, inp_edges, feats, flow, ii)
+            if len(chunk_slices) == 1:
+                if inp_edges is not None:
+                    _, _, _, damping, upmask = upd.forward_nhwc(net, inp_edges, feats, flow, ii)
+                else:
+                    _, _, _, damping, upmask = upd.forward_nhwc(net, None, feats, flow, ii, inp_frames=inps_frames, inp_index=inp_index)
+                dw = upd.last_dw
+                damping_buf[uniq_ii] = damping                               # factor_graph.py:238
             else:
-                _, _, _, damping, upmask = upd.forward_nhwc(net, None, feats, flow, ii, inp_frames=inps_frames, inp_index=inp_index)
-            _, _, tgt, wgt = db.ba_inputs(coords1, upd.last_dw)               # target = coords1 + delta, [E,2,h,w] for ba (:233,253-254)
-            damping_buf[uniq_ii] = damping                                   # factor_graph.py:238
+                dw = torch.empty(E, ht, wd, 4, device=dev, dtype=torch.float32)
+                for s, iis, ixs, uq in zip(chunk_slices, ii_chunks, idx_chunks, uniq_chunks):
+                    f_s = feats[:, s] if feats.dim() == 5 else feats[s]
+                    if inp_edges is not None:
+                        _, _, _, damping, upmask = upd.forward_nhwc(net[s], inp_edges[s], f_s, flow[s], iis)
+                    else:
+                        _, _, _, damping, upmask = upd.forward_nhwc(net[s], None, f_s, flow[s], iis, inp_frames=inps_frames, inp_index=ixs)
+                    dw[s] = upd.last_dw
+                    damping_buf[uq] = damping
+            _, _, tgt, wgt = db.ba_inputs(coords1, dw)                        # target = coords1 + delta, [E,2,h,w] for ba (:233,253-254)
             eta_ba = (0.2 * damping_buf[kx_t] + 1e-7).contiguous()            # factor_graph.py:251 (rows = depth blocks)
         else:
             tgt, wgt, eta_ba = targets, weights, eta
@@ -307,7 +473,7 @@ def main():
         e3.record()
         if timed:
             lk_ms.append((e0, e1)); up_ms.append((e1, e2)); ba_ms.append((e2, e3))
-        return feats
+        return coords1
 
     def barrier():
         if world > 1:
@@ -334,13 +500,33 @@ def main():
     up = float(np.mean([a.elapsed_time(b) for a, b in up_ms])) if up_ms else 0.0
     ba = float(np.mean([a.elapsed_time(b) for a, b in ba_ms])) if ba_ms else 0.0
 
+    check = sens_out = None
+    if world == 1 and upd is not None and corr is not None and inp_edges is None:
+        if not args.no_check:
+            def product():
+                step(False)
+                torch.cuda.synchronize()
+                return poses.clone(), disps.clone()
+            try:
+                check = check_step(db, upd, g, dev, (poses0, disps0, net, ii, jj, fmaps, inps_frames, inp_index, target_prev,
+                                                     torch.full((N, ht, wd), 1e-6, device=dev), kx_t, uniq_ii, intr, sens), product)
+            except torch.cuda.OutOfMemoryError as exc:        # C5 on one GPU: no room for the reference-layout copies
+                check = {"ok": None, "skipped": "out of memory for the reference-layout run: %s" % str(exc)[:80]}
+            torch.cuda.empty_cache()
+        if not args.no_sensitivity:
+            coords_bench, _ = db.reproject(poses0, disps0, intr, ii, jj)
+            try:
+                sens_out = lookup_sensitivity(db, corr, g, coords_bench, ii, jj, fmaps, dev, lk)
+            except torch.cuda.OutOfMemoryError as exc:
+                sens_out = {"skipped": "out of memory: %s" % str(exc)[:80]}
+
     dist_info = None
     if world > 1:                                               # auditable record of the process group behind a multi-GPU line
         per_rank = [None] * world
         dist.all_gather_object(per_rank, {"rank": rank, "device": torch.cuda.get_device_name(local), "local_rank": local,
                                           "edges": int(E), "frames": [int(bounds[rank]), int(min(bounds[rank + 1], N))]})
         dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": per_rank,
-                     "allreduce_bytes_per_gn_iteration": int(solver.last_exchange_bytes)}
+                     "allreduce_bytes_per_gn_iteration": int(solver.last_exchange_bytes), "packed_exchange": bool(solver.last_exchange_packed)}
     if rank == 0:
         ms = 1000.0 * elapsed / max(1, args.steps)
         ep_total = E_all * HW
@@ -349,12 +535,13 @@ def main():
         achieved = lookup_bytes / (lk * 1e-3) / 1e9 if lk > 0 else 0.0
         # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc, separate passes, gfx950
         # FETCH_SIZE correction; scripts/pmc_bench_lookup.sh), scaled to this rank's edge-pixels; None if not measured
-        traffic = None
+        traffic = traffic_src = None
         try:
             cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_lookup_pmc.json"))
             pmc = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))             # the latest round's passes
             variant = "nhwc" if (upd is not None and corr is not None and not ref_layout) else "nchw"
             traffic = pmc[variant]["hbm_bytes_per_edge_pixel"] * E * HW
+            traffic_src = "profiles/%s (rocprofv3 --pmc passes of the same kernel at 4096 edges, committed; not re-measured in this run)" % cands[-1]
         except (OSError, KeyError, ValueError):
             pass
         out = {
@@ -363,18 +550,23 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32 (BA; fp64 solve) / f16 (correlation pyramid)", "data": "synthetic",
-            "config": {"workload": "%s: %d keyframes, %d edges, %dx%d, ba itrs=%d lm=%g ep=%g" % (
-                cfg.name, N, E_all, ht, wd, g["itrs"], g["lm"], g["ep"]),
+            "config": {"workload": "%s: %d keyframes, %d edges, %dx%d, ba itrs=%d lm=%g ep=%g%s" % (
+                cfg.name, N, E_all, ht, wd, g["itrs"], g["lm"], g["ep"], ", stereo + sensor depth" if cfg.stereo else ""),
                 "stages": "reproject + corr lookup (4 levels, materialised fp16 pyramid, MI355X layout) + %sba" % (
                     "ConvGRU update operator (random-init weights) + " if upd is not None else ""),
-                "parallelism": "edge-sharded x%d" % world},
+                "parallelism": "edge-sharded x%d" % world, "update_operator_chunks": len(chunk_slices),
+                "pyramid_GB": (corr.bytes() / 1e9 if corr is not None else 0.0)},
             "ms_per_global_ba": ba, "ms_corr_lookup": lk, "ms_update_operator": up,
             "roofline": {"kernel": "pyr_lookup_kernel<64, %s> (1 launch = 4-level pyramid lookup of all edges)" % (
                 "channel-last" if (upd is not None and corr is not None and not ref_layout) else "reference layout"), "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch_group": lookup_bytes},
         }
+        if sens_out is not None:
+            out["roofline_sensitivity"] = sens_out
+        if check is not None:
+            out["check"] = check
         if dist_info is not None:
             out["dist"] = dist_info
         if upd is not None and up > 0:
@@ -399,6 +591,90 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def main_lowmem(args, dev, world, rank):
+    """`--lowmem`: the global-BA iteration (FactorGraph.update_lowmem, reference factor_graph.py:266-330) on the whole graph:
+    per step reproject -> correlation features of every edge -> update operator -> ONE ba (lm = 1e-5, ep = 1e-2) over all
+    keyframes.  `--lowmem-corr alt`: on-the-fly alt-correlation in chunks of --chunk-frames source frames (the reference's
+    scheme; altcorr_mfma_kernel); `pyramid`: the pyramid of all edges built once per update_lowmem call (its build time is
+    inside the timed region, amortised over the call's steps)."""
+    assert world == 1, "--lowmem is a single-GPU measurement"
+    import droid_backends as db
+    from droid_amd import synthetic as syn
+    from droid_amd import corr as corr_mod
+    from droid_amd.depth_video import DepthVideo
+    from droid_amd.factor_graph import FactorGraph
+    from droid_amd.update import UpdateModule, empty_state_dict
+    from droid_amd.weights import deterministic_state_dict
+    cfg = syn.CONFIGS[args.config]
+    g = syn.make_graph(cfg, with_features=True)
+    N, ht, wd = g["n_frames"], g["ht"], g["wd"]
+    HW = ht * wd
+    E = len(g["ii"])
+    d = lambda a, **kw: torch.as_tensor(np.ascontiguousarray(a), **kw).to(dev)
+
+    class _SD:
+        def state_dict(self):
+            return empty_state_dict()
+    upd = UpdateModule(dev).load_state_dict(deterministic_state_dict(_SD(), seed=1234))
+    video = DepthVideo(image_size=[8 * ht, 8 * wd], buffer=N + 2, stereo=cfg.stereo, device=str(dev))
+    poses0, disps0 = d(g["poses"]), d(g["disps"])
+    video.poses[:N] = poses0; video.disps[:N] = disps0; video.intrinsics[:N] = d(g["intrinsics"])
+    video.disps_sens[:N] = d(g["disps_sens"])
+    video.fmaps[:N] = d(g["fmaps"]); video.nets[:N] = d(g["nets"]); video.inps[:N] = d(g["inps"])
+    video.counter.value = N
+    fg = FactorGraph(video, upd, corr_impl="alt", max_factors=16 * N, upsample=False, chunk_frames=args.chunk_frames)
+    order = np.argsort(g["ii"], kind="stable")
+    fg.add_factors(d(g["ii"][order]), d(g["jj"][order]))
+    assert len(fg.ii) == E
+    net0, target0, weight0 = fg._net.clone(), fg.target.clone(), fg.weight.clone()
+    mode = args.lowmem_corr
+    if mode == "auto":
+        mode = "pyramid" if fg._pyramid_fits(E, ht, wd) else "alt"
+    steps_per_call = 8                                       # update_lowmem's default (droid_backend.py calls it with 7 and 12)
+    # HIP-event time of the alt-correlation launches (4 levels per chunk)
+    alt_ev = []
+    orig_call = corr_mod.AltCorrBlock.__call__
+
+    def timed_call(self, *a, **kw):
+        e0, e1 = _ev(), _ev()
+        e0.record(); r = orig_call(self, *a, **kw); e1.record()
+        alt_ev.append((e0, e1))
+        return r
+    corr_mod.AltCorrBlock.__call__ = timed_call
+
+    def call():
+        video.poses[:N] = poses0; video.disps[:N] = disps0
+        fg._net.copy_(net0); fg.target = target0.clone(); fg.weight = weight0.clone(); fg.damping.fill_(1e-6)
+        fg.update_lowmem(steps=steps_per_call, corr=mode)
+
+    call(); torch.cuda.synchronize()                         # code objects, LDS opt-ins, allocator pool
+    for _ in range(max(0, args.warmup - 1)):
+        call()
+    torch.cuda.synchronize()
+    alt_ev.clear()
+    ncalls = max(1, args.steps // steps_per_call)
+    t0 = time.perf_counter()
+    for _ in range(ncalls):
+        call()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    nsteps = ncalls * steps_per_call
+    ms = 1e3 * elapsed / nsteps
+    alt_ms = sum(a.elapsed_time(b) for a, b in alt_ev) / nsteps if alt_ev else None
+    out = {"metric": "global-BA update iterations/sec (edges*pixels/s), FactorGraph.update_lowmem", "value": E * HW / (ms * 1e-3),
+           "unit": "edge-pixels/s", "n_gpus": 1, "steps": nsteps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "f32 (BA; fp64 solve) / f16 (features)", "data": "synthetic",
+           "config": {"workload": "%s: %d keyframes, %d edges, %dx%d, update_lowmem(steps=%d) calls, ba itrs=2 lm=1e-5 ep=1e-2" % (
+               cfg.name, N, E, ht, wd, steps_per_call), "correlation": mode, "chunk_frames": args.chunk_frames}}
+    if alt_ms is not None:
+        flops = 65536.0 * E * HW                              # SURVEY 8(d): 4 levels x 64 taps x 128 channels x 2
+        tf = flops / (alt_ms * 1e-3) / 1e12
+        out["roofline_altcorr"] = {"kernel": "altcorr_mfma_kernel (4 launches per chunk; HIP events around AltCorrBlock.__call__, "
+                                   "incl. its level stack copies)", "bound": "mfma", "ms_per_step": alt_ms, "achieved": tf, "peak": 2500.0,
+                                   "unit": "TFLOP/s", "frac": tf / 2500.0, "algorithmic_flops": flops}
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":

@@ -111,6 +111,13 @@ class CorrBlock:
     def supported(ht, wd):
         return ht % 8 == 0 and wd in (16, 32, 64)
 
+    @staticmethod
+    def bytes_per_edge(ht, wd):
+        """size of one edge's record (csrc/corr_pyramid.hip make_dims: per level and 8x8 source block (h2 + 1 zero row) x w2
+        displacement cells x 64 pixels, fp16) = dh_corr_pyramid_bytes(1, ht, wd)"""
+        nblk = (ht // 8) * (wd // 8)
+        return sum(nblk * ((ht >> l) + 1) * (wd >> l) * 64 * 2 for l in range(4))
+
     def __call__(self, coords):
         batch, num, ht, wd, _ = coords.shape
         out = droid_backends.corr_pyramid_lookup(self.pyramid, coords.reshape(batch * num, ht, wd, 2).contiguous())

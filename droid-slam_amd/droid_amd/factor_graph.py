@@ -171,10 +171,54 @@ class FactorGraph:
         self.age += 1
 
     # ---- global BA (factor_graph.py:266-330) --------------------------------------------------------------------------
-    def update_lowmem(self, t0=None, t1=None, itrs=2, use_inactive=False, EP=1e-7, steps=8):
+    def _pyramid_fits(self, E, ht, wd):
+        """True if the materialised pyramid of all E edges plus the full-batch activations of the update operator fit into
+        the HBM that is free right now (288 GB per MI355X: 512 keyframes / 4096 edges at 48x64 need 105 + ~40 GB)"""
+        if not CorrBlock.supported(ht, wd):
+            return False
+        free, _ = torch.cuda.mem_get_info(self.device)
+        free += torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)    # cached by torch, reusable
+        need = E * CorrBlock.bytes_per_edge(ht, wd) + E * ht * wd * 3584                               # + ~3.5 KB of activations per edge-pixel
+        return need < 0.9 * free
+
+    def _ba_global(self, tb, wb, itrs, use_inactive, EP, t):
+        ii, jj = self.ii, self.jj
+        if use_inactive:
+            ii = torch.cat([self.ii_inac, ii]); jj = torch.cat([self.jj_inac, jj])
+            tb = torch.cat([self.target_inac[0].permute(0, 3, 1, 2), tb]).contiguous()
+            wb = torch.cat([self.weight_inac[0].permute(0, 3, 1, 2), wb]).contiguous()
+        eta = (.2 * self.damping[torch.unique(ii)] + EP).contiguous()
+        self.age += 1
+        self.video.ba(tb, wb, eta, ii, jj, 1, t, itrs=itrs, lm=1e-5, ep=1e-2, motion_only=False)
+        self.video.dirty[:t] = True
+
+    def update_lowmem(self, t0=None, t1=None, itrs=2, use_inactive=False, EP=1e-7, steps=8, corr="auto"):
+        """`steps` global-BA iterations over all edges (factor_graph.py:266-330).  Correlation features, `corr` =
+          "alt"      the reference's scheme: on-the-fly correlation (MFMA alt-corr kernel) in chunks of `chunk_frames` source
+                     frames, nothing materialised;
+          "pyramid"  the 4-level pyramid of every edge is built ONCE for the whole call (fmaps do not change during it) and
+                     each step is one full-batch lookup + update operator, like update(): the build is amortised over the
+                     steps and the lookup is HBM-bound instead of recomputing 8x8 x 128-channel dot products per step;
+          "auto"     "pyramid" when it fits into the free HBM (105 GB for 4096 edges at 48x64), else "alt".
+        The pyramid is dropped when the call returns."""
         v = self.video
         t = v.counter.value
         num, rig, ch, ht, wd = v.fmaps.shape
+        if corr == "pyramid" or (corr == "auto" and self._pyramid_fits(len(self.ii), ht, wd)):
+            c = (self.ii == self.jj).long() if rig > 1 else torch.zeros_like(self.ii)
+            block = CorrBlock(v.fmaps[self.ii, 0][None], v.fmaps[self.jj, c][None])
+            ref_layout = self.update_op.wants_reference_layout_corr(ht, wd)
+            for _ in range(steps):
+                coords1 = v.reproject(self.ii, self.jj)[0][0]
+                feats = block(coords1[None])[0] if ref_layout else block.lookup_nhwc(coords1[None])
+                dw, damping, upmask, uniq = self._operator(self._net, coords1, self.target[0].contiguous(), feats, self.ii)
+                target, weight, tb, wb = db.ba_inputs(coords1, dw)
+                self.target, self.weight = target[None], weight[None]
+                self.damping[uniq] = damping
+                if self.upsample:
+                    v.upsample(uniq, upmask)
+                self._ba_global(tb, wb, itrs, use_inactive, EP, t)
+            return
         corr_op = AltCorrBlock(v.fmaps.view(1, num * rig, ch, ht, wd))
         s = self.chunk_frames
         for _ in range(steps):
@@ -197,7 +241,7 @@ class FactorGraph:
                 iis, jjs = self.ii[e], self.jj[e]
                 c1 = coords1[e].contiguous()
                 corr1 = corr_op(c1[None], rig * iis, rig * jjs + (iis == jjs).long())         # [1,M,196,h,w]
-                feats = self.update_op.corr_to_nhwc(corr1[0])
+                feats = corr1[0] if self.update_op.wants_reference_layout_corr(ht, wd) else self.update_op.corr_to_nhwc(corr1[0])
                 net = self._net[e].contiguous()
                 dw, damping, upmask, uniq = self._operator(net, c1, target_prev[e].contiguous(), feats, iis)
                 if self.upsample:
@@ -207,15 +251,7 @@ class FactorGraph:
                 target[e] = tg; weight[e] = wg; tb[e] = tbe; wb[e] = wbe
                 self.damping[uniq] = damping
             self.target, self.weight = target[None], weight[None]
-            ii, jj = self.ii, self.jj
-            if use_inactive:
-                ii = torch.cat([self.ii_inac, ii]); jj = torch.cat([self.jj_inac, jj])
-                tb = torch.cat([self.target_inac[0].permute(0, 3, 1, 2), tb]).contiguous()
-                wb = torch.cat([self.weight_inac[0].permute(0, 3, 1, 2), wb]).contiguous()
-            eta = (.2 * self.damping[torch.unique(ii)] + EP).contiguous()
-            self.age += 1
-            v.ba(tb, wb, eta, ii, jj, 1, t, itrs=itrs, lm=1e-5, ep=1e-2, motion_only=False)
-            v.dirty[:t] = True
+            self._ba_global(tb, wb, itrs, use_inactive, EP, t)
 
     # ---- edge creation policies (factor_graph.py:332-412) ---------------------------------------------------------------
     def add_neighborhood_factors(self, t0, t1, r=3):

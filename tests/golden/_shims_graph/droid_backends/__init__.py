@@ -22,8 +22,10 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
 
 
 def corr_index_forward(volume, coords, radius):
-    out = _ocorr.corr_index_forward(_np(volume.float()), _np(coords.float()), int(radius))
-    return [torch.as_tensor(out).to(volume.dtype)]
+    outs = []
+    for s in range(0, volume.shape[0], 16):           # bounded fp32 copies (a 512-edge level-0 volume is 19 GB in fp32)
+        outs.append(torch.as_tensor(_ocorr.corr_index_forward(_np(volume[s:s + 16].float()), _np(coords[s:s + 16].float()), int(radius))).to(volume.dtype))
+    return [torch.cat(outs, 0)]
 
 
 def altcorr_forward(fmap1, fmap2, coords, ii, jj, radius):

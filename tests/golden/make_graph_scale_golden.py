@@ -1,0 +1,119 @@
+#!/usr/bin/env python
+"""Generate tests/golden/graph_c2_python.npz and graph_stereo_python.npz by running the REFERENCE's own factor_graph.py +
+depth_video.py + modules/corr.py + droid_net.py, unmodified, on CPU (build container only: needs /root/reference):
+
+    python tests/golden/make_graph_scale_golden.py
+
+Same replacements as make_graph_golden.py (droid_backends -> oracle-backed shim, lietorch / torch_scatter shims, the two
+hard-coded "cuda" devices); the update operator runs under torch.autocast(fp16) like under factor_graph.py's decorators.
+
+Scenario C2 (BASELINE configs[1] at FULL size: 64 keyframes / 512 edges / 48x64, the seeded synthetic graph of
+droid_amd.synthetic.make_graph("C2", with_features=True)): FactorGraph.add_factors on all 512 edges, then two
+FactorGraph.update iterations (factor_graph.py:214-263).  Kept per iteration: poses, depths, damping of every frame; the
+hidden state / target / weight of 12 sample edges (first, middle, last four) and per-edge means of |target - coords0| and
+weight for ALL edges (the full hidden state would be 200 MB).
+Scenario S (stereo, BASELINE configs[4]'s ingredients at 6 keyframes / 16x64): DepthVideo(stereo=True), fmaps of both
+cameras, stereo self-edges (i, i) + temporal edges, two update iterations: pins `fmaps[jj, c]` (factor_graph.py:128-133) and
+the stereo branch of the BA (droid_kernels.cu:228-238) inside one composed iteration.
+"""
+import os
+import sys
+import time
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_graph_golden as base                   # sets up sys.path, the shims and the two device patches
+
+from droid_amd import synthetic as syn
+from droid_amd.weights import fill_deterministic
+from golden_inputs import graph_scenario, C2_SAMPLE_EDGES, stereo_scenario
+
+ref_dv, ref_fg, ref_net = base.ref_dv, base.ref_fg, base.ref_net
+
+
+def update_operator(seed):
+    m = ref_net.UpdateModule()
+    fill_deterministic(m, seed=seed)
+    m.agg.eta[2] = base._SoftplusF32()
+    m.eval()
+
+    def update_op(*a, **kw):
+        with torch.no_grad(), torch.autocast("cpu", dtype=torch.float16):
+            return m(*a, **kw)
+    return update_op
+
+
+def snap(out, tag, video, fg, N, sample=None):
+    out[tag + "_poses"] = video.poses[:N].numpy().copy(); out[tag + "_disps"] = video.disps[:N].numpy().copy()
+    out[tag + "_damping"] = fg.damping[:N].numpy().copy()
+    tgt, wgt, net = fg.target[0], fg.weight[0], fg.net[0]
+    if sample is None:
+        out[tag + "_target"] = tgt.numpy().copy(); out[tag + "_weight"] = wgt.numpy().copy()
+        out[tag + "_net"] = net.float().numpy().astype(np.float16)
+    else:
+        out[tag + "_target_s"] = tgt[sample].numpy().copy(); out[tag + "_weight_s"] = wgt[sample].numpy().copy()
+        out[tag + "_net_s"] = net[sample].float().numpy().astype(np.float16)
+        out[tag + "_flow_mean"] = (tgt - fg.coords0).abs().mean(dim=(1, 2, 3)).numpy().copy()
+        out[tag + "_weight_mean"] = wgt.mean(dim=(1, 2, 3)).numpy().copy()
+        out[tag + "_net_absmean"] = net.float().abs().mean(dim=(1, 2, 3)).numpy().copy()
+
+
+def scenario_c2():
+    g = syn.make_graph("C2", with_features=True)
+    N, ht, wd = g["n_frames"], g["ht"], g["wd"]
+    video = ref_dv.DepthVideo(image_size=[8 * ht, 8 * wd], buffer=N + 2, stereo=False, device="cpu")
+    video.poses[:N] = torch.as_tensor(g["poses"]); video.disps[:N] = torch.as_tensor(g["disps"])
+    video.intrinsics[:N] = torch.as_tensor(g["intrinsics"])
+    video.fmaps[:N] = torch.as_tensor(g["fmaps"]); video.nets[:N] = torch.as_tensor(g["nets"]); video.inps[:N] = torch.as_tensor(g["inps"])
+    video.counter.value = N
+    out = {}
+    with torch.no_grad():
+        fg = ref_fg.FactorGraph(video, update_operator(1234), device="cpu", corr_impl="volume", max_factors=-1, upsample=False)
+        t = time.time()
+        fg.add_factors(torch.as_tensor(g["ii"]), torch.as_tensor(g["jj"]))
+        print("C2 add_factors (512 all-pairs volumes): %.1f s" % (time.time() - t), flush=True)
+        assert len(fg.ii) == len(g["ii"])
+        out["ii"], out["jj"] = fg.ii.numpy().copy(), fg.jj.numpy().copy()
+        sample = torch.as_tensor(C2_SAMPLE_EDGES)
+        for k in (1, 2):
+            t = time.time()
+            fg.update(t0=1, t1=None, itrs=2, use_inactive=False)
+            print("C2 update %d: %.1f s" % (k, time.time() - t), flush=True)
+            snap(out, "U%d" % k, video, fg, N, sample)
+    np.savez_compressed(os.path.join(HERE, "graph_c2_python.npz"), **out)
+    print("graph_c2: |dpose| %.3e %.3e  |ddisp| %.3e %.3e" % (
+        np.abs(out["U1_poses"] - g["poses"]).max(), np.abs(out["U2_poses"] - g["poses"]).max(),
+        np.abs(out["U1_disps"] - g["disps"]).max(), np.abs(out["U2_disps"] - g["disps"]).max()))
+
+
+def scenario_stereo():
+    S = stereo_scenario()
+    N, ht, wd = S["n_frames"], S["ht"], S["wd"]
+    video = ref_dv.DepthVideo(image_size=[8 * ht, 8 * wd], buffer=N + 2, stereo=True, device="cpu")
+    video.poses[:N] = torch.as_tensor(S["poses"]); video.disps[:N] = torch.as_tensor(S["disps"])
+    video.intrinsics[:N] = torch.as_tensor(S["intrinsics"])
+    video.fmaps[:N] = torch.as_tensor(S["fmaps"]); video.nets[:N] = torch.as_tensor(S["nets"]); video.inps[:N] = torch.as_tensor(S["inps"])
+    video.counter.value = N
+    out = {}
+    with torch.no_grad():
+        fg = ref_fg.FactorGraph(video, update_operator(S["weight_seed"]), device="cpu", corr_impl="volume", max_factors=-1, upsample=True)
+        fg.add_factors(torch.as_tensor(S["ii"]), torch.as_tensor(S["jj"]))
+        out["ii"], out["jj"] = fg.ii.numpy().copy(), fg.jj.numpy().copy()
+        out["target0"] = fg.target[0].numpy().copy()
+        for k in (1, 2):
+            fg.update(t0=1, t1=None, itrs=2, use_inactive=False)
+            snap(out, "U%d" % k, video, fg, N)
+            out["U%d_disps_up" % k] = video.disps_up[:N].numpy().astype(np.float16)
+    np.savez_compressed(os.path.join(HERE, "graph_stereo_python.npz"), **out)
+    print("graph_stereo: %d edges (%d stereo); |dpose| %.3e %.3e" % (
+        len(out["ii"]), int((out["ii"] == out["jj"]).sum()), np.abs(out["U1_poses"] - S["poses"]).max(), np.abs(out["U2_poses"] - S["poses"]).max()))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["stereo", "c2"]
+    if "stereo" in which:
+        scenario_stereo()
+    if "c2" in which:
+        scenario_c2()

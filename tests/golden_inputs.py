@@ -49,3 +49,20 @@ def encoder_inputs():
     mean = np.array([0.485, 0.456, 0.406], dtype=np.float32)[:, None, None]
     std = np.array([0.229, 0.224, 0.225], dtype=np.float32)[:, None, None]
     return torch.as_tensor((img - mean) / std)
+
+
+# edges of the C2 graph (512 edges) whose full hidden state / target / weight is kept in graph_c2_python.npz
+C2_SAMPLE_EDGES = [0, 1, 2, 3, 254, 255, 256, 257, 508, 509, 510, 511]
+
+
+def stereo_scenario(n_frames=6):
+    """Six stereo keyframes at 16 x 64: feature maps of both cameras, stereo self-edges (i, i) followed by the temporal
+    edges |i - j| <= 2 (tests/golden/make_graph_scale_golden.py, scenario S)."""
+    S = graph_scenario(n_frames)
+    N, ht, wd = S["n_frames"], S["ht"], S["wd"]
+    rng = np.random.default_rng(78)
+    right = rng.standard_normal((N, 128, ht, wd)).astype(np.float16)
+    S["fmaps"] = np.stack([S["fmaps"], right], 1)                       # [N, 2, 128, h, w]
+    es = [(i, i) for i in range(N)] + [(i, j) for i in range(N) for j in range(N) if i != j and abs(i - j) <= 2]
+    S["ii"] = np.array([e[0] for e in es], dtype=np.int64); S["jj"] = np.array([e[1] for e in es], dtype=np.int64)
+    return S

@@ -104,14 +104,14 @@ def test_proximity_factors_and_update_lowmem_match_reference(db, golden_dir):
     S = graph_scenario()
     N = S["n_frames"]
     outs = []
-    for chunk in (8, 2):
+    for chunk, corr in ((8, "alt"), (2, "alt"), (8, "pyramid")):       # "pyramid": built once per call, full-batch steps
         video, upd = _setup(S)
         fg = FactorGraph(video, upd, corr_impl="alt", max_factors=16 * N, upsample=False, chunk_frames=chunk)
         dist = video.distance(beta=S["prox_beta"]).reshape(-1).cpu().numpy()
         assert np.abs(dist - G["B_dist"]).max() <= 1e-4 * max(1.0, np.abs(G["B_dist"]).max())
         fg.add_proximity_factors(rad=S["prox_rad"], nms=S["prox_nms"], thresh=S["prox_thresh"], beta=S["prox_beta"])
         assert np.array_equal(fg.ii.cpu().numpy(), G["B_ii"]) and np.array_equal(fg.jj.cpu().numpy(), G["B_jj"])
-        fg.update_lowmem(steps=2)
+        fg.update_lowmem(steps=2, corr=corr)
         torch.cuda.synchronize()
         _compare(video, fg, G, "B2", N, scale=2.0, disps_up=False)
         outs.append((video.poses.clone(), video.disps.clone()))

@@ -1,0 +1,279 @@
+"""GPU parity AT THE SIZES bench.py TIMES (BASELINE configs[1] = C2: 64 keyframes / 512 edges; configs[2] = C3: 512
+keyframes / 4096 edges; 48x64), for the three stages whose parity cases elsewhere are two orders of magnitude smaller:
+
+  * the fused 4-level pyramid lookup on ALL 4096 edges (105 GB pyramid, 2.47e9 output elements: > 2^31) against the
+    reference's own corr_index_forward (oracle/_ref = src/correlation_kernels.cu compiled for gfx950) on reference-layout
+    volumes of the first / middle / last 8 edges, and against the CPU oracle on two edges;
+  * the update operator on 4096 edges (more than one tile per CU through xcd_decode, persistent corr0 workgroups, the
+    512-frame context gather): equal to itself on slices (batch invariance) and to the autocast oracle on a sampled subset,
+    both context-feature conventions;
+  * one composed FactorGraph.update at C2 against a golden written by the reference's unmodified factor_graph.py +
+    depth_video.py + droid_net.py (tests/golden/make_graph_scale_golden.py), and the stereo scenario (fmaps[jj, c], stereo
+    edges in the BA) against its golden.
+
+    python -m pytest tests/test_scale_gpu.py -m gpu -x -q
+"""
+import os
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import build_ref, corr as ocorr, update as oupd
+from droid_amd import synthetic as syn
+from golden_inputs import C2_SAMPLE_EDGES, stereo_scenario
+
+
+@pytest.fixture(scope="module")
+def db():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    import droid_backends
+    return droid_backends
+
+
+@pytest.fixture(scope="module")
+def ref():
+    loaded = build_ref.load()
+    if loaded is None:
+        pytest.skip("oracle/_ref/droid_backends_ref.so not built (oracle/build_ref.py needs /root/reference)")
+    return loaded
+
+
+@pytest.fixture(scope="module")
+def c3():
+    return syn.make_graph("C3", with_features=True)
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda().contiguous()
+
+
+class _SD:
+    def state_dict(self):
+        return oupd.empty_state_dict()
+
+
+def _free():
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------------------------------ lookup, 4096 edges
+def _reference_layout_lookup(ref_mod, f1, f2, coords):
+    """CorrBlock of the reference (modules/corr.py:23-50) on the GPU: fp16 all-pairs matmul / 16, three avg_pool2d, the
+    reference's corr_index_forward per level.  f1, f2 [n,128,h,w] fp16, coords [n,h,w,2] -> [n,196,h,w] fp16"""
+    n, C, h, w = f1.shape
+    a = f1.reshape(n, C, h * w) / 4.0
+    b = f2.reshape(n, C, h * w) / 4.0
+    corr = torch.matmul(a.transpose(1, 2), b).reshape(n * h * w, 1, h, w)
+    c = coords.permute(0, 3, 1, 2).contiguous()
+    outs = []
+    for l in range(4):
+        vol = corr.reshape(n, h, w, h >> l, w >> l).contiguous()
+        o, = ref_mod.corr_index_forward(vol, (c / 2 ** l).contiguous(), 3)
+        outs.append(o.reshape(n, 49, h, w))
+        corr = torch.nn.functional.avg_pool2d(corr, 2, stride=2)
+    return torch.cat(outs, 1)
+
+
+def test_pyramid_lookup_on_all_c3_edges_vs_reference(db, ref, c3):
+    g = c3
+    E, h, w = len(g["ii"]), g["ht"], g["wd"]
+    fm = dev(g["fmaps"])[:, 0]                                          # [512,128,h,w] fp16
+    ii, jj = dev(g["ii"]), dev(g["jj"])
+    pyr = db.corr_pyramid_build(fm[ii].contiguous(), fm[jj].contiguous())
+    assert pyr.numel() * 2 == E * 25559040 // 1 or pyr.shape[0] == E    # one record per edge
+    coords, _ = db.reproject(dev(g["poses"]), dev(g["disps"]), dev(g["intrinsics"]), ii, jj)       # the bench's own flow
+    # second coordinate set: the same flow with a per-edge shift and a slow shear, some windows leave the image
+    rng = np.random.default_rng(3)
+    shift = torch.as_tensor(rng.uniform(-9, 9, (E, 1, 1, 2)).astype(np.float32)).cuda()
+    yy = torch.arange(h, device="cuda", dtype=torch.float32).view(1, h, 1, 1)
+    coords_b = coords + shift + 0.11 * yy
+    sel = torch.cat([torch.arange(0, 8), torch.arange(E // 2 - 4, E // 2 + 4), torch.arange(E - 8, E)]).cuda()
+    for cc in (coords, coords_b):
+        out = db.corr_pyramid_lookup(pyr, cc.contiguous())
+        torch.cuda.synchronize()
+        assert out.shape == (E, 196, h, w) and out.numel() > 2 ** 31
+        want = _reference_layout_lookup(ref[0], fm[ii[sel]].contiguous(), fm[jj[sel]].contiguous(), cc[sel].contiguous())
+        got = out[sel].float()
+        scale = want.float().abs().max().item()
+        assert scale > 1.0                                              # the sample is not all zeros
+        # the reference accumulates its bilinear sum in fp16 and pools fp16 volumes: 2^-8 of the tensor's scale
+        assert (got - want.float()).abs().max().item() <= 2.0 ** -8 * scale
+        # and two edges against the CPU oracle (fp64 arithmetic on fp16-rounded volumes): 2^-9
+        for e in (0, E - 1):
+            f1 = g["fmaps"][g["ii"][e], 0][None]; f2 = g["fmaps"][g["jj"][e], 0][None]
+            o = ocorr.corr_block_lookup(ocorr.corr_pyramid(f1, f2, 4), cc[e][None].cpu().numpy(), 3)
+            assert np.abs(out[e].float().cpu().numpy() - o[0]).max() <= 2.0 ** -9 * np.abs(o).max()
+        del out, want, got
+    del pyr
+    _free()
+
+
+# ------------------------------------------------------------------------------------------ update operator, 4096 edges
+def test_update_operator_on_all_c3_edges_batch_invariance_and_oracle(db, c3):
+    from droid_amd.update import UpdateModule
+    from droid_amd.weights import deterministic_state_dict
+    g = c3
+    E, h, w = len(g["ii"]), g["ht"], g["wd"]
+    sd = deterministic_state_dict(_SD(), seed=1234)
+    upd = UpdateModule("cuda").load_state_dict(sd)
+    ii = dev(g["ii"])
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    net0 = dev(g["nets"])[ii].permute(0, 2, 3, 1).contiguous()                          # [E,h,w,128] f16
+    inps = dev(g["inps"]).permute(0, 2, 3, 1).contiguous()                              # [512,h,w,128] f16 (frame level)
+    feats = (2.0 * torch.randn(E, 196, h, w, device="cuda", generator=gen)).half()
+    flow = torch.zeros(E, h, w, 8, device="cuda", dtype=torch.float16)
+    flow[..., :4] = (4.0 * torch.randn(E, h, w, 4, device="cuda", generator=gen)).clamp(-64, 64).half()
+    assert upd.wants_reference_layout_corr(h, w)
+
+    def run(idx, per_edge_inp):
+        """the operator on the edges `idx` (None = all) -> net', dw, eta, upmask (+ the source frames of the rows of eta)"""
+        sl = slice(None) if idx is None else idx
+        net = net0[sl].clone()
+        e_ii = ii[sl].contiguous()
+        if per_edge_inp:
+            out = upd.forward_nhwc(net, inps[e_ii].contiguous(), feats[sl].contiguous(), flow[sl].contiguous(), e_ii)
+        else:
+            out = upd.forward_nhwc(net, None, feats[sl].contiguous(), flow[sl].contiguous(), e_ii, inp_frames=inps, inp_index=e_ii)
+        torch.cuda.synchronize()
+        return out[0], upd.last_dw, out[3], out[4], torch.unique(e_ii)
+
+    full = run(None, False)
+    assert torch.isfinite(full[0].float()).all() and torch.isfinite(full[1]).all()
+    frames_all = full[4]
+    # ---- batch invariance: the edges of three groups of source frames, run on their own
+    for fr in ([0, 1], [255, 256, 257], [510, 511]):
+        idx = torch.nonzero(torch.isin(ii, torch.tensor(fr, device="cuda")))[:, 0]
+        assert 8 <= idx.numel() <= 64
+        part = run(idx, False)
+        assert (part[0].float() - full[0][idx].float()).abs().max().item() <= 2.0 ** -10            # <= 1 fp16 ulp of tanh-bounded values
+        d = (part[1] - full[1][idx]).abs().max().item()
+        assert d <= 2.0 ** -10 * max(1.0, full[1][idx].abs().max().item())
+        rows = torch.searchsorted(frames_all, part[4])
+        assert (part[2] - full[2][rows]).abs().max().item() <= 2.0 ** -10 * full[2][rows].abs().max().item() + 1e-7
+        assert (part[3].float() - full[3][rows].float()).abs().max().item() <= 2.0 ** -9 * max(1.0, full[3][rows].float().abs().max().item())
+    # ---- the per-edge context convention (448-channel gate convolutions) on all edges agrees with the frame-level one
+    per_edge = run(None, True)
+    assert (per_edge[0].float() - full[0].float()).abs().max().item() <= 2.0 ** -8      # same sums associated differently, fp16 stores
+    assert (per_edge[1] - full[1]).abs().max().item() <= 2.0 ** -8 * max(1.0, full[1].abs().max().item())
+    # ---- the autocast oracle (pinned bit for bit to the reference module) on the edges of frames 255..257, both conventions
+    idx = torch.nonzero(torch.isin(ii, torch.tensor([255, 256, 257], device="cuda")))[:, 0]
+    c = lambda t: t.float().cpu()
+    nchw = lambda t: c(t).permute(0, 3, 1, 2).contiguous()
+    with torch.no_grad():
+        want = oupd.update_forward(sd, nchw(net0[idx]).half(), nchw(inps[ii[idx]]).half(), c(feats[idx]).half(),
+                                   nchw(flow[idx][..., :4]), c(ii[idx]).long(), autocast=True)
+    rows = torch.searchsorted(frames_all, torch.unique(ii[idx]))
+    tol = 2.0 ** -9
+    for got in (full, per_edge):
+        assert (nchw(got[0][idx]) - want[0].float()).abs().max().item() <= tol
+        assert (c(got[1][idx][..., :2]) - want[1].float()).abs().max().item() <= tol * max(1.0, want[1].float().abs().max().item())
+        assert (c(got[1][idx][..., 2:]) - want[2].float()).abs().max().item() <= tol
+        assert (c(got[2][rows]) - want[3].float()).abs().max().item() <= tol * want[3].float().abs().max().item() + 1e-6
+        assert (nchw(got[3][rows]) - want[4].float()).abs().max().item() <= tol * max(1.0, want[4].float().abs().max().item())
+    _free()
+
+
+# ------------------------------------------------------------------------------------------ composed iterations
+def _rot_angle(q, qr):
+    v = q[:, 3:4] * -qr[:, :3] + qr[:, 3:4] * q[:, :3] + np.cross(q[:, :3], -qr[:, :3])
+    return 2 * np.linalg.norm(v, axis=-1)
+
+
+def _video(N, ht, wd, poses, disps, intrinsics, fmaps, nets, inps, stereo=False):
+    from droid_amd.depth_video import DepthVideo
+    video = DepthVideo(image_size=[8 * ht, 8 * wd], buffer=N + 2, stereo=stereo, device="cuda:0")
+    d = lambda a: torch.as_tensor(a).cuda()
+    video.poses[:N] = d(poses); video.disps[:N] = d(disps); video.intrinsics[:N] = d(intrinsics)
+    if stereo:
+        video.fmaps[:N] = d(fmaps)
+    else:
+        video.fmaps[:N, 0] = d(fmaps)
+    video.nets[:N] = d(nets); video.inps[:N] = d(inps)
+    video.tstamp[:N] = torch.arange(N, device="cuda").float()
+    video.counter.value = N
+    return video
+
+
+def test_composed_update_at_c2_matches_reference_factor_graph(db, golden_dir):
+    """BASELINE configs[1] at full size: FactorGraph.add_factors on the 512 edges of the seeded C2 graph + two
+    FactorGraph.update iterations against the reference's factor_graph.py golden.  The golden run evaluates the update
+    operator under fp16 autocast and geometry / BA in fp64; iteration 2 starts from iteration 1's differences."""
+    from droid_amd.factor_graph import FactorGraph
+    from droid_amd.update import UpdateModule
+    from droid_amd.weights import deterministic_state_dict
+    G = np.load(os.path.join(golden_dir, "graph_c2_python.npz"))
+    g = syn.make_graph("C2", with_features=True)
+    N, ht, wd = g["n_frames"], g["ht"], g["wd"]
+    video = _video(N, ht, wd, g["poses"], g["disps"], np.tile(g["intrinsics"], (N, 1)), g["fmaps"][:, 0], g["nets"], g["inps"])
+    upd = UpdateModule("cuda").load_state_dict(deterministic_state_dict(_SD(), seed=1234))
+    fg = FactorGraph(video, upd, corr_impl="volume", max_factors=-1, upsample=False)
+    fg.add_factors(torch.as_tensor(g["ii"]), torch.as_tensor(g["jj"]))
+    assert np.array_equal(fg.ii.cpu().numpy(), G["ii"]) and np.array_equal(fg.jj.cpu().numpy(), G["jj"])
+    sample = torch.as_tensor(C2_SAMPLE_EDGES).cuda()
+    yy, xx = np.meshgrid(np.arange(ht, dtype=np.float32), np.arange(wd, dtype=np.float32), indexing="ij")
+    coords0 = torch.as_tensor(np.stack([xx, yy], -1)).cuda()
+    c = lambda t: t.float().cpu().numpy()
+    for k, scale in ((1, 1.0), (2, 3.0)):
+        fg.update(t0=1, t1=None, itrs=2, use_inactive=False)
+        torch.cuda.synchronize()
+        tag = "U%d" % k
+        p, rp = c(video.poses)[:N], G[tag + "_poses"]
+        assert np.abs(p[:, :3] - rp[:, :3]).max() <= 2e-3 * scale
+        assert _rot_angle(p[:, 3:].astype(np.float64), rp[:, 3:].astype(np.float64)).max() <= 2e-3 * scale
+        d, rd = c(video.disps)[:N], G[tag + "_disps"]
+        e = np.abs(d - rd) / np.maximum(1.0, np.abs(rd))
+        assert np.quantile(e, 0.99) <= 1e-2 * scale and e.max() <= 0.2 * scale
+        assert np.abs(c(fg.net[0][sample]) - G[tag + "_net_s"].astype(np.float32)).max() <= 2.0 ** -8 * scale
+        tg, rtg = c(fg.target[0][sample]), G[tag + "_target_s"]
+        assert np.quantile(np.abs(tg - rtg), 0.999) <= 2e-2 * scale and np.abs(tg - rtg).max() <= 0.5 * scale
+        assert np.abs(c(fg.weight[0][sample]) - G[tag + "_weight_s"]).max() <= 2.0 ** -8 * scale
+        dm, rdm = c(fg.damping)[:N], G[tag + "_damping"]
+        assert np.abs(dm - rdm).max() <= 2.0 ** -8 * np.abs(rdm).max() * scale + 1e-6
+        # every edge: mean flow magnitude, mean confidence, mean |hidden state| (a wrong edge anywhere in the batch shows here)
+        fm = c((fg.target[0] - coords0).abs().mean(dim=(1, 2, 3)))
+        assert np.abs(fm - G[tag + "_flow_mean"]).max() <= 2e-3 * scale * max(1.0, np.abs(G[tag + "_flow_mean"]).max())
+        assert np.abs(c(fg.weight[0].mean(dim=(1, 2, 3))) - G[tag + "_weight_mean"]).max() <= 2.0 ** -10 * scale
+        assert np.abs(c(fg.net[0].float().abs().mean(dim=(1, 2, 3))) - G[tag + "_net_absmean"]).max() <= 2.0 ** -10 * scale
+    _free()
+
+
+def test_composed_stereo_update_matches_reference_factor_graph(db, golden_dir):
+    """DepthVideo(stereo=True): pyramid from fmaps[jj, c] (c = 1 on stereo self-edges, factor_graph.py:128-133), stereo edges
+    in the BA (droid_kernels.cu:228-238), two composed update iterations with upsampling vs the reference golden"""
+    from droid_amd.factor_graph import FactorGraph
+    from droid_amd.update import UpdateModule
+    from droid_amd.weights import deterministic_state_dict
+    G = np.load(os.path.join(golden_dir, "graph_stereo_python.npz"))
+    S = stereo_scenario()
+    N, ht, wd = S["n_frames"], S["ht"], S["wd"]
+    video = _video(N, ht, wd, S["poses"], S["disps"], S["intrinsics"], S["fmaps"], S["nets"], S["inps"], stereo=True)
+    upd = UpdateModule("cuda").load_state_dict(deterministic_state_dict(_SD(), seed=S["weight_seed"]))
+    fg = FactorGraph(video, upd, corr_impl="volume", max_factors=-1, upsample=True)
+    fg.add_factors(torch.as_tensor(S["ii"]), torch.as_tensor(S["jj"]))
+    assert np.array_equal(fg.ii.cpu().numpy(), G["ii"]) and np.array_equal(fg.jj.cpu().numpy(), G["jj"])
+    assert np.abs(fg.target[0].cpu().numpy() - G["target0"]).max() < 2e-4
+    c = lambda t: t.float().cpu().numpy()
+    for k, scale in ((1, 1.0), (2, 2.0)):
+        fg.update(t0=1, t1=None, itrs=2, use_inactive=False)
+        torch.cuda.synchronize()
+        tag = "U%d" % k
+        p, rp = c(video.poses)[:N], G[tag + "_poses"]
+        assert np.abs(p[:, :3] - rp[:, :3]).max() <= 2e-3 * scale
+        assert _rot_angle(p[:, 3:].astype(np.float64), rp[:, 3:].astype(np.float64)).max() <= 2e-3 * scale
+        d, rd = c(video.disps)[:N], G[tag + "_disps"]
+        e = np.abs(d - rd) / np.maximum(1.0, np.abs(rd))
+        assert np.quantile(e, 0.99) <= 1e-2 * scale and e.max() <= 0.1 * scale
+        assert np.abs(c(fg.net[0]) - G[tag + "_net"].astype(np.float32)).max() <= 2.0 ** -8 * scale
+        tg, rtg = c(fg.target[0]), G[tag + "_target"]
+        assert np.quantile(np.abs(tg - rtg), 0.999) <= 2e-2 * scale and np.abs(tg - rtg).max() <= 0.5 * scale
+        assert np.abs(c(fg.weight[0]) - G[tag + "_weight"]).max() <= 2.0 ** -8 * scale
+        du, rdu = c(video.disps_up)[:N], G[tag + "_disps_up"].astype(np.float32)
+        e = np.abs(du - rdu) / np.maximum(1.0, np.abs(rdu))
+        assert np.quantile(e, 0.99) <= 1e-2 * scale + 2.0 ** -10
