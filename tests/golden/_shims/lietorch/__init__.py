@@ -93,6 +93,34 @@ class SE3(_Group):
     def retr(self, xi):
         return SE3.exp(xi) * self
 
+    @staticmethod
+    def Identity(*shape, device="cpu", dtype=torch.float32):
+        d = torch.zeros(*shape, 7, dtype=dtype)
+        d[..., 6] = 1.0
+        return SE3(d)
+
+    def log(self):
+        """inverse of exp (lietorch SE3.log: SO3 log of the unit quaternion, tau = V(phi)^-1 t); the same expressions as
+        oracle/se3.py se3_log, in float64, returned in the data's dtype"""
+        d = self.data.double()
+        t, v, w = d[..., :3], d[..., 3:6], d[..., 6:7]
+        n2 = (v * v).sum(-1, keepdim=True)
+        n = n2.sqrt()
+        small = n2 < 1e-20
+        ns = torch.where(small, torch.ones_like(n), n)
+        k = torch.where(small, 2.0 / w - (2.0 / 3.0) * n2 / w ** 3, 2.0 * torch.atan2(ns, w) / ns)
+        k = torch.where((~small) & (w < 0), 2.0 * torch.atan(ns / torch.where(w == 0, torch.ones_like(w), w)) / ns, k)
+        phi = k * v
+        th2 = (phi * phi).sum(-1, keepdim=True)
+        th = th2.sqrt()
+        tiny = th < 1e-6
+        ths = torch.where(tiny, torch.ones_like(th), th)
+        c = torch.where(tiny, 1.0 / 12.0 + th2 / 720.0,
+                        (1.0 - 0.5 * ths * torch.cos(0.5 * ths) / torch.sin(0.5 * ths)) / torch.where(tiny, torch.ones_like(th2), th2))
+        c1 = _cross(phi, t)
+        c2 = _cross(phi, c1)
+        return torch.cat([t - 0.5 * c1 + c * c2, phi], -1).to(self.data.dtype)
+
 
 class Sim3(_Group):
     manifold_dim = 7

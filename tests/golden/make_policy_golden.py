@@ -1,0 +1,181 @@
+#!/usr/bin/env python
+"""Generate tests/golden/policy_python.npz by running the REFERENCE's own motion_filter.py, trajectory_filler.py and
+droid_frontend.py (with factor_graph.py / depth_video.py / droid_net.py / modules / geom), unmodified, on CPU (build container
+only: needs /root/reference):
+
+    python tests/golden/make_policy_golden.py [motion] [filler] [frontend] [--probe]
+
+Replacements (process-local, never the reference files): droid_backends -> oracle-backed shim, lietorch / torch_scatter / cv2
+shims; torch.autocast(device_type="cuda") -> CPU fp16 autocast (the classes decorate their methods with it; on a GPU the
+encoders and the update operator run in fp16); Tensor.cuda() -> identity; the default device of FactorGraph.__init__ and the
+hard-coded "cuda" of torch.as_tensor inside projective_ops / trajectory_filler; softplus of GraphAgg.eta in fp32 as GPU
+autocast does.
+
+  M  MotionFilter.track (motion_filter.py:52-91) on a 10-frame pan: per frame the mean flow magnitude of the one update
+     iteration, the keyframe decision, and the features stored for the accepted keyframes.
+  T  PoseTrajectoryFiller.__call__ (trajectory_filler.py:42-111) on 18 non-keyframes (a batch of 16 + 2): interpolated start
+     poses, encoder, two edges per frame, six motion-only update iterations -> filled poses.
+  F  DroidFrontend (droid_frontend.py:65-164): initialisation (8 + 8 update iterations, proximity edges in between) and six
+     keyframe updates incl. both branches of the keyframe-removal test; after every call the graph (ii, jj, age, inactive
+     edges), t1 / counter and the poses / depths.
+--probe: the same scenarios with the update operator evaluated in fp32 instead of fp16 autocast -> how far continuous
+quantities move under rounding-level perturbations (calibrates the tolerances of tests/test_policy_gpu.py).
+"""
+import os
+import sys
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/droid_slam"
+sys.path[:0] = [os.path.join(HERE, "_shims_graph"), os.path.join(HERE, "_shims"), REF, ROOT, os.path.join(ROOT, "droid-slam_amd"),
+                os.path.join(ROOT, "tests")]
+PROBE = "--probe" in sys.argv
+
+# ---- process-local patches that must precede the import of the reference modules
+_Autocast = torch.autocast
+
+
+class _CpuAutocast(_Autocast):
+    """torch.autocast(device_type="cuda", enabled=...) as the reference writes it -> fp16 autocast on the CPU"""
+
+    def __init__(self, device_type="cuda", dtype=None, enabled=True, cache_enabled=None):
+        super().__init__("cpu", dtype=torch.float16, enabled=enabled and not PROBE)
+
+
+torch.autocast = _CpuAutocast
+torch.Tensor.cuda = lambda self, *a, **k: self
+
+import droid_backends                               # oracle-backed shim
+assert "_shims_graph" in droid_backends.__file__
+import make_graph_golden as base                    # format_indicies + projective_ops patches, _SoftplusF32
+import droid_net as ref_net
+import depth_video as ref_dv
+import factor_graph as ref_fg
+import motion_filter as ref_mf
+import trajectory_filler as ref_tf
+import droid_frontend as ref_fe
+from droid_amd.weights import fill_deterministic
+import golden_inputs as gi
+
+ref_fg.FactorGraph.__init__.__defaults__ = ("cpu", "volume", -1, False)
+ref_tf.torch = base._TorchProxy()                   # torch.as_tensor(..., device="cuda") (trajectory_filler.py:46)
+
+
+def droid_net():
+    net = ref_net.DroidNet()
+    fill_deterministic(net.fnet, seed=gi.POLICY_SEEDS["fnet"])
+    fill_deterministic(net.cnet, seed=gi.POLICY_SEEDS["cnet"])
+    fill_deterministic(net.update, seed=gi.POLICY_SEEDS["update"], scale=2.0)
+    net.update.agg.eta[2] = base._SoftplusF32()
+    return net.eval()
+
+
+def scenario_video(S, buffer_extra=24):
+    N, ht, wd = S["n_frames"], S["ht"], S["wd"]
+    video = ref_dv.DepthVideo(image_size=[8 * ht, 8 * wd], buffer=N + buffer_extra, stereo=False, device="cpu")
+    video.poses[:N] = torch.as_tensor(S["poses"]); video.disps[:N] = torch.as_tensor(S["disps"])
+    video.intrinsics[:N] = torch.as_tensor(S["intrinsics"])
+    video.fmaps[:N, 0] = torch.as_tensor(S["fmaps"]); video.nets[:N] = torch.as_tensor(S["nets"]); video.inps[:N] = torch.as_tensor(S["inps"])
+    video.tstamp[:N] = torch.arange(N).float()
+    video.counter.value = N
+    return video
+
+
+def scenario_motion(out):
+    net = droid_net()
+    ht, wd = gi.POLICY_IMAGE
+    video = ref_dv.DepthVideo(image_size=[ht, wd], buffer=16, stereo=False, device="cpu")
+    mf = ref_mf.MotionFilter(net, video, thresh=gi.MOTION_FILTER_THRESH, device="cpu")
+    deltas = []
+    upd = mf.update
+
+    def recording_update(*a, **kw):
+        r = upd(*a, **kw)
+        deltas.append(r[1].norm(dim=-1).mean().item())
+        return r
+    mf.update = recording_update
+    intr = torch.tensor(gi.MOTION_FILTER_INTRINSICS)
+    counters = []
+    with torch.no_grad():
+        for k, s in enumerate(gi.MOTION_FILTER_SHIFTS):
+            mf.track(float(k), gi.policy_image(7, s), intrinsics=intr)
+            counters.append(video.counter.value)
+    n = video.counter.value
+    out["M_delta"] = np.array(deltas); out["M_counter"] = np.array(counters)
+    out["M_fmaps"] = video.fmaps[:n].numpy().copy(); out["M_nets"] = video.nets[:n].numpy().copy(); out["M_inps"] = video.inps[:n].numpy().copy()
+    out["M_tstamp"] = video.tstamp[:n].numpy().copy(); out["M_intrinsics"] = video.intrinsics[:n].numpy().copy()
+    print("motion filter: deltas", np.round(deltas, 4), "counter", counters)
+
+
+def scenario_filler(out):
+    net = droid_net()
+    S = gi.graph_scenario()
+    video = scenario_video(S)
+    poses0, disps0 = video.poses.clone(), video.disps.clone()
+    filler = ref_tf.PoseTrajectoryFiller(net, video, device="cpu")
+    with torch.no_grad():
+        Gs = filler(gi.filler_stream())
+    out["T_poses"] = Gs.data.numpy().copy()
+    assert video.counter.value == S["n_frames"] and torch.equal(video.poses[:6], poses0[:6]) and torch.equal(video.disps[:6], disps0[:6])
+    print("filler: poses", out["T_poses"].shape, "first", np.round(out["T_poses"][0], 4))
+
+
+def scenario_frontend(out):
+    from types import SimpleNamespace
+    net = droid_net()
+    S = gi.graph_scenario(n_frames=14)
+    video = scenario_video(S)
+    args = SimpleNamespace(**gi.FRONTEND_ARGS)
+    fe = ref_fe.DroidFrontend(net, video, args)
+    dist_log = []
+    vd = video.distance
+
+    def recording_distance(ii=None, jj=None, beta=0.3, bidirectional=True):
+        d = vd(ii, jj, beta=beta, bidirectional=bidirectional)
+        if isinstance(ii, list) and len(ii) == 1:
+            dist_log.append(float(d.item()))
+        return d
+    video.distance = recording_distance
+
+    def put(k, src):
+        d = lambda a: torch.as_tensor(a)
+        video.tstamp[k] = float(src); video.intrinsics[k] = d(S["intrinsics"][src])
+        video.fmaps[k, 0] = d(S["fmaps"][src]); video.nets[k] = d(S["nets"][src]); video.inps[k] = d(S["inps"][src])
+
+    def snapshot(tag):
+        g = fe.graph
+        t = video.counter.value
+        for name in ("ii", "jj", "age", "ii_inac", "jj_inac", "ii_bad", "jj_bad"):
+            out["F_%s_%s" % (tag, name)] = getattr(g, name).numpy().copy()
+        out["F_%s_t1"] = np.array([fe.t1, t])
+        out["F_%s_state" % tag] = np.array([fe.t1, t])
+        out["F_%s_poses" % tag] = video.poses[:t + 1].numpy().copy(); out["F_%s_disps" % tag] = video.disps[:t + 1].numpy().copy()
+        out["F_%s_tstamp" % tag] = video.tstamp[:t].numpy().copy()
+        print("frontend %-5s t1=%d counter=%d edges=%d inactive=%d  keyframe distances so far %s" % (
+            tag, fe.t1, t, len(g.ii), len(g.ii_inac), np.round(dist_log, 3)), flush=True)
+    with torch.no_grad():
+        gi.drive_frontend(video, fe, S, put, snapshot)
+    out["F_keyframe_distance"] = np.array(dist_log)
+    out.pop("F_%s_t1", None)
+
+
+if __name__ == "__main__":
+    which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["motion", "filler", "frontend"]
+    path = os.path.join(HERE, "policy_python.npz" if not PROBE else "/tmp/policy_probe.npz")
+    out = dict(np.load(path)) if os.path.exists(path) else {}
+    if "motion" in which:
+        scenario_motion(out)
+    if "filler" in which:
+        scenario_filler(out)
+    if "frontend" in which:
+        scenario_frontend(out)
+    np.savez_compressed(path, **out)
+    if PROBE:
+        G = np.load(os.path.join(HERE, "policy_python.npz"))
+        for k in sorted(out):
+            if k in G and G[k].shape == out[k].shape and G[k].dtype.kind == "f":
+                print("probe %-22s max |fp32 - fp16 autocast| = %.3e" % (k, np.abs(G[k].astype(np.float64) - out[k]).max()))
+            elif k in G and (G[k].shape != out[k].shape or not np.array_equal(G[k], out[k])):
+                print("probe %-22s DIFFERS (discrete)" % k)

@@ -66,3 +66,55 @@ def stereo_scenario(n_frames=6):
     es = [(i, i) for i in range(N)] + [(i, j) for i in range(N) for j in range(N) if i != j and abs(i - j) <= 2]
     S["ii"] = np.array([e[0] for e in es], dtype=np.int64); S["jj"] = np.array([e[1] for e in es], dtype=np.int64)
     return S
+
+
+# ---------------------------------------------------------------------------------------------- policies (f1 / f2 / f3)
+POLICY_SEEDS = dict(fnet=11, cnet=12, update=1234)
+POLICY_IMAGE = (128, 512)                        # 16 x 64 at 1/8 resolution: the production kernels of the HIP path
+
+
+def policy_image(seed, shift=0):
+    """smooth random BGR image [1,3,128,512] uint8 (numpy only: identical on every host), shifted right by `shift` pixels"""
+    ht, wd = POLICY_IMAGE
+    rng = np.random.default_rng(seed)
+    img = np.kron(rng.uniform(0, 255, (3, ht // 8, wd // 8 + 16)), np.ones((8, 8)))
+    for ax in (1, 2):                                    # 9-tap box filter along both axes (cumulative sums)
+        c = np.cumsum(np.pad(img, [(0, 0)] + [(5, 4) if a == ax else (0, 0) for a in (1, 2)], mode="edge"), axis=ax)
+        img = (np.take(c, np.arange(9, c.shape[ax]), axis=ax) - np.take(c, np.arange(0, c.shape[ax] - 9), axis=ax)) / 9.0
+    img = img[:, :, 128 - shift:128 - shift + wd]
+    return torch.as_tensor(np.clip(np.rint(img), 0, 255).astype(np.uint8))[None]
+
+
+MOTION_FILTER_SHIFTS = [0, 0, 2, 10, 11, 24, 24, 40, 41, 72]      # camera pans: pixels of image shift per incoming frame
+MOTION_FILTER_INTRINSICS = [200.0, 200.0, 256.0, 64.0]
+
+
+def filler_stream(n=18):
+    """image stream of the pose filler: (tstamp, image [1,3,H,W] uint8, intrinsics [4]) for n non-keyframes between / at /
+    beyond the keyframe time stamps 0..5 (18 frames: one full batch of 16 + a remainder, trajectory_filler.py:96-107)"""
+    ts = np.round(np.linspace(0.0, 5.4, n) + 0.013 * np.arange(n), 3)
+    ts[4] = 2.0                                           # exactly at a keyframe
+    return [(float(t), policy_image(100 + k), torch.tensor(MOTION_FILTER_INTRINSICS)) for k, t in enumerate(ts)]
+
+
+FRONTEND_ARGS = dict(upsample=True, warmup=8, beta=0.3, frontend_nms=1, keyframe_thresh=0.3, frontend_window=20, frontend_thresh=16.0,
+                     frontend_radius=2)
+
+
+def drive_frontend(video, fe, pool, put, snapshot):
+    """the frontend's life on a synthetic sequence: `warmup` keyframes present -> initialisation; then one keyframe at a time
+    is appended behind the last one (what MotionFilter.track does: features / time stamp of the next frame of `pool`, pose
+    and depth guesses left as the frontend set them) and the frontend is called.  Runs unchanged against the reference's
+    DroidFrontend (golden) and droid_amd.policies.DroidFrontend (test)."""
+    nxt = FRONTEND_ARGS["warmup"]
+    video.counter.value = nxt
+    fe()
+    snapshot("init")
+    while nxt < pool["n_frames"]:
+        k = video.counter.value
+        put(k, nxt)
+        video.counter.value = k + 1
+        nxt += 1
+        fe()
+        snapshot("f%d" % nxt)
+MOTION_FILTER_THRESH = 0.905
