@@ -1,11 +1,11 @@
-"""The callers of the update iteration: local-BA frontend, global-BA backend, non-keyframe pose filler.
+"""The callers of the update iteration: local-BA frontend, global-BA backend, keyframe selection, non-keyframe pose filler.
 
 Host-side mirrors of the reference's policy classes -- DroidFrontend (droid_slam/droid_frontend.py:13-164), DroidBackend
-(droid_slam/droid_backend.py:9-43) and the motion-only part of PoseTrajectoryFiller (droid_slam/trajectory_filler.py:42-84)
--- on top of droid_amd.factor_graph.FactorGraph / droid_amd.depth_video.DepthVideo.  Same hyper-parameters, same order of
-graph edits and update calls; the work itself (distances, NMS, update iterations, BA, SE(3) log/exp of the motion model)
-runs in the kernels of libdroid_hip.  Image encoders are outside this module: keyframes arrive with their feature /
-context maps already in the DepthVideo.
+(droid_slam/droid_backend.py:9-43), MotionFilter (droid_slam/motion_filter.py:20-91) and PoseTrajectoryFiller
+(droid_slam/trajectory_filler.py:21-111) -- on top of droid_amd.factor_graph.FactorGraph / droid_amd.depth_video.DepthVideo /
+droid_amd.encoder.FeatureNets.  Same hyper-parameters, same order of graph edits and update calls; the work itself
+(encoders, distances, NMS, update iterations, BA, SE(3) log/exp of the motion model) runs in the kernels of libdroid_hip.
+Pinned to the reference's own classes by tests/golden/policy_python.npz (tests/test_policy_gpu.py).
 """
 import torch
 
@@ -114,6 +114,7 @@ class DroidBackend:
         self.backend_radius = args.backend_radius
         self.backend_nms = args.backend_nms
         self.chunk_frames = chunk_frames
+        self.lowmem_corr = "auto"          # FactorGraph.update_lowmem: pyramid built once per call when it fits, else alt-corr chunks
 
     @torch.no_grad()
     def __call__(self, steps=12, normalize=True):
@@ -123,7 +124,7 @@ class DroidBackend:
             v.normalize()
         graph = FactorGraph(v, self.update_op, corr_impl="alt", max_factors=16 * t, upsample=self.upsample, chunk_frames=self.chunk_frames)
         graph.add_proximity_factors(rad=self.backend_radius, nms=self.backend_nms, thresh=self.backend_thresh, beta=self.beta)
-        graph.update_lowmem(steps=steps)
+        graph.update_lowmem(steps=steps, corr=self.lowmem_corr)
         graph.clear_edges()
         v.dirty[:t] = True
         return graph
@@ -210,3 +211,37 @@ def fill_poses(update_op, video, tstamps, fmaps, intrinsics=None, iters=6):
     out = SE3(video.poses[N:N + M].clone())
     video.counter.value -= M
     return out
+
+
+class PoseTrajectoryFiller:
+    """poses of the non-keyframes of an image stream (trajectory_filler.py:21-111): batches of 16 frames -> feature encoder ->
+    `fill_poses`.  `nets` = droid_amd.encoder.FeatureNets (only its feature encoder is used, like in the reference)."""
+
+    def __init__(self, nets, update_op, video, batch=16):
+        self.nets, self.update, self.video, self.batch = nets, update_op, video, batch
+        self.count = 0
+
+    @torch.no_grad()
+    def _fill(self, tstamps, images, intrinsics):
+        from .encoder import normalize_images
+        dev = self.video.device
+        images = torch.stack(images, 0).to(dev)                                  # [M,cams,3,H,W] uint8 BGR
+        intr = torch.stack(intrinsics, 0).to(dev)
+        fmaps = self.nets.fnet(normalize_images(images))                          # [M,cams,128,h,w] (no context features needed)
+        N, M = self.video.counter.value, len(tstamps)
+        self.video.images[N:N + M] = images[:, 0]
+        return [fill_poses(self.update, self.video, tstamps, fmaps, intrinsics=intr / 8.0)]
+
+    @torch.no_grad()
+    def __call__(self, image_stream):
+        """image_stream yields (tstamp, image [cams,3,H,W] uint8, intrinsics [4]); returns SE3 [number of frames]"""
+        import lietorch
+        pose_list, tstamps, images, intrinsics = [], [], [], []
+        for (tstamp, image, intrinsic) in image_stream:
+            tstamps.append(tstamp); images.append(image); intrinsics.append(intrinsic)
+            if len(tstamps) == self.batch:
+                pose_list += self._fill(tstamps, images, intrinsics)
+                tstamps, images, intrinsics = [], [], []
+        if len(tstamps) > 0:
+            pose_list += self._fill(tstamps, images, intrinsics)
+        return lietorch.cat(pose_list, 0)

@@ -79,6 +79,34 @@ def build(force=False):
     return SO
 
 
+PYZIP = os.path.join(OUT, "ref_py.zip")
+# the reference's hot-path CALLERS, to be run UNCHANGED on this repo's droid_backends / lietorch / torch_scatter on a GPU
+# (tests/test_ref_callers_gpu.py).  /root/reference does not exist on the GPU box, so they travel the way the compiled
+# reference does: as one git-ignored archive under oracle/_ref/ (python imports straight from it, zipimport); nothing
+# of the reference is unpacked into the tree or committed.
+PY_FILES = ["factor_graph.py", "depth_video.py", "droid_net.py", "droid_frontend.py", "droid_backend.py", "motion_filter.py",
+            "trajectory_filler.py", "cuda_timer.py", "geom/__init__.py", "geom/ba.py", "geom/chol.py", "geom/graph_utils.py",
+            "geom/projective_ops.py", "geom/losses.py", "modules/__init__.py", "modules/clipping.py", "modules/corr.py",
+            "modules/extractor.py", "modules/gru.py",
+            "data_readers/__init__.py", "data_readers/rgbd_utils.py"]          # (imported by geom/graph_utils.py at module scope)
+
+
+def stage_python(force=False):
+    """oracle/_ref/ref_py.zip <- the reference's droid_slam/*.py listed above, byte for byte"""
+    pydir = os.path.join(REF, "droid_slam")
+    if not os.path.isdir(pydir):
+        return PYZIP if os.path.exists(PYZIP) else None
+    import zipfile
+    srcs = [os.path.join(pydir, f) for f in PY_FILES]
+    if not force and os.path.exists(PYZIP) and os.path.getmtime(PYZIP) >= max(map(os.path.getmtime, srcs + [os.path.abspath(__file__)])):
+        return PYZIP
+    os.makedirs(OUT, exist_ok=True)
+    with zipfile.ZipFile(PYZIP, "w", zipfile.ZIP_DEFLATED) as z:
+        for f, src in zip(PY_FILES, srcs):
+            z.write(src, "droid_slam/" + f)
+    return PYZIP
+
+
 def load():
     """Import the reference module (tests only).  Returns (droid_backends_ref, torch.ops.droid_ref) or None."""
     if not os.path.exists(SO):
@@ -92,4 +120,4 @@ def load():
 
 
 if __name__ == "__main__":
-    print("built:", build(force="--force" in sys.argv))
+    print("built:", build(force="--force" in sys.argv), stage_python(force="--force" in sys.argv))

@@ -15,11 +15,12 @@ autocast does.
      iteration, the keyframe decision, and the features stored for the accepted keyframes.
   T  PoseTrajectoryFiller.__call__ (trajectory_filler.py:42-111) on 18 non-keyframes (a batch of 16 + 2): interpolated start
      poses, encoder, two edges per frame, six motion-only update iterations -> filled poses.
+  K  DroidBackend.__call__ (droid_backend.py:24-42) with two global-BA steps.
   F  DroidFrontend (droid_frontend.py:65-164): initialisation (8 + 8 update iterations, proximity edges in between) and six
      keyframe updates incl. both branches of the keyframe-removal test; after every call the graph (ii, jj, age, inactive
      edges), t1 / counter and the poses / depths.
---probe: the same scenarios with the update operator evaluated in fp32 instead of fp16 autocast -> how far continuous
-quantities move under rounding-level perturbations (calibrates the tolerances of tests/test_policy_gpu.py).
+--probe: the same scenarios with the stored feature / context maps moved by one fp16 ulp on half of their values -> how far
+the outputs move under rounding-level perturbations (calibrates the tolerances of tests/test_policy_gpu.py).
 """
 import os
 import sys
@@ -41,7 +42,7 @@ class _CpuAutocast(_Autocast):
     """torch.autocast(device_type="cuda", enabled=...) as the reference writes it -> fp16 autocast on the CPU"""
 
     def __init__(self, device_type="cuda", dtype=None, enabled=True, cache_enabled=None):
-        super().__init__("cpu", dtype=torch.float16, enabled=enabled and not PROBE)
+        super().__init__("cpu", dtype=torch.float16, enabled=enabled)
 
 
 torch.autocast = _CpuAutocast
@@ -80,6 +81,11 @@ def scenario_video(S, buffer_extra=24):
     video.fmaps[:N, 0] = torch.as_tensor(S["fmaps"]); video.nets[:N] = torch.as_tensor(S["nets"]); video.inps[:N] = torch.as_tensor(S["inps"])
     video.tstamp[:N] = torch.arange(N).float()
     video.counter.value = N
+    if PROBE:                                         # one fp16 ulp up or down on half of the feature values
+        g = torch.Generator().manual_seed(5)
+        for buf in (video.fmaps, video.nets, video.inps):
+            r = torch.randint(-1, 2, buf.shape, generator=g, dtype=torch.int16)
+            buf.copy_((buf.view(torch.int16) + r * ((torch.rand(buf.shape, generator=g) < 0.5) & (buf.abs() > 1e-3))).view(torch.float16))
     return video
 
 
@@ -161,8 +167,24 @@ def scenario_frontend(out):
     out.pop("F_%s_t1", None)
 
 
+def scenario_backend(out):
+    """K  DroidBackend.__call__ (droid_backend.py:24-42): normalize -> proximity edges over all keyframes -> update_lowmem(steps=2)
+    -> clear_edges, on the 6-keyframe scenario"""
+    from types import SimpleNamespace
+    import droid_backend as ref_be
+    net = droid_net()
+    S = gi.graph_scenario()
+    video = scenario_video(S)
+    be = ref_be.DroidBackend(net, video, SimpleNamespace(**gi.BACKEND_ARGS))
+    with torch.no_grad():
+        be(steps=2)
+    N = S["n_frames"]
+    out["K_poses"] = video.poses[:N].numpy().copy(); out["K_disps"] = video.disps[:N].numpy().copy()
+    print("backend: |dpose| %.3e mean disp %.4f" % (np.abs(out["K_poses"] - S["poses"]).max(), out["K_disps"].mean()))
+
+
 if __name__ == "__main__":
-    which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["motion", "filler", "frontend"]
+    which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["motion", "filler", "frontend", "backend"]
     path = os.path.join(HERE, "policy_python.npz" if not PROBE else "/tmp/policy_probe.npz")
     out = dict(np.load(path)) if os.path.exists(path) else {}
     if "motion" in which:
@@ -171,11 +193,13 @@ if __name__ == "__main__":
         scenario_filler(out)
     if "frontend" in which:
         scenario_frontend(out)
+    if "backend" in which:
+        scenario_backend(out)
     np.savez_compressed(path, **out)
     if PROBE:
         G = np.load(os.path.join(HERE, "policy_python.npz"))
         for k in sorted(out):
             if k in G and G[k].shape == out[k].shape and G[k].dtype.kind == "f":
-                print("probe %-22s max |fp32 - fp16 autocast| = %.3e" % (k, np.abs(G[k].astype(np.float64) - out[k]).max()))
+                print("probe %-22s max |perturbed - golden| = %.3e" % (k, np.abs(G[k].astype(np.float64) - out[k]).max()))
             elif k in G and (G[k].shape != out[k].shape or not np.array_equal(G[k], out[k])):
                 print("probe %-22s DIFFERS (discrete)" % k)

@@ -118,3 +118,4 @@ def drive_frontend(video, fe, pool, put, snapshot):
         fe()
         snapshot("f%d" % nxt)
 MOTION_FILTER_THRESH = 0.905
+BACKEND_ARGS = dict(upsample=False, beta=0.25, backend_thresh=1e3, backend_radius=1, backend_nms=1)

@@ -1,7 +1,8 @@
 """GPU: droid_amd.factor_graph.FactorGraph / depth_video.DepthVideo / policies (host mirrors over the HIP kernels) against
 vectors written by the REFERENCE's own factor_graph.py + depth_video.py + droid_net.py run on CPU with oracle kernels
 (tests/golden/graph_python.npz): one composed update iteration incl. inactive edges and upsampling (a1), update_lowmem
-(a2), add_proximity_factors with the device NMS (f1), cvx_upsample and the motion-only pose filler (f3).
+(a2), add_proximity_factors with the device NMS (f1), cvx_upsample (f3).  The policy classes (frontend, backend, motion filter,
+pose filler) are compared with the reference's own classes in tests/test_policy_gpu.py.
 
 Tolerances: the golden run evaluates the update operator under fp16 autocast and the geometry / BA in fp64; the HIP path
 stores fp16 activations and runs the BA in fp32 (fp64 solve).  After one update iteration the hidden state agrees to a few
@@ -183,62 +184,6 @@ def test_se3_log_and_motion_model(db):
     assert np.abs((M[:, :3, :3] @ X[..., None])[..., 0] + M[:, :3, 3] - Y).max() < 1e-5
 
 
-def test_pose_filler_recovers_interpolated_poses(db):
-    """motion-only BA of non-keyframes (trajectory_filler.py:42-84 without the encoder): frames that are exact copies of
-    keyframes (features, time stamps in between) are initialised by SE(3) interpolation and refined without touching
-    keyframe poses or depths"""
-    from droid_amd.policies import fill_poses
-    S = graph_scenario()
-    N = S["n_frames"]
-    video, upd = _setup(S, buffer_extra=6)
-    poses0, disps0 = video.poses.clone(), video.disps.clone()
-    tst = [1.0, 2.5, 4.0]
-    fm = video.fmaps[[1, 2, 4]].clone()
-    out = fill_poses(upd, video, tst, fm)
-    torch.cuda.synchronize()
-    assert video.counter.value == N
-    assert torch.equal(video.poses[:N], poses0[:N]) and torch.equal(video.disps[:N], disps0[:N])
-    got = out.data.cpu().numpy()
-    assert np.isfinite(got).all() and np.abs(np.linalg.norm(got[:, 3:], axis=-1) - 1).max() < 1e-4
-    # frames stamped exactly at a keyframe start from that keyframe's pose and stay close to it
-    kp = poses0[[1, 4]].cpu().numpy()
-    assert np.abs(got[[0, 2], :3] - kp[:, :3]).max() < 0.1
-
-
-def test_frontend_and_backend_policies_run_on_a_short_sequence(db):
-    """DroidFrontend (initialisation with 8 + 8 update iterations, then per-keyframe updates incl. the keyframe-removal
-    branch) and DroidBackend (proximity edges + update_lowmem) on a synthetic 10-keyframe sequence: the policies of
-    droid_frontend.py:65-164 / droid_backend.py:25-43 execute end to end on the device and keep the state sane"""
-    from types import SimpleNamespace
-    from droid_amd.policies import DroidFrontend, DroidBackend
-    S = graph_scenario(n_frames=10)
-    N = S["n_frames"]
-    video, upd = _setup(S, buffer_extra=4)
-    args = SimpleNamespace(upsample=True, warmup=8, beta=0.3, frontend_nms=1, keyframe_thresh=0.5, frontend_window=20,
-                           frontend_thresh=16.0, frontend_radius=2, backend_thresh=22.0, backend_radius=2, backend_nms=3)
-    video.counter.value = 8                                   # the first `warmup` keyframes have arrived
-    fe = DroidFrontend(upd, video, args)
-    fe()
-    assert fe.is_initialized and fe.t1 == 8
-    for k in (9, 10):                                         # two more keyframes
-        video.counter.value = k
-        fe()
-    torch.cuda.synchronize()
-    t = video.counter.value
-    assert 8 <= t <= 10 and fe.t1 == t
-    p = video.poses[:t].cpu().numpy(); dd = video.disps[:t].cpu().numpy()
-    assert np.isfinite(p).all() and np.isfinite(dd).all() and dd.min() >= 0.001
-    assert np.abs(np.linalg.norm(p[:, 3:], axis=-1) - 1).max() < 1e-4 and np.array_equal(p[0], S["poses"][0])
-    assert len(fe.graph.ii) <= 48 + 2 * 5 * (args.frontend_radius + 1) and int(fe.graph.age.max()) <= fe.max_age + 1
-    be = DroidBackend(upd, video, args, chunk_frames=64)
-    g = be(steps=2)
-    torch.cuda.synchronize()
-    assert len(g.ii) == 0                                     # clear_edges
-    p2 = video.poses[:t].cpu().numpy()
-    assert np.isfinite(p2).all() and np.abs(np.linalg.norm(p2[:, 3:], axis=-1) - 1).max() < 1e-4
-    assert abs(float(video.disps[:t].mean()) - 1.0) < 0.5     # normalised to unit mean disparity before the global BA
-
-
 def test_reconstruction_dump_and_point_cloud(db, tmp_path):
     """demo.py:60-76 dump format (keys, shapes, dtypes, round trip) and the viewers' point-cloud extraction
     (view_reconstruction.py:15-38): points of a consistent synthetic scene survive the multi-view filter"""
@@ -281,38 +226,3 @@ def test_encoders_match_reference_module_under_autocast(db, golden_dir):
         ref = G[tag].astype(np.float32)
         assert y.shape == ref.shape
         assert np.abs(y - ref).max() <= 2.0 ** -7 * np.abs(ref).max(), tag       # ~20 fp16-stored layers deep
-
-
-def test_motion_filter_adds_keyframes_on_motion(db):
-    """MotionFilter.track (motion_filter.py:52-91): the first frame always enters the video; a frame identical to the
-    last keyframe does not (flow magnitude ~ 0 after one update iteration), a shifted one does"""
-    from droid_amd.depth_video import DepthVideo
-    from droid_amd.encoder import FeatureNets, empty_state_dict as enc_sd
-    from droid_amd.policies import MotionFilter
-    from droid_amd.update import UpdateModule
-    from droid_amd.weights import deterministic_state_dict
-    ht, wd = 128, 512                               # 16 x 64 at 1/8 resolution
-    sd = {}
-    for pre, dim, seed in (("fnet.", 128, 11), ("cnet.", 256, 12)):
-        class _S:
-            def state_dict(self):
-                return enc_sd(dim)
-        sd.update({pre + k: v for k, v in deterministic_state_dict(_S(), seed=seed).items()})
-    nets = FeatureNets().load_state_dict(sd)
-    upd = UpdateModule().load_state_dict(deterministic_state_dict(_SD(), seed=1234))
-    video = DepthVideo(image_size=[ht, wd], buffer=8, device="cuda:0")
-    mf = MotionFilter(nets, upd, video, thresh=0.05)
-    g = torch.Generator().manual_seed(0)
-    base = torch.nn.functional.interpolate(torch.rand(1, 3, ht // 8, wd // 8, generator=g), scale_factor=8, mode="bilinear")[0]
-    img0 = (base * 255).byte()[None]
-    intr = torch.tensor([200.0, 200.0, wd / 2, ht / 2])
-    mf.track(0, img0, intrinsics=intr)
-    assert video.counter.value == 1 and torch.equal(video.intrinsics[0].cpu(), intr / 8)
-    assert video.fmaps[0].abs().max() > 0 and video.nets[0].abs().max() <= 1.0 and video.inps[0].min() >= 0
-    n0 = video.counter.value
-    mf.track(1, img0, intrinsics=intr)                                       # no motion at all: delta of one update
-    d_same = mf.last_delta
-    mf.track(2, torch.roll(img0, shifts=24, dims=-1), intrinsics=intr)        # 3 feature pixels of horizontal motion
-    d_shift = mf.last_delta
-    assert np.isfinite(d_same) and np.isfinite(d_shift)
-    assert video.counter.value in (n0, n0 + 1, n0 + 2)
