@@ -211,5 +211,14 @@ __device__ __forceinline__ float to_float(float f) { return f; }
 template <typename T> __device__ __forceinline__ T from_float(float f);
 template <> __device__ __forceinline__ float from_float<float>(float f) { return f; }
 template <> __device__ __forceinline__ __half from_float<__half>(float f) { return __float2half(f); }
+// arithmetic type of a lookup on volumes of element type T: the reference computes the bilinear blend in scalar_t
+// (src/correlation_kernels.cu:40-67), i.e. in double for double volumes; half / float volumes are blended in fp32 here
+template <typename T> struct BlendType { using type = float; };
+template <> struct BlendType<double> { using type = double; };
+__device__ __forceinline__ double to_blend(double v) { return v; }
+__device__ __forceinline__ float to_blend(float v) { return v; }
+__device__ __forceinline__ float to_blend(__half v) { return __half2float(v); }
+template <typename T, typename A> __device__ __forceinline__ T from_blend(A v) { return (T)v; }
+template <> __device__ __forceinline__ __half from_blend<__half, float>(float v) { return __float2half(v); }
 
 }  // namespace dh

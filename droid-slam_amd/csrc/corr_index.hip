@@ -17,6 +17,7 @@
 // Generic path (any radius, unaligned slices): four-tap gather per output.
 #include "common.h"
 #include "gather8.h"
+#include <type_traits>
 
 namespace {
 
@@ -88,23 +89,24 @@ __global__ __launch_bounds__(256) void corr_index_fwd_generic_kernel(
   const int yx = (int)(p - (long)n * HW1);
   const float x0 = coords[((long)n * 2 + 0) * HW1 + yx];
   const float y0 = coords[((long)n * 2 + 1) * HW1 + yx];
+  using A = typename dh::BlendType<T>::type;
   float fxf = floorf(x0), fyf = floorf(y0);
-  const float dx = x0 - fxf, dy = y0 - fyf;
+  const A dx = (A)(x0 - fxf), dy = (A)(y0 - fyf);
   fxf = fminf(fmaxf(fxf, -65536.f), 65536.f);
   fyf = fminf(fmaxf(fyf, -65536.f), 65536.f);
   const int rd = 2 * r + 1;
   const T* slice = volume + p * (long)h2 * w2;
   T* out = corr + (long)n * rd * rd * HW1 + yx;
-  auto tap = [&](int x1, int y1) -> float {
-    return ((unsigned)x1 < (unsigned)w2 && (unsigned)y1 < (unsigned)h2) ? to_float(slice[(long)y1 * w2 + x1]) : 0.f;
+  auto tap = [&](int x1, int y1) -> A {
+    return ((unsigned)x1 < (unsigned)w2 && (unsigned)y1 < (unsigned)h2) ? dh::to_blend(slice[(long)y1 * w2 + x1]) : (A)0;
   };
   for (int a = 0; a < rd; ++a) {
     const int x1 = (int)fxf - r + a;
     for (int b = 0; b < rd; ++b) {
       const int y1 = (int)fyf - r + b;
-      float t00 = tap(x1, y1), t10 = tap(x1 + 1, y1), t01 = tap(x1, y1 + 1), t11 = tap(x1 + 1, y1 + 1);
-      float top = t00 + dx * (t10 - t00), bot = t01 + dx * (t11 - t01);
-      out[(long)(a * rd + b) * HW1] = dh::from_float<T>(top + dy * (bot - top));
+      A t00 = tap(x1, y1), t10 = tap(x1 + 1, y1), t01 = tap(x1, y1 + 1), t11 = tap(x1 + 1, y1 + 1);
+      A top = t00 + dx * (t10 - t00), bot = t01 + dx * (t11 - t01);
+      out[(long)(a * rd + b) * HW1] = dh::from_blend<T, A>(top + dy * (bot - top));
     }
   }
 }
@@ -120,15 +122,16 @@ __global__ __launch_bounds__(256) void corr_index_bwd_kernel(
   const int yx = (int)(p - (long)n * HW1);
   const float x0 = coords[((long)n * 2 + 0) * HW1 + yx];
   const float y0 = coords[((long)n * 2 + 1) * HW1 + yx];
+  using A = typename dh::BlendType<T>::type;
   float fxf = floorf(x0), fyf = floorf(y0);
-  const float dx = x0 - fxf, dy = y0 - fyf;
+  const A dx = (A)(x0 - fxf), dy = (A)(y0 - fyf);
   fxf = fminf(fmaxf(fxf, -65536.f), 65536.f);
   fyf = fminf(fmaxf(fyf, -65536.f), 65536.f);
   const int rd = 2 * r + 1;
   T* slice = volume_grad + p * (long)h2 * w2;
   const T* g = corr_grad + (long)n * rd * rd * HW1 + yx;
-  auto G = [&](int a, int b) -> float {
-    return (a >= 0 && a < rd && b >= 0 && b < rd) ? to_float(g[(long)(a * rd + b) * HW1]) : 0.f;
+  auto G = [&](int a, int b) -> A {
+    return (a >= 0 && a < rd && b >= 0 && b < rd) ? dh::to_blend(g[(long)(a * rd + b) * HW1]) : (A)0;
   };
   for (int i = 0; i <= rd; ++i) {
     const int x1 = (int)fxf - r + i;
@@ -136,9 +139,9 @@ __global__ __launch_bounds__(256) void corr_index_bwd_kernel(
     for (int j = 0; j <= rd; ++j) {
       const int y1 = (int)fyf - r + j;
       if ((unsigned)y1 >= (unsigned)h2) continue;
-      float v = G(i - 1, j - 1) * (dx * dy) + G(i - 1, j) * (dx * (1.f - dy)) +
-                G(i, j - 1) * ((1.f - dx) * dy) + G(i, j) * ((1.f - dx) * (1.f - dy));
-      slice[(long)y1 * w2 + x1] = dh::from_float<T>(v);
+      A v = G(i - 1, j - 1) * (dx * dy) + G(i - 1, j) * (dx * ((A)1 - dy)) +
+            G(i, j - 1) * (((A)1 - dx) * dy) + G(i, j) * (((A)1 - dx) * ((A)1 - dy));
+      slice[(long)y1 * w2 + x1] = dh::from_blend<T, A>(v);
     }
   }
 }
@@ -151,10 +154,15 @@ int launch_fwd(const void* volume, const float* coords, void* corr, int N, int h
   const unsigned grid = (unsigned)((npix + 255) / 256);
   const long S = (long)h2 * w2;
   const bool aligned = ((S * sizeof(T)) % 16 == 0) && (((uintptr_t)volume) % 16 == 0) && S > 0;
-  if (radius == 3 && aligned) {
-    hipLaunchKernelGGL(corr_index_fwd_r3_kernel<T>, dim3(grid), dim3(256), 0, st,
-                       (const T*)volume, coords, (T*)corr, N, h1 * w1, h2, w2);
-  } else {
+  if constexpr (!std::is_same<T, double>::value) {
+    if (radius == 3 && aligned) {
+      hipLaunchKernelGGL(corr_index_fwd_r3_kernel<T>, dim3(grid), dim3(256), 0, st,
+                         (const T*)volume, coords, (T*)corr, N, h1 * w1, h2, w2);
+      DH_LAUNCH_CHECK();
+      return DH_OK;
+    }
+  }
+  {
     hipLaunchKernelGGL(corr_index_fwd_generic_kernel<T>, dim3(grid), dim3(256), 0, st,
                        (const T*)volume, coords, (T*)corr, N, h1 * w1, h2, w2, radius);
   }
@@ -171,6 +179,7 @@ extern "C" int dh_corr_index_fwd(const void* volume, const float* coords, void* 
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DH_F16) return launch_fwd<__half>(volume, coords, corr, N, h1, w1, h2, w2, radius, st);
   if (dtype == DH_F32) return launch_fwd<float>(volume, coords, corr, N, h1, w1, h2, w2, radius, st);
+  if (dtype == DH_F64) return launch_fwd<double>(volume, coords, corr, N, h1, w1, h2, w2, radius, st);   // correlation_kernels.cu:146 dispatches double too
   return DH_ERR_UNSUPPORTED;
 }
 
@@ -178,19 +187,22 @@ extern "C" int dh_corr_index_bwd(const float* coords, const void* corr_grad, voi
                                  int N, int h1, int w1, int h2, int w2, int radius, dh_stream_t stream) {
   if (N < 0 || h1 <= 0 || w1 <= 0 || h2 <= 0 || w2 <= 0 || radius < 0 || radius > 16) return DH_ERR_ARG;
   if (N > 0 && (!coords || !corr_grad || !volume_grad)) return DH_ERR_ARG;
-  if (dtype != DH_F16 && dtype != DH_F32) return DH_ERR_UNSUPPORTED;
+  if (dtype != DH_F16 && dtype != DH_F32 && dtype != DH_F64) return DH_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const long npix = (long)N * h1 * w1;
   if (npix == 0) return DH_OK;
-  const size_t esz = dtype == DH_F16 ? 2 : 4;
+  const size_t esz = dtype == DH_F16 ? 2 : dtype == DH_F32 ? 4 : 8;
   if (hipMemsetAsync(volume_grad, 0, (size_t)npix * h2 * w2 * esz, st) != hipSuccess) return DH_ERR_LAUNCH;
   const unsigned grid = (unsigned)((npix + 255) / 256);
   if (dtype == DH_F16)
     hipLaunchKernelGGL(corr_index_bwd_kernel<__half>, dim3(grid), dim3(256), 0, st, coords,
                        (const __half*)corr_grad, (__half*)volume_grad, N, h1 * w1, h2, w2, radius);
-  else
+  else if (dtype == DH_F32)
     hipLaunchKernelGGL(corr_index_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, coords,
                        (const float*)corr_grad, (float*)volume_grad, N, h1 * w1, h2, w2, radius);
+  else
+    hipLaunchKernelGGL(corr_index_bwd_kernel<double>, dim3(grid), dim3(256), 0, st, coords,
+                       (const double*)corr_grad, (double*)volume_grad, N, h1 * w1, h2, w2, radius);
   DH_LAUNCH_CHECK();
   return DH_OK;
 }

@@ -424,7 +424,10 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // register allocator use 168 VGPRs at 3 waves/SIMD: the inline-asm tap loads must never be spilled or copied
 // while they are in flight (scripts/audit_asm_loads.py checks the generated ISA for exactly that at build time).
 typedef unsigned int u32x4_nt __attribute__((ext_vector_type(4)));
-template <int W, bool NHWC>
+// MODE (reference-layout output only; opts().lookup_mode): 0 = product; 1 = tap loads with the `nt` cache policy; ablations that
+// give WRONG results and exist to attribute the kernel's time (scripts/bench_lookup.py --mode): 2 = no output stores,
+// 3 = no tap loads.
+template <int W, bool NHWC, int MODE = 0>
 __global__ __launch_bounds__(NHWC ? 64 : W * 8, NHWC ? 3 : 4) void pyr_lookup_kernel(const __half* __restrict__ pyr, const float* __restrict__ coords,
                                                                __half* __restrict__ out, PyrDims D) {
   extern __shared__ __half s_out[];               // [49][8 rows][W], swizzled
@@ -480,8 +483,11 @@ __global__ __launch_bounds__(NHWC ? 64 : W * 8, NHWC ? 3 : 4) void pyr_lookup_ke
       const bool inside = (unsigned)y2 < (unsigned)h2;
       const int rowoff = inside ? wrap(y2 - G.y1l, h2) * (w2 * 128) + G.sboff : h2 * (w2 * 128);      // else block 0's all-zero row
 #pragma unroll
-      for (int m = 0; m < NPAIR; ++m)
-        asm volatile("global_load_dword %0, %1, %2" : "=v"(T.raw[jj][m]) : "v"(rowoff + G.coloff[m]), "s"(G.base));
+      for (int m = 0; m < NPAIR; ++m) {
+        if (MODE == 1) asm volatile("global_load_dword %0, %1, %2 nt" : "=v"(T.raw[jj][m]) : "v"(rowoff + G.coloff[m]), "s"(G.base));
+        else if (MODE == 3) asm volatile("v_mov_b32 %0, %1" : "=v"(T.raw[jj][m]) : "v"(rowoff + G.coloff[m]));
+        else asm volatile("global_load_dword %0, %1, %2" : "=v"(T.raw[jj][m]) : "v"(rowoff + G.coloff[m]), "s"(G.base));
+      }
     }
   };
   // ties every tap register to this point so that no use can be scheduled above the preceding wait
@@ -611,7 +617,8 @@ __global__ __launch_bounds__(NHWC ? 64 : W * 8, NHWC ? 3 : 4) void pyr_lookup_ke
         if (it * NTHREADS + NTHREADS <= NPIECES || o < NPIECES) {
           const int sg = o % NBX, row = (o / NBX) % 8, ch = o / (NBX * 8);
           const uint4 val = *reinterpret_cast<const uint4*>(s_out + (ch * 8 + row) * W + (sg ^ (row & (NBX - 1))) * 8);
-          __builtin_nontemporal_store(__builtin_bit_cast(u32x4_nt, val), reinterpret_cast<u32x4_nt*>(obase + (long)ch * HW + row * W + sg * 8));
+          if (MODE == 2) { if (val.x == 0x12345678u && val.y == 0x9abcdef0u) out[0] = __float2half(0.f); }    // keeps the LDS reads alive
+          else __builtin_nontemporal_store(__builtin_bit_cast(u32x4_nt, val), reinterpret_cast<u32x4_nt*>(obase + (long)ch * HW + row * W + sg * 8));
         }
       }
       lds_barrier();
@@ -683,7 +690,14 @@ int launch_lookup(const void* pyramid, const float* coords, void* out, int E, in
   const size_t lds = NHWC ? (size_t)64 * 56 * sizeof(__half) : (size_t)NCH_OUT * 8 * w * sizeof(__half);
   const dim3 grid(NHWC ? (h / 8) * (w / 8) : h / 8, E);
   const dim3 block(NHWC ? 64 : w * 8);
-  if (w == 64)
+  const int mode = NHWC ? 0 : opts().lookup_mode;
+  if (w == 64 && mode == 1)
+    hipLaunchKernelGGL((pyr_lookup_kernel<64, NHWC, 1>), grid, block, lds, st, (const __half*)pyramid, coords, (__half*)out, D);
+  else if (w == 64 && mode == 2)
+    hipLaunchKernelGGL((pyr_lookup_kernel<64, NHWC, 2>), grid, block, lds, st, (const __half*)pyramid, coords, (__half*)out, D);
+  else if (w == 64 && mode == 3)
+    hipLaunchKernelGGL((pyr_lookup_kernel<64, NHWC, 3>), grid, block, lds, st, (const __half*)pyramid, coords, (__half*)out, D);
+  else if (w == 64)
     hipLaunchKernelGGL((pyr_lookup_kernel<64, NHWC>), grid, block, lds, st, (const __half*)pyramid, coords, (__half*)out, D);
   else if (w == 32)
     hipLaunchKernelGGL((pyr_lookup_kernel<32, NHWC>), grid, block, lds, st, (const __half*)pyramid, coords, (__half*)out, D);

@@ -29,10 +29,11 @@ void check_status(int rc, const char* what) {
   TORCH_CHECK(rc == DH_OK, what, ": ", dh_status_string(rc));
 }
 
-int dtype_code(const torch::Tensor& t, const char* name) {
+int dtype_code(const torch::Tensor& t, const char* name, bool allow_f64 = false) {
   if (t.scalar_type() == torch::kFloat16) return DH_F16;
   if (t.scalar_type() == torch::kFloat32) return DH_F32;
-  TORCH_CHECK(false, name, " must be float16 or float32");
+  if (allow_f64 && t.scalar_type() == torch::kFloat64) return DH_F64;
+  TORCH_CHECK(false, name, allow_f64 ? " must be float16, float32 or float64" : " must be float16 or float32");
   return -1;
 }
 
@@ -199,7 +200,7 @@ std::vector<torch::Tensor> corr_index_forward(torch::Tensor volume, torch::Tenso
   const int N = (int)volume.size(0), h1 = (int)volume.size(1), w1 = (int)volume.size(2);
   torch::Tensor corr = torch::empty({N, 2 * radius + 1, 2 * radius + 1, h1, w1}, volume.options());
   check_status(dh_corr_index_fwd(volume.data_ptr(), coords.data_ptr<float>(), corr.data_ptr(),
-                                 dtype_code(volume, "volume"), N, h1, w1, (int)volume.size(3), (int)volume.size(4),
+                                 dtype_code(volume, "volume", true), N, h1, w1, (int)volume.size(3), (int)volume.size(4),
                                  radius, cur_stream()),
                "corr_index_forward");
   return {corr};
@@ -211,10 +212,34 @@ std::vector<torch::Tensor> corr_index_backward(torch::Tensor volume, torch::Tens
   TORCH_CHECK(corr_grad.scalar_type() == volume.scalar_type(), "corr_grad dtype must match volume");
   torch::Tensor volume_grad = torch::empty_like(volume);
   check_status(dh_corr_index_bwd(coords.data_ptr<float>(), corr_grad.data_ptr(), volume_grad.data_ptr(),
-                                 dtype_code(volume, "volume"), (int)volume.size(0), (int)volume.size(1),
+                                 dtype_code(volume, "volume", true), (int)volume.size(0), (int)volume.size(1),
                                  (int)volume.size(2), (int)volume.size(3), (int)volume.size(4), radius, cur_stream()),
                "corr_index_backward");
   return {volume_grad};
+}
+
+// ---- reference-layout volume + pooling for any image size (droid_amd.corr.CorrBlockRef) ----------------------
+torch::Tensor corr_volume_build(torch::Tensor fmap1, torch::Tensor fmap2) {
+  CHECK_INPUT(fmap1); CHECK_INPUT(fmap2);
+  TORCH_CHECK(fmap1.dim() == 4 && fmap1.sizes() == fmap2.sizes() && fmap1.scalar_type() == fmap2.scalar_type(),
+              "corr_volume_build: fmaps [E,C,h,w] of equal shape and dtype");
+  const int E = (int)fmap1.size(0), C = (int)fmap1.size(1), h = (int)fmap1.size(2), w = (int)fmap1.size(3);
+  torch::Tensor vol = torch::empty({E, h, w, h, w}, fmap1.options());
+  check_status(dh_corr_volume_build(fmap1.data_ptr(), fmap2.data_ptr(), vol.data_ptr(), dtype_code(fmap1, "fmap1"), E, C, h, w, cur_stream()),
+               "corr_volume_build");
+  return vol;
+}
+
+torch::Tensor corr_volume_pool(torch::Tensor vol) {
+  CHECK_INPUT(vol);
+  TORCH_CHECK(vol.dim() >= 3, "corr_volume_pool: volume [..., h2, w2]");
+  const int h2 = (int)vol.size(-2), w2 = (int)vol.size(-1);
+  std::vector<int64_t> shape(vol.sizes().begin(), vol.sizes().end());
+  shape[shape.size() - 2] = h2 / 2; shape[shape.size() - 1] = w2 / 2;
+  torch::Tensor out = torch::empty(shape, vol.options());
+  const long n = h2 * w2 > 0 ? vol.numel() / ((long)h2 * w2) : 0;
+  check_status(dh_corr_volume_pool(vol.data_ptr(), out.data_ptr(), dtype_code(vol, "volume"), n, h2, w2, cur_stream()), "corr_volume_pool");
+  return out;
 }
 
 std::vector<torch::Tensor> altcorr_forward(torch::Tensor fmap1, torch::Tensor fmap2, torch::Tensor coords,
@@ -555,6 +580,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("ba_build", &ba_build, "per-rank reduced camera system (split BA)");
   m.def("ba_finish", &ba_finish, "damp + solve + back-substitute + retract (split BA)");
   m.def("altcorr_forward_nhwc", &altcorr_forward_nhwc, "on-the-fly correlation on the fp16 MFMA, channel-last features");
+  m.def("corr_volume_build", &corr_volume_build, "all-pairs volume in the reference layout (any image size)");
+  m.def("corr_volume_pool", &corr_volume_pool, "2x2 average pooling of the last two dims of a reference-layout volume");
   m.def("corr_pyramid_build", &corr_pyramid_build, "all-pairs correlation pyramid, MI355X layout");
   m.def("corr_pyramid_lookup", &corr_pyramid_lookup, "fused 4-level lookup on the MI355X pyramid");
   m.def("corr_pyramid_lookup_nhwc", &corr_pyramid_lookup_nhwc, "fused 4-level lookup, channel-last output for the update operator");

@@ -26,6 +26,7 @@ Options& opts() {
     const char* pb = getenv("DH_PYR_BUILD");
     v.pyr_build_chunk = (pb && !strcmp(pb, "chunk")) ? 1 : 0;
     v.ba_strict = env_int("DH_BA_STRICT", 1);
+    v.lookup_mode = env_int("DH_LOOKUP_MODE", 0);
     return v;
   }();
   return o;
@@ -46,6 +47,7 @@ static int* slot(const char* name) {
   if (!strcmp(name, "dma_var")) return &o.dma_var;
   if (!strcmp(name, "pyr_build_chunk")) return &o.pyr_build_chunk;
   if (!strcmp(name, "ba_strict")) return &o.ba_strict;
+  if (!strcmp(name, "lookup_mode")) return &o.lookup_mode;
   return nullptr;
 }
 

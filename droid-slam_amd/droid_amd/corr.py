@@ -17,7 +17,8 @@ import droid_backends
 
 
 class CorrBlockRef:
-    """Reference-layout pyramid (any image size); lookups through droid_backends.corr_index_forward."""
+    """Reference-layout pyramid (any image size): volume and pooling by droid_backends.corr_volume_build / corr_volume_pool
+    (MFMA contraction over the channels for fp16 features), lookups through droid_backends.corr_index_forward."""
 
     def __init__(self, fmap1, fmap2, num_levels=4, radius=3, chunk=64):
         self.num_levels = num_levels
@@ -27,15 +28,16 @@ class CorrBlockRef:
         self.corr_pyramid = [
             torch.empty(num, ht, wd, ht // 2 ** l, wd // 2 ** l, dtype=fmap1.dtype, device=fmap1.device)
             for l in range(num_levels)]
-        f1 = fmap1[0].reshape(num, dim, ht * wd) / 4.0
-        f2 = fmap2[0].reshape(num, dim, ht * wd) / 4.0
+        f1, f2 = fmap1[0].contiguous(), fmap2[0].contiguous()
+        if f1.dtype not in (torch.float16, torch.float32):
+            f1, f2 = f1.float(), f2.float()
         for s in range(0, num, chunk):                      # bounded temporaries, volumes written in place
             e = min(num, s + chunk)
-            corr = torch.matmul(f1[s:e].transpose(1, 2), f2[s:e]).reshape((e - s) * ht * wd, 1, ht, wd)
+            corr = droid_backends.corr_volume_build(f1[s:e], f2[s:e])          # [n,h,w,h,w]
             for l in range(num_levels):
-                self.corr_pyramid[l][s:e] = corr.view(e - s, ht, wd, ht // 2 ** l, wd // 2 ** l)
+                self.corr_pyramid[l][s:e] = corr
                 if l + 1 < num_levels:
-                    corr = F.avg_pool2d(corr, 2, stride=2)
+                    corr = droid_backends.corr_volume_pool(corr)
 
     def __call__(self, coords):
         batch, num, ht, wd, _ = coords.shape
@@ -75,7 +77,9 @@ class AltCorrBlock:
         for l in range(num_levels):
             self.pyramid.append(f.view(B, N, C, H // 2 ** l, W // 2 ** l))
             if l + 1 < num_levels:
-                f = F.avg_pool2d(f, 2, stride=2)
+                # 2x2 mean of the last two dims (F.avg_pool2d(f, 2, stride=2), corr.py:100), same kernel as the volume pooling
+                f = (droid_backends.corr_volume_pool(f.contiguous()) if f.is_cuda and f.dtype in (torch.float16, torch.float32)
+                     else F.avg_pool2d(f, 2, stride=2))
         self.mfma = (B == 1 and radius == 3 and C == 128 and fmaps.dtype == torch.float16 and H % 8 == 0 and W % 8 == 0
                      and fmaps.is_cuda)
         if self.mfma:

@@ -37,6 +37,7 @@ extern "C" {
 /* element types of correlation volumes / feature maps */
 #define DH_F16 0
 #define DH_F32 1
+#define DH_F64 2   /* dh_corr_index_fwd / _bwd only (the reference dispatches double there too, correlation_kernels.cu:146,167) */
 
 typedef void* dh_stream_t;
 
@@ -68,6 +69,14 @@ int dh_corr_index_fwd(const void* volume, const float* coords, void* corr, int d
 /* volume_grad [N,h1,w1,h2,w2] (dtype) is fully overwritten with the adjoint of the lookup. */
 int dh_corr_index_bwd(const float* coords, const void* corr_grad, void* volume_grad, int dtype,
                       int N, int h1, int w1, int h2, int w2, int radius, dh_stream_t stream);
+
+/* All-pairs correlation volume in the reference layout and its 2x2 average pooling, any image size.  Replaces
+ * CorrBlock.corr + F.avg_pool2d of CorrBlock.__init__ (reference droid_slam/modules/corr.py:23-38,63-71).
+ *   fmap1, fmap2 [E,C,h,w] (dtype) -> volume [E,h,w,h,w] (dtype): sum_c (f1/4)(f2/4), fp32 accumulation
+ *   in [n_slices,h2,w2] -> out [n_slices,h2/2,w2/2] (floor), mean of each 2x2 block */
+int dh_corr_volume_build(const void* fmap1, const void* fmap2, void* volume, int dtype,
+                         int E, int C, int h, int w, dh_stream_t stream);
+int dh_corr_volume_pool(const void* in, void* out, int dtype, long n_slices, int h2, int w2, dh_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * On-the-fly ("alt") correlation.  Replaces altcorr_forward / altcorr_backward

@@ -13,6 +13,8 @@ ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--flow", default="reproj")
 ap.add_argument("--build-reps", type=int, default=0)
 ap.add_argument("--nhwc", action="store_true", help="channel-last variant (feeds the update operator)")
+ap.add_argument("--modes", default="", help="comma list of lookup_mode values to time one after the other on the same pyramid "
+                "(0 product, 1 nt tap loads, 2 no output stores, 3 no tap loads -- 2 / 3 are timing ablations with wrong results)")
 a = ap.parse_args()
 E, h, w = a.edges, 48, 64
 torch.manual_seed(0)
@@ -49,6 +51,17 @@ t = []
 for _ in range(a.reps):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); out = look(pyr, coords); e1.record(); torch.cuda.synchronize(); t.append(e0.elapsed_time(e1))
+for mode in [int(m) for m in a.modes.split(",") if m != ""]:
+    db.set_option("lookup_mode", mode)
+    look(pyr, coords); torch.cuda.synchronize()
+    tm = []
+    for _ in range(a.reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); o2 = look(pyr, coords); e1.record(); torch.cuda.synchronize(); tm.append(e0.elapsed_time(e1))
+    ok = bool(torch.equal(o2, out)) if mode < 2 else None
+    print("lookup_mode %d: median %.3f ms min %.3f  (880 B/ep -> %.1f GB/s)%s" % (mode, float(np.median(tm)), min(tm), 880.0 * E * h * w / float(np.median(tm)) / 1e6,
+                                                                                  "" if ok is None else "  output identical to mode 0: %s" % ok))
+db.set_option("lookup_mode", 0)
 ms = float(np.median(t)); nbytes = 880.0 * E * h * w
 print("lookup%s %s E=%d: median %.3f ms min %.3f  -> %.1f GB/s algorithmic (%.1f%% of 8 TB/s)" % (
     " channel-last" if a.nhwc else "", a.flow, E, ms, min(t), nbytes / ms / 1e6, nbytes / ms / 1e6 / 80.0))

@@ -9,7 +9,7 @@ Replacements (process-local, never the reference files): droid_backends -> oracl
 shims; torch.autocast(device_type="cuda") -> CPU fp16 autocast (the classes decorate their methods with it; on a GPU the
 encoders and the update operator run in fp16); Tensor.cuda() -> identity; the default device of FactorGraph.__init__ and the
 hard-coded "cuda" of torch.as_tensor inside projective_ops / trajectory_filler; softplus of GraphAgg.eta in fp32 as GPU
-autocast does.
+autocast does; torch.argsort -> stable (a GPU's radix sort is; factor_graph.py:121 ranks edges of equal age with it).
 
   M  MotionFilter.track (motion_filter.py:52-91) on a 10-frame pan: per frame the mean flow magnitude of the one update
      iteration, the keyframe decision, and the features stored for the accepted keyframes.
@@ -47,6 +47,11 @@ class _CpuAutocast(_Autocast):
 
 torch.autocast = _CpuAutocast
 torch.Tensor.cuda = lambda self, *a, **k: self
+# FactorGraph.add_factors ranks edges with torch.argsort(self.age) (factor_graph.py:121) without stable=True: ties between
+# edges of equal age are broken by whatever the backend's sort does.  On a GPU that is a radix sort (stable); torch's CPU
+# sort is not.  The golden takes the GPU's order.
+_argsort = torch.argsort
+torch.argsort = lambda x, *a, **k: _argsort(x, *a, **{**k, "stable": True})
 
 import droid_backends                               # oracle-backed shim
 assert "_shims_graph" in droid_backends.__file__

@@ -97,7 +97,7 @@ def filler_stream(n=18):
     return [(float(t), policy_image(100 + k), torch.tensor(MOTION_FILTER_INTRINSICS)) for k, t in enumerate(ts)]
 
 
-FRONTEND_ARGS = dict(upsample=True, warmup=8, beta=0.3, frontend_nms=1, keyframe_thresh=0.3, frontend_window=20, frontend_thresh=16.0,
+FRONTEND_ARGS = dict(upsample=True, warmup=8, beta=0.3, frontend_nms=1, keyframe_thresh=0.375, frontend_window=20, frontend_thresh=16.0,
                      frontend_radius=2)
 
 

@@ -818,3 +818,36 @@ def test_ba_config_c3_full_size_properties(db):
     assert np.isfinite(p).all() and np.isfinite(disps.cpu().numpy()).all()
     assert np.abs(np.linalg.norm(p[:, 3:], axis=-1) - 1).max() < 1e-4
     assert np.array_equal(p[0], g["poses"][0])
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("shape", [(3, 128, 30, 40), (2, 128, 48, 64), (2, 40, 9, 13)])
+def test_reference_layout_volume_build_and_pooling(db, dtype, shape):
+    """corr_volume_build / corr_volume_pool (any image size: TUM's 30x40, odd sizes, C not a multiple of 16) against
+    CorrBlock.corr + F.avg_pool2d of the reference formulation (modules/corr.py:32-38,63-71) evaluated by torch"""
+    E, C, h, w = shape
+    g = torch.Generator(device="cuda").manual_seed(E * h + w)
+    f1 = torch.randn(E, C, h, w, device="cuda", generator=g).to(dtype)
+    f2 = torch.randn(E, C, h, w, device="cuda", generator=g).to(dtype)
+    vol = db.corr_volume_build(f1, f2)
+    want = torch.matmul((f1.float().reshape(E, C, h * w) / 4.0).transpose(1, 2), f2.float().reshape(E, C, h * w) / 4.0)
+    assert vol.shape == (E, h, w, h, w) and vol.dtype == dtype
+    tol = 2.0 ** -10 if dtype == torch.float16 else 1e-5
+    assert (vol.float().reshape(E, h * w, h * w) - want).abs().max().item() <= tol * want.abs().max().item()
+    cur = vol
+    for _ in range(3):
+        nxt = db.corr_volume_pool(cur)
+        ref = torch.nn.functional.avg_pool2d(cur.float().reshape(-1, 1, cur.shape[-2], cur.shape[-1]), 2, stride=2)
+        assert nxt.shape[-2:] == ref.shape[-2:] and nxt.shape[:3] == (E, h, w)
+        assert (nxt.float().reshape(ref.shape) - ref).abs().max().item() <= (2.0 ** -10 if dtype == torch.float16 else 1e-6) * max(1.0, ref.abs().max().item())
+        cur = nxt
+    # the block built on them serves lookups at this size (the product path for images outside the MI355X pyramid layout)
+    from droid_amd.corr import CorrBlockRef
+    from oracle import corr as ocorr
+    if C == 128:
+        blk = CorrBlockRef(f1[None], f2[None])
+        rng = np.random.default_rng(5)
+        cc = np.stack([rng.uniform(-2, w + 1, (E, h, w)), rng.uniform(-2, h + 1, (E, h, w))], -1).astype(np.float32)
+        got = blk(torch.as_tensor(cc).cuda()[None])[0].float().cpu().numpy()
+        o = ocorr.corr_block_lookup(ocorr.corr_pyramid(f1.float().cpu().numpy(), f2.float().cpu().numpy(), 4), cc, 3)
+        assert np.abs(got - o).max() <= (2.0 ** -8 if dtype == torch.float16 else 1e-4) * np.abs(o).max()

@@ -265,6 +265,22 @@ def test_corr_index_forward_vs_reference(db, ref, dtype, shape):
     assert (a.float() - b.float()).abs().max().item() <= tol
 
 
+def test_corr_index_double_volumes_vs_reference(db, ref):
+    """the reference dispatches corr_index_forward / backward for double volumes as well (correlation_kernels.cu:146,167)"""
+    rng = np.random.default_rng(12)
+    shape = (2, 6, 8, 12, 16)
+    vol = dev(rng.standard_normal(shape), torch.float64)
+    coords = dev(np.stack([rng.uniform(-3, 18, (2, 6, 8)), rng.uniform(-3, 14, (2, 6, 8))], 1).astype(np.float32))
+    for r in (3, 2):
+        a, = db.corr_index_forward(vol, coords, r)
+        b, = ref[0].corr_index_forward(vol, coords, r)
+        assert a.dtype == torch.float64 and (a - b).abs().max().item() < 1e-12
+        g = dev(rng.standard_normal((2, 2 * r + 1, 2 * r + 1, 6, 8)), torch.float64)
+        a, = db.corr_index_backward(vol, coords, g, r)
+        b, = ref[0].corr_index_backward(vol, coords, g, r)
+        assert (a - b).abs().max().item() < 1e-12
+
+
 def test_corr_index_backward_vs_reference(db, ref):
     rng = np.random.default_rng(5)
     shape = (2, 6, 8, 12, 16)
