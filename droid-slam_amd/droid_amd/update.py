@@ -364,6 +364,10 @@ class UpdateModule:
         if ii is None:
             ii = torch.arange(num, device=net.device)
         n = self.to_nhwc(net[0]); i = self.to_nhwc(inp[0])
+        if n.data_ptr() == net.data_ptr():
+            # a channel-last fp16 input (what the encoders of this library produce) makes to_nhwc a view: forward_nhwc
+            # updates its hidden state in place, the reference interface must not touch the caller's tensor
+            n = n.clone()
         c = corr[0].half().contiguous() if self.wants_reference_layout_corr(ht, wd) else self.corr_to_nhwc(corr[0])
         f = self.to_nhwc(flow[0], 8)
         ii = ii.to(net.device)

@@ -266,7 +266,9 @@ def test_corr_index_forward_vs_reference(db, ref, dtype, shape):
 
 
 def test_corr_index_double_volumes_vs_reference(db, ref):
-    """the reference dispatches corr_index_forward / backward for double volumes as well (correlation_kernels.cu:146,167)"""
+    """the reference dispatches corr_index_forward / backward for double volumes as well (correlation_kernels.cu:146,167).
+    Its bilinear weights are FLOAT products cast to double (`scalar_t(dx * dy)`, :58-67), so its double result carries
+    float rounding of the weights (6e-8 relative); this library blends double volumes in double: they agree to that level."""
     rng = np.random.default_rng(12)
     shape = (2, 6, 8, 12, 16)
     vol = dev(rng.standard_normal(shape), torch.float64)
@@ -274,11 +276,11 @@ def test_corr_index_double_volumes_vs_reference(db, ref):
     for r in (3, 2):
         a, = db.corr_index_forward(vol, coords, r)
         b, = ref[0].corr_index_forward(vol, coords, r)
-        assert a.dtype == torch.float64 and (a - b).abs().max().item() < 1e-12
+        assert a.dtype == torch.float64 and (a - b).abs().max().item() < 4e-7 * max(1.0, b.abs().max().item())
         g = dev(rng.standard_normal((2, 2 * r + 1, 2 * r + 1, 6, 8)), torch.float64)
         a, = db.corr_index_backward(vol, coords, g, r)
         b, = ref[0].corr_index_backward(vol, coords, g, r)
-        assert (a - b).abs().max().item() < 1e-12
+        assert (a - b).abs().max().item() < 4e-7 * max(1.0, b.abs().max().item())
 
 
 def test_corr_index_backward_vs_reference(db, ref):
