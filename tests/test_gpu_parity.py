@@ -851,3 +851,22 @@ def test_reference_layout_volume_build_and_pooling(db, dtype, shape):
         got = blk(torch.as_tensor(cc).cuda()[None])[0].float().cpu().numpy()
         o = ocorr.corr_block_lookup(ocorr.corr_pyramid(f1.float().cpu().numpy(), f2.float().cpu().numpy(), 4), cc, 3)
         assert np.abs(got - o).max() <= (2.0 ** -8 if dtype == torch.float16 else 1e-4) * np.abs(o).max()
+
+
+def test_update_forward_leaves_a_channel_last_hidden_state_untouched(db):
+    """UpdateModule.forward (the reference's interface, droid_net.py:111) must not modify its arguments: a hidden state that
+    already lies channel-last in memory (what this library's encoders hand to MotionFilter) makes the layout conversion a
+    view, and forward_nhwc updates its hidden state in place"""
+    from oracle import update as oupd
+    from droid_amd.update import UpdateModule
+    from droid_amd.weights import deterministic_state_dict
+    mod = UpdateModule().load_state_dict(deterministic_state_dict(_SD(oupd.empty_state_dict()), seed=7))
+    g = torch.Generator(device="cuda").manual_seed(1)
+    net = torch.tanh(torch.randn(1, 2, 16, 64, 128, device="cuda", generator=g)).half().permute(0, 1, 4, 2, 3)   # [1,E,128,h,w], channel-last memory
+    inp = torch.relu(torch.randn(1, 2, 16, 64, 128, device="cuda", generator=g)).half().permute(0, 1, 4, 2, 3)
+    corr = torch.randn(1, 2, 196, 16, 64, device="cuda", generator=g).half()
+    before = net.clone()
+    out1 = mod(net, inp, corr)[0].clone()
+    assert torch.equal(net, before)
+    out2 = mod(net, inp, corr)[0]
+    assert torch.equal(out1, out2)
