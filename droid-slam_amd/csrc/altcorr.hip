@@ -202,7 +202,7 @@ __device__ __forceinline__ int wave_max_i(int v) {
 __global__ __launch_bounds__(AWPB * 64) void altcorr_mfma_kernel(
     const __half* __restrict__ f1, const __half* __restrict__ f2, const float* __restrict__ coords,
     const int64_t* __restrict__ us, const int64_t* __restrict__ vs, __half* __restrict__ corr,
-    int H, int W, int H2, int W2, int nblk) {
+    int H, int W, int H2, int W2, int nblk, float inv_scale, long corr_stride_m) {
   extern __shared__ __half s_alt[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int blk = blockIdx.x * AWPB + wv;
@@ -216,14 +216,14 @@ __global__ __launch_bounds__(AWPB * 64) void altcorr_mfma_kernel(
   const int yy = lane >> 3, xx = lane & 7;
   const int pix = (by * 8 + yy) * W + bx * 8 + xx;
   const float* cb = coords + (long)m * 2 * HW;
-  const float x0 = cb[pix], y0 = cb[HW + pix];
+  const float x0 = cb[pix] * inv_scale, y0 = cb[HW + pix] * inv_scale;      // (a power of two: exact, as coords / 2**level)
   float fxf = floorf(x0), fyf = floorf(y0);
   const float dx = x0 - fxf, dy = y0 - fyf;
   fxf = fminf(fmaxf(fxf, -65536.f), 65536.f);
   fyf = fminf(fmaxf(fyf, -65536.f), 65536.f);
   const int X0 = (int)fxf - 3, Y0 = (int)fyf - 3;
   const int Xmin = wave_min_i(X0), Xmax = wave_max_i(X0), Ymin = wave_min_i(Y0), Ymax = wave_max_i(Y0);
-  __half* out = corr + (long)m * 49 * HW + pix;
+  __half* out = corr + (long)m * corr_stride_m + pix;
   const __half* f1b = f1 + (long)ix * HW * AC;
   const __half* f2b = f2 + (long)jx * H2 * W2 * AC;
 
@@ -422,14 +422,23 @@ extern "C" int dh_altcorr_bwd(const void* fmap1, const void* fmap2, const float*
 extern "C" int dh_altcorr_fwd_nhwc(const void* fmap1, const void* fmap2, const float* coords,
                                    const int64_t* ii, const int64_t* jj, void* corr,
                                    int N1, int N2, int C, int H, int W, int H2, int W2, int M, dh_stream_t stream) {
+  return dh_altcorr_fwd_nhwc_level(fmap1, fmap2, coords, ii, jj, corr, N1, N2, C, H, W, H2, W2, M, 0, 49L * H * W, stream);
+}
+
+extern "C" int dh_altcorr_fwd_nhwc_level(const void* fmap1, const void* fmap2, const float* coords,
+                                         const int64_t* ii, const int64_t* jj, void* corr,
+                                         int N1, int N2, int C, int H, int W, int H2, int W2, int M,
+                                         int level, long corr_stride_m, dh_stream_t stream) {
   if (N1 <= 0 || N2 <= 0 || H <= 0 || W <= 0 || H2 <= 0 || W2 <= 0 || M < 0) return DH_ERR_ARG;
+  if (level < 0 || level > 15 || corr_stride_m < 49L * H * W) return DH_ERR_ARG;
   if (C != AC || H % 8 || W % 8) return DH_ERR_UNSUPPORTED;
   if (M == 0) return DH_OK;
   if (!fmap1 || !fmap2 || !coords || !ii || !jj || !corr) return DH_ERR_ARG;
   const int nblk = (H / 8) * (W / 8);
   const size_t lds = (size_t)AWPB * (64 * SF_LD + 64 * SC_LD) * sizeof(__half);
   hipLaunchKernelGGL(altcorr_mfma_kernel, dim3((nblk + AWPB - 1) / AWPB, M), dim3(AWPB * 64), lds, (hipStream_t)stream,
-                     (const __half*)fmap1, (const __half*)fmap2, coords, ii, jj, (__half*)corr, H, W, H2, W2, nblk);
+                     (const __half*)fmap1, (const __half*)fmap2, coords, ii, jj, (__half*)corr, H, W, H2, W2, nblk,
+                     1.0f / (float)(1 << level), corr_stride_m);
   DH_LAUNCH_CHECK();
   return DH_OK;
 }

@@ -296,6 +296,27 @@ torch::Tensor altcorr_forward_nhwc(torch::Tensor fmap1, torch::Tensor fmap2, tor
   return out;
 }
 
+// all levels of AltCorrBlock.__call__ into one [M, 49 * levels, H, W] tensor (no per-level stack copies)
+torch::Tensor altcorr_forward_nhwc_levels(torch::Tensor fmap1, std::vector<torch::Tensor> fmap2_levels, torch::Tensor coords,
+                                          torch::Tensor ii, torch::Tensor jj) {
+  CHECK_INPUT(fmap1); CHECK_INPUT(coords); CHECK_INPUT(ii); CHECK_INPUT(jj);
+  CHECK_F32(coords); CHECK_I64(ii); CHECK_I64(jj);
+  TORCH_CHECK(fmap1.scalar_type() == torch::kFloat16 && fmap1.dim() == 4 && coords.dim() == 4 && coords.size(1) == 2, "altcorr_forward_nhwc_levels: shapes");
+  const int N1 = (int)fmap1.size(0), H = (int)fmap1.size(1), W = (int)fmap1.size(2), C = (int)fmap1.size(3), M = (int)ii.size(0);
+  const int L = (int)fmap2_levels.size();
+  TORCH_CHECK(coords.size(0) == M && coords.size(2) == H && coords.size(3) == W && L >= 1, "altcorr_forward_nhwc_levels: shapes");
+  torch::Tensor out = torch::empty({M, 49 * L, H, W}, fmap1.options());
+  for (int l = 0; l < L; ++l) {
+    const torch::Tensor& f2 = fmap2_levels[l];
+    CHECK_INPUT(f2);
+    TORCH_CHECK(f2.scalar_type() == torch::kFloat16 && f2.dim() == 4 && f2.size(3) == C, "altcorr_forward_nhwc_levels: level features [N2,h,w,C] float16");
+    check_status(dh_altcorr_fwd_nhwc_level(fmap1.data_ptr(), f2.data_ptr(), coords.data_ptr<float>(), ii.data_ptr<int64_t>(), jj.data_ptr<int64_t>(),
+                                           (char*)out.data_ptr() + (size_t)l * 49 * H * W * 2, N1, (int)f2.size(0), C, H, W, (int)f2.size(1), (int)f2.size(2), M,
+                                           l, (long)49 * L * H * W, cur_stream()), "altcorr_forward_nhwc_levels");
+  }
+  return out;
+}
+
 // ---- MI355X-native correlation pyramid (own layout; droid_amd.corr.CorrBlock) ----------------------------
 torch::Tensor corr_pyramid_build(torch::Tensor fmap1, torch::Tensor fmap2) {
   CHECK_INPUT(fmap1); CHECK_INPUT(fmap2);
@@ -579,6 +600,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("ba_ex", &ba_ex, "bundle adjustment with a per-pixel depth-prior weight");
   m.def("ba_build", &ba_build, "per-rank reduced camera system (split BA)");
   m.def("ba_finish", &ba_finish, "damp + solve + back-substitute + retract (split BA)");
+  m.def("altcorr_forward_nhwc_levels", &altcorr_forward_nhwc_levels, "all pyramid levels of the on-the-fly correlation into one [M,49L,H,W] tensor");
   m.def("altcorr_forward_nhwc", &altcorr_forward_nhwc, "on-the-fly correlation on the fp16 MFMA, channel-last features");
   m.def("corr_volume_build", &corr_volume_build, "all-pairs volume in the reference layout (any image size)");
   m.def("corr_volume_pool", &corr_volume_pool, "2x2 average pooling of the last two dims of a reference-layout volume");

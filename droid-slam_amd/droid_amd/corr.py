@@ -87,13 +87,13 @@ class AltCorrBlock:
 
     def __call__(self, coords, ii, jj):
         c = coords.permute(0, 1, 4, 2, 3).contiguous()
+        if self.mfma:
+            # the four levels of an edge side by side in one tensor, the 2^-level scaling of the coordinates inside the kernel
+            return droid_backends.altcorr_forward_nhwc_levels(self.nhwc[0], self.nhwc, c[0], ii.contiguous(), jj.contiguous())[None]
         outs = []
         for l in range(self.num_levels):
-            if self.mfma:
-                corr = droid_backends.altcorr_forward_nhwc(self.nhwc[0], self.nhwc[l], (c[0] / 2 ** l).contiguous(), ii, jj)[None]
-            else:
-                corr, = droid_backends.altcorr_forward(self.pyramid[0], self.pyramid[l].contiguous(), c / 2 ** l,
-                                                       ii, jj, self.radius)
+            corr, = droid_backends.altcorr_forward(self.pyramid[0], self.pyramid[l].contiguous(), c / 2 ** l,
+                                                   ii, jj, self.radius)
             outs.append(corr.flatten(2, 3))
         return torch.stack(outs, dim=2).flatten(2, 3)
 

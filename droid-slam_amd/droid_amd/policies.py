@@ -161,7 +161,9 @@ class MotionFilter:
         if v.counter.value == 0:
             self.net, self.inp = context()
             self.fmap = gmap
-            v.append(tstamp, image[0], Id, 1.0, depth, intr8, gmap, self.net[0], self.inp[0])
+            # (the reference stores net[0,0] / inp[0,0] here, motion_filter.py:74: channel 0 of the context maps, broadcast
+            # over all 128 channels of keyframe 0 by the buffer assignment; later keyframes get all channels, :88.  Kept.)
+            v.append(tstamp, image[0], Id, 1.0, depth, intr8, gmap, self.net[0, 0], self.inp[0, 0])
             return
         yy, xx = torch.meshgrid(torch.arange(ht, device=dev, dtype=torch.float32), torch.arange(wd, device=dev, dtype=torch.float32), indexing="ij")
         coords0 = torch.stack([xx, yy], -1)[None, None]

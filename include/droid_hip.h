@@ -95,6 +95,14 @@ int dh_altcorr_fwd(const void* fmap1, const void* fmap2, const float* coords,
 int dh_altcorr_fwd_nhwc(const void* fmap1, const void* fmap2, const float* coords,
                         const int64_t* ii, const int64_t* jj, void* corr,
                         int N1, int N2, int C, int H, int W, int H2, int W2, int M, dh_stream_t stream);
+/* one pyramid level of AltCorrBlock.__call__ (corr.py:104-117) written in place: coords [M,2,H,W] are FULL-resolution
+ * coordinates, divided by 2^level here (exact); edge m's 49 planes go to corr + m * corr_stride_m (elements), so the four
+ * levels of an edge land side by side in one [M,196,H,W] tensor (corr = base + level * 49 * H * W, corr_stride_m = 196 * H * W)
+ * without the stack / flatten copies of the reference formulation. */
+int dh_altcorr_fwd_nhwc_level(const void* fmap1, const void* fmap2, const float* coords,
+                              const int64_t* ii, const int64_t* jj, void* corr,
+                              int N1, int N2, int C, int H, int W, int H2, int W2, int M,
+                              int level, long corr_stride_m, dh_stream_t stream);
 /* corr_grad [B,M,2r+1,2r+1,H,W] f32 (x offset outer); fmap1_grad/fmap2_grad f32, ACCUMULATED into
  * (caller zero-fills), shapes of fmap1/fmap2. */
 int dh_altcorr_bwd(const void* fmap1, const void* fmap2, const float* coords,
