@@ -352,6 +352,188 @@ __global__ __launch_bounds__(AWPB * 64) void altcorr_mfma_kernel(
   }
 }
 
+// ---- second form of the MFMA kernel (default; DH_ALTCORR_V1=1 selects the first) ----------------------------------------
+// The first form spends its time waiting: a wave stages 64 targets x 256 B through 64 registers, then multiplies, then
+// blends, four times in a row, and 26 KB of LDS per wave leave six waves per CU to hide that chain (measured 437 us per
+// 512 edges and level: 2 % of the MFMA peak).  Here
+//   * targets arrive by LDS-DMA (`global_load_lds_dwordx4`: no staging registers), 32 targets (2 window rows x 16 columns)
+//     per group = eight 1-KB pieces; rows are 256 B unpadded, the 16-byte slot of a row XOR-ed with the row index (the
+//     DMA's lane-linear LDS image is permuted on the SOURCE side: lane (target t, slot s) fetches slot s ^ (t & 15)), so
+//     the fragment reads stay conflict-free;
+//   * the next group's DMA is issued as soon as the current group's MFMAs have consumed the tile, and lands while the
+//     products are written to the [pixel][target] tile and blended;
+//   * out-of-image targets are fetched from a clamped address and zeroed at the blend (the reference's zero padding);
+//   * 12.6 KB of LDS and ~130 registers per wave: 12 waves per CU.
+// Same arithmetic as the first form: fp32 accumulation over the 128 channels, product rounded to fp16 after the 1/16
+// scale, separable blend in fp32.
+typedef __attribute__((address_space(3))) char lds_char_t;
+constexpr int A2_WPB = 4;                      // waves (source blocks) per workgroup
+constexpr int A2_TG = 32;                      // targets per group
+constexpr int A2_F_BYTES = A2_TG * AC * 2;     // 8192
+constexpr int A2_C_LD = A2_TG + 4;             // [pixel][32 targets (+4)] row stride in halves: 72 B
+constexpr int A2_C_BYTES = 64 * A2_C_LD * 2;   // 4608
+constexpr int A2_WAVE_BYTES = A2_F_BYTES + A2_C_BYTES;
+
+__global__ __launch_bounds__(A2_WPB * 64, 3) void altcorr_mfma2_kernel(
+    const __half* __restrict__ f1, const __half* __restrict__ f2, const float* __restrict__ coords,
+    const int64_t* __restrict__ us, const int64_t* __restrict__ vs, __half* __restrict__ corr,
+    int H, int W, int H2, int W2, int nblk, float inv_scale, long corr_stride_m) {
+  extern __shared__ __attribute__((aligned(16))) char s_alt2[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int blk = blockIdx.x * A2_WPB + wv;
+  if (blk >= nblk) return;                         // whole wave (no workgroup barrier below)
+  char* const sF = s_alt2 + wv * A2_WAVE_BYTES;
+  __half* const sC = reinterpret_cast<__half*>(sF + A2_F_BYTES);
+  const unsigned sF_lds = (unsigned)(uintptr_t)(lds_char_t*)sF;
+  const int m = blockIdx.y;
+  const int nbx = W / 8, by = blk / nbx, bx = blk - by * nbx;
+  const int HW = H * W;
+  const int ix = (int)us[m], jx = (int)vs[m];
+  const int yy = lane >> 3, xx = lane & 7;
+  const int pix = (by * 8 + yy) * W + bx * 8 + xx;
+  const float* cb = coords + (long)m * 2 * HW;
+  const float x0 = cb[pix] * inv_scale, y0 = cb[HW + pix] * inv_scale;
+  float fxf = floorf(x0), fyf = floorf(y0);
+  const float dx = x0 - fxf, dy = y0 - fyf;
+  fxf = fminf(fmaxf(fxf, -65536.f), 65536.f);
+  fyf = fminf(fmaxf(fyf, -65536.f), 65536.f);
+  const int X0 = (int)fxf - 3, Y0 = (int)fyf - 3;
+  const int Xmin = wave_min_i(X0), Xmax = wave_max_i(X0), Ymin = wave_min_i(Y0), Ymax = wave_max_i(Y0);
+  __half* out = corr + (long)m * corr_stride_m + pix;
+  const __half* f1b = f1 + (long)ix * HW * AC;
+  const __half* f2b = f2 + (long)jx * H2 * W2 * AC;
+
+  if (Xmax - Xmin > 8 || Ymax - Ymin > 8) {
+    // ---- incoherent block: per-lane scalar evaluation (same arithmetic order of the blend) ----
+    const __half* a = f1b + (long)pix * AC;
+    float prevs[7];
+    for (int j = 0; j < 8; ++j) {
+      float t[8];
+      for (int i = 0; i < 8; ++i) {
+        const int y2 = Y0 + j, x2 = X0 + i;
+        float sacc = 0.f;
+        if ((unsigned)y2 < (unsigned)H2 && (unsigned)x2 < (unsigned)W2) {
+          const __half* b = f2b + ((long)y2 * W2 + x2) * AC;
+          for (int c = 0; c < AC; c += 8) {
+            const uint4 av = *reinterpret_cast<const uint4*>(a + c), bv = *reinterpret_cast<const uint4*>(b + c);
+            const __half2* ah = reinterpret_cast<const __half2*>(&av);
+            const __half2* bh = reinterpret_cast<const __half2*>(&bv);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const float2 af = __half22float2(ah[q]), bf = __half22float2(bh[q]); sacc += af.x * bf.x + af.y * bf.y; }
+          }
+        }
+        t[i] = __half2float(__float2half(sacc * 0.0625f));
+      }
+      float c7[7];
+      for (int q = 0; q < 7; ++q) c7[q] = t[q] + dx * (t[q + 1] - t[q]);
+      if (j > 0)
+        for (int q = 0; q < 7; ++q) out[(long)(q * 7 + (j - 1)) * HW] = __float2half(prevs[q] + dy * (c7[q] - prevs[q]));
+      for (int q = 0; q < 7; ++q) prevs[q] = c7[q];
+    }
+    return;
+  }
+
+  // ---- source features of the block: B operands, resident (lane holds column = pixel nt*32 + (lane & 31), k-chunk lane >> 5)
+  half8 bfrag[2][8];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int pn = nt * 32 + (lane & 31);
+    const __half* row = f1b + ((long)(by * 8 + (pn >> 3)) * W + bx * 8 + (pn & 7)) * AC + (lane >> 5) * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) bfrag[nt][ks] = *reinterpret_cast<const half8*>(row + ks * 16);
+  }
+  // DMA role: piece i of a group covers targets 4i .. 4i+3; lane -> (target 4i + (lane >> 4), LDS slot lane & 15)
+  const int d_t = lane >> 4, d_s = lane & 15;
+  // one group = window rows Yg, Yg + 1; 16 columns from Xmin.  Source address per lane, clamped into the image.
+#define A2_DMA_GROUP(g_)                                                                                               \
+  {                                                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                    \
+      const int t = 4 * i + d_t;                              /* target inside the group */                            \
+      const int y = min(max(Ymin + 2 * (g_) + (t >> 4), 0), H2 - 1), x = min(max(Xmin + (t & 15), 0), W2 - 1);         \
+      const int voff = (y * W2 + x) * (AC * 2) + ((d_s ^ (t & 15)) << 4);                                              \
+      const unsigned dst = __builtin_amdgcn_readfirstlane(sF_lds + i * 1024);                                          \
+      unsigned keep_;                                                                                                  \
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" \
+                   : "=&s"(keep_) : "v"(voff), "s"(f2b), "s"(dst) : "memory");                                         \
+    }                                                                                                                  \
+  }
+  const int c0 = X0 - Xmin;                       // first tap column inside the 16-wide tile, 0..8
+  const int sh = (c0 & 3) * 16;                   // funnel shift (bits) inside the aligned 8-byte words
+  // column validity of this lane's 8 taps (row validity is per group row)
+  uint32_t colmask = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) colmask |= ((unsigned)(X0 + i) < (unsigned)W2 ? 1u : 0u) << i;
+  float prev[7];
+  A2_DMA_GROUP(0)
+#pragma unroll 1
+  for (int g = 0; g < 8; ++g) {
+    const int Yg = Ymin + 2 * g;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this group's eight pieces have landed (the bfrag loads too)
+    __builtin_amdgcn_wave_barrier();
+    f32x16 acc[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[b][q] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      // A fragment: row = target lane & 31, channels ks*16 + (lane >> 5)*8 .. +8 = logical slot 2*ks + (lane >> 5)
+      const int t = lane & 31;
+      const half8 af = *reinterpret_cast<const half8*>(sF + t * 256 + (((2 * ks + (lane >> 5)) ^ (t & 15)) << 4));
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bfrag[nt][ks], acc[nt], 0, 0, 0);
+    }
+    // the tile has been read (the MFMAs above hold their operands in registers once issued; wait for the LDS reads)
+    __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    if (g + 1 < 8) A2_DMA_GROUP(g + 1)
+    // D[target][pixel] -> sC[pixel][target] (fp16, scaled by 1/16): lane = pixel nt*32 + (lane & 31), 4 consecutive targets per store
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const __half2 lo = __floats2half2_rn(acc[nt][4 * qq] * 0.0625f, acc[nt][4 * qq + 1] * 0.0625f);
+        const __half2 hi = __floats2half2_rn(acc[nt][4 * qq + 2] * 0.0625f, acc[nt][4 * qq + 3] * 0.0625f);
+        uint2 pk; pk.x = __builtin_bit_cast(uint32_t, lo); pk.y = __builtin_bit_cast(uint32_t, hi);
+        *reinterpret_cast<uint2*>(sC + (nt * 32 + (lane & 31)) * A2_C_LD + 8 * qq + 4 * (lane >> 5)) = pk;
+      }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    // lane = pixel: consume the rows of this group that belong to its window
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int j = Yg + r - Y0;                  // window row of this pixel
+      if (j < 0 || j > 7) continue;
+      const __half* rowp = sC + lane * A2_C_LD + r * 16 + (c0 & ~3);
+      const uint64_t w0 = *reinterpret_cast<const uint64_t*>(rowp);
+      const uint64_t w1 = *reinterpret_cast<const uint64_t*>(rowp + 4);
+      const uint64_t w2 = *reinterpret_cast<const uint64_t*>(rowp + 8);
+      const uint64_t t03 = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
+      const uint64_t t47 = sh ? (w1 >> sh) | (w2 << (64 - sh)) : w1;
+      const uint32_t rmask = (unsigned)(Yg + r) < (unsigned)H2 ? colmask : 0u;
+      float t[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        t[i] = (rmask >> i) & 1u ? (float)__builtin_bit_cast(_Float16, (unsigned short)(t03 >> (16 * i))) : 0.f;
+        t[4 + i] = (rmask >> (4 + i)) & 1u ? (float)__builtin_bit_cast(_Float16, (unsigned short)(t47 >> (16 * i))) : 0.f;
+      }
+      float c7[7];
+#pragma unroll
+      for (int q = 0; q < 7; ++q) c7[q] = t[q] + dx * (t[q + 1] - t[q]);
+      if (j > 0) {
+#pragma unroll
+        for (int q = 0; q < 7; ++q) out[(long)(q * 7 + (j - 1)) * HW] = __float2half(prev[q] + dy * (c7[q] - prev[q]));
+      }
+#pragma unroll
+      for (int q = 0; q < 7; ++q) prev[q] = c7[q];
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);           // sC reads done before the next group overwrites it
+    __builtin_amdgcn_wave_barrier();
+  }
+#undef A2_DMA_GROUP
+}
+
 template <typename T>
 int launch_fwd(const void* fmap1, const void* fmap2, const float* coords, const int64_t* ii, const int64_t* jj,
                void* corr, int B, int N1, int N2, int C, int H, int W, int H2, int W2, int M, int radius,
@@ -435,10 +617,17 @@ extern "C" int dh_altcorr_fwd_nhwc_level(const void* fmap1, const void* fmap2, c
   if (M == 0) return DH_OK;
   if (!fmap1 || !fmap2 || !coords || !ii || !jj || !corr) return DH_ERR_ARG;
   const int nblk = (H / 8) * (W / 8);
-  const size_t lds = (size_t)AWPB * (64 * SF_LD + 64 * SC_LD) * sizeof(__half);
-  hipLaunchKernelGGL(altcorr_mfma_kernel, dim3((nblk + AWPB - 1) / AWPB, M), dim3(AWPB * 64), lds, (hipStream_t)stream,
-                     (const __half*)fmap1, (const __half*)fmap2, coords, ii, jj, (__half*)corr, H, W, H2, W2, nblk,
-                     1.0f / (float)(1 << level), corr_stride_m);
+  if (opts().altcorr_v1) {
+    const size_t lds = (size_t)AWPB * (64 * SF_LD + 64 * SC_LD) * sizeof(__half);
+    hipLaunchKernelGGL(altcorr_mfma_kernel, dim3((nblk + AWPB - 1) / AWPB, M), dim3(AWPB * 64), lds, (hipStream_t)stream,
+                       (const __half*)fmap1, (const __half*)fmap2, coords, ii, jj, (__half*)corr, H, W, H2, W2, nblk,
+                       1.0f / (float)(1 << level), corr_stride_m);
+  } else {
+    if (((uintptr_t)fmap2) % 16 || (long)H2 * W2 * AC * 2 >= (1L << 31)) return DH_ERR_ARG;      // 16-byte DMA pieces, 32-bit lane offsets
+    hipLaunchKernelGGL(altcorr_mfma2_kernel, dim3((nblk + A2_WPB - 1) / A2_WPB, M), dim3(A2_WPB * 64), (size_t)A2_WPB * A2_WAVE_BYTES,
+                       (hipStream_t)stream, (const __half*)fmap1, (const __half*)fmap2, coords, ii, jj, (__half*)corr, H, W, H2, W2, nblk,
+                       1.0f / (float)(1 << level), corr_stride_m);
+  }
   DH_LAUNCH_CHECK();
   return DH_OK;
 }
