@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--op-chunks", type=int, default=0, help="run the update operator over this many contiguous groups of source "
                     "frames (0 = automatic: 1, or 2 when the pyramid leaves less than 70 GB of HBM -- C5 on one GPU)")
     ap.add_argument("--no-check", action="store_true", help="skip the untimed output check of the step (N = 1 only): the same "
-                    "iteration through the reference-layout entry points (torch.matmul volumes + corr_index_forward, the "
+                    "iteration through the reference-layout entry points (reference-layout volumes + corr_index_forward, the "
                     "reference interface of the update operator with per-edge context features, ba) from the same state")
     ap.add_argument("--no-sensitivity", action="store_true", help="skip the untimed flow-sensitivity runs of the lookup kernel")
     ap.add_argument("--lowmem", action="store_true", help="time FactorGraph.update_lowmem steps (the global-BA iteration, "
@@ -261,7 +261,7 @@ def lookup_sensitivity(db, corr, g, coords_bench, ii, jj, fmaps, dev, lk_ms):
 
 def check_step(db, upd, g, dev, state, product_step):
     """Untimed: the timed iteration again from a saved state, and the same iteration through the REFERENCE-LAYOUT entry points
-    -- all-pairs volumes by torch.matmul + droid_backends.corr_index_forward per level (CorrBlockRef = modules/corr.py:23-50),
+    -- all-pairs volumes in the reference layout + droid_backends.corr_index_forward per level (CorrBlockRef = modules/corr.py:23-50),
     motion features in torch (factor_graph.py:221-222), the update operator through its reference interface with per-edge
     context features (448-channel gate convolutions), droid_backends.ba -- from the same poses / depths / hidden state."""
     from droid_amd.corr import CorrBlockRef
@@ -315,8 +315,8 @@ def check_step(db, upd, g, dev, state, product_step):
            "disps_rel_q99": float(torch.quantile(rel.flatten()[:: max(1, rel.numel() // 1000000)], 0.99)), "disps_rel_max": float(rel.max()),
            "hidden_state_max_abs_diff": float((net_a.float() - net_b.float()).abs().max()),
            "pose_update_norm": float((pa[:, :3] - poses0[:, :3]).abs().max()),
-           "against": "reference-layout entry points (torch.matmul volumes + corr_index_forward, UpdateModule.forward with per-edge "
-                      "context features, ba) from the same state"}
+           "against": "reference-layout entry points (reference-layout volumes + corr_index_forward per level, UpdateModule.forward with "
+                      "per-edge context features, ba) from the same state"}
     res["ok"] = bool(res["max_dtrans"] <= 2e-3 and res["max_drot_rad"] <= 2e-3 and res["disps_rel_q99"] <= 1e-2
                      and res["hidden_state_max_abs_diff"] <= 2.0 ** -7 and np.isfinite(res["max_dtrans"]) and res["pose_update_norm"] > 0)
     return res
