@@ -82,12 +82,13 @@ def _reference_layout_lookup(ref_mod, f1, f2, coords):
 
 
 def test_pyramid_lookup_on_all_c3_edges_vs_reference(db, ref, c3):
+    from droid_amd.corr import CorrBlock
     g = c3
     E, h, w = len(g["ii"]), g["ht"], g["wd"]
     fm = dev(g["fmaps"])[:, 0]                                          # [512,128,h,w] fp16
     ii, jj = dev(g["ii"]), dev(g["jj"])
     pyr = db.corr_pyramid_build(fm[ii].contiguous(), fm[jj].contiguous())
-    assert pyr.numel() * 2 == E * 25559040 // 1 or pyr.shape[0] == E    # one record per edge
+    assert pyr.shape[0] == E and pyr.numel() * 2 == E * CorrBlock.bytes_per_edge(h, w)          # one record per edge
     coords, _ = db.reproject(dev(g["poses"]), dev(g["disps"]), dev(g["intrinsics"]), ii, jj)       # the bench's own flow
     # second coordinate set: the same flow with a per-edge shift and a slow shear, some windows leave the image
     rng = np.random.default_rng(3)
