@@ -2,7 +2,7 @@
 # HBM traffic of the lookup kernel at C3 size (4096 edges), both output variants: FETCH_SIZE / WRITE_SIZE in
 # separate rocprofv3 --pmc passes (MI355X_MICROARCH.md: FETCH_SIZE counts 64 B per 128-B request on gfx950 -> x2).
 export TMPDIR=/tmp
-OUT=gpurun_out/pmc_c3; mkdir -p $OUT
+OUT=${PMC_OUT:-gpurun_out/pmc_c3}; mkdir -p $OUT
 for variant in "" "--nhwc"; do
   tag=${variant:+nhwc}; tag=${tag:-nchw}
   timeout 200 python scripts/bench_lookup.py --edges 4096 --flow reproj $variant 2>&1 | grep lookup
