@@ -190,3 +190,43 @@ def test_option_store(built):
     db.set_option("chol_lookahead", v)
     with pytest.raises(RuntimeError):
         db.set_option("no_such_option", 1)
+
+
+def test_round3_entry_points_and_host_helpers(built):
+    """argument checks of the entry points added in round 3 (no launch), the option epoch, and the host-side size / staging
+    helpers that mirror them"""
+    lib = ctypes.CDLL(built)
+    assert lib.dh_corr_volume_build(None, None, None, 0, 2, 128, 30, 40, None) == 1            # null pointers
+    assert lib.dh_corr_volume_build(None, None, None, 0, 0, 128, 30, 40, None) == 0            # no edges: nothing to do
+    assert lib.dh_corr_volume_pool(None, None, 0, ctypes.c_long(0), 30, 40, None) == 0
+    assert lib.dh_corr_volume_pool(None, None, 7, ctypes.c_long(4), 30, 40, None) == 1         # null pointers before the dtype is looked at
+    assert lib.dh_altcorr_fwd_nhwc_level(None, None, None, None, None, None, 2, 2, 128, 48, 64, 24, 32, 3, 1, ctypes.c_long(10), None) == 1   # stride < 49 HW
+    assert lib.dh_reproject_ex(None, None, None, 1, None, None, None, None, 0, 48, 64, None) == 0
+    assert lib.dh_corr_index_fwd(None, None, None, 2, 0, 4, 4, 4, 4, 3, None) == 0             # DH_F64 accepted
+    e0 = lib.dh_options_epoch()
+    v = ctypes.c_int()
+    assert lib.dh_get_option(b"lookup_mode", ctypes.byref(v)) == 0
+    assert lib.dh_set_option(b"lookup_mode", v.value) == 0 and lib.dh_options_epoch() == e0    # same value: no new epoch
+    assert lib.dh_set_option(b"lookup_mode", v.value + 1) == 0 and lib.dh_options_epoch() == e0 + 1
+    lib.dh_set_option(b"lookup_mode", v.value)
+    assert lib.dh_get_option(b"ba_strict", ctypes.byref(v)) == 0 and v.value == 1               # ba reports bad arguments by default
+    from droid_amd.corr import CorrBlock
+    lib.dh_corr_pyramid_bytes.restype = ctypes.c_size_t
+    for h, w in ((48, 64), (40, 64), (16, 16), (24, 32)):
+        assert CorrBlock.bytes_per_edge(h, w) == lib.dh_corr_pyramid_bytes(1, h, w)
+    assert not CorrBlock.supported(30, 40) and CorrBlock.supported(40, 64)
+
+
+def test_reference_python_is_staged_as_an_archive_only():
+    """oracle/build_ref.py stages the reference's callers for the -m gpu test as ONE git-ignored archive (no reference source
+    file is unpacked into the tree)"""
+    from oracle import build_ref
+    if not os.path.isdir(os.path.join(build_ref.REF, "droid_slam")):
+        pytest.skip("reference checkout not present")
+    z = build_ref.stage_python()
+    import zipfile
+    names = zipfile.ZipFile(z).namelist()
+    assert "droid_slam/factor_graph.py" in names and "droid_slam/depth_video.py" in names
+    assert z.startswith(os.path.join(ROOT, "oracle", "_ref"))
+    tracked = subprocess.run(["git", "ls-files", "oracle/_ref"], cwd=ROOT, stdout=subprocess.PIPE, text=True).stdout.strip()
+    assert tracked == ""
