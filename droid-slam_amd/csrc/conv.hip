@@ -196,35 +196,12 @@ inline bool staged_epilogue_ok(const ConvParams& P) {
   return true;
 }
 
-// TN = 32-cout accumulator tiles per wave, BNT = couts of the workgroup tile (128 or 64)
-template <int EPI, int TN, int BNT>
-__device__ __forceinline__ void staged_epilogue(const ConvParams& P, f32x16 (&acc)[2][TN], __half* __restrict__ sT, long m0, int n0,
-                                                int wm0, int wn0, int tid, int HW) {
-  constexpr int ELD = BNT + 8;            // LDS row stride of the staged tile (halves)
-  constexpr int PPR = BNT / 8;            // 16-byte pieces per pixel row
-  const int lane = tid & 63;
-  const int img = (int)(m0 / HW);
-  __syncthreads();                        // the operand tiles of the main loop are dead
-#pragma unroll
-  for (int b = 0; b < TN; ++b) {
-    const int cl = wn0 + b * 32 + (lane & 31), co = n0 + cl;
-    const float add = (co < P.CoutPad ? P.bias[co] : 0.f) + ((P.gterm && co < P.CoutPad) ? P.gterm[(long)img * P.CoutPad + co] : 0.f);
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int row = wm0 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-        float v = acc[a][b][q] + add;
-        switch (EPI) {
-          case EPI_RELU: v = fmaxf(v, 0.f); break;
-          case EPI_SIGMOID: case EPI_GRU_ZR: v = sigmoidf_(v); break;
-          case EPI_GRU_Q: v = tanhf_(v); break;
-          default: break;
-        }
-        sT[row * ELD + cl] = __float2half(v);
-      }
-  }
-  __syncthreads();
+// second phase of the staged epilogues: the workgroup walks the fp16 tile [256 px][BNT couts] in 16-byte pieces (8 couts of
+// one pixel), applies the gate algebra with 16-byte operand loads and stores a pixel's couts as one run
+template <int EPI, int BNT>
+__device__ __forceinline__ void staged_tile_store(const ConvParams& P, const __half* __restrict__ sT, long m0, int n0, int tid) {
+  constexpr int ELD = BNT + 8;
+  constexpr int PPR = BNT / 8;
   // 256 px x PPR pieces; thread -> (pixel row, piece): PPR consecutive lanes cover the couts of one pixel
 #pragma unroll
   for (int it = 0; it < PPR / 2; ++it) {
@@ -260,6 +237,38 @@ __device__ __forceinline__ void staged_epilogue(const ConvParams& P, f32x16 (&ac
     }
     *reinterpret_cast<uint4*>(reinterpret_cast<__half*>(P.out) + pix * P.out_stride + co) = v;
   }
+}
+
+// TN = 32-cout accumulator tiles per wave, BNT = couts of the workgroup tile (128 or 64)
+template <int EPI, int TN, int BNT>
+__device__ __forceinline__ void staged_epilogue(const ConvParams& P, f32x16 (&acc)[2][TN], __half* __restrict__ sT, long m0, int n0,
+                                                int wm0, int wn0, int tid, int HW) {
+  constexpr int ELD = BNT + 8;            // LDS row stride of the staged tile (halves)
+  constexpr int PPR = BNT / 8;            // 16-byte pieces per pixel row
+  const int lane = tid & 63;
+  const int img = (int)(m0 / HW);
+  __syncthreads();                        // the operand tiles of the main loop are dead
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const int cl = wn0 + b * 32 + (lane & 31), co = n0 + cl;
+    const float add = (co < P.CoutPad ? P.bias[co] : 0.f) + ((P.gterm && co < P.CoutPad) ? P.gterm[(long)img * P.CoutPad + co] : 0.f);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = wm0 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        float v = acc[a][b][q] + add;
+        switch (EPI) {
+          case EPI_RELU: v = fmaxf(v, 0.f); break;
+          case EPI_SIGMOID: case EPI_GRU_ZR: v = sigmoidf_(v); break;
+          case EPI_GRU_Q: v = tanhf_(v); break;
+          default: break;
+        }
+        sT[row * ELD + cl] = __float2half(v);
+      }
+  }
+  __syncthreads();
+  staged_tile_store<EPI, BNT>(P, sT, m0, n0, tid);
 }
 
 // EPI_HEADS0: first layer of the delta | weight heads (3x3, 128 -> 256, relu) FUSED with the second layer's channel
@@ -1016,6 +1025,212 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
   else conv_epilogue<EPI, 2, 2>(P, acc, (long)P.N * HW, m0, n0, wm0, wn0, lane, HW);
 }
 
+// ---- 3x3 as Winograd F(2,3) along x (direct along y): PROTOTYPE, opt-in (weights_layout = DH_CONV_LAYOUT_WINO) -------------
+// One output row pair (x = 2p, 2p+1) needs the four input columns 2p-1 .. 2p+2:
+//     V0 = d0 - d2   V1 = d1 + d2   V2 = d2 - d1   V3 = d1 - d3            (input transform, per kernel row dy)
+//     U0 = g0        U1 = (g0 + g1 + g2) / 2   U2 = (g0 - g1 + g2) / 2   U3 = g2   (weight transform, packed by the host)
+//     M_t = sum over (channels, dy) of V_t . U_t                             (4 GEMMs instead of 3 taps, on HALF the rows)
+//     y(2p) = M0 + M1 + M2     y(2p+1) = M1 - M2 - M3
+// i.e. 16 instead of 24 MFMAs per (32-channel chunk, dy) step and wave -- 1.5x fewer MACs -- for twice the accumulators.
+// Same tile as conv3x3_halo2_kernel (4 image rows x 64 columns x 128 couts, 8 waves = 4 rows x 2 cout halves, weights of a
+// (chunk, dy) group by LDS-DMA into two buffers), but the MFMA rows are the 32 column PAIRS of the wave's image row:
+// acc[position][cout tile] = 8 tiles = 128 registers -> one workgroup per CU.  The halo is transformed on its way into LDS
+// ([6 rows][4 positions][32 pairs][32 channels], 48 KB): a thread loads the four columns of one (row, pair, 8-channel slot)
+// and writes the four transformed slots.  Accumulator start values (the gates' context term) enter through the transform's
+// null space: M0 = c(2p), M3 = -c(2p+1).  The output transform feeds the same LDS-staged epilogue as the other kernels.
+// Precision: V is a sum of two fp16 values rounded to fp16, U is rounded to fp16 from fp32 -- roundings the direct form
+// does not have (tests/test_gpu_parity.py::test_conv_winograd_prototype quantifies them).
+constexpr int WV_BYTES = 6 * 4 * 32 * 64;                 // 49,152: transformed halo
+constexpr int WU_BYTES = 4 * 128 * 64;                    // 32,768: one (chunk, dy) weight group [4 positions][128 couts][32 ch]
+constexpr int WINO_LDS_BYTES = WV_BYTES + 2 * WU_BYTES;   // 114,688 (the staged epilogue tile needs 69,632)
+
+__device__ __forceinline__ u32x4 pk_sub4(const u32x4& a, const u32x4& b) {
+  u32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const __half2 x = __builtin_bit_cast(__half2, a[i]), y = __builtin_bit_cast(__half2, b[i]);
+    r[i] = __builtin_bit_cast(uint32_t, __hsub2(x, y));
+  }
+  return r;
+}
+__device__ __forceinline__ u32x4 pk_add4(const u32x4& a, const u32x4& b) {
+  u32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const __half2 x = __builtin_bit_cast(__half2, a[i]), y = __builtin_bit_cast(__half2, b[i]);
+    r[i] = __builtin_bit_cast(uint32_t, __hadd2(x, y));
+  }
+  return r;
+}
+
+template <int EPI, bool CINIT = false>
+__global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(ConvParams P) {
+  extern __shared__ __half s_conv[];
+  char* const lds = reinterpret_cast<char*>(s_conv);
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)s_conv;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wrow = wave & 3, wn0 = (wave >> 2) * 64;
+  long m0; int n0;
+  xcd_decode(P, m0, n0, 128);
+  const int HW = P.H * P.W;
+  const int img = (int)(m0 / HW), y0 = (int)((m0 - (long)img * HW) / 64);
+  const int nchunks = P.Ctot / H2CK, nsteps = nchunks * 3;
+  const int kh = lane >> 5;
+
+  // halo roles: item id = tid + 512*i (i = 0, 1; the second only for tid < 256) -> halo row id >> 7, pair (id >> 2) & 31, slot id & 3
+  const int aq = tid & 3, apair = (tid >> 2) & 31;
+  // weight DMA: per-lane offset + wave-uniform base pointer
+  const int b_voff = lane * 16;
+  const char* const bsrc = reinterpret_cast<const char*>(P.wt_halo) + (long)(n0 >> 7) * nsteps * WU_BYTES;
+  int b_row[2], b_x[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int r = wn0 + b * 32 + (lane & 31);
+    b_row[b] = r * 64; b_x[b] = ((r >> 2) & 3) ^ kh;
+  }
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[t][b][q] = 0.f;
+  if constexpr (CINIT) {
+    // start values c(pixel, cout): M0 = c(even pixel), M3 = -c(odd pixel) (see above).  32 lanes read one 128-byte run.
+    const float* base = P.cinit + ((long)P.cinit_idx[img] * HW + (m0 - (long)img * HW) + wrow * 64) * P.cinit_stride + P.cinit_off + n0 + wn0 + (lane & 31);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const bool co_ok = n0 + wn0 + b * 32 + (lane & 31) < P.Cout;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int pair = (q & 3) + 8 * (q >> 2) + 4 * kh;
+        acc[0][b][q] = co_ok ? base[(long)(2 * pair) * P.cinit_stride + b * 32] : 0.f;
+        acc[3][b][q] = co_ok ? -base[(long)(2 * pair + 1) * P.cinit_stride + b * 32] : 0.f;
+      }
+    }
+  }
+
+  u32x4 ra[2][4];
+#define WN_FETCH_A(chunk_)                                                                                           \
+  {                                                                                                                  \
+    int cs = (chunk_) * H2CK, sgi = 0;                                                                               \
+    _Pragma("unroll") for (int q = 0; q < MAXSEG - 1; ++q)                                                           \
+      if (sgi == q && q + 1 < P.nseg && cs >= P.segC[q]) { cs -= P.segC[q]; sgi = q + 1; }                          \
+    const __half* base = P.in[0]; int segs = P.segS[0];                                                              \
+    _Pragma("unroll") for (int q = 1; q < MAXSEG; ++q) if (sgi == q) { base = P.in[q]; segs = P.segS[q]; }           \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                  \
+      const int hr = (tid >> 7) + 4 * i;                     /* halo row of item i: 0..3, then 4..5 (tid < 256) */    \
+      const int y = y0 - 1 + hr;                                                                                     \
+      const bool rok = hr < 6 && (unsigned)y < (unsigned)P.H;                                                        \
+      _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                                \
+        const int col = 2 * apair - 1 + k;                                                                           \
+        const bool ok = rok && (unsigned)col < 64u;                                                                  \
+        ra[i][k] = *reinterpret_cast<const u32x4*>(base + (long)(ok ? (img * P.H + y) * 64 + col : 0) * segs + cs + aq * 8); \
+      }                                                                                                              \
+    }                                                                                                                \
+  }
+#define WN_GLDS16S(sbase_, voff_, ldsaddr_)                                                                          \
+  {                                                                                                                  \
+    unsigned keep_;                                                                                                  \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep_) : "v"(voff_), "s"(sbase_), "s"(ldsaddr_) : "memory");                                \
+  }
+#define WN_DMA_B(step_)                                                                                              \
+  {                                                                                                                  \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                  \
+      const unsigned long gaddr = (unsigned long)(bsrc + (long)(step_) * WU_BYTES + (wave + 8 * q) * 1024);           \
+      const unsigned glo = __builtin_amdgcn_readfirstlane((unsigned)gaddr);                                          \
+      const unsigned ghi = __builtin_amdgcn_readfirstlane((unsigned)(gaddr >> 32));                                  \
+      const void* gs = reinterpret_cast<const void*>(((unsigned long)ghi << 32) | glo);                              \
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + WV_BYTES + ((step_) & 1) * WU_BYTES + (wave + 8 * q) * 1024); \
+      WN_GLDS16S(gs, b_voff, dst)                                                                                    \
+    }                                                                                                                \
+  }
+
+  WN_FETCH_A(0)
+  WN_DMA_B(0)
+  for (int c = 0; c < nchunks; ++c) {
+    // every wave has finished the previous chunk's reads of the transformed halo
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int hr = (tid >> 7) + 4 * i;
+      if (hr < 6) {
+        const int y = y0 - 1 + hr;
+        const bool rok = (unsigned)y < (unsigned)P.H;
+        u32x4 d[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int col = 2 * apair - 1 + k;
+          const uint32_t m = (rok && (unsigned)col < 64u) ? 0xffffffffu : 0u;
+          d[k] = ra[i][k] & m;
+        }
+        const u32x4 v0 = pk_sub4(d[0], d[2]), v1 = pk_add4(d[1], d[2]), v2 = pk_sub4(d[2], d[1]), v3 = pk_sub4(d[1], d[3]);
+        const int R0 = (hr * 4) * 32 + apair;                     // row of position 0; position t is 32 rows further
+#define WN_PUT(t_, v_) { const int R = R0 + (t_) * 32; *reinterpret_cast<u32x4*>(lds + R * 64 + ((aq ^ ((R >> 2) & 3)) << 4)) = v_; }
+        WN_PUT(0, v0) WN_PUT(1, v1) WN_PUT(2, v2) WN_PUT(3, v3)
+#undef WN_PUT
+      }
+    }
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int step = c * 3 + dy;
+      // group `step` has landed (DMA issued a step ago), the halo stores are done; at dy == 1 the next chunk's 8 halo loads,
+      // issued after those pieces, may stay in flight
+      if (dy == 1 && c + 1 < nchunks) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (step + 1 < nsteps) WN_DMA_B(step + 1)
+      if (dy == 0 && c + 1 < nchunks) WN_FETCH_A(c + 1)
+      const char* const Bcur = lds + WV_BYTES + (step & 1) * WU_BYTES;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int R = ((wrow + dy) * 4 + t) * 32 + (lane & 31);
+        const int a_row = R * 64, a_x = ((R >> 2) & 3) ^ kh;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const half8 af = *reinterpret_cast<const half8*>(lds + a_row + (((ks * 2) ^ a_x) << 4));
+          half8 bf[2];
+#pragma unroll
+          for (int b = 0; b < 2; ++b) bf[b] = *reinterpret_cast<const half8*>(Bcur + t * (128 * 64) + b_row[b] + (((ks * 2) ^ b_x[b]) << 4));
+#pragma unroll
+          for (int b = 0; b < 2; ++b) acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf[b], acc[t][b], 0, 0, 0);
+        }
+      }
+    }
+  }
+#undef WN_FETCH_A
+#undef WN_DMA_B
+#undef WN_GLDS16S
+  // ---- output transform + the staged epilogue's first phase (bias / activation, fp16 into the [256 px][128 cout] LDS tile)
+  constexpr int ELD = 128 + 8;
+  __half* const sT = s_conv;
+  __syncthreads();                        // the operand tiles of the main loop are dead
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int cl = wn0 + b * 32 + (lane & 31), co = n0 + cl;
+    const float add = (co < P.CoutPad ? P.bias[co] : 0.f) + ((P.gterm && co < P.CoutPad) ? P.gterm[(long)img * P.CoutPad + co] : 0.f);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int pair = (q & 3) + 8 * (q >> 2) + 4 * kh;
+      float ve = acc[0][b][q] + acc[1][b][q] + acc[2][b][q] + add;
+      float vo = acc[1][b][q] - acc[2][b][q] - acc[3][b][q] + add;
+      switch (EPI) {
+        case EPI_RELU: ve = fmaxf(ve, 0.f); vo = fmaxf(vo, 0.f); break;
+        case EPI_SIGMOID: case EPI_GRU_ZR: ve = sigmoidf_(ve); vo = sigmoidf_(vo); break;
+        case EPI_GRU_Q: ve = tanhf_(ve); vo = tanhf_(vo); break;
+        default: break;
+      }
+      const int row = wrow * 64 + 2 * pair;
+      sT[row * ELD + cl] = __float2half(ve);
+      sT[(row + 1) * ELD + cl] = __float2half(vo);
+    }
+  }
+  __syncthreads();
+  staged_tile_store<EPI, 128>(P, sT, m0, n0, tid);
+}
+
 // ---- 7x7 on 4 input channels (the flow encoder's first layer: motion features -> 128) -----------------------------------
 // In the generic loop this layer costs as much as a 128 -> 64 3x3 convolution: its K = 49 taps x 8 (4 real + 4 padded)
 // channels is walked in 64-wide chunks of gathered 16-byte pieces.  Here the whole problem sits in LDS: the 10 x 72 pixel
@@ -1279,6 +1494,36 @@ int launch_halo2(const ConvParams& P0, hipStream_t st) {
   return DH_OK;
 }
 
+template <int EPI>
+bool wino_ok(const ConvParams& P) {
+  if (!P.wt_halo || P.KH != 3 || P.KW != 3 || P.W != 64 || P.H % 4 || P.CoutPad % 128 || P.Ctot % H2CK) return false;
+  for (int i = 0; i < P.nseg; ++i) if (P.segC[i] % H2CK) return false;
+  if (P.cinit && EPI != EPI_GRU_ZR && EPI != EPI_GRU_Q) return false;
+  if (EPI != EPI_RELU && EPI != EPI_LINEAR && EPI != EPI_SIGMOID && EPI != EPI_GRU_ZR && EPI != EPI_GRU_Q) return false;
+  return staged_epilogue_ok<EPI>(P);
+}
+
+template <int EPI>
+int launch_wino(const ConvParams& P0, hipStream_t st) {
+  ConvParams P = P0;
+  const long M = (long)P.N * P.H * P.W;
+  dim3 grid((unsigned)(M / BM), (unsigned)(P.CoutPad / 128));
+  P.ny = (int)grid.y;
+  if (opts().conv_xcd && grid.x % 8 == 0) { P.xcd_tiles = (int)(grid.x / 8); grid = dim3(grid.x * grid.y, 1); }
+  if constexpr (EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q) {
+    if (P.cinit) {
+      DH_LDS_OPTIN((&conv3x3_wino_kernel<EPI, true>), WINO_LDS_BYTES);
+      hipLaunchKernelGGL((conv3x3_wino_kernel<EPI, true>), grid, dim3(512), WINO_LDS_BYTES, st, P);
+      DH_LAUNCH_CHECK();
+      return DH_OK;
+    }
+  }
+  DH_LDS_OPTIN((&conv3x3_wino_kernel<EPI>), WINO_LDS_BYTES);
+  hipLaunchKernelGGL((conv3x3_wino_kernel<EPI>), grid, dim3(512), WINO_LDS_BYTES, st, P);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
 // halo2 layout of `weights_halo`: cout tile 128, channel count a multiple of 32 (DH_CONV_HALO2=0, read by both sides,
 // selects the 16-channel slabs of the first halo kernel instead)
 bool dma_layout(int CoutPad, int Ctot);
@@ -1521,6 +1766,19 @@ extern "C" int dh_conv2d_nhwc_f16_ex(const void* const* inputs, const int* in_ch
                                      const float* gterm, const void* aux0, int aux0_stride, const void* aux1, int aux1_stride,
                                      float* red, const float* cinit, const int64_t* cinit_idx, int cinit_stride, int cinit_off,
                                      dh_stream_t stream) {
+  return dh_conv2d_nhwc_f16_ex2(inputs, in_channels, in_strides, n_inputs, weights, weights_halo, DH_CONV_LAYOUT_AUTO, bias, N, H, W, KH, KW,
+                                Cout, CoutPad, Kpad, epilogue, out, out_is_f32, out_stride, gterm, aux0, aux0_stride, aux1, aux1_stride, red,
+                                cinit, cinit_idx, cinit_stride, cinit_off, stream);
+}
+
+extern "C" int dh_conv2d_nhwc_f16_ex2(const void* const* inputs, const int* in_channels, const int* in_strides, int n_inputs,
+                                      const void* weights, const void* weights_halo, int weights_layout, const float* bias,
+                                      int N, int H, int W, int KH, int KW, int Cout, int CoutPad, int Kpad, int epilogue,
+                                      void* out, int out_is_f32, int out_stride,
+                                      const float* gterm, const void* aux0, int aux0_stride, const void* aux1, int aux1_stride,
+                                      float* red, const float* cinit, const int64_t* cinit_idx, int cinit_stride, int cinit_off,
+                                      dh_stream_t stream) {
+  if (weights_layout != DH_CONV_LAYOUT_AUTO && weights_layout != DH_CONV_LAYOUT_WINO) return DH_ERR_ARG;
   if (n_inputs < 1 || n_inputs > MAXSEG || !inputs || !in_channels || !weights || !bias) return DH_ERR_ARG;
   if (N < 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0 || !(KH & 1) || !(KW & 1)) return DH_ERR_ARG;
   if (Cout <= 0 || CoutPad < Cout || CoutPad % 32 || Kpad <= 0 || Kpad % BK) return DH_ERR_ARG;
@@ -1552,6 +1810,17 @@ extern "C" int dh_conv2d_nhwc_f16_ex(const void* const* inputs, const int* in_ch
   P.gterm = gterm; P.aux0 = (const __half*)aux0; P.aux0_stride = aux0_stride;
   P.aux1 = (const __half*)aux1; P.aux1_stride = aux1_stride; P.red = red;
   hipStream_t st = (hipStream_t)stream;
+  if (weights_layout == DH_CONV_LAYOUT_WINO) {              // prototype: F(2,3) along x; weights_halo = droid_amd.update.pack_conv_wino
+    switch (P.epi) {
+      case EPI_LINEAR: if (!P.out_f32 && wino_ok<EPI_LINEAR>(P)) return launch_wino<EPI_LINEAR>(P, st); break;
+      case EPI_RELU: if (wino_ok<EPI_RELU>(P)) return launch_wino<EPI_RELU>(P, st); break;
+      case EPI_SIGMOID: if (wino_ok<EPI_SIGMOID>(P)) return launch_wino<EPI_SIGMOID>(P, st); break;
+      case EPI_GRU_ZR: if (wino_ok<EPI_GRU_ZR>(P)) return launch_wino<EPI_GRU_ZR>(P, st); break;
+      case EPI_GRU_Q: if (wino_ok<EPI_GRU_Q>(P)) return launch_wino<EPI_GRU_Q>(P, st); break;
+      default: break;
+    }
+    return DH_ERR_UNSUPPORTED;
+  }
   if (dma_ok(P)) {
     switch (P.epi) {
       case EPI_LINEAR: return launch_dma<EPI_LINEAR>(P, st);

@@ -407,7 +407,7 @@ void conv2d_nhwc(std::vector<torch::Tensor> inputs, torch::Tensor weight, c10::o
                  int64_t Cout, int64_t epilogue, c10::optional<torch::Tensor> out, int64_t out_stride,
                  c10::optional<torch::Tensor> gterm, c10::optional<torch::Tensor> aux0, c10::optional<torch::Tensor> aux1,
                  c10::optional<torch::Tensor> red, c10::optional<torch::Tensor> cinit, c10::optional<torch::Tensor> cinit_idx,
-                 int64_t cinit_off, bool out_raw_f32) {
+                 int64_t cinit_off, bool out_raw_f32, int64_t weights_layout) {
   TORCH_CHECK(!inputs.empty() && inputs.size() <= 4, "conv2d_nhwc: 1..4 inputs");
   const void* ptrs[4]; int chans[4], strides[4];
   const int64_t N = inputs[0].size(0), H = inputs[0].size(1), W = inputs[0].size(2);
@@ -438,7 +438,7 @@ void conv2d_nhwc(std::vector<torch::Tensor> inputs, torch::Tensor weight, c10::o
     ci = ct.data_ptr<float>(); cidx = it.data_ptr<int64_t>(); cstride = (int)ct.size(3);
   }
   TORCH_CHECK(!out_raw_f32 || out_f32, "conv2d_nhwc: out_raw_f32 needs a float32 output");
-  check_status(dh_conv2d_nhwc_f16_ex(ptrs, chans, strides, (int)inputs.size(), weight.data_ptr(), opt_ptr(weight_halo), bias.data_ptr<float>(),
+  check_status(dh_conv2d_nhwc_f16_ex2(ptrs, chans, strides, (int)inputs.size(), weight.data_ptr(), opt_ptr(weight_halo), (int)weights_layout, bias.data_ptr<float>(),
                                      (int)N, (int)H, (int)W, (int)KH, (int)KW, (int)Cout, (int)weight.size(0), (int)weight.size(1),
                                      (int)epilogue, opt_ptr(out), out_f32 ? (out_raw_f32 ? 2 : 1) : 0, (int)out_stride,
                                      gterm.has_value() ? gterm->data_ptr<float>() : nullptr,
@@ -613,7 +613,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("conv2d_nhwc", &conv2d_nhwc, "implicit-GEMM NHWC convolution on the fp16 MFMA with fused epilogues",
         py::arg("inputs"), py::arg("weight"), py::arg("weight_halo"), py::arg("bias"), py::arg("KH"), py::arg("KW"), py::arg("Cout"),
         py::arg("epilogue"), py::arg("out"), py::arg("out_stride"), py::arg("gterm"), py::arg("aux0"), py::arg("aux1"), py::arg("red"),
-        py::arg("cinit") = py::none(), py::arg("cinit_idx") = py::none(), py::arg("cinit_off") = 0, py::arg("out_raw_f32") = false);
+        py::arg("cinit") = py::none(), py::arg("cinit_idx") = py::none(), py::arg("cinit_off") = 0, py::arg("out_raw_f32") = false,
+        py::arg("weights_layout") = 0);
   m.def("motion_features", &motion_features, "cat(coords1 - coords0, target - coords1).clamp(-64, 64) as fp16 NHWC");
   m.def("ba_inputs", &ba_inputs, "target = coords1 + delta, weight; also in ba's [E,2,h,w] layout");
   m.def("cvx_upsample", &cvx_upsample, "convex 8x upsampling of depth maps");

@@ -136,6 +136,28 @@ def pack_conv_halo(weight):
     return w.half().contiguous()
 
 
+LAYOUT_AUTO, LAYOUT_WINO = 0, 4          # DH_CONV_LAYOUT_* of include/droid_hip.h
+
+
+def pack_conv_wino(weight):
+    """[Cout,Ctot,3,3] -> [CoutPad/128, Ctot/32, 3 dy, 4 positions, 128, 4 slots, 8] f16 for conv3x3_wino_kernel (PROTOTYPE:
+    Winograd F(2,3) along x): per kernel row the three taps g0 g1 g2 become (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2), computed in
+    fp32 and rounded once; rows / slots ordered like the halo2 layout (slot s of row r stored at s ^ ((r >> 2) & 3)).
+    None if the shape is not eligible (Cout padded to a multiple of 128, Ctot % 32 == 0)."""
+    cout, ctot, kh, kw = weight.shape
+    cp = _round_up(cout, 32)
+    if kh != 3 or kw != 3 or ctot % 32 or cp % 128:
+        return None
+    g = torch.zeros(cp, ctot, 3, 3, dtype=torch.float32, device=weight.device)
+    g[:cout] = weight.float()
+    u = torch.stack([g[..., 0], 0.5 * (g[..., 0] + g[..., 1] + g[..., 2]), 0.5 * (g[..., 0] - g[..., 1] + g[..., 2]), g[..., 2]], -1)   # [cp, ctot, dy, t]
+    u = u.reshape(cp // 128, 128, ctot // 32, 4, 8, 3, 4).permute(0, 2, 5, 6, 1, 3, 4)        # [T, chunk, dy, t, row, slot, 8]
+    r = torch.arange(128, device=weight.device)
+    src = torch.arange(4, device=weight.device)[None, :] ^ ((r[:, None] >> 2) & 3)
+    u = torch.gather(u, 5, src[None, None, None, None, :, :, None].expand(*u.shape[:4], 128, 4, 8))
+    return u.half().contiguous()
+
+
 def pack_conv_7x7_c4(weight):
     """[128,4,7,7] -> [128, 7 dy, 8 dx (7 + one zero tap), 4 ch] f16: the kernel-ordered copy for conv7x7_c4_kernel
     (csrc/conv.hip): a k-step of 16 is four x-adjacent taps of one kernel row."""
@@ -153,8 +175,8 @@ def _halo_layout_options():
 
 
 class _Conv:
-    def __init__(self, wp, bp, k, cout, wh=None):
-        self.w, self.b, self.k, self.cout, self.wh = wp, bp, k, cout, wh
+    def __init__(self, wp, bp, k, cout, wh=None, layout=LAYOUT_AUTO):
+        self.w, self.b, self.k, self.cout, self.wh, self.layout = wp, bp, k, cout, wh, layout
         # the kernel-ordered copy `wh` was laid out for the option values of this moment; csrc/conv.hip picks its kernel from
         # the option values at launch time -> remember them, re-check whenever any option changed (options_epoch)
         self._epoch = droid_backends.options_epoch()
@@ -163,7 +185,7 @@ class _Conv:
     def _check_layout(self):
         epoch = droid_backends.options_epoch()
         if epoch != self._epoch:
-            if self.wh is not None and _halo_layout_options() != self._layout:
+            if self.wh is not None and self.layout == LAYOUT_AUTO and _halo_layout_options() != self._layout:
                 raise RuntimeError("conv weights were packed for (conv_dma, conv_halo2) = %s, the options now say %s: "
                                    "call load_state_dict again after changing them" % (self._layout, _halo_layout_options()))
             self._epoch = epoch
@@ -177,7 +199,7 @@ class _Conv:
                               dtype=torch.float32 if out_raw_f32 else torch.float16, device=x0.device)
         stride = 0 if out is None else (out.shape[-1] if out_stride is None else out_stride)
         droid_backends.conv2d_nhwc(list(inputs), self.w, self.wh, self.b, self.k, self.k, self.cout, epi, out, stride,
-                                   gterm, aux0, aux1, red, cinit, cinit_idx, cinit_off, out_raw_f32)
+                                   gterm, aux0, aux1, red, cinit, cinit_idx, cinit_off, out_raw_f32, self.layout)
         return out
 
 
@@ -226,9 +248,13 @@ class UpdateModule:
         wq = g("gru.convq.weight")
         edge_ch = torch.cat([torch.arange(0, 128), torch.arange(256, 448)]).to(self.device)
         wzr_e = torch.cat([wz, wr], 0)[:, edge_ch].contiguous()
-        P["zr_e"] = _Conv(*pack_conv(wzr_e, torch.cat([g("gru.convz.bias"), g("gru.convr.bias")], 0)), 3, 256, pack_conv_halo(wzr_e))
+        # (DH_CONV_WINO=1 / set_option("conv_wino", 1) before loading: the two per-edge gate convolutions through the Winograd
+        # F(2,3) prototype kernel instead of conv3x3_halo2_kernel -- A/B measurements)
+        wino = droid_backends.get_option("conv_wino") == 1
+        gate = lambda w: (pack_conv_wino(w), LAYOUT_WINO) if wino else (pack_conv_halo(w), LAYOUT_AUTO)
+        P["zr_e"] = _Conv(*pack_conv(wzr_e, torch.cat([g("gru.convz.bias"), g("gru.convr.bias")], 0)), 3, 256, *gate(wzr_e))
         wq_e = wq[:, edge_ch].contiguous()
-        P["q_e"] = _Conv(*pack_conv(wq_e, g("gru.convq.bias")), 3, 128, pack_conv_halo(wq_e))
+        P["q_e"] = _Conv(*pack_conv(wq_e, g("gru.convq.bias")), 3, 128, *gate(wq_e))
         wctx = torch.cat([wz, wr, wq], 0)[:, 128:256].contiguous()
         P["ctx"] = _Conv(*pack_conv(wctx, torch.zeros(384, device=self.device)), 3, 384, pack_conv_halo(wctx))
         for n in ("z", "r", "q"):

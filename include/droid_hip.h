@@ -271,6 +271,19 @@ int dh_conv2d_nhwc_f16_ex(const void* const* inputs, const int* in_channels, con
                           const float* gterm, const void* aux0, int aux0_stride, const void* aux1, int aux1_stride,
                           float* red, const float* cinit, const int64_t* cinit_idx, int cinit_stride, int cinit_off,
                           dh_stream_t stream);
+/* the same with an explicit layout of `weights_halo`: DH_CONV_LAYOUT_AUTO = what dh_conv2d_nhwc_f16_ex does (layout follows
+ * the options "conv_dma" / "conv_halo2"); DH_CONV_LAYOUT_WINO = PROTOTYPE: 3x3 as Winograd F(2,3) along x, weights_halo =
+ * [CoutPad/128][Ctot/32][3 dy][4 positions][128][4 slots (XOR-swizzled like the halo2 layout)][8] f16 with the transformed
+ * taps (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2); W == 64, H % 4 == 0, staged epilogues only, else DH_ERR_UNSUPPORTED. */
+#define DH_CONV_LAYOUT_AUTO 0
+#define DH_CONV_LAYOUT_WINO 4
+int dh_conv2d_nhwc_f16_ex2(const void* const* inputs, const int* in_channels, const int* in_strides, int n_inputs,
+                          const void* weights, const void* weights_halo, int weights_layout, const float* bias,
+                          int N, int H, int W, int KH, int KW, int Cout, int CoutPad, int Kpad, int epilogue,
+                          void* out, int out_is_f32, int out_stride,
+                          const float* gterm, const void* aux0, int aux0_stride, const void* aux1, int aux1_stride,
+                          float* red, const float* cinit, const int64_t* cinit_idx, int cinit_stride, int cinit_off,
+                          dh_stream_t stream);
 
 /* corr_encoder.0 (reference droid_net.py:83-86: 1x1 convolution 196 -> 128 + relu) on the REFERENCE-layout correlation
  * features: x [E,196,HW] f16 (what dh_corr_pyramid_lookup / corr_index_forward produce, channel = level*49 + xoff*7 + yoff),

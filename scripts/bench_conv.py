@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "droid-slam_amd")]
 import torch
 import droid_backends as db
-from droid_amd.update import pack_conv, pack_conv_halo, EPI_RELU, EPI_LINEAR
+from droid_amd.update import pack_conv, pack_conv_halo, pack_conv_wino, EPI_RELU, EPI_LINEAR, LAYOUT_WINO
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 h, w = 48, 64
 torch.manual_seed(0)
@@ -39,3 +39,18 @@ for name, cins, cout, k in shapes:
         a.record(); run(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
     ms = min(ts); fl = 2.0 * n * h * w * sum(cins) * k * k * cout
     print("%-38s %8.3f ms  %7.1f TFLOP/s (useful)  %6.1f%% of 2.5 PF" % (name, ms, fl / ms / 1e9, fl / ms / 1e9 / 25.0))
+    ww = pack_conv_wino(wgt) if (k == 3 and os.environ.get("DH_WINO")) else None
+    if ww is not None:                      # the Winograd F(2,3) prototype on the same operands (DH_WINO=1)
+        out2 = torch.empty_like(out)
+        runw = lambda: db.conv2d_nhwc(xs, wp, ww, bp, k, k, cout, epi, out2, cout, None, None, None, None, weights_layout=LAYOUT_WINO)
+        runw(); torch.cuda.synchronize()
+        x = torch.cat([t[:2] for t in xs], -1).float().permute(0, 3, 1, 2)
+        ref = torch.nn.functional.conv2d(x, wgt.half().float(), None, padding=1).permute(0, 2, 3, 1).clamp_min(0)
+        e_dir = (out[:2].float() - ref).abs().max().item(); e_win = (out2[:2].float() - ref).abs().max().item()
+        ts = []
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); runw(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
+        msw = min(ts)
+        print("%-38s %8.3f ms  %7.1f TFLOP/s (useful)  %6.1f%% of 2.5 PF   winograd F(2,3)x: x%.2f vs direct; max |err| vs fp32 conv: direct %.4f, winograd %.4f (|ref| max %.2f)" % (
+            "  -> winograd prototype", msw, fl / msw / 1e9, fl / msw / 1e9 / 25.0, ms / msw, e_dir, e_win, ref.abs().max().item()))

@@ -870,3 +870,45 @@ def test_update_forward_leaves_a_channel_last_hidden_state_untouched(db):
     assert torch.equal(net, before)
     out2 = mod(net, inp, corr)[0]
     assert torch.equal(out1, out2)
+
+
+def test_conv_winograd_prototype(db):
+    """conv3x3_wino_kernel (Winograd F(2,3) along x, opt-in prototype) against torch's fp32 convolution and against the direct
+    kernel on the same operands: multi-segment input, two cout tiles, image borders, relu epilogue; and the two gate
+    convolutions of the update operator (accumulator start values through the transform's null space, GRU epilogues)
+    against the autocast oracle at the operator's 2^-9."""
+    from oracle import update as oupd
+    from droid_amd.update import pack_conv, pack_conv_halo, pack_conv_wino, EPI_RELU, LAYOUT_WINO, UpdateModule
+    from droid_amd.weights import deterministic_state_dict
+    torch.manual_seed(3)
+    for (N, H, cins, cout) in ((3, 8, (128, 128, 64), 256), (2, 12, (64,), 128)):
+        xs = [torch.randn(N, H, 64, c, device="cuda").half() for c in cins]
+        wgt = torch.randn(cout, sum(cins), 3, 3, device="cuda") / (sum(cins) * 9) ** 0.5
+        bias = torch.randn(cout, device="cuda")
+        wp, bp = pack_conv(wgt, bias)
+        ref = torch.nn.functional.conv2d(torch.cat(xs, -1).float().permute(0, 3, 1, 2), wgt.half().float(), bias, padding=1).permute(0, 2, 3, 1).clamp_min(0)
+        out_d = torch.empty(N, H, 64, cout, device="cuda", dtype=torch.float16); out_w = torch.empty_like(out_d)
+        db.conv2d_nhwc(xs, wp, pack_conv_halo(wgt), bp, 3, 3, cout, EPI_RELU, out_d, cout, None, None, None, None)
+        db.conv2d_nhwc(xs, wp, pack_conv_wino(wgt), bp, 3, 3, cout, EPI_RELU, out_w, cout, None, None, None, None, weights_layout=LAYOUT_WINO)
+        torch.cuda.synchronize()
+        scale = ref.abs().max().item()
+        e_d = (out_d.float() - ref).abs().max().item(); e_w = (out_w.float() - ref).abs().max().item()
+        assert e_d <= 2.0 ** -10 * scale + 2.0 ** -11                 # direct: one fp16 rounding of the result
+        assert e_w <= 2.0 ** -8 * scale, (e_w, scale)                 # winograd: + fp16 roundings of the transformed inputs / weights
+    # the operator with its two per-edge gate convolutions in Winograd form
+    E, h, w = 6, 16, 64
+    sd = deterministic_state_dict(_SD(oupd.empty_state_dict()), seed=7)
+    net, inp, corr, flow = _update_inputs(E, h, w, seed=E + h)
+    ii = torch.tensor([0, 0, 1, 2, 2, 2], dtype=torch.int64)
+    inp = inp[[int(torch.nonzero(ii == f)[0]) for f in ii.tolist()]]
+    with torch.no_grad():
+        ref = oupd.update_forward(sd, net.half(), inp.half(), corr.half(), flow, ii, autocast=True)
+    db.set_option("conv_wino", 1)
+    try:
+        mod = UpdateModule(share_inp_by_source_frame=True).load_state_dict(sd)
+    finally:
+        db.set_option("conv_wino", 0)
+    assert mod.params["zr_e"].layout == LAYOUT_WINO and mod.params["q_e"].layout == LAYOUT_WINO
+    n, d, wt, eta, up = mod(net[None].cuda().half(), inp[None].cuda().half(), corr[None].cuda().half(), flow[None].cuda(), ii.cuda(), None)
+    torch.cuda.synchronize()
+    _check_update((n[0], d[0], wt[0], eta[0], up[0]), ref, 3)
