@@ -1044,23 +1044,12 @@ constexpr int WV_BYTES = 6 * 4 * 32 * 64;                 // 49,152: transformed
 constexpr int WU_BYTES = 4 * 128 * 64;                    // 32,768: one (chunk, dy) weight group [4 positions][128 couts][32 ch]
 constexpr int WINO_LDS_BYTES = WV_BYTES + 2 * WU_BYTES;   // 114,688 (the staged epilogue tile needs 69,632)
 
-__device__ __forceinline__ u32x4 pk_sub4(const u32x4& a, const u32x4& b) {
-  u32x4 r;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const __half2 x = __builtin_bit_cast(__half2, a[i]), y = __builtin_bit_cast(__half2, b[i]);
-    r[i] = __builtin_bit_cast(uint32_t, __hsub2(x, y));
-  }
-  return r;
+using half2v = __attribute__((ext_vector_type(2))) _Float16;
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2v, a) - __builtin_bit_cast(half2v, b));
 }
-__device__ __forceinline__ u32x4 pk_add4(const u32x4& a, const u32x4& b) {
-  u32x4 r;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const __half2 x = __builtin_bit_cast(__half2, a[i]), y = __builtin_bit_cast(__half2, b[i]);
-    r[i] = __builtin_bit_cast(uint32_t, __hadd2(x, y));
-  }
-  return r;
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2v, a) + __builtin_bit_cast(half2v, b));
 }
 
 template <int EPI, bool CINIT = false>
@@ -1160,14 +1149,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(ConvParams P) {
       if (hr < 6) {
         const int y = y0 - 1 + hr;
         const bool rok = (unsigned)y < (unsigned)P.H;
-        u32x4 d[4];
+        uint32_t msk[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int col = 2 * apair - 1 + k;
-          const uint32_t m = (rok && (unsigned)col < 64u) ? 0xffffffffu : 0u;
-          d[k] = ra[i][k] & m;
+        for (int k = 0; k < 4; ++k) msk[k] = (rok && (unsigned)(2 * apair - 1 + k) < 64u) ? 0xffffffffu : 0u;
+        u32x4 v0, v1, v2, v3;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {             // component by component: two channels per 32-bit lane
+          const uint32_t d0 = ra[i][0][e] & msk[0], d1 = ra[i][1][e] & msk[1], d2 = ra[i][2][e] & msk[2], d3 = ra[i][3][e] & msk[3];
+          v0[e] = pk_sub(d0, d2); v1[e] = pk_add(d1, d2); v2[e] = pk_sub(d2, d1); v3[e] = pk_sub(d1, d3);
         }
-        const u32x4 v0 = pk_sub4(d[0], d[2]), v1 = pk_add4(d[1], d[2]), v2 = pk_sub4(d[2], d[1]), v3 = pk_sub4(d[1], d[3]);
         const int R0 = (hr * 4) * 32 + apair;                     // row of position 0; position t is 32 rows further
 #define WN_PUT(t_, v_) { const int R = R0 + (t_) * 32; *reinterpret_cast<u32x4*>(lds + R * 64 + ((aq ^ ((R >> 2) & 3)) << 4)) = v_; }
         WN_PUT(0, v0) WN_PUT(1, v1) WN_PUT(2, v2) WN_PUT(3, v3)
