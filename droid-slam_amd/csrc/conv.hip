@@ -1033,7 +1033,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
 //     y(2p) = M0 + M1 + M2     y(2p+1) = M1 - M2 - M3
 // i.e. 16 instead of 24 MFMAs per (32-channel chunk, dy) step and wave -- 1.5x fewer MACs -- for twice the accumulators.
 // Same tile as conv3x3_halo2_kernel (4 image rows x 64 columns x 128 couts, 8 waves = 4 rows x 2 cout halves, weights of a
-// (chunk, dy) group by LDS-DMA into two buffers), but the MFMA rows are the 32 column PAIRS of the wave's image row:
+// (chunk, dy) group by LDS-DMA, here two steps ahead into three buffers), but the MFMA rows are the 32 column PAIRS of the wave's image row:
 // acc[position][cout tile] = 8 tiles = 128 registers -> one workgroup per CU.  The halo is transformed on its way into LDS
 // ([6 rows][4 positions][32 pairs][32 channels], 48 KB): a thread loads the four columns of one (row, pair, 8-channel slot)
 // and writes the four transformed slots.  Accumulator start values (the gates' context term) enter through the transform's
@@ -1042,7 +1042,8 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
 // does not have (tests/test_gpu_parity.py::test_conv_winograd_prototype quantifies them).
 constexpr int WV_BYTES = 6 * 4 * 32 * 64;                 // 49,152: transformed halo
 constexpr int WU_BYTES = 4 * 128 * 64;                    // 32,768: one (chunk, dy) weight group [4 positions][128 couts][32 ch]
-constexpr int WINO_LDS_BYTES = WV_BYTES + 2 * WU_BYTES;   // 114,688 (the staged epilogue tile needs 69,632)
+constexpr int WU_BUFS = 3;                               // weight groups are fetched TWO steps ahead (a step is only 16 MFMAs per wave)
+constexpr int WINO_LDS_BYTES = WV_BYTES + WU_BUFS * WU_BYTES;   // 147,456 (the staged epilogue tile needs 69,632)
 
 using half2v = __attribute__((ext_vector_type(2))) _Float16;
 __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) {
@@ -1133,13 +1134,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(ConvParams P) {
       const unsigned glo = __builtin_amdgcn_readfirstlane((unsigned)gaddr);                                          \
       const unsigned ghi = __builtin_amdgcn_readfirstlane((unsigned)(gaddr >> 32));                                  \
       const void* gs = reinterpret_cast<const void*>(((unsigned long)ghi << 32) | glo);                              \
-      const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + WV_BYTES + ((step_) & 1) * WU_BYTES + (wave + 8 * q) * 1024); \
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + WV_BYTES + ((step_) % WU_BUFS) * WU_BYTES + (wave + 8 * q) * 1024); \
       WN_GLDS16S(gs, b_voff, dst)                                                                                    \
     }                                                                                                                \
   }
 
   WN_FETCH_A(0)
   WN_DMA_B(0)
+  if (nsteps > 1) WN_DMA_B(1)
   for (int c = 0; c < nchunks; ++c) {
     // every wave has finished the previous chunk's reads of the transformed halo
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1167,13 +1169,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(ConvParams P) {
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
       const int step = c * 3 + dy;
-      // group `step` has landed (DMA issued a step ago), the halo stores are done; at dy == 1 the next chunk's 8 halo loads,
-      // issued after those pieces, may stay in flight
-      if (dy == 1 && c + 1 < nchunks) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if (step + 1 < nsteps) WN_DMA_B(step + 1)
+      // group `step` (DMA issued two steps ago) has landed; younger operations that may stay in flight (vector memory
+      // operations complete in order): the 4 pieces of group step + 1 and, from dy == 1 on, the next chunk's 8 halo loads
+      if (step + 1 >= nsteps) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else if (dy == 0 || c + 1 >= nchunks) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (step + 2 < nsteps) WN_DMA_B(step + 2)             // into the buffer last read in step - 1
       if (dy == 0 && c + 1 < nchunks) WN_FETCH_A(c + 1)
-      const char* const Bcur = lds + WV_BYTES + (step & 1) * WU_BYTES;
+      const char* const Bcur = lds + WV_BYTES + (step % WU_BUFS) * WU_BYTES;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int R = ((wrow + dy) * 4 + t) * 32 + (lane & 31);
