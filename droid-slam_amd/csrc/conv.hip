@@ -1297,91 +1297,81 @@ __global__ __launch_bounds__(512, 4) void conv7x7_c4_kernel(ConvParams P) {
 // hidden state for the gate product: 1.86 ms = 1.7 TB/s.  Here a workgroup requests its whole 256 px x 128 ch tile at once
 // (8 x 16 bytes per thread: 128 KB in flight per CU with two workgroups), the tile stays in LDS as MFMA operand AND as the
 // gate's second factor, and the weights come from L2 straight into B fragments (two halves of K).
+// (Round 3 tried persistent workgroups -- one per CU, the next tile's loads issued under the current tile's MFMAs and gate
+// algebra, weights resident in 64 registers: 1.66 instead of 1.45 ms.  Two workgroups per CU overlapping each other's phases
+// beat one workgroup overlapping its own loads; kept as it was.)
 constexpr int GLD = 128 + 8;                          // LDS row stride (halves)
-// Round 3: persistent workgroups.  One tile per workgroup left the chip at 2.2 TB/s (1.45 ms at 4096 edges): load 64 KB ->
-// LDS -> 32 MFMAs -> 64 sigmoids per lane -> reduce, nothing of the next tile in flight meanwhile.  Now a workgroup walks
-// tiles blockIdx.x, + gridDim.x, ...: the NEXT tile's 8 x 16 bytes per thread are requested as soon as the current tile sits
-// in LDS and land during its MFMAs and gate algebra; the 128 x 128 weights stay in registers (64 per lane) for all tiles.
-// One workgroup per CU (~190 registers); same arithmetic, same order of the partial sums per tile.
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void glo_reduce_kernel(ConvParams P, int ntiles) {
+__global__ __launch_bounds__(512, 4) void glo_reduce_kernel(ConvParams P) {
   extern __shared__ __half s_conv[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wrow = wave & 3, wn0 = (wave >> 2) * 64, wm0 = wrow * 64;
+  const long m0 = (long)blockIdx.x * BM;
   const int HW = P.H * P.W;
-  const int p = lane & 31, kh = lane >> 5;
-  half8 bf[2][8];
+  const int img = (int)(m0 / HW);
+  uint4 ra[8];
 #pragma unroll
-  for (int b = 0; b < 2; ++b)
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
-      bf[b][ks] = *reinterpret_cast<const half8*>(P.wt + (long)(wn0 + b * 32 + p) * P.Kpad + ks * 16 + kh * 8);
-  float bias[2];
-#pragma unroll
-  for (int b = 0; b < 2; ++b) bias[b] = P.bias[wn0 + b * 32 + p];
-  u32x4 ra[8];        // (native vectors: arrays of HIP's uint4 struct assigned under a condition end up in scratch)
-  int tile = blockIdx.x;
-  if (tile < ntiles) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int id = tid + 512 * i;
-      ra[i] = *reinterpret_cast<const u32x4*>(P.in[0] + ((long)tile * BM + (id >> 4)) * P.segS[0] + (id & 15) * 8);
-    }
+  for (int i = 0; i < 8; ++i) {
+    const int id = tid + 512 * i;
+    ra[i] = *reinterpret_cast<const uint4*>(P.in[0] + (m0 + (id >> 4)) * P.segS[0] + (id & 15) * 8);
   }
-  float* const sR = reinterpret_cast<float*>(s_conv + BM * GLD);          // [8 waves][64] partial sums behind the tile
-  for (; tile < ntiles; tile += gridDim.x) {
-    const long m0 = (long)tile * BM;
-    const int img = (int)(m0 / HW);
+  const int p = lane & 31, kh = lane >> 5;
+  half8 bf[2][4];
+  auto load_b = [&](int half) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int id = tid + 512 * i;
-      *reinterpret_cast<u32x4*>(s_conv + (id >> 4) * GLD + (id & 15) * 8) = ra[i];
-    }
-    __syncthreads();
-    const int next = tile + gridDim.x;
-    if (next < ntiles) {
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int id = tid + 512 * i;
-        ra[i] = *reinterpret_cast<const u32x4*>(P.in[0] + ((long)next * BM + (id >> 4)) * P.segS[0] + (id & 15) * 8);
-      }
-    }
-    f32x16 acc[2][2];
-    zero_acc<2, 2>(acc);
+      for (int ks = 0; ks < 4; ++ks)
+        bf[b][ks] = *reinterpret_cast<const half8*>(P.wt + (long)(wn0 + b * 32 + p) * P.Kpad + (half * 4 + ks) * 16 + kh * 8);
+  };
+  load_b(0);
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
+  for (int i = 0; i < 8; ++i) {
+    const int id = tid + 512 * i;
+    *reinterpret_cast<uint4*>(s_conv + (id >> 4) * GLD + (id & 15) * 8) = ra[i];
+  }
+  f32x16 acc[2][2];
+  zero_acc<2, 2>(acc);
+  __syncthreads();
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
       half8 af[2];
 #pragma unroll
       for (int a = 0; a < 2; ++a)
-        af[a] = *reinterpret_cast<const half8*>(s_conv + (wm0 + a * 32 + p) * GLD + ks * 16 + kh * 8);
+        af[a] = *reinterpret_cast<const half8*>(s_conv + (wm0 + a * 32 + p) * GLD + (half * 4 + ks) * 16 + kh * 8);
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b][ks], acc[a][b], 0, 0, 0);
     }
-    // gate * feature, summed over the wave's 64 pixels per cout (same roundings as conv_epilogue's EPI_GLO)
-    float sum[2];
+    if (half == 0) load_b(1);
+  }
+  // gate * feature, summed over the wave's 64 pixels per cout (same roundings as conv_epilogue's EPI_GLO)
+  float sum[2];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int co = wn0 + b * 32 + p;
-      float t = 0.f;
+  for (int b = 0; b < 2; ++b) {
+    const int co = wn0 + b * 32 + p;
+    const float bias = P.bias[co];
+    float t = 0.f;
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int row = wm0 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh;
-          const float g = round_h(sigmoidf_(acc[a][b][q] + bias[b]));
-          t += round_h(g * __half2float(s_conv[row * GLD + co]));
-        }
-      sum[b] = t + __shfl_xor(t, 32, 64);
-    }
-    if (lane < 32) { sR[wave * 64 + p] = sum[0]; sR[wave * 64 + 32 + p] = sum[1]; }
-    __syncthreads();                                  // partial sums visible; every wave is done with the tile
-    if (tid < 128) {
-      const int hb = tid >> 6, c = tid & 63;          // cout half -> waves 4*hb .. 4*hb+3
-      const float t = (sR[(hb * 4 + 0) * 64 + c] + sR[(hb * 4 + 1) * 64 + c]) + (sR[(hb * 4 + 2) * 64 + c] + sR[(hb * 4 + 3) * 64 + c]);
-      atomicAdd(&P.red[(long)img * P.Cout + tid], t);
-    }
-    // (the next iteration's tile stores only touch the tile region; sR is rewritten after the next __syncthreads pair)
+      for (int q = 0; q < 16; ++q) {
+        const int row = wm0 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh;
+        const float g = round_h(sigmoidf_(acc[a][b][q] + bias));
+        t += round_h(g * __half2float(s_conv[row * GLD + co]));
+      }
+    sum[b] = t + __shfl_xor(t, 32, 64);
+  }
+  __syncthreads();                                    // the tile is dead: its head becomes [8 waves][64] partial sums
+  float* sR = reinterpret_cast<float*>(s_conv);
+  if (lane < 32) { sR[wave * 64 + p] = sum[0]; sR[wave * 64 + 32 + p] = sum[1]; }
+  __syncthreads();
+  if (tid < 128) {
+    const int hb = tid >> 6, c = tid & 63;            // cout half -> waves 4*hb .. 4*hb+3
+    const float t = (sR[(hb * 4 + 0) * 64 + c] + sR[(hb * 4 + 1) * 64 + c]) + (sR[(hb * 4 + 2) * 64 + c] + sR[(hb * 4 + 3) * 64 + c]);
+    atomicAdd(&P.red[(long)img * P.Cout + tid], t);
   }
 }
 
@@ -1858,8 +1848,7 @@ extern "C" int dh_conv2d_nhwc_f16_ex2(const void* const* inputs, const int* in_c
   }
   if (glo_ok(P)) {
     DH_LDS_OPTIN(&glo_reduce_kernel, 80 * 1024);
-    const int ntiles = (int)((long)P.N * P.H * P.W / BM);
-    hipLaunchKernelGGL(glo_reduce_kernel, dim3((unsigned)std::min(ntiles, 256)), dim3(512), BM * GLD * 2 + 8 * 64 * 4, st, P, ntiles);
+    hipLaunchKernelGGL(glo_reduce_kernel, dim3((unsigned)((long)P.N * P.H * P.W / BM)), dim3(512), BM * GLD * 2, st, P);
     DH_LAUNCH_CHECK();
     return DH_OK;
   }
