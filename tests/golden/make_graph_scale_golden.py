@@ -111,8 +111,35 @@ def scenario_stereo():
         len(out["ii"]), int((out["ii"] == out["jj"]).sum()), np.abs(out["U1_poses"] - S["poses"]).max(), np.abs(out["U2_poses"] - S["poses"]).max()))
 
 
+def scenario_tum_size():
+    """scenario N: 6 keyframes at 30 x 40 (TUM's 240 x 320 images): neither the pyramid layout (w in {16,32,64}, h % 8 == 0) nor
+    the production convolution tiling (w == 64) applies -> reference-layout volumes with FLOOR pooling (30x40, 15x20, 7x10,
+    3x5), the generic convolution loop, per-edge context features.  Two update iterations with upsampling."""
+    S = graph_scenario(6, 30, 40)
+    N, ht, wd = S["n_frames"], S["ht"], S["wd"]
+    video = ref_dv.DepthVideo(image_size=[8 * ht, 8 * wd], buffer=N + 2, stereo=False, device="cpu")
+    video.poses[:N] = torch.as_tensor(S["poses"]); video.disps[:N] = torch.as_tensor(S["disps"])
+    video.intrinsics[:N] = torch.as_tensor(S["intrinsics"])
+    video.fmaps[:N, 0] = torch.as_tensor(S["fmaps"]); video.nets[:N] = torch.as_tensor(S["nets"]); video.inps[:N] = torch.as_tensor(S["inps"])
+    video.counter.value = N
+    out = {}
+    with torch.no_grad():
+        fg = ref_fg.FactorGraph(video, update_operator(S["weight_seed"]), device="cpu", corr_impl="volume", max_factors=-1, upsample=True)
+        fg.add_neighborhood_factors(0, N, r=2)
+        out["ii"], out["jj"] = fg.ii.numpy().copy(), fg.jj.numpy().copy()
+        out["target0"] = fg.target[0].numpy().copy()
+        for k in (1, 2):
+            fg.update(t0=1, t1=None, itrs=2, use_inactive=False)
+            snap(out, "U%d" % k, video, fg, N)
+            out["U%d_disps_up" % k] = video.disps_up[:N].numpy().astype(np.float16)
+    np.savez_compressed(os.path.join(HERE, "graph_tum_size_python.npz"), **out)
+    print("graph_tum_size: %d edges; |dpose| %.3e %.3e" % (len(out["ii"]), np.abs(out["U1_poses"] - S["poses"]).max(), np.abs(out["U2_poses"] - S["poses"]).max()))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["stereo", "c2"]
+    which = sys.argv[1:] or ["stereo", "c2", "tum"]
+    if "tum" in which:
+        scenario_tum_size()
     if "stereo" in which:
         scenario_stereo()
     if "c2" in which:

@@ -21,18 +21,20 @@ def update_autocast_inputs():
     return t(net), t(inp), t(corr), t(flow), torch.as_tensor(c["ii"]), torch.as_tensor(c["jj"])
 
 
-def graph_scenario(n_frames=6):
+def graph_scenario(n_frames=6, ht=16, wd=64):
     """Six keyframes at 16 x 64 (1/8 resolution; W = 64 so the HIP path takes its production kernels): state of a
-    DepthVideo (poses, depths, features) for the factor-graph golden run (tests/golden/make_graph_golden.py)."""
+    DepthVideo (poses, depths, features) for the factor-graph golden run (tests/golden/make_graph_golden.py).
+    (ht, wd) = (30, 40) is TUM's 240 x 320: outside the pyramid layout and the production convolution tiling, i.e. the
+    generic paths (reference-layout volumes, generic convolution loop)."""
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "droid-slam_amd"))
     from droid_amd import synthetic as syn
-    ht, wd, N = 16, 64, n_frames
+    N = n_frames
     rng = np.random.default_rng(77)
     cfg = syn.GraphConfig("scn", N, 2 * (N - 1) + 2 * (N - 2), radius=2)
     g = syn.make_graph(cfg, seed=5, ht=ht, wd=wd)
-    intr = np.array([24.0, 24.0, 32.0, 8.0], dtype=np.float32)
+    intr = np.array([24.0, 24.0, wd / 2.0, ht / 2.0], dtype=np.float32)
     disps = (0.7 + 0.6 * g["disps_gt"] / g["disps_gt"].max()).astype(np.float32)
     return dict(ht=ht, wd=wd, n_frames=N, weight_seed=1234,
                 poses=g["poses"].astype(np.float32), disps=disps, intrinsics=np.tile(intr, (N, 1)),

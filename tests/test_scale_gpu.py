@@ -278,3 +278,44 @@ def test_composed_stereo_update_matches_reference_factor_graph(db, golden_dir):
         du, rdu = c(video.disps_up)[:N], G[tag + "_disps_up"].astype(np.float32)
         e = np.abs(du - rdu) / np.maximum(1.0, np.abs(rdu))
         assert np.quantile(e, 0.99) <= 1e-2 * scale + 2.0 ** -10
+
+
+def test_composed_update_at_tum_image_size_matches_reference_factor_graph(db, golden_dir):
+    """30 x 40 at 1/8 resolution (TUM's 240 x 320, evaluation_scripts/test_tum.py): outside the pyramid layout and the
+    production convolution tiling, so the iteration runs on reference-layout volumes (hand-written build + floor pooling),
+    corr_index_forward per level, the generic convolution loop and per-edge context features; two composed update
+    iterations with upsampling against the reference's factor_graph.py golden"""
+    from droid_amd.corr import CorrBlock, CorrBlockRef
+    from droid_amd.factor_graph import FactorGraph
+    from droid_amd.update import UpdateModule
+    from droid_amd.weights import deterministic_state_dict
+    from golden_inputs import graph_scenario
+    G = np.load(os.path.join(golden_dir, "graph_tum_size_python.npz"))
+    S = graph_scenario(6, 30, 40)
+    N, ht, wd = S["n_frames"], S["ht"], S["wd"]
+    assert not CorrBlock.supported(ht, wd)
+    video = _video(N, ht, wd, S["poses"], S["disps"], S["intrinsics"], S["fmaps"], S["nets"], S["inps"])
+    upd = UpdateModule("cuda").load_state_dict(deterministic_state_dict(_SD(), seed=S["weight_seed"]))
+    fg = FactorGraph(video, upd, corr_impl="volume", max_factors=-1, upsample=True)
+    fg.add_neighborhood_factors(0, N, r=2)
+    assert isinstance(fg.corr, CorrBlockRef) and [tuple(v.shape[-2:]) for v in fg.corr.corr_pyramid] == [(30, 40), (15, 20), (7, 10), (3, 5)]
+    assert np.array_equal(fg.ii.cpu().numpy(), G["ii"]) and np.array_equal(fg.jj.cpu().numpy(), G["jj"])
+    assert np.abs(fg.target[0].cpu().numpy() - G["target0"]).max() < 2e-4
+    c = lambda t: t.float().cpu().numpy()
+    for k, scale in ((1, 1.0), (2, 2.0)):
+        fg.update(t0=1, t1=None, itrs=2, use_inactive=False)
+        torch.cuda.synchronize()
+        tag = "U%d" % k
+        p, rp = c(video.poses)[:N], G[tag + "_poses"]
+        assert np.abs(p[:, :3] - rp[:, :3]).max() <= 2e-3 * scale
+        assert _rot_angle(p[:, 3:].astype(np.float64), rp[:, 3:].astype(np.float64)).max() <= 2e-3 * scale
+        d, rd = c(video.disps)[:N], G[tag + "_disps"]
+        e = np.abs(d - rd) / np.maximum(1.0, np.abs(rd))
+        assert np.quantile(e, 0.99) <= 1e-2 * scale and e.max() <= 0.1 * scale
+        assert np.abs(c(fg.net[0]) - G[tag + "_net"].astype(np.float32)).max() <= 2.0 ** -8 * scale
+        tg, rtg = c(fg.target[0]), G[tag + "_target"]
+        assert np.quantile(np.abs(tg - rtg), 0.999) <= 2e-2 * scale and np.abs(tg - rtg).max() <= 0.5 * scale
+        assert np.abs(c(fg.weight[0]) - G[tag + "_weight"]).max() <= 2.0 ** -8 * scale
+        du, rdu = c(video.disps_up)[:N], G[tag + "_disps_up"].astype(np.float32)
+        e = np.abs(du - rdu) / np.maximum(1.0, np.abs(rdu))
+        assert np.quantile(e, 0.99) <= 1e-2 * scale + 2.0 ** -10
