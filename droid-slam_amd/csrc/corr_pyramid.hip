@@ -412,6 +412,7 @@ struct LevelGeom {                                  // per-lane addressing / wei
   float dx, dy;
 };
 struct HalfTaps { uint32_t raw[HALF_ROWS][NPAIR]; };
+struct HalfTapsQ { u32x4 q[NPAIR]; };            // MODE 4 (timing ablation): one 16-byte load per cell pair and window-row group
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -425,8 +426,8 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // while they are in flight (scripts/audit_asm_loads.py checks the generated ISA for exactly that at build time).
 typedef unsigned int u32x4_nt __attribute__((ext_vector_type(4)));
 // MODE (reference-layout output only; opts().lookup_mode): 0 = product; 1 = tap loads with the `nt` cache policy; ablations that
-// give WRONG results and exist to attribute the kernel's time (scripts/bench_lookup.py --mode): 2 = no output stores,
-// 3 = no tap loads.
+// give WRONG results and exist to attribute the kernel's time (scripts/bench_lookup.py --modes): 2 = no output stores,
+// 3 = no tap loads, 4 = the tap loads as 16-byte "quad" loads (5 instead of 20 per half level, no transpose).
 template <int W, bool NHWC, int MODE = 0>
 __global__ __launch_bounds__(NHWC ? 64 : W * 8, NHWC ? 3 : 4) void pyr_lookup_kernel(const __half* __restrict__ pyr, const float* __restrict__ coords,
                                                                __half* __restrict__ out, PyrDims D) {
@@ -484,11 +485,28 @@ __global__ __launch_bounds__(NHWC ? 64 : W * 8, NHWC ? 3 : 4) void pyr_lookup_ke
       const int rowoff = inside ? wrap(y2 - G.y1l, h2) * (w2 * 128) + G.sboff : h2 * (w2 * 128);      // else block 0's all-zero row
 #pragma unroll
       for (int m = 0; m < NPAIR; ++m) {
+        if (MODE == 4) continue;
         if (MODE == 1) asm volatile("global_load_dword %0, %1, %2 nt" : "=v"(T.raw[jj][m]) : "v"(rowoff + G.coloff[m]), "s"(G.base));
         else if (MODE == 3) asm volatile("v_mov_b32 %0, %1" : "=v"(T.raw[jj][m]) : "v"(rowoff + G.coloff[m]));
         else asm volatile("global_load_dword %0, %1, %2" : "=v"(T.raw[jj][m]) : "v"(rowoff + G.coloff[m]), "s"(G.base));
       }
     }
+  };
+  // MODE 4, timing ablation of "quad loads" (WRONG results: no transpose): lane (quad q = lane >> 2, r = lane & 3) fetches
+  // for window row r of the half the 16 bytes that hold the cell pair's dwords of its quad's four pixels -- the same lines as
+  // the 20 dword loads, in 5 instructions
+  auto requestQ = [&](int l, const LevelGeom& G, int half, HalfTapsQ& T) {
+    const int w2 = W >> l, h2 = D.h2[l];
+    const int r = lane & 3;
+    const int y2 = G.Y0 + half * HALF_ROWS + r;
+    const bool inside = (unsigned)y2 < (unsigned)h2;
+    const int rowoff = (inside ? wrap(y2 - G.y1l, h2) * (w2 * 128) + G.sboff : h2 * (w2 * 128)) - 4 * r;
+#pragma unroll
+    for (int m = 0; m < NPAIR; ++m)
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(T.q[m]) : "v"(rowoff + G.coloff[m]), "s"(G.base));
+  };
+  auto landedQ = [&](HalfTapsQ& T) {
+    asm volatile("" : "+v"(T.q[0]), "+v"(T.q[1]), "+v"(T.q[2]), "+v"(T.q[3]), "+v"(T.q[4]));
   };
   // ties every tap register to this point so that no use can be scheduled above the preceding wait
   auto landed = [&](HalfTaps& T) {
@@ -561,22 +579,30 @@ __global__ __launch_bounds__(NHWC ? 64 : W * 8, NHWC ? 3 : 4) void pyr_lookup_ke
 
   LevelGeom G, Gn;
   HalfTaps A, B;
+  HalfTapsQ QA, QB;
+  constexpr int NB_ = MODE == 4 ? NPAIR : BATCH;          // vector-memory operations per batch
+  auto unpack = [&](const HalfTapsQ& Q, HalfTaps& T) {    // (MODE 4: no transpose, register moves only)
+#pragma unroll
+    for (int jj = 0; jj < HALF_ROWS; ++jj)
+#pragma unroll
+      for (int m = 0; m < NPAIR; ++m) T.raw[jj][m] = Q.q[m][jj];
+  };
   geom(0, G);
-  request(0, G, 0, A);
-  request(0, G, 1, B);
+  if (MODE == 4) { requestQ(0, G, 0, QA); requestQ(0, G, 1, QB); }
+  else { request(0, G, 0, A); request(0, G, 1, B); }
 #pragma unroll
   for (int l = 0; l < NLEV; ++l) {
     const bool more = l + 1 < NLEV;
-    // issue order so far: ... A_l(BATCH) B_l(BATCH) [stores of level l-1 (>= MIN_STORES)]
-    if (l == 0) wait_vm<BATCH>(); else wait_vm<BATCH + MIN_STORES>();
-    landed(A);
+    // issue order so far: ... A_l(NB_) B_l(NB_) [stores of level l-1 (>= MIN_STORES)]
+    if (l == 0) wait_vm<NB_>(); else wait_vm<NB_ + MIN_STORES>();
+    if (MODE == 4) { landedQ(QA); unpack(QA, A); } else landed(A);
     consume(G, A, 0);
-    if (more) { geom(l + 1, Gn); request(l + 1, Gn, 0, A); }
-    // younger than B_l: [stores of level l-1] [A_{l+1}(BATCH)]
-    if (l == 0) wait_vm<BATCH>(); else if (more) wait_vm<BATCH + MIN_STORES>(); else wait_vm<0>();
-    landed(B);
+    if (more) { geom(l + 1, Gn); if (MODE == 4) requestQ(l + 1, Gn, 0, QA); else request(l + 1, Gn, 0, A); }
+    // younger than B_l: [stores of level l-1] [A_{l+1}(NB_)]
+    if (l == 0) wait_vm<NB_>(); else if (more) wait_vm<NB_ + MIN_STORES>(); else wait_vm<0>();
+    if (MODE == 4) { landedQ(QB); unpack(QB, B); } else landed(B);
     consume(G, B, 1);
-    if (more) request(l + 1, Gn, 1, B);
+    if (more) { if (MODE == 4) requestQ(l + 1, Gn, 1, QB); else request(l + 1, Gn, 1, B); }
     if (NHWC) {
       asm volatile("" ::: "memory");       // the stores below stay younger than the B_{l+1} requests (wait counts)
 #pragma unroll
@@ -697,6 +723,8 @@ int launch_lookup(const void* pyramid, const float* coords, void* out, int E, in
     hipLaunchKernelGGL((pyr_lookup_kernel<64, NHWC, 2>), grid, block, lds, st, (const __half*)pyramid, coords, (__half*)out, D);
   else if (w == 64 && mode == 3)
     hipLaunchKernelGGL((pyr_lookup_kernel<64, NHWC, 3>), grid, block, lds, st, (const __half*)pyramid, coords, (__half*)out, D);
+  else if (w == 64 && mode == 4)
+    hipLaunchKernelGGL((pyr_lookup_kernel<64, NHWC, 4>), grid, block, lds, st, (const __half*)pyramid, coords, (__half*)out, D);
   else if (w == 64)
     hipLaunchKernelGGL((pyr_lookup_kernel<64, NHWC>), grid, block, lds, st, (const __half*)pyramid, coords, (__half*)out, D);
   else if (w == 32)
