@@ -33,7 +33,8 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0           # MI355X spec (MI355X_MICROARCH.md)
-LOOKUP_BYTES_PER_EP_F16 = 880
+LOOKUP_BYTES_PER_EP_F16 = 880   # 2 * (240 taps + 196 samples) + 8 B of coordinates
+LOOKUP_FUSED_BYTES_PER_EP_F16 = 744   # the lookup fused with the 196 -> 128 layer that reads it: 2 * (240 taps + 128 outputs) + 8
 
 
 def parse():
@@ -47,6 +48,8 @@ def parse():
     ap.add_argument("--no-lookup", action="store_true", help="skip the correlation pyramid (BA-only diagnostics)")
     ap.add_argument("--nhwc-lookup", action="store_true", help="A/B: channel-last lookup output (7 pad channels per level) + "
                     "implicit-GEMM first correlation layer, instead of the reference-layout output + corr0_nchw")
+    ap.add_argument("--unfused-lookup", action="store_true", help="A/B: the stand-alone lookup kernel (reference-layout output) + the "
+                    "operator's own first correlation layer, instead of the fused kernel (corr_pyramid_lookup_corr0)")
     ap.add_argument("--per-edge-inp", action="store_true", help="context features gathered per edge and convolved with the "
                     "other 320 gate inputs (the reference's data flow) instead of once per source frame (A/B)")
     ap.add_argument("--op-chunks", type=int, default=0, help="run the update operator over this many contiguous groups of source "
@@ -206,8 +209,8 @@ def _ev():
     return torch.cuda.Event(enable_timing=True)
 
 
-def _lookup_rate(ms, E, HW):
-    gbs = LOOKUP_BYTES_PER_EP_F16 * E * HW / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+def _lookup_rate(ms, E, HW, bytes_per_ep=LOOKUP_BYTES_PER_EP_F16):
+    gbs = bytes_per_ep * E * HW / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     return {"ms": ms, "GB/s": gbs, "frac": gbs / HBM_PEAK_GBS}
 
 
@@ -221,7 +224,7 @@ def _time_ms(fn, reps=3):
     return float(np.median(ts))
 
 
-def lookup_sensitivity(db, corr, g, coords_bench, ii, jj, fmaps, dev, lk_ms):
+def lookup_sensitivity(db, corr, g, coords_bench, ii, jj, fmaps, dev, lk_ms, upd=None):
     """The pyramid layout coalesces when the 64 pixels of an 8x8 source block want the same displacement cells, i.e. it is
     sensitive to the spatial coherence of the flow (the reference layout is not).  Same kernel, same pyramid, three flows:
       bench    the step's own coords (reprojection with the bench's initial state: depth 1 everywhere)
@@ -242,10 +245,14 @@ def lookup_sensitivity(db, corr, g, coords_bench, ii, jj, fmaps, dev, lk_ms):
     coords_random = d(np.stack([rng.uniform(0, wd, (E, ht, wd)), rng.uniform(0, ht, (E, ht, wd))], -1).astype(np.float32))
     flows = {"bench": coords_bench, "planes": coords_planes, "random": coords_random}
     out = {}
+    fused = upd is not None and bool(db.get_option("lookup_fused"))
     for name, c in flows.items():
         c = c.contiguous()
-        ms = lk_ms if name == "bench" and lk_ms > 0 else _time_ms(lambda: corr(c[None]))
-        out[name] = _lookup_rate(ms, E, HW)
+        ms = lk_ms if name == "bench" and lk_ms > 0 and not fused else _time_ms(lambda: corr(c[None]))
+        out[name] = _lookup_rate(ms, E, HW)                 # the stand-alone lookup kernel (880 B/ep)
+    if fused:                                               # the kernel of the timed step (744 B/ep)
+        out["fused_kernel"] = {name: _lookup_rate(lk_ms if name == "bench" and lk_ms > 0 else _time_ms(lambda: corr.lookup_corr0(c.contiguous()[None], upd)),
+                                                  E, HW, LOOKUP_FUSED_BYTES_PER_EP_F16) for name, c in flows.items()}
     n = min(256, E)
     rig = fmaps.shape[1]
     cidx = (ii[:n] == jj[:n]).long() if rig > 1 else torch.zeros_like(ii[:n])
@@ -430,6 +437,8 @@ def main():
 
     # the update operator takes the unpadded reference-layout features where its first layer has the kernel for them
     ref_layout = upd is not None and upd.wants_reference_layout_corr(ht, wd) and not args.nhwc_lookup
+    # default: the lookup runs fused with the first layer of the operator's correlation encoder (option lookup_fused)
+    fused_lookup = upd is not None and corr is not None and bool(db.get_option("lookup_fused")) and not args.nhwc_lookup and not args.unfused_lookup
 
     def step(timed):
         """one FactorGraph.update iteration (reference factor_graph.py:214-263)"""
@@ -439,25 +448,30 @@ def main():
         e0.record()
         fused = upd is not None and corr is not None
         # channel-last features straight into the update operator; the reference-layout [E,196,h,w] otherwise
-        feats = (corr.lookup_nhwc(coords1[None]) if (fused and not ref_layout) else corr(coords1[None])[0]) if corr is not None else None
+        corr0 = feats = None
+        if fused_lookup:
+            corr0 = corr.lookup_corr0(coords1[None], upd)                     # [E,h,w,128]: lookup + Conv2d(196,128,1) + ReLU
+        elif corr is not None:
+            feats = corr.lookup_nhwc(coords1[None]) if (fused and not ref_layout) else corr(coords1[None])[0]
         e1.record()
-        if upd is not None and feats is not None:
+        if upd is not None and (feats is not None or corr0 is not None):
             flow = db.motion_features(coords1, target_prev)                   # factor_graph.py:221-222
             if len(chunk_slices) == 1:
                 if inp_edges is not None:
-                    _, _, _, damping, upmask = upd.forward_nhwc(net, inp_edges, feats, flow, ii)
+                    _, _, _, damping, upmask = upd.forward_nhwc(net, inp_edges, feats, flow, ii, corr0=corr0)
                 else:
-                    _, _, _, damping, upmask = upd.forward_nhwc(net, None, feats, flow, ii, inp_frames=inps_frames, inp_index=inp_index)
+                    _, _, _, damping, upmask = upd.forward_nhwc(net, None, feats, flow, ii, inp_frames=inps_frames, inp_index=inp_index, corr0=corr0)
                 dw = upd.last_dw
                 damping_buf[uniq_ii] = damping                               # factor_graph.py:238
             else:
                 dw = torch.empty(E, ht, wd, 4, device=dev, dtype=torch.float32)
                 for s, iis, ixs, uq in zip(chunk_slices, ii_chunks, idx_chunks, uniq_chunks):
-                    f_s = feats[:, s] if feats.dim() == 5 else feats[s]
+                    f_s = None if feats is None else (feats[:, s] if feats.dim() == 5 else feats[s])
+                    c_s = None if corr0 is None else corr0[s]
                     if inp_edges is not None:
-                        _, _, _, damping, upmask = upd.forward_nhwc(net[s], inp_edges[s], f_s, flow[s], iis)
+                        _, _, _, damping, upmask = upd.forward_nhwc(net[s], inp_edges[s], f_s, flow[s], iis, corr0=c_s)
                     else:
-                        _, _, _, damping, upmask = upd.forward_nhwc(net[s], None, f_s, flow[s], iis, inp_frames=inps_frames, inp_index=ixs)
+                        _, _, _, damping, upmask = upd.forward_nhwc(net[s], None, f_s, flow[s], iis, inp_frames=inps_frames, inp_index=ixs, corr0=c_s)
                     dw[s] = upd.last_dw
                     damping_buf[uq] = damping
             _, _, tgt, wgt = db.ba_inputs(coords1, dw)                        # target = coords1 + delta, [E,2,h,w] for ba (:233,253-254)
@@ -516,7 +530,7 @@ def main():
         if not args.no_sensitivity:
             coords_bench, _ = db.reproject(poses0, disps0, intr, ii, jj)
             try:
-                sens_out = lookup_sensitivity(db, corr, g, coords_bench, ii, jj, fmaps, dev, lk)
+                sens_out = lookup_sensitivity(db, corr, g, coords_bench, ii, jj, fmaps, dev, lk, upd if fused_lookup else None)
             except torch.cuda.OutOfMemoryError as exc:
                 sens_out = {"skipped": "out of memory: %s" % str(exc)[:80]}
 
@@ -531,7 +545,7 @@ def main():
         ms = 1000.0 * elapsed / max(1, args.steps)
         ep_total = E_all * HW
         # (the channel-last variant also writes 7 zero channels per level: 936 B/ep physical; only the 880 B count)
-        lookup_bytes = LOOKUP_BYTES_PER_EP_F16 * E * HW
+        lookup_bytes = (LOOKUP_FUSED_BYTES_PER_EP_F16 if fused_lookup else LOOKUP_BYTES_PER_EP_F16) * E * HW
         achieved = lookup_bytes / (lk * 1e-3) / 1e9 if lk > 0 else 0.0
         # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc, separate passes, gfx950
         # FETCH_SIZE correction; scripts/pmc_bench_lookup.sh), scaled to this rank's edge-pixels; None if not measured
@@ -539,7 +553,7 @@ def main():
         try:
             cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_lookup_pmc.json"))
             pmc = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))             # the latest round's passes
-            variant = "nhwc" if (upd is not None and corr is not None and not ref_layout) else "nchw"
+            variant = "fused" if fused_lookup else "nhwc" if (upd is not None and corr is not None and not ref_layout) else "nchw"
             traffic = pmc[variant]["hbm_bytes_per_edge_pixel"] * E * HW
             traffic_src = "profiles/%s (rocprofv3 --pmc passes of the same kernel at 4096 edges, committed; not re-measured in this run)" % cands[-1]
         except (OSError, KeyError, ValueError):
@@ -552,17 +566,24 @@ def main():
             "dtype": "f32 (BA; fp64 solve) / f16 (correlation pyramid)", "data": "synthetic",
             "config": {"workload": "%s: %d keyframes, %d edges, %dx%d, ba itrs=%d lm=%g ep=%g%s" % (
                 cfg.name, N, E_all, ht, wd, g["itrs"], g["lm"], g["ep"], ", stereo + sensor depth" if cfg.stereo else ""),
-                "stages": "reproject + corr lookup (4 levels, materialised fp16 pyramid, MI355X layout) + %sba" % (
+                "stages": "reproject + corr lookup (4 levels, materialised fp16 pyramid, MI355X layout%s) + %sba" % (
+                    ", fused with the correlation encoder's first layer" if fused_lookup else "",
                     "ConvGRU update operator (random-init weights) + " if upd is not None else ""),
                 "parallelism": "edge-sharded x%d" % world, "update_operator_chunks": len(chunk_slices),
                 "pyramid_GB": (corr.bytes() / 1e9 if corr is not None else 0.0)},
             "ms_per_global_ba": ba, "ms_corr_lookup": lk, "ms_update_operator": up,
-            "roofline": {"kernel": "pyr_lookup_kernel<64, %s> (1 launch = 4-level pyramid lookup of all edges)" % (
+            "roofline": {"kernel": "pyr_lookup_corr0_kernel<64> (1 launch = 4-level pyramid lookup of all edges + the 196 -> 128 layer that "
+                         "consumes it; 744 B/ep = 2*(240 taps + 128 outputs) + 8)" if fused_lookup else
+                         "pyr_lookup_kernel<64, %s> (1 launch = 4-level pyramid lookup of all edges)" % (
                 "channel-last" if (upd is not None and corr is not None and not ref_layout) else "reference layout"), "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch_group": lookup_bytes},
         }
+        if fused_lookup and lk > 0:
+            # what the same launch replaces, for comparison with earlier rounds' lines: the stand-alone lookup's 880 B/ep
+            # (its 392 B/ep of samples now stay in registers) over the fused kernel's duration -- work-equivalent, NOT bytes moved
+            out["roofline"]["standalone_lookup_equivalent_GBs"] = LOOKUP_BYTES_PER_EP_F16 * E * HW / (lk * 1e-3) / 1e9
         if sens_out is not None:
             out["roofline_sensitivity"] = sens_out
         if check is not None:

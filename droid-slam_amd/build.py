@@ -85,7 +85,23 @@ def audit_asm_loads(force=False, verbose=False):
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("in-flight register hazard in corr_pyramid.hip:\n" + r.stdout)
-    open(stamp, "w").write(r.stdout)
+    # the persistent fused kernel (pyr_lookup_corr0_kernel) has a loop and flag-dependent waits that the straight-line replay
+    # of the script cannot follow; what is checked at build time is that it has no scratch at all (a spill reload is a
+    # vector-memory operation the explicit vmcnt counts do not know about); its in-flight discipline is covered on the GPU
+    # by tests/test_gpu_parity.py::test_lookup_fused_with_first_encoder_layer (several loop iterations per workgroup)
+    import re
+    seen = 0
+    for fn in re.split(r"\n\t\.globl\t", open(asm).read())[1:]:
+        name = fn.split()[0]
+        if "pyr_lookup_corr0_kernel" not in name:
+            continue
+        seen += 1
+        m = re.search(r"; ScratchSize: (\d+)", fn)
+        if m is None or int(m.group(1)) != 0:
+            raise RuntimeError("register spills in %s: ScratchSize %s" % (name, m.group(1) if m else "?"))
+    if not seen:
+        raise RuntimeError("pyr_lookup_corr0_kernel not found in " + asm)
+    open(stamp, "w").write(r.stdout + "pyr_lookup_corr0_kernel: %d instantiations, no scratch\n" % seen)
 
 
 def audit_spills(force=False, verbose=False):

@@ -653,6 +653,258 @@ __global__ __launch_bounds__(NHWC ? 64 : W * 8, NHWC ? 3 : 4) void pyr_lookup_ke
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Fused lookup + first correlation-encoder layer (droid_net.py:96-100: Conv2d(196, 128, 1) + ReLU on the lookup's output):
+// the 196 window samples of a pixel never leave the registers of its lane.  A lane converts them to fp16 exactly as the
+// unfused kernel stores them, v_permlane32_swap turns eight packed dwords of every lane into the B operands of two
+// 32-pixel tiles, the weights ([13 k-steps][128 couts][16 channels] fp16, 52 KB) sit in LDS for the life of a PERSISTENT
+// workgroup, and v_mfma_f32_32x32x16_f16 accumulates D[128 couts][64 pixels] (128 accumulator registers).  What goes to HBM
+// is the 128-channel layer output (256 B per edge-pixel) instead of the 392 B of samples that the 1x1 layer would read back.
+// K order: level l, k-step s < 3 holds the level's channels kk = 16 s .. 16 s + 15 (kk = yoff * 7 + xoff, i.e. the order
+// in which the interpolation produces them); the four channels kk = 48 share the 13th k-step.
+constexpr int FK_STEPS = NLEV * 3 + 1;
+constexpr int F_COUT = 128;
+constexpr int FW_BYTES = FK_STEPS * F_COUT * 32;          // 53248
+constexpr int FT_ROWB = F_COUT * 2 + 16;                  // transposition tile: 32 pixel rows of 128 couts + 16 B pad
+constexpr int FT_BYTES = 32 * FT_ROWB;                    // 8704 per wave
+constexpr int FX_BYTES = 2048;                            // B operands of the 13th k-step
+constexpr int FC_BYTES = 1024;                            // coordinates of this block and of the next one (2 x [x 64][y 64] f32)
+constexpr int FWAVE_BYTES = FT_BYTES + FX_BYTES + FC_BYTES;
+constexpr int F_STORES = 2 * 8;                           // output store instructions per wave and block
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using half2f = __attribute__((ext_vector_type(2))) _Float16;
+
+template <int W, int MODE = 0>
+__global__ __launch_bounds__(W * 8, 1) void pyr_lookup_corr0_kernel(const __half* __restrict__ pyr, const float* __restrict__ coords,
+                                                                    const __half* __restrict__ wpk, const float* __restrict__ bias,
+                                                                    __half* __restrict__ out, PyrDims D, int n_strips) {
+  extern __shared__ __align__(16) unsigned char f_smem[];
+  constexpr int NBX = W / 8, NTHREADS = W * 8;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int bx = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = D.h, HW = h * W, NBY = h / 8;
+  const int yy = lane >> 3, xx = lane & 7;
+  // weights + bias -> LDS, once per workgroup
+  for (int i = tid; i < FW_BYTES / 16; i += NTHREADS)
+    reinterpret_cast<uint4*>(f_smem)[i] = reinterpret_cast<const uint4*>(wpk)[i];
+  float* s_bias = reinterpret_cast<float*>(f_smem + FW_BYTES);
+  if (tid < F_COUT) s_bias[tid] = bias[tid];
+  unsigned char* tile = f_smem + FW_BYTES + F_COUT * 4 + bx * FWAVE_BYTES;
+  for (int i = lane; i < FX_BYTES / 16; i += 64) reinterpret_cast<uint4*>(tile + FT_BYTES)[i] = uint4{0u, 0u, 0u, 0u};
+  __syncthreads();
+  const unsigned char* wlane = f_smem + (lane & 31) * 32 + (lane >> 5) * 16;       // + (ks * 4 + mt) * 1024
+
+  int strip = blockIdx.x;
+  if (strip >= n_strips) return;
+  int e = strip / NBY, by = strip - e * NBY;
+  // the lane's coordinates live in LDS (two slots: the next block's arrive by LDS-DMA while this block is in progress)
+  float* cslot = reinterpret_cast<float*>(tile + FT_BYTES + FX_BYTES);
+  int cur = 0;
+  {
+    const float2 v = reinterpret_cast<const float2*>(coords)[(long)e * HW + (long)(by * 8 + yy) * W + bx * 8 + xx];
+    cslot[lane] = v.x; cslot[64 + lane] = v.y;
+  }
+
+  // part 1: what the tap requests need (row / column offsets); part 2: what the interpolation needs (weights, masks).  Kept
+  // apart so that the next level's part 2 is not alive while this level is interpolated (registers: 2 waves / SIMD).
+  auto geom = [&](int l, LevelGeom& G, int part) {
+    const int w2 = W >> l;
+    const int y1 = by * 8 + yy, x1 = bx * 8 + xx;
+    const int sb = by * NBX + bx;
+    const float inv = 1.0f / (float)(1 << l);
+    const float cx = cslot[cur * 128 + lane] * inv, cy = cslot[cur * 128 + 64 + lane] * inv;
+    float fxf = floorf(cx), fyf = floorf(cy);
+    if (part == 2) { G.dx = cx - fxf; G.dy = cy - fyf; }
+    fxf = fminf(fmaxf(fxf, -65536.f), 65536.f);
+    fyf = fminf(fmaxf(fyf, -65536.f), 65536.f);
+    const int X0 = (int)fxf - RAD;
+    const int u0 = (X0 - (x1 >> l)) & (w2 - 1);
+    if (part == 1) {
+      G.Y0 = (int)fyf - RAD;
+      G.y1l = y1 >> l;
+      G.base = pyr + (long)e * D.edge_elems + D.lev_off[l];
+      G.sboff = (int)((long)sb * D.blk_elems[l] * 2);
+      const int k0 = u0 >> 1;
+#pragma unroll
+      for (int m = 0; m < NPAIR; ++m) {
+        const int mm = (m == NPAIR - 1) ? NPAIR - 2 + (u0 & 1) : m;
+        G.coloff[m] = (((k0 + mm) & (w2 / 2 - 1)) * 64 + lane) * 4;
+      }
+    } else {
+      G.par16 = (u0 & 1) * 16;
+#pragma unroll
+      for (int n = 0; n < WIN / 2; ++n) {
+        const uint32_t lo = (unsigned)(X0 + 2 * n) < (unsigned)w2 ? 0xffffu : 0u;
+        const uint32_t hi = (unsigned)(X0 + 2 * n + 1) < (unsigned)w2 ? 0xffff0000u : 0u;
+        G.cmask[n] = lo | hi;
+      }
+    }
+  };
+  auto request = [&](int l, const LevelGeom& G, int half, HalfTaps& T) {
+    const int w2 = W >> l, h2 = D.h2[l];
+#pragma unroll
+    for (int jj = 0; jj < HALF_ROWS; ++jj) {
+      const int y2 = G.Y0 + half * HALF_ROWS + jj;
+      const bool inside = (unsigned)y2 < (unsigned)h2;
+      // (select by mask: a branch per window row would cut the interpolation into basic blocks)
+      const int rowoff = inside ? wrap(y2 - G.y1l, h2) * (w2 * 128) + G.sboff : h2 * (w2 * 128);
+#pragma unroll
+      for (int m = 0; m < NPAIR; ++m)
+        if (MODE == 3) asm volatile("v_mov_b32 %0, %1" : "=v"(T.raw[jj][m]) : "v"(rowoff + G.coloff[m]));
+        else asm volatile("global_load_dword %0, %1, %2" : "=v"(T.raw[jj][m]) : "v"(rowoff + G.coloff[m]), "s"(G.base));
+    }
+  };
+  auto landed = [&](HalfTaps& T) {
+#pragma unroll
+    for (int jj = 0; jj < HALF_ROWS; ++jj)
+      asm volatile("" : "+v"(T.raw[jj][0]), "+v"(T.raw[jj][1]), "+v"(T.raw[jj][2]), "+v"(T.raw[jj][3]), "+v"(T.raw[jj][4]));
+  };
+
+  f32x16 acc[4][2];
+  uint32_t piece[4];                     // the 8 channels being packed (one 16-byte piece of a B operand)
+  float prev[OUTW];
+  // B operands of the level in the wave's tile: [k-step s][pixel tile nt][kh][32 pixels][8 channels] fp16; lane = pixel
+  unsigned char* fwr = tile + (lane >> 5) * 1024 + (lane & 31) * 16;              // + (s * 4 + kh) * 512
+  const unsigned char* frd = tile + (lane >> 5) * 512 + (lane & 31) * 16;        // + (s * 4 + nt * 2) * 512
+  // four MFMAs: k-step ks (12 = the shared 13th) on pixel tile nt.  (Issuing them between the rows of the following half
+  // level's interpolation, to run the matrix pipe in the shadow of the wave's own vector instructions, was measured: k-step 0
+  // placed that way changes nothing, 1.852 vs 1.854 ms; all three k-steps that way need 7 registers more than exist.)
+  auto unit = [&](int ks, int nt) {
+    const int off = ks < NLEV * 3 ? ((ks % 3) * 4 + nt * 2) * 512 : FT_BYTES + nt * 1024;
+    const half8 bf = *reinterpret_cast<const half8*>(frd + off);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      if (MODE == 5 && mt > 0) continue;                 // timing ablation: a quarter of the MFMAs (wrong results)
+      const half8 af = *reinterpret_cast<const half8*>(wlane + (ks * 4 + mt) * 1024);
+      acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[mt][nt], 0, 0, 0);
+    }
+  };
+  auto consume = [&](int l, const LevelGeom& G, const HalfTaps& T, int half) {
+    const float dx = G.dx, dy = G.dy;
+#pragma unroll
+    for (int jj = 0; jj < HALF_ROWS; ++jj) {
+      const int j = half * HALF_ROWS + jj;
+      float t[WIN];
+#pragma unroll
+      for (int n = 0; n < WIN / 2; ++n) {
+        const uint32_t pr = __builtin_amdgcn_alignbit(T.raw[jj][n + 1], T.raw[jj][n], G.par16) & G.cmask[n];
+        t[2 * n] = (float)__builtin_bit_cast(_Float16, (unsigned short)(pr & 0xffffu));
+        t[2 * n + 1] = (float)__builtin_bit_cast(_Float16, (unsigned short)(pr >> 16));
+      }
+      float c[OUTW];
+#pragma unroll
+      for (int a = 0; a < OUTW; ++a) c[a] = t[a] + dx * (t[a + 1] - t[a]);
+      if (j > 0) {
+#pragma unroll
+        for (int a = 0; a < OUTW; ++a) {
+          const float o = prev[a] + dy * (c[a] - prev[a]);
+          const int ch = (j - 1) * OUTW + a;
+          const uint32_t hv = (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)o);
+          if (ch == NCH_OUT - 1) {       // 13th k-step, k = l
+            *reinterpret_cast<unsigned short*>(fwr + FT_BYTES + l * 2) = (unsigned short)hv;
+          } else {
+            const int d = (ch >> 1) & 3;
+            if (ch & 1) piece[d] |= hv << 16; else piece[d] = hv;
+            if ((ch & 7) == 7) {
+              const int q = ch >> 3, s = q >> 1, kh = q & 1;
+              *reinterpret_cast<u32x4*>(fwr + (s * 4 + kh) * 512) = u32x4{piece[0], piece[1], piece[2], piece[3]};
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < OUTW; ++a) prev[a] = c[a];
+    }
+  };
+
+  LevelGeom G, R;                        // G: interpolation part of the current level; R: request part of the level in flight
+  HalfTaps A, B;
+  geom(0, R, 1);
+  request(0, R, 0, A); request(0, R, 1, B);
+  bool first = true;
+  for (;;) {
+    const int next = strip + gridDim.x;
+    const bool has_next = next < n_strips;
+    const int en = next / NBY, byn = next - en * NBY;
+    // accumulators start from the bias
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b4 = *reinterpret_cast<const float4*>(s_bias + mt * 32 + g * 8 + (lane >> 5) * 4);
+        acc[mt][0][4 * g] = b4.x; acc[mt][0][4 * g + 1] = b4.y; acc[mt][0][4 * g + 2] = b4.z; acc[mt][0][4 * g + 3] = b4.w;
+        acc[mt][1][4 * g] = b4.x; acc[mt][1][4 * g + 1] = b4.y; acc[mt][1][4 * g + 2] = b4.z; acc[mt][1][4 * g + 3] = b4.w;
+      }
+    const int e_cur = e, by_cur = by;
+#pragma unroll
+    for (int l = 0; l < NLEV; ++l) {
+      const bool more = l + 1 < NLEV;
+      // issue order: ... A_l B_l [16 stores of the previous block, l == 0 only] [next coords, after B_1's request]
+      if (l == 0 && !first && MODE != 2) wait_vm<BATCH + F_STORES>(); else wait_vm<BATCH>();
+      landed(A);
+      geom(l, G, 2);
+      consume(l, G, A, 0);                 // channels 0..20
+      if (more) { geom(l + 1, R, 1); request(l + 1, R, 0, A); }
+      else if (has_next) {
+        cur ^= 1; e = en; by = byn;
+        geom(0, R, 1); request(0, R, 0, A);
+      }
+      if (l == 0 && !first && MODE != 2) wait_vm<BATCH + F_STORES>(); else if (more || has_next) wait_vm<BATCH>(); else wait_vm<0>();
+      landed(B);
+      consume(l, G, B, 1);                 // channels 21..48
+#pragma unroll
+      for (int s = 0; s < 3; ++s) { unit(l * 3 + s, 0); unit(l * 3 + s, 1); }
+      if (more || has_next) request(more ? l + 1 : 0, R, 1, B);
+      if (l == 0 && has_next) {           // the next block's coordinates: LDS-DMA, no registers held across the levels
+        const int voff = ((byn * 8 + yy) * W + bx * 8 + xx) * 8;
+        const float* cbase = coords + (long)en * HW * 2;
+        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(cslot + (cur ^ 1) * 128));
+        unsigned keep_;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\t"
+                     "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %2, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep_) : "v"(voff), "v"(voff + 4), "s"(cbase), "s"(dst) : "memory");
+      }
+    }
+    // the 13th k-step (sample 48 of the four levels: k = level, the rest of that operand region stays zero)
+    unit(NLEV * 3, 0); unit(NLEV * 3, 1);
+    // ReLU, fp16, transposition through the wave's tile, 1 KB runs to the channel-last output
+    asm volatile("" ::: "memory");
+    __half* obase = out + (((long)e_cur * h + by_cur * 8) * W + bx * 8) * F_COUT;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x16& a = acc[mt][nt];
+          // ReLU after the rounding (same result: rounding is monotonic and keeps the sign), two values per instruction
+          const half2f z = {(_Float16)0.f, (_Float16)0.f};
+          const half2f lo = __builtin_elementwise_max(half2f{(_Float16)a[4 * g], (_Float16)a[4 * g + 1]}, z);
+          const half2f hi = __builtin_elementwise_max(half2f{(_Float16)a[4 * g + 2], (_Float16)a[4 * g + 3]}, z);
+          *reinterpret_cast<uint2*>(tile + (lane & 31) * FT_ROWB + (mt * 32 + g * 8 + (lane >> 5) * 4) * 2) =
+              uint2{__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi)};
+        }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int p = it * 64 + lane, px = p >> 4, slot = p & 15;
+        const uint4 v = *reinterpret_cast<const uint4*>(tile + px * FT_ROWB + slot * 16);
+        const int row = nt * 4 + (px >> 3), col = px & 7;
+        if (MODE == 2) { if (v.x == 0x12345678u && v.y == 0x9abcdef0u) out[0] = __float2half(0.f); }       // timing ablation: no output stores
+        else __builtin_nontemporal_store(__builtin_bit_cast(u32x4_nt, v), reinterpret_cast<u32x4_nt*>(obase + ((long)row * W + col) * F_COUT + slot * 8));
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+    }
+    asm volatile("" ::: "memory");
+    if (!has_next) break;
+    strip = next;
+    first = false;
+  }
+}
+
 // the skewed chunks of the build kernel need 64 % w2_l == 0 and cell pairs need w2_l even on every level:
 // w in {16,32,64}; h multiple of 8
 bool dims_ok(int h, int w) { return h >= 8 && h % 8 == 0 && (w == 16 || w == 32 || w == 64); }
@@ -750,4 +1002,42 @@ extern "C" int dh_corr_pyramid_lookup_nhwc(const void* pyramid, const float* coo
   if (E == 0) return DH_OK;
   if (!pyramid || !coords || !out) return DH_ERR_ARG;
   return launch_lookup<true>(pyramid, coords, out, E, h, w, (hipStream_t)stream);
+}
+
+extern "C" int dh_corr_pyramid_lookup_corr0(const void* pyramid, const float* coords, const void* wpk, const float* bias, void* out,
+                                            int E, int h, int w, dh_stream_t stream) {
+  if (E < 0 || !dims_ok(h, w)) return DH_ERR_ARG;
+  if (E == 0) return DH_OK;
+  if (!pyramid || !coords || !wpk || !bias || !out) return DH_ERR_ARG;
+  const PyrDims D = make_dims(h, w);
+  const int n_strips = E * (h / 8);
+  const size_t lds = (size_t)FW_BYTES + F_COUT * 4 + (size_t)(w / 8) * FWAVE_BYTES;
+  static int cu_count[64];
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+    if (!cu_count[dev]) { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cu_count[dev] = n; }
+    if (cu_count[dev]) cus = cu_count[dev];
+  }
+  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(160 * 1024 / lds, (size_t)(16 / (w / 8))));   // LDS and 2 waves / SIMD
+  const dim3 grid((unsigned)std::min<long>(n_strips, (long)cus * per_cu)), block(w * 8);
+  hipStream_t st = (hipStream_t)stream;
+  const int mode = opts().lookup_mode;                     // 2 / 3 / 5: timing ablations (wrong results), see the kernel
+  if (w == 64 && (mode == 2 || mode == 3 || mode == 5)) {
+#define DH_FUSED_MODE(M_)                                                                                                      \
+    { DH_LDS_OPTIN((&pyr_lookup_corr0_kernel<64, M_>), 160 * 1024);                                                            \
+      hipLaunchKernelGGL((pyr_lookup_corr0_kernel<64, M_>), grid, block, lds, st, (const __half*)pyramid, coords, (const __half*)wpk, bias, (__half*)out, D, n_strips); }
+    if (mode == 2) DH_FUSED_MODE(2) else if (mode == 3) DH_FUSED_MODE(3) else DH_FUSED_MODE(5)
+#undef DH_FUSED_MODE
+  } else if (w == 64) {
+    DH_LDS_OPTIN((&pyr_lookup_corr0_kernel<64>), 160 * 1024);
+    hipLaunchKernelGGL((pyr_lookup_corr0_kernel<64>), grid, block, lds, st, (const __half*)pyramid, coords, (const __half*)wpk, bias, (__half*)out, D, n_strips);
+  } else if (w == 32) {
+    DH_LDS_OPTIN((&pyr_lookup_corr0_kernel<32>), 160 * 1024);
+    hipLaunchKernelGGL((pyr_lookup_corr0_kernel<32>), grid, block, lds, st, (const __half*)pyramid, coords, (const __half*)wpk, bias, (__half*)out, D, n_strips);
+  } else {
+    DH_LDS_OPTIN((&pyr_lookup_corr0_kernel<16>), 160 * 1024);
+    hipLaunchKernelGGL((pyr_lookup_corr0_kernel<16>), grid, block, lds, st, (const __half*)pyramid, coords, (const __half*)wpk, bias, (__half*)out, D, n_strips);
+  }
+  DH_LAUNCH_CHECK();
+  return DH_OK;
 }

@@ -364,6 +364,21 @@ torch::Tensor corr_pyramid_lookup_nhwc(torch::Tensor pyramid, torch::Tensor coor
   return out;
 }
 
+torch::Tensor corr_pyramid_lookup_corr0(torch::Tensor pyramid, torch::Tensor coords, torch::Tensor wpk, torch::Tensor bias) {
+  CHECK_INPUT(pyramid); CHECK_INPUT(coords); CHECK_F32(coords); CHECK_INPUT(wpk); CHECK_INPUT(bias);
+  TORCH_CHECK(pyramid.scalar_type() == torch::kFloat16, "pyramid must be float16");
+  TORCH_CHECK(coords.dim() == 4 && coords.size(3) == 2, "corr_pyramid_lookup_corr0: coords [E,h,w,2]");
+  TORCH_CHECK(wpk.scalar_type() == torch::kFloat16 && wpk.numel() == 13 * 128 * 16, "corr_pyramid_lookup_corr0: wpk [13,128,16] float16");
+  TORCH_CHECK(bias.scalar_type() == torch::kFloat32 && bias.numel() == 128, "corr_pyramid_lookup_corr0: bias [128] float32");
+  const int E = (int)coords.size(0), h = (int)coords.size(1), w = (int)coords.size(2);
+  TORCH_CHECK(pyramid.size(0) == E && (size_t)pyramid.size(1) * 2 == dh_corr_pyramid_bytes(1, h, w),
+              "corr_pyramid_lookup_corr0: pyramid does not match coords");
+  torch::Tensor out = torch::empty({E, h, w, 128}, pyramid.options());
+  check_status(dh_corr_pyramid_lookup_corr0(pyramid.data_ptr(), coords.data_ptr<float>(), wpk.data_ptr(), bias.data_ptr<float>(),
+                                            out.data_ptr(), E, h, w, cur_stream()), "corr_pyramid_lookup_corr0");
+  return out;
+}
+
 torch::Tensor corr0_nchw(torch::Tensor x, torch::Tensor wp, torch::Tensor bias) {
   CHECK_INPUT(x); CHECK_INPUT(wp); CHECK_INPUT(bias);
   TORCH_CHECK(x.scalar_type() == torch::kFloat16 && x.dim() == 4 && x.size(1) == 196, "corr0_nchw: x [E,196,h,w] float16");
@@ -607,6 +622,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("corr_pyramid_build", &corr_pyramid_build, "all-pairs correlation pyramid, MI355X layout");
   m.def("corr_pyramid_lookup", &corr_pyramid_lookup, "fused 4-level lookup on the MI355X pyramid");
   m.def("corr_pyramid_lookup_nhwc", &corr_pyramid_lookup_nhwc, "fused 4-level lookup, channel-last output for the update operator");
+  m.def("corr_pyramid_lookup_corr0", &corr_pyramid_lookup_corr0, "4-level lookup fused with the correlation encoder's first layer (1x1, 196 -> 128, ReLU)");
   m.def("corr0_nchw", &corr0_nchw, "corr_encoder.0 (1x1, 196 -> 128, relu) on the reference-layout lookup output [E,196,h,w] -> [E,h,w,128]");
   m.def("glo_gemv", &glo_gemv, "global-context GEMV of the ConvGRU gates: fp16(bias + fp16(red * scale) wt)");
   m.def("segment_mean", &segment_mean, "mean over row segments (GraphAgg scatter_mean)");

@@ -17,6 +17,7 @@ struct Options {
   int dma_var;          // DH_DMA_VAR (0): timing ablations of that experiment
   int pyr_build_chunk;  // DH_PYR_BUILD=chunk (0): first form of the pyramid build kernel
   int lookup_mode;      // DH_LOOKUP_MODE (0): pyramid lookup variant: 1 = nt tap loads; 2 / 3 = timing ablations (no stores / no loads, wrong results)
+  int lookup_fused;     // DH_LOOKUP_FUSED (1): read by the host side (droid_amd.factor_graph, bench.py): lookup and the correlation encoder's first layer in one kernel (dh_corr_pyramid_lookup_corr0); 0 = dh_corr_pyramid_lookup + dh_corr0_nchw_f16
   int altcorr_v1;       // DH_ALTCORR_V1 (0): first form of the MFMA alt-correlation kernel (register staging) for A/B runs
   int conv_wino;        // DH_CONV_WINO (0): read by the host packer only (droid_amd.update): gate convolutions through the Winograd F(2,3) prototype
   int ba_strict;        // DH_BA_STRICT (1): dh_ba / dh_ba_build synchronise and return DH_ERR_ARG on bad indices / eta rows; 0 = asynchronous, such calls apply no update

@@ -132,6 +132,13 @@ class CorrBlock:
         batch, num, ht, wd, _ = coords.shape
         return droid_backends.corr_pyramid_lookup_nhwc(self.pyramid, coords.reshape(batch * num, ht, wd, 2).contiguous())
 
+    def lookup_corr0(self, coords, update_op):
+        """[1,E,h,w,2] -> [E,h,w,128] f16: the lookup and the first layer of the update operator's correlation encoder
+        (Conv2d(196,128,1) + ReLU, droid_net.py:96-100) in one kernel; pass it to UpdateModule.forward_nhwc(corr0=...)"""
+        batch, num, ht, wd, _ = coords.shape
+        wpk, bias = update_op.params["corr0_fused"]
+        return droid_backends.corr_pyramid_lookup_corr0(self.pyramid, coords.reshape(batch * num, ht, wd, 2).contiguous(), wpk, bias)
+
     def cat(self, other):
         self.pyramid = torch.cat([self.pyramid, other.pyramid], 0)
         return self

@@ -122,12 +122,23 @@ class FactorGraph:
         self.rm_factors(m, store=False)
 
     # ---- the update iteration (factor_graph.py:214-263) ------------------------------------------------------------
-    def _operator(self, net, coords1, target_prev, feats, ii):
+    def _operator(self, net, coords1, target_prev, feats, ii, corr0=None):
         """motion features + update operator on a set of edges -> (dw [E,h,w,4], damping [K,h,w], upmask, uniq)"""
         flow = db.motion_features(coords1, target_prev)
         uniq, ix, inp_frames, ctx = self._context(ii)
-        _, _, _, damping, upmask = self.update_op.forward_nhwc(net, None, feats, flow, ii, inp_frames=inp_frames, inp_index=ix, ctx=ctx)
+        _, _, _, damping, upmask = self.update_op.forward_nhwc(net, None, feats, flow, ii, inp_frames=inp_frames, inp_index=ix, ctx=ctx,
+                                                               corr0=corr0)
         return self.update_op.last_dw, damping, upmask, uniq
+
+    def _pyramid_features(self, block, coords1):
+        """correlation features of all edges from a CorrBlock -> (feats, corr0) for _operator: by default the lookup runs fused
+        with the correlation encoder's first layer (CorrBlock.lookup_corr0; option lookup_fused), else as the reference-layout
+        / channel-last lookup that the operator's first layer reads back"""
+        if db.get_option("lookup_fused"):
+            return None, block.lookup_corr0(coords1[None], self.update_op)
+        if self.update_op.wants_reference_layout_corr(*coords1.shape[1:3]):
+            return block(coords1[None])[0], None
+        return block.lookup_nhwc(coords1[None]), None
 
     def _context(self, ii):
         """source frames of the edge list, their context features channel-last and the gates' per-frame context term
@@ -149,11 +160,10 @@ class FactorGraph:
         if self.corr_impl != "volume":
             raise RuntimeError("update() needs corr_impl='volume' (use update_lowmem for 'alt')")
         if self._native_corr:
-            feats = (self.corr(coords1[None])[0] if self.update_op.wants_reference_layout_corr(*coords1.shape[1:3])
-                     else self.corr.lookup_nhwc(coords1[None]))
+            feats, corr0 = self._pyramid_features(self.corr, coords1)
         else:
-            feats = self.update_op.corr_to_nhwc(self.corr(coords1[None])[0])
-        dw, damping, upmask, uniq = self._operator(self._net, coords1, self.target[0].contiguous(), feats, ii)
+            feats, corr0 = self.update_op.corr_to_nhwc(self.corr(coords1[None])[0]), None
+        dw, damping, upmask, uniq = self._operator(self._net, coords1, self.target[0].contiguous(), feats, ii, corr0)
         if t0 is None:
             t0 = max(1, ii.min().item() + 1)
         target, weight, tb, wb = db.ba_inputs(coords1, dw)
@@ -207,11 +217,10 @@ class FactorGraph:
         if corr == "pyramid" or (corr == "auto" and self._pyramid_fits(len(self.ii), ht, wd)):
             c = (self.ii == self.jj).long() if rig > 1 else torch.zeros_like(self.ii)
             block = CorrBlock(v.fmaps[self.ii, 0][None], v.fmaps[self.jj, c][None])
-            ref_layout = self.update_op.wants_reference_layout_corr(ht, wd)
             for _ in range(steps):
                 coords1 = v.reproject(self.ii, self.jj)[0][0]
-                feats = block(coords1[None])[0] if ref_layout else block.lookup_nhwc(coords1[None])
-                dw, damping, upmask, uniq = self._operator(self._net, coords1, self.target[0].contiguous(), feats, self.ii)
+                feats, corr0 = self._pyramid_features(block, coords1)
+                dw, damping, upmask, uniq = self._operator(self._net, coords1, self.target[0].contiguous(), feats, self.ii, corr0)
                 target, weight, tb, wb = db.ba_inputs(coords1, dw)
                 self.target, self.weight = target[None], weight[None]
                 self.damping[uniq] = damping

@@ -139,6 +139,19 @@ def pack_conv_halo(weight):
 LAYOUT_AUTO, LAYOUT_WINO = 0, 4          # DH_CONV_LAYOUT_* of include/droid_hip.h
 
 
+def pack_corr0_fused(w0):
+    """corr_encoder.0.weight [128,196] (input channel = level*49 + xoff*7 + yoff, corr.py:46-50) -> [13,128,16] fp16 in the
+    K order of csrc/corr_pyramid.hip pyr_lookup_corr0_kernel: k-step level*3 + s holds the level's samples kk = 16s..16s+15
+    with kk = yoff*7 + xoff (the order the interpolation produces them in); the four samples kk = 48 share k-step 12."""
+    out = torch.zeros(13, 128, 16, dtype=torch.float32, device=w0.device)
+    for l in range(4):
+        for kk in range(48):
+            xoff, yoff = kk % 7, kk // 7
+            out[l * 3 + kk // 16, :, kk % 16] = w0[:, l * 49 + xoff * 7 + yoff]
+        out[12, :, l] = w0[:, l * 49 + 48]
+    return out.half().contiguous()
+
+
 def pack_conv_wino(weight):
     """[Cout,Ctot,3,3] -> [CoutPad/128, Ctot/32, 3 dy, 4 positions, 128, 4 slots, 8] f16 for conv3x3_wino_kernel (PROTOTYPE:
     Winograd F(2,3) along x): per kernel row the three taps g0 g1 g2 become (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2), computed in
@@ -230,6 +243,8 @@ class UpdateModule:
         w0n = torch.zeros(128, 208, device=self.device)
         w0n[:, :COR_PLANES] = w0.reshape(128, COR_PLANES)
         P["corr0_nchw"] = (w0n.half().contiguous(), g("corr_encoder.0.bias").float().contiguous())
+        # the same layer inside the lookup kernel (droid_backends.corr_pyramid_lookup_corr0): [13 k-steps][128][16] fp16
+        P["corr0_fused"] = (pack_corr0_fused(w0.reshape(128, COR_PLANES)), P["corr0_nchw"][1])
         self.cmap = cmap
         P["corr2"] = conv("corr_encoder.2")
         P["flow0"] = conv("flow_encoder.0", 8)
@@ -316,7 +331,7 @@ class UpdateModule:
             self._seg_key, self._seg = key, (order, seg_off, ii)       # (ii kept alive: its address is part of the key)
         return self._seg[0], self._seg[1]
 
-    def forward_nhwc(self, net, inp, corr, flow, ii, inp_frames=None, inp_index=None, ctx=None):
+    def forward_nhwc(self, net, inp, corr, flow, ii, inp_frames=None, inp_index=None, ctx=None, corr0=None):
         """net [E,h,w,128] f16 (updated IN PLACE), corr = [E,196,h,w] f16 in the reference's layout (pixel counts that are a
         multiple of 128) or [4,E,h,w,56] f16, the level-planar channel-last output of
         droid_backends.corr_pyramid_lookup_nhwc (channel order: corr_channel_map), flow [E,h,w,8] f16 (4 + zero pad),
@@ -325,10 +340,14 @@ class UpdateModule:
           * inp = None, inp_frames [K',h,w,128] f16 + inp_index [E] int64: edge e uses row inp_index[e] (what the reference's
             callers pass in effect: video.inps[ii]); the gate convolutions then run over 320 instead of 448 channels on top
             of one per-frame convolution (`context_term`, passed in as `ctx` [K',h,w,384] f32 if the caller keeps it).
+        corr0 [E,h,w,128] f16 (then corr is ignored): the output of the correlation encoder's first layer, as
+        CorrBlock.lookup_corr0 produces it inside the lookup kernel.
         -> (net, delta [E,h,w,2] f32, weight [E,h,w,2] f32, eta [K,h,w] f32, upmask [K,h,w,576] f16)."""
         P = self.params
         E, h, w, _ = net.shape
-        if corr.dim() == 4 and corr.shape[1] == COR_PLANES:      # reference layout [E,196,h,w] (see wants_reference_layout_corr)
+        if corr0 is not None:
+            c0 = corr0
+        elif corr.dim() == 4 and corr.shape[1] == COR_PLANES:      # reference layout [E,196,h,w] (see wants_reference_layout_corr)
             c0 = droid_backends.corr0_nchw(corr, P["corr0_nchw"][0], P["corr0_nchw"][1])
         else:
             c0 = P["corr0"]([corr[0], corr[1], corr[2], corr[3]], EPI_RELU)

@@ -134,6 +134,14 @@ int dh_corr_pyramid_lookup(const void* pyramid, const float* coords, void* out,
  *   out [4,E,h,w,56] f16 (level-planar), channel = yoff*7 + xoff, channels 49..55 are zero. */
 int dh_corr_pyramid_lookup_nhwc(const void* pyramid, const float* coords, void* out,
                                 int E, int h, int w, dh_stream_t stream);
+/* the lookup fused with the layer that consumes it, the correlation encoder's Conv2d(196, 128, 1) + ReLU
+ * (reference droid_slam/droid_net.py:96-100, first layer of corr_encoder on the output of corr.py:46-50): the 196 window
+ * samples are rounded to fp16 as dh_corr_pyramid_lookup stores them and multiplied out of registers on the matrix cores.
+ *   wpk  [13][128][16] f16: k-step l*3+s (s < 3) = channels kk = 16s..16s+15 of level l, kk = yoff*7 + xoff (reference
+ *        input channel l*49 + xoff*7 + yoff); k-step 12: k = l < 4 is channel kk = 48 of level l, the rest zero.
+ *   bias [128] f32;  out [E,h,w,128] f16 (channel-last). */
+int dh_corr_pyramid_lookup_corr0(const void* pyramid, const float* coords, const void* wpk, const float* bias, void* out,
+                                 int E, int h, int w, dh_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Dense bundle adjustment.  Replaces ba (reference src/droid.cpp:93-122 -> ba_cuda,

@@ -13,6 +13,7 @@ ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--flow", default="reproj")
 ap.add_argument("--build-reps", type=int, default=0)
 ap.add_argument("--nhwc", action="store_true", help="channel-last variant (feeds the update operator)")
+ap.add_argument("--fused", action="store_true", help="also time corr_pyramid_lookup_corr0 (lookup + first encoder layer) against lookup + corr0_nchw")
 ap.add_argument("--modes", default="", help="comma list of lookup_mode values to time one after the other on the same pyramid "
                 "(0 product, 1 nt tap loads, 2 no output stores, 3 no tap loads -- 2 / 3 are timing ablations with wrong results)")
 a = ap.parse_args()
@@ -65,3 +66,31 @@ db.set_option("lookup_mode", 0)
 ms = float(np.median(t)); nbytes = 880.0 * E * h * w
 print("lookup%s %s E=%d: median %.3f ms min %.3f  -> %.1f GB/s algorithmic (%.1f%% of 8 TB/s)" % (
     " channel-last" if a.nhwc else "", a.flow, E, ms, min(t), nbytes / ms / 1e6, nbytes / ms / 1e6 / 80.0))
+if a.fused:
+    sys.path.insert(0, os.path.join(ROOT, "droid-slam_amd"))
+    from droid_amd.update import pack_corr0_fused
+    wgt = torch.randn(128, 196, device="cuda") * 0.05
+    bias = torch.randn(128, device="cuda") * 0.3
+    wpk = pack_corr0_fused(wgt)
+    wp = torch.zeros(128, 208, device="cuda", dtype=torch.half); wp[:, :196] = wgt.half()
+    def timed(fn):
+        fn(); torch.cuda.synchronize(); tt = []
+        for _ in range(a.reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); r = fn(); e1.record(); torch.cuda.synchronize(); tt.append(e0.elapsed_time(e1))
+        return float(np.median(tt)), r
+    t_f, o_f = timed(lambda: db.corr_pyramid_lookup_corr0(pyr, coords, wpk, bias))
+    t_l, smp = timed(lambda: db.corr_pyramid_lookup(pyr, coords))
+    t_c, o_u = timed(lambda: db.corr0_nchw(smp, wp, bias))
+    d = (o_f.float() - o_u.float()).abs().max().item()
+    print("fused lookup+corr0: %.3f ms   unfused: lookup %.3f + corr0_nchw %.3f = %.3f ms   max |diff| %.3e (scale %.2f)  reads+writes 744 B/ep -> %.1f GB/s" % (
+        t_f, t_l, t_c, t_l + t_c, d, o_u.float().abs().max().item(), 744.0 * E * h * w / t_f / 1e6))
+    for mode in (2, 3, 5, 6, 7, 6, 7):
+        db.set_option("lookup_mode", mode)
+        tm, _ = timed(lambda: db.corr_pyramid_lookup_corr0(pyr, coords, wpk, bias))
+        print("  fused, variant %d (%s): %.3f ms" % (mode, {2: "no output stores", 3: "no tap loads", 5: "a quarter of the MFMAs", 6: "MFMAs after each level", 7: "k-step 0 inside the second half level"}[mode], tm))
+    db.set_option("lookup_mode", 0)
+    for rep in range(2):
+        t_f2, _ = timed(lambda: db.corr_pyramid_lookup_corr0(pyr, coords, wpk, bias))
+        t_l2, _ = timed(lambda: db.corr_pyramid_lookup(pyr, coords))
+        print("  again, product kernels: fused %.3f ms, unfused lookup %.3f ms" % (t_f2, t_l2))

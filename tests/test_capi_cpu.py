@@ -177,6 +177,17 @@ def test_convolution_weight_packing_layouts(built):
     # correlation channel map: our level-planar (yoff, xoff) order against the reference's (xoff, yoff) order
     m = U.corr_channel_map()
     assert m.numel() == 224 and (m >= 0).sum() == 196 and sorted(m[m >= 0].tolist()) == list(range(196))
+    # first correlation layer packed for the fused lookup kernel: every reference channel exactly once, in the kernel's K order
+    w0 = torch.randn(128, 196).half().float()
+    p = U.pack_corr0_fused(w0)
+    assert tuple(p.shape) == (13, 128, 16) and p.dtype == torch.float16
+    seen = set()
+    for l in range(4):
+        for kk in range(48):
+            ch = l * 49 + (kk % 7) * 7 + kk // 7                      # level*49 + xoff*7 + yoff, kk = yoff*7 + xoff
+            assert torch.equal(p[l * 3 + kk // 16, :, kk % 16].float(), w0[:, ch]); seen.add(ch)
+        assert torch.equal(p[12, :, l].float(), w0[:, l * 49 + 48]); seen.add(l * 49 + 48)
+    assert seen == set(range(196)) and torch.count_nonzero(p[12, :, 4:]) == 0
     for k, v in saved.items():
         db.set_option(k, v)
 
@@ -202,6 +213,10 @@ def test_round3_entry_points_and_host_helpers(built):
     assert lib.dh_corr_volume_pool(None, None, 7, ctypes.c_long(4), 30, 40, None) == 1         # null pointers before the dtype is looked at
     assert lib.dh_altcorr_fwd_nhwc_level(None, None, None, None, None, None, 2, 2, 128, 48, 64, 24, 32, 3, 1, ctypes.c_long(10), None) == 1   # stride < 49 HW
     assert lib.dh_reproject_ex(None, None, None, 1, None, None, None, None, 0, 48, 64, None) == 0
+    assert lib.dh_corr_pyramid_lookup_corr0(None, None, None, None, None, 0, 48, 64, None) == 0     # no edges
+    assert lib.dh_corr_pyramid_lookup_corr0(None, None, None, None, None, 2, 48, 64, None) == 1     # null pointers
+    assert lib.dh_corr_pyramid_lookup_corr0(None, None, None, None, None, 2, 30, 40, None) == 1     # not a pyramid shape
+    assert lib.dh_get_option(b"lookup_fused", ctypes.byref(ctypes.c_int())) == 0
     assert lib.dh_corr_index_fwd(None, None, None, 2, 0, 4, 4, 4, 4, 3, None) == 0             # DH_F64 accepted
     e0 = lib.dh_options_epoch()
     v = ctypes.c_int()

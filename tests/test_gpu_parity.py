@@ -705,6 +705,36 @@ def test_corr0_on_reference_layout_features(db):
         db.corr0_nchw(torch.zeros(1, 196, 12, 16, device="cuda").half(), wp, bias)      # 192 pixels: not a multiple of 128
 
 
+def test_lookup_fused_with_first_encoder_layer(db):
+    """droid_backends.corr_pyramid_lookup_corr0 (lookup + Conv2d(196,128,1) + ReLU of droid_net.py:96-100 in one kernel) ==
+    the 1x1 layer in fp32 on the fp16 samples that corr_pyramid_lookup stores, for windows inside, across and outside the
+    image, at all three widths, and with more strips than persistent workgroups (E*h/8 > number of CUs)"""
+    from droid_amd.update import pack_corr0_fused
+    torch.manual_seed(5)
+    rng = np.random.default_rng(8)
+    for (E, h, w) in [(3, 16, 64), (4, 8, 16), (3, 16, 32), (1, 48, 64), (120, 48, 64)]:
+        f1 = torch.randn(E, 128, h, w, device="cuda").half()
+        f2 = torch.randn(E, 128, h, w, device="cuda").half()
+        pyr = db.corr_pyramid_build(f1, f2)
+        coords = dev(_smooth_coords(rng, E, h, w))
+        coords[E // 2] += 7.3                                             # one edge with windows leaving the image
+        wgt = (torch.randn(128, 196, device="cuda") * 0.05)
+        bias = torch.randn(128, device="cuda") * 0.3
+        wpk = pack_corr0_fused(wgt)
+        samples = db.corr_pyramid_lookup(pyr, coords)                     # [E,196,h,w] f16
+        out = db.corr_pyramid_lookup_corr0(pyr, coords, wpk, bias)
+        torch.cuda.synchronize()
+        assert out.shape == (E, h, w, 128) and out.dtype == torch.half
+        ref = torch.empty(E, h, w, 128, device="cuda")
+        for e0 in range(0, E, 8):
+            ref[e0:e0 + 8] = torch.relu(torch.einsum("ekhw,ck->ehwc", samples[e0:e0 + 8].float(), wgt.half().float()) + bias)
+        assert ref.abs().max() > 1.0
+        err = (out.float() - ref).abs().max().item()
+        assert err <= 2.0 ** -9 * ref.abs().max().item(), (E, h, w, err)
+        assert torch.equal(out, db.corr_pyramid_lookup_corr0(pyr, coords, wpk, bias))       # deterministic
+        del pyr, samples, out, ref
+
+
 def test_update_operator_same_result_from_both_correlation_layouts(db):
     """forward_nhwc on the reference-layout features [E,196,h,w] (corr0_nchw) and on the channel-last level-planar
     features (implicit GEMM): same operator, results within one fp16 rounding of the first layer"""
