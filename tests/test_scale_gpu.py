@@ -112,6 +112,25 @@ def test_pyramid_lookup_on_all_c3_edges_vs_reference(db, ref, c3):
             o = ocorr.corr_block_lookup(ocorr.corr_pyramid(f1, f2, 4), cc[e][None].cpu().numpy(), 3)
             assert np.abs(out[e].float().cpu().numpy() - o[0]).max() <= 2.0 ** -9 * np.abs(o).max()
         del out, want, got
+    # the kernel the iteration runs: the same lookup fused with corr_encoder.0 (Conv2d(196,128,1) + ReLU, droid_net.py:96-100),
+    # all 4096 edges in one launch (24576 strips on 256 persistent workgroups), against the layer applied in fp32 to the
+    # reference's own samples on the edge sample
+    from droid_amd.update import pack_corr0_fused
+    torch.manual_seed(2)
+    wgt = torch.randn(128, 196, device="cuda") * 0.05
+    bias = torch.randn(128, device="cuda") * 0.3
+    for cc in (coords, coords_b):
+        c0 = db.corr_pyramid_lookup_corr0(pyr, cc.contiguous(), pack_corr0_fused(wgt), bias)
+        torch.cuda.synchronize()
+        assert c0.shape == (E, h, w, 128)
+        want = _reference_layout_lookup(ref[0], fm[ii[sel]].contiguous(), fm[jj[sel]].contiguous(), cc[sel].contiguous())
+        lay = torch.relu(torch.einsum("ekhw,ck->ehwc", want.float(), wgt.half().float()) + bias)
+        scale = lay.abs().max().item()
+        assert scale > 1.0
+        # the reference's fp16 bilinear sums differ from the fp32 ones by up to 2^-8 of the samples' scale per sample; through
+        # 196 weights of size 0.05 that is far below 2^-7 of the layer's scale
+        assert (c0[sel].float() - lay).abs().max().item() <= 2.0 ** -7 * scale
+        del c0, want, lay
     del pyr
     _free()
 
