@@ -754,6 +754,10 @@ __global__ __launch_bounds__(W * 8, 1) void pyr_lookup_corr0_kernel(const __half
         if (MODE == 3) asm volatile("v_mov_b32 %0, %1" : "=v"(T.raw[jj][m]) : "v"(rowoff + G.coloff[m]));
         else asm volatile("global_load_dword %0, %1, %2" : "=v"(T.raw[jj][m]) : "v"(rowoff + G.coloff[m]), "s"(G.base));
     }
+    // MODE 6 = the synchronous twin of the product kernel: every batch is waited for where it is issued, so no register is ever
+    // in flight across compiler-scheduled code.  Same arithmetic in the same order -> the test suite requires bit-identical
+    // output from MODE 0, which is how the product binary's explicit vmcnt bookkeeping is checked on real launches.
+    if (MODE == 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
   auto landed = [&](HalfTaps& T) {
 #pragma unroll
@@ -864,6 +868,7 @@ __global__ __launch_bounds__(W * 8, 1) void pyr_lookup_corr0_kernel(const __half
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\t"
                      "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %2, %3\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep_) : "v"(voff), "v"(voff + 4), "s"(cbase), "s"(dst) : "memory");
+        if (MODE == 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
     }
     // the 13th k-step (sample 48 of the four levels: k = level, the rest of that operand region stays zero)
@@ -1021,12 +1026,12 @@ extern "C" int dh_corr_pyramid_lookup_corr0(const void* pyramid, const float* co
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(160 * 1024 / lds, (size_t)(16 / (w / 8))));   // LDS and 2 waves / SIMD
   const dim3 grid((unsigned)std::min<long>(n_strips, (long)cus * per_cu)), block(w * 8);
   hipStream_t st = (hipStream_t)stream;
-  const int mode = opts().lookup_mode;                     // 2 / 3 / 5: timing ablations (wrong results), see the kernel
-  if (w == 64 && (mode == 2 || mode == 3 || mode == 5)) {
+  const int mode = opts().lookup_mode;                     // 2 / 3 / 5: timing ablations (wrong results); 6: synchronous twin (same results)
+  if (w == 64 && (mode == 2 || mode == 3 || mode == 5 || mode == 6)) {
 #define DH_FUSED_MODE(M_)                                                                                                      \
     { DH_LDS_OPTIN((&pyr_lookup_corr0_kernel<64, M_>), 160 * 1024);                                                            \
       hipLaunchKernelGGL((pyr_lookup_corr0_kernel<64, M_>), grid, block, lds, st, (const __half*)pyramid, coords, (const __half*)wpk, bias, (__half*)out, D, n_strips); }
-    if (mode == 2) DH_FUSED_MODE(2) else if (mode == 3) DH_FUSED_MODE(3) else DH_FUSED_MODE(5)
+    if (mode == 2) DH_FUSED_MODE(2) else if (mode == 3) DH_FUSED_MODE(3) else if (mode == 5) DH_FUSED_MODE(5) else DH_FUSED_MODE(6)
 #undef DH_FUSED_MODE
   } else if (w == 64) {
     DH_LDS_OPTIN((&pyr_lookup_corr0_kernel<64>), 160 * 1024);

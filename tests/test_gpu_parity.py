@@ -705,7 +705,7 @@ def test_corr0_on_reference_layout_features(db):
         db.corr0_nchw(torch.zeros(1, 196, 12, 16, device="cuda").half(), wp, bias)      # 192 pixels: not a multiple of 128
 
 
-def test_lookup_fused_with_first_encoder_layer(db):
+def test_lookup_fused_with_first_encoder_layer(db, option):
     """droid_backends.corr_pyramid_lookup_corr0 (lookup + Conv2d(196,128,1) + ReLU of droid_net.py:96-100 in one kernel) ==
     the 1x1 layer in fp32 on the fp16 samples that corr_pyramid_lookup stores, for windows inside, across and outside the
     image, at all three widths, and with more strips than persistent workgroups (E*h/8 > number of CUs)"""
@@ -732,6 +732,15 @@ def test_lookup_fused_with_first_encoder_layer(db):
         err = (out.float() - ref).abs().max().item()
         assert err <= 2.0 ** -9 * ref.abs().max().item(), (E, h, w, err)
         assert torch.equal(out, db.corr_pyramid_lookup_corr0(pyr, coords, wpk, bias))       # deterministic
+        if w == 64:
+            # the synchronous twin of the kernel (lookup_mode 6: every tap batch is waited for where it is issued) computes the same
+            # sums in the same order: bit-identical output <=> the product kernel's explicit vmcnt bookkeeping let no register be
+            # read, copied or spilled while its load was in flight on this launch
+            option("lookup_mode", 6)
+            sync = db.corr_pyramid_lookup_corr0(pyr, coords, wpk, bias)
+            option("lookup_mode", 0)
+            assert torch.equal(out, sync)
+            del sync
         del pyr, samples, out, ref
 
 

@@ -123,6 +123,13 @@ def test_pyramid_lookup_on_all_c3_edges_vs_reference(db, ref, c3):
         c0 = db.corr_pyramid_lookup_corr0(pyr, cc.contiguous(), pack_corr0_fused(wgt), bias)
         torch.cuda.synchronize()
         assert c0.shape == (E, h, w, 128)
+        db.set_option("lookup_mode", 6)                                 # synchronous twin: see test_lookup_fused_with_first_encoder_layer
+        try:
+            sync = db.corr_pyramid_lookup_corr0(pyr, cc.contiguous(), pack_corr0_fused(wgt), bias)
+        finally:
+            db.set_option("lookup_mode", 0)
+        assert torch.equal(c0, sync)
+        del sync
         want = _reference_layout_lookup(ref[0], fm[ii[sel]].contiguous(), fm[jj[sel]].contiguous(), cc[sel].contiguous())
         lay = torch.relu(torch.einsum("ekhw,ck->ehwc", want.float(), wgt.half().float()) + bias)
         scale = lay.abs().max().item()
