@@ -857,9 +857,9 @@ __global__ __launch_bounds__(W * 8, 1) void pyr_lookup_corr0_kernel(const __half
       if (l == 0 && !first && MODE != 2) wait_vm<BATCH + F_STORES>(); else if (more || has_next) wait_vm<BATCH>(); else wait_vm<0>();
       landed(B);
       consume(l, G, B, 1);                 // channels 21..48
+      if (more || has_next) request(more ? l + 1 : 0, R, 1, B);      // (before the MFMAs: the batch has their time to land)
 #pragma unroll
       for (int s = 0; s < 3; ++s) { unit(l * 3 + s, 0); unit(l * 3 + s, 1); }
-      if (more || has_next) request(more ? l + 1 : 0, R, 1, B);
       if (l == 0 && has_next) {           // the next block's coordinates: LDS-DMA, no registers held across the levels
         const int voff = ((byn * 8 + yy) * W + bx * 8 + xx) * 8;
         const float* cbase = coords + (long)en * HW * 2;
