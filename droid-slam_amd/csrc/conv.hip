@@ -76,8 +76,10 @@ __device__ __forceinline__ void xcd_decode(const ConvParams& P, long& m0, int& n
   }
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
-__device__ __forceinline__ float tanhf_(float x) { const float e = __expf(-2.f * fabsf(x)); const float t = (1.f - e) / (1.f + e); return x < 0 ? -t : t; }
+// v_rcp_f32 (1 ulp) instead of the IEEE division sequence (ten instructions per gate value): every result is rounded to fp16
+// right after, as the reference's autocast does with its own fp32 sigmoid / tanh
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { const float e = __expf(-2.f * fabsf(x)); const float t = (1.f - e) * __builtin_amdgcn_rcpf(1.f + e); return x < 0 ? -t : t; }
 __device__ __forceinline__ float round_h(float v) { return __half2float(__float2half(v)); }
 
 // v if ok else 0, component-wise (a select on the 128-bit vector is lowered through scratch memory by hipcc)
