@@ -655,11 +655,13 @@ __global__ __launch_bounds__(NHWC ? 64 : W * 8, NHWC ? 3 : 4) void pyr_lookup_ke
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Fused lookup + first correlation-encoder layer (droid_net.py:96-100: Conv2d(196, 128, 1) + ReLU on the lookup's output):
-// the 196 window samples of a pixel never leave the registers of its lane.  A lane converts them to fp16 exactly as the
-// unfused kernel stores them, v_permlane32_swap turns eight packed dwords of every lane into the B operands of two
-// 32-pixel tiles, the weights ([13 k-steps][128 couts][16 channels] fp16, 52 KB) sit in LDS for the life of a PERSISTENT
-// workgroup, and v_mfma_f32_32x32x16_f16 accumulates D[128 couts][64 pixels] (128 accumulator registers).  What goes to HBM
-// is the 128-channel layer output (256 B per edge-pixel) instead of the 392 B of samples that the 1x1 layer would read back.
+// the 196 window samples of a pixel never leave the CU.  A lane converts them to fp16 exactly as the unfused kernel stores
+// them and writes them, eight channels (one 16-byte piece) at a time, into its wave's LDS tile in the B-operand layout of
+// v_mfma_f32_32x32x16_f16 ([k-step][pixel tile][k half][32 pixels][8 channels]: the writes and the wave's own ds_read_b128
+// fragment reads are contiguous); the weights ([13 k-steps][128 couts][16 channels] fp16, 52 KB) sit in LDS for the life of a
+// PERSISTENT workgroup, and the MFMA accumulates D[128 couts][64 pixels] (128 accumulator registers per lane).  What goes to
+// HBM is the 128-channel layer output (256 B per edge-pixel) instead of the 392 B of samples that the 1x1 layer would read
+// back.  (The operands went through registers at first -- 24 packed dwords + v_permlane32_swap per level -- which spilled.)
 // K order: level l, k-step s < 3 holds the level's channels kk = 16 s .. 16 s + 15 (kk = yoff * 7 + xoff, i.e. the order
 // in which the interpolation produces them); the four channels kk = 48 share the 13th k-step.
 constexpr int FK_STEPS = NLEV * 3 + 1;
