@@ -1359,10 +1359,15 @@ __global__ __launch_bounds__(512, 4) void glo_reduce_kernel(ConvParams P) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
+      for (int q = 0; q < 16; q += 2) {
+        if ((q & 7) == 0) __builtin_amdgcn_sched_barrier(0);      // (keeps the 32 LDS reads from being hoisted in one block: spills)
+        // two rows at a time: the gate values rounded to fp16 as a pair, the products as ONE packed fp16 multiply (the
+        // exact product of two fp16 numbers has 22 significant bits, so rounding it from fp32 or inside v_pk_mul_f16 is the
+        // same single rounding), their fp32 sum as one v_dot2 against (1, 1)
         const int row = wm0 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh;
-        const float g = round_h(sigmoidf_(acc[a][b][q] + bias));
-        t += round_h(g * __half2float(s_conv[row * GLD + co]));
+        const half2v g = {(_Float16)sigmoidf_(acc[a][b][q] + bias), (_Float16)sigmoidf_(acc[a][b][q + 1] + bias)};
+        const half2v n = {__builtin_bit_cast(_Float16, s_conv[row * GLD + co]), __builtin_bit_cast(_Float16, s_conv[(row + 1) * GLD + co])};
+        t = __builtin_amdgcn_fdot2(g * n, half2v{(_Float16)1.f, (_Float16)1.f}, t, false);
       }
     sum[b] = t + __shfl_xor(t, 32, 64);
   }
