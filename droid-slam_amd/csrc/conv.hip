@@ -1232,6 +1232,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(ConvParams P) {
 // halo of a 4-row tile with its 4 real channels (5.6 KB) and ALL weights [128 cout][7 dy][8 dx (7 + one zero tap)][4 ch]
 // (57 KB, row stride 464 B: conflict-free ds_read_b128).  A k-step of 16 = four x-adjacent taps of one kernel row, which are
 // 16 contiguous bytes of the halo per lane pair: K = 7 x 32 = 224 -> 14 k-steps instead of 25, no staging inside the loop.
+// (Round 3 measured a persistent form -- one workgroup per CU walking the tiles, a wave's 28 B fragments resident in 112
+// registers, the next tile's halo fetched under the epilogue: 0.555-0.588 ms against 0.565-0.576 ms for this kernel on
+// 2048 edges.  Reloading the weights per tile is not what the kernel waits for; not kept.)
 constexpr int C7_COLS = 72, C7_ROWS = 10, C7_K = 224, C7_WLD = C7_K + 8;
 constexpr int C7_A_BYTES = C7_ROWS * C7_COLS * 8, C7_W_BYTES = 128 * C7_WLD * 2;
 constexpr int C7_LDS_BYTES = (C7_A_BYTES + C7_W_BYTES) > BM * (128 + 8) * 2 ? (C7_A_BYTES + C7_W_BYTES) : BM * (128 + 8) * 2;
