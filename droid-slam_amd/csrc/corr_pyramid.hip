@@ -243,11 +243,16 @@ __global__ __launch_bounds__(256) void pyr_build_kernel(const __half* __restrict
 // quad-swizzled for the ds_read_b128 of the B fragments) and prefetched a step ahead.  Steps h2 .. h2+R-2 revisit the
 // first target rows for the displacement rows that wrap around (15 % more MFMA work at level 0, nothing else).
 // one level of the ring build; NTL = 16-target tiles per target row (compile time: everything below stays in registers)
-template <int NTL>
+// NT = threads of the workgroup: 256 (4 waves = 4 source row pairs, every wave all NTL target tiles) or 512 (8 waves: the
+// second four take the upper half of the target tiles -- twice the waves per CU on the same 80 KB of LDS)
+template <int NTL, int NT>
 __device__ __forceinline__ void ring_level(const half8 (&afrag)[4], const __half* __restrict__ trow0, __half* __restrict__ lbase,
                                            unsigned char* __restrict__ ring, unsigned char* __restrict__ sB,
                                            int l, int h2, int w2, int by, int bx, int tid) {
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = (tid >> 6) & 3, wt = tid >> 8;      // wave = source row pair, wt = target half (NT = 512)
+  constexpr int NTW = (NT == 512 && NTL >= 2) ? NTL / 2 : NTL;           // target tiles of this wave: wt * NTW .. + NTW
+  const bool has_tiles = NT == 256 || NTL >= 2 || wt == 0;
+  const int nt0 = (NT == 512 && NTL >= 2) ? wt * NTW : 0;
   const int j = lane & 15, yy = 2 * wave + (lane >> 5), xq = ((lane >> 4) & 1) * 4;     // pixel p_r = yy*8 + xq + r
   const int R = 8 >> l, ybase = (by * 8) >> l;
   const int rowbytes = w2 * 128;                                  // one displacement row: w2/2 pairs x 64 px x 4 B
@@ -255,12 +260,12 @@ __device__ __forceinline__ void ring_level(const half8 (&afrag)[4], const __half
   const int d = ((by * 8 + yy) >> l) - ybase;                      // this lane's source row offset inside the block
   // byte offset inside a ring row of the value (tile nt, register r) of this lane -- the same at every step -- or -1
   // for the padding columns of a row shorter than 16 targets
-  int soff[NTL][4];
+  int soff[NTW][4];
 #pragma unroll
-  for (int nt = 0; nt < NTL; ++nt)
+  for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int x2 = nt * 16 + j, x1l = (bx * 8 + xq + r) >> l;
+      const int x2 = (nt0 + nt) * 16 + j, x1l = (bx * 8 + xq + r) >> l;
       const int u = wrap(x2 - x1l, w2), up = u >> 1, p = yy * 8 + xq + r;
       const int f = (up & 3) | ((up & 4) << 2);
       soff[nt][r] = x2 < w2 ? ((up * 64 + (p ^ f)) << 2) + ((u & 1) << 1) : -1;
@@ -268,11 +273,13 @@ __device__ __forceinline__ void ring_level(const half8 (&afrag)[4], const __half
   // B staging role: piece id = tid + 256*q -> (target id>>4, quad id&15), q < NTL.  Target rows are fetched THREE steps
   // ahead into registers.  (A __syncthreads() would drain vmcnt and with it the prefetch: the LDS traffic of a step only
   // needs lgkmcnt(0) + s_barrier.)
-  u32x4 breg[3][NTL];     // (native vectors: arrays of HIP's uint4 struct assigned under a condition end up in scratch)
-  int b_src[NTL], b_dst[NTL];
+  constexpr int NQ = (NTL * 256 + NT - 1) / NT;        // 16-byte pieces of a target row per thread
+  const bool stages = NTL * 256 >= NT || tid < NTL * 256;
+  u32x4 breg[3][NQ];      // (native vectors: arrays of HIP's uint4 struct assigned under a condition end up in scratch)
+  int b_src[NQ], b_dst[NQ];
 #pragma unroll
-  for (int q = 0; q < NTL; ++q) {
-    const int id = tid + 256 * q, row = id >> 4, quad = id & 15;
+  for (int q = 0; q < NQ; ++q) {
+    const int id = tid + NT * q, row = id >> 4, quad = id & 15;
     b_src[q] = min(row, w2 - 1) * CH + quad * 8;
     b_dst[q] = row * 256 + ((quad ^ (row & 15)) << 4);
   }
@@ -280,28 +287,30 @@ __device__ __forceinline__ void ring_level(const half8 (&afrag)[4], const __half
 #define RING_FETCH_B(k_, s_)                                                                                         \
   if ((k_) < nsteps) {                                                                                               \
     const __half* trow = trow0 + (long)((ybase + (k_)) % h2) * w2 * CH;                                              \
-    _Pragma("unroll") for (int q = 0; q < NTL; ++q) breg[s_][q] = *reinterpret_cast<const u32x4*>(trow + b_src[q]);  \
+    if (stages) { _Pragma("unroll") for (int q = 0; q < NQ; ++q) breg[s_][q] = *reinterpret_cast<const u32x4*>(trow + b_src[q]); } \
   }
 #define RING_STEP(k_, s_)                                                                                            \
   if ((k_) < nsteps) {                                                                                               \
     const int k = (k_);                                                                                              \
-    _Pragma("unroll") for (int q = 0; q < NTL; ++q) *reinterpret_cast<u32x4*>(sB + b_dst[q]) = breg[s_][q];          \
+    if (stages) { _Pragma("unroll") for (int q = 0; q < NQ; ++q) *reinterpret_cast<u32x4*>(sB + b_dst[q]) = breg[s_][q]; } \
     RING_BARRIER();                         /* target row staged; last step's completed row has been read out */    \
     RING_FETCH_B(k + 3, s_)                                                                                          \
     const int v = k - d;                    /* displacement row this lane's pixels contribute to */                  \
     const bool vok = v >= 0 && v < h2;                                                                               \
     unsigned char* const rslot = ring + (v & (R - 1)) * rowbytes;                                                    \
-    f32x4 acc[NTL];                                                                                                  \
-    _Pragma("unroll") for (int nt = 0; nt < NTL; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};                          \
+    f32x4 acc[NTW];                                                                                                  \
+    _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};                          \
+    if (has_tiles) {                                                                                                 \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {        /* the tiles' accumulation chains interleaved */       \
-      half8 b[NTL];                                                                                                  \
-      _Pragma("unroll") for (int nt = 0; nt < NTL; ++nt)                                                             \
-        b[nt] = *reinterpret_cast<const half8*>(sB + (nt * 16 + j) * 256 + (((ks * 4 + (lane >> 4)) ^ j) << 4));     \
-      _Pragma("unroll") for (int nt = 0; nt < NTL; ++nt)                                                             \
+      half8 b[NTW];                                                                                                  \
+      _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt)                                                             \
+        b[nt] = *reinterpret_cast<const half8*>(sB + ((nt0 + nt) * 16 + j) * 256 + (((ks * 4 + (lane >> 4)) ^ j) << 4)); \
+      _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt)                                                             \
         acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag[ks], b[nt], acc[nt], 0, 0, 0);                        \
     }                                                                                                                \
-    if (vok) {                                                                                                       \
-      _Pragma("unroll") for (int nt = 0; nt < NTL; ++nt)                                                             \
+    }                                                                                                                \
+    if (vok && has_tiles) {                                                                                          \
+      _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt)                                                             \
         _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                                \
           if (NTL > 1 || soff[nt][r] >= 0)                                                                           \
             *reinterpret_cast<__half*>(rslot + soff[nt][r]) = __float2half(acc[nt][r] * 0.0625f);                    \
@@ -311,7 +320,7 @@ __device__ __forceinline__ void ring_level(const half8 (&afrag)[4], const __half
     if (vdone >= 0 && vdone < h2) {                                                                                  \
       const unsigned char* src = ring + (vdone & (R - 1)) * rowbytes;                                                \
       __half* dst = lbase + (long)vdone * (rowbytes >> 1);                                                           \
-      for (int n4 = tid; n4 < w2 * 8; n4 += 256) {                                                                   \
+      for (int n4 = tid; n4 < w2 * 8; n4 += NT) {                                                                    \
         const int up = n4 >> 4, p0 = (n4 & 15) << 2;                                                                 \
         const int f = (up & 3) | ((up & 4) << 2);                                                                    \
         const uint4 c = *reinterpret_cast<const uint4*>(src + ((up * 64 + (p0 ^ (f & 16))) << 2));                   \
@@ -337,18 +346,18 @@ __device__ __forceinline__ void ring_level(const half8 (&afrag)[4], const __half
 #undef RING_BARRIER
   // the all-zero row v = h2 of this level
   uint4* z = reinterpret_cast<uint4*>(lbase + (long)h2 * w2 * 64);
-  for (int o = tid; o < w2 * 8; o += 256) z[o] = uint4{0u, 0u, 0u, 0u};
+  for (int o = tid; o < w2 * 8; o += NT) z[o] = uint4{0u, 0u, 0u, 0u};
 }
 
-template <int W>
-__global__ __launch_bounds__(256) void pyr_build_ring_kernel(const __half* __restrict__ f1T, const __half* __restrict__ f2T,
+template <int W, int NT = 256>
+__global__ __launch_bounds__(NT) void pyr_build_ring_kernel(const __half* __restrict__ f1T, const __half* __restrict__ f2T,
                                                              __half* __restrict__ pyr, PyrDims D, long f1_stride_e,
                                                              long f2_stride_e) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_ring_raw[];
   unsigned char* const ring = s_ring_raw;                          // [R][w2 * 32 dwords]
   unsigned char* const sB = s_ring_raw + (size_t)W * 1024;         // [target][256 B], 16-byte quads XOR-ed with row & 15
   const int e = blockIdx.y, sb = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;
   constexpr int nbx = W / 8;
   const int by = sb / nbx, bx = sb - by * nbx;
   // A fragments of this wave's 16 source pixels (rows yy = 2*wave, 2*wave+1): lane holds A[i = lane&15][k = (lane>>4)*8..+8]
@@ -366,7 +375,7 @@ __global__ __launch_bounds__(256) void pyr_build_ring_kernel(const __half* __res
   {                                                                                                                  \
     constexpr int w2 = W >> (l_);                                                                                    \
     constexpr int NTL = w2 >= 16 ? w2 / 16 : 1;                                                                      \
-    ring_level<NTL>(afrag, bbase + (long)D.tgt_off[l_] * CH, obase + D.lev_off[l_] + (long)sb * D.blk_elems[l_],     \
+    ring_level<NTL, NT>(afrag, bbase + (long)D.tgt_off[l_] * CH, obase + D.lev_off[l_] + (long)sb * D.blk_elems[l_],     \
                     ring, sB, l_, h >> (l_), w2, by, bx, tid);                                                       \
   }
   RING_LEVEL(0) RING_LEVEL(1) RING_LEVEL(2) RING_LEVEL(3)
@@ -952,7 +961,11 @@ extern "C" int dh_corr_pyramid_build(const void* fmap1, const void* fmap2, void*
   } else {
     const size_t lds = (size_t)w * 1024 + (size_t)(w > 16 ? w : 16) * 256;       // row ring + one staged target row
     const dim3 grid(D.nblk, E);
-    if (w == 64) {
+    if (w == 64 && opts().pyr_build_waves == 8) {
+      DH_LDS_OPTIN((&pyr_build_ring_kernel<64, 512>), 80 * 1024);
+      hipLaunchKernelGGL((pyr_build_ring_kernel<64, 512>), grid, dim3(512), lds, st, (const __half*)f1T, (const __half*)f2T,
+                         (__half*)pyramid, D, s1, s2);
+    } else if (w == 64) {
       DH_LDS_OPTIN((&pyr_build_ring_kernel<64>), 80 * 1024);
       hipLaunchKernelGGL(pyr_build_ring_kernel<64>, grid, dim3(256), lds, st, (const __half*)f1T, (const __half*)f2T,
                          (__half*)pyramid, D, s1, s2);

@@ -16,6 +16,7 @@ struct Options {
   int conv_xcd;         // DH_CONV_XCD (1): XCD-aware workgroup order of the 3x3 halo2 kernel (conv.hip xcd_decode)
   int dma_var;          // DH_DMA_VAR (0): timing ablations of that experiment
   int pyr_build_chunk;  // DH_PYR_BUILD=chunk (0): first form of the pyramid build kernel
+  int pyr_build_waves;  // DH_PYR_BUILD_WAVES (8): waves per workgroup of the row-ring build kernel at w = 64 (4 = the first form)
   int lookup_mode;      // DH_LOOKUP_MODE (0): pyramid lookup variant: 1 = nt tap loads; 2 / 3 = timing ablations (no stores / no loads, wrong results); fused kernel: also 5 (a quarter of the MFMAs) and 6 = synchronous twin (every tap batch waited for at issue; same results, used by the tests)
   int lookup_fused;     // DH_LOOKUP_FUSED (1): read by the host side (droid_amd.factor_graph, bench.py): lookup and the correlation encoder's first layer in one kernel (dh_corr_pyramid_lookup_corr0); 0 = dh_corr_pyramid_lookup + dh_corr0_nchw_f16
   int altcorr_v1;       // DH_ALTCORR_V1 (0): first form of the MFMA alt-correlation kernel (register staging) for A/B runs

@@ -26,6 +26,7 @@ Options& opts() {
     const char* pb = getenv("DH_PYR_BUILD");
     v.pyr_build_chunk = (pb && !strcmp(pb, "chunk")) ? 1 : 0;
     v.ba_strict = env_int("DH_BA_STRICT", 1);
+    v.pyr_build_waves = env_int("DH_PYR_BUILD_WAVES", 8);
     v.lookup_mode = env_int("DH_LOOKUP_MODE", 0);
     v.lookup_fused = env_int("DH_LOOKUP_FUSED", 1);
     v.altcorr_v1 = env_int("DH_ALTCORR_V1", 0);
@@ -50,6 +51,7 @@ static int* slot(const char* name) {
   if (!strcmp(name, "dma_var")) return &o.dma_var;
   if (!strcmp(name, "pyr_build_chunk")) return &o.pyr_build_chunk;
   if (!strcmp(name, "ba_strict")) return &o.ba_strict;
+  if (!strcmp(name, "pyr_build_waves")) return &o.pyr_build_waves;
   if (!strcmp(name, "lookup_mode")) return &o.lookup_mode;
   if (!strcmp(name, "lookup_fused")) return &o.lookup_fused;
   if (!strcmp(name, "altcorr_v1")) return &o.altcorr_v1;

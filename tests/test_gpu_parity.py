@@ -469,6 +469,10 @@ def test_native_pyramid_build_kernels_are_bit_identical(db, option):
         option("pyr_build_chunk", 0)
         b = db.corr_pyramid_build(f1, f2)
         assert torch.equal(a, b)
+        option("pyr_build_waves", 4)                     # w = 64: the four-wave form of the row-ring kernel (8 waves is the default)
+        c = db.corr_pyramid_build(f1, f2)
+        option("pyr_build_waves", 8)
+        assert torch.equal(b, c)
 
 
 def test_native_pyramid_cat_and_index(db):
