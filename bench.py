@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--no-check", action="store_true", help="skip the untimed output check of the step (N = 1 only): the same "
                     "iteration through the reference-layout entry points (reference-layout volumes + corr_index_forward, the "
                     "reference interface of the update operator with per-edge context features, ba) from the same state")
+    ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic in this run (rocprofv3 --pmc pass in a child process)")
     ap.add_argument("--no-sensitivity", action="store_true", help="skip the untimed flow-sensitivity runs of the lookup kernel")
     ap.add_argument("--lowmem", action="store_true", help="time FactorGraph.update_lowmem steps (the global-BA iteration, "
                     "reference factor_graph.py:266-330) instead of FactorGraph.update steps")
@@ -64,6 +65,73 @@ def parse():
                     "global-BA iteration: on-the-fly alt-correlation in source-frame chunks, or a pyramid built once per call")
     ap.add_argument("--chunk-frames", type=int, default=64, help="source frames per chunk of the alt-correlation path")
     return ap.parse_args()
+
+
+def measure_lookup_traffic(variant, edges, timeout_s=240):
+    """HBM bytes per edge-pixel of the lookup kernel, measured now: `rocprofv3 --kernel-trace --pmc <TCC_EA0 request counters>`
+    around scripts/bench_lookup.py (same kernel, same reprojection flow, `edges` edges), one pass -- the four counters fill
+    the TCC's four slots (MI355X_MICROARCH.md "rocprofv3 PMC slots"); bytes = RDREQ_128B * 128 + (RDREQ - RDREQ_128B) * 64 +
+    WRREQ_64B * 64 + (WRREQ - WRREQ_64B) * 32 -- request sizes, so the guide's x2 correction of FETCH_SIZE (which tallies a
+    128-byte request at 64) is not needed.  -> (bytes per edge-pixel, source note) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if rp is None:
+        return None, "rocprofv3 not on PATH"
+    tmp = tempfile.mkdtemp(prefix="dh_pmc_", dir="/tmp")
+    flag = {"fused": ["--fused"], "nhwc": ["--nhwc"], "nchw": []}[variant]
+    cmd = [rp, "--kernel-trace", "--pmc", "TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_128B_sum", "TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum",
+           "--output-format", "csv", "-d", tmp, "-o", "run", "--", sys.executable, os.path.join(ROOT, "scripts", "bench_lookup.py"),
+           "--edges", str(edges), "--reps", "2", "--flow", "reproj"] + flag
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout_s,
+                           env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp")
+        files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            return None, "rocprofv3 --pmc pass failed (rc %d): %s" % (r.returncode, r.stdout.strip()[-200:])
+        want = "pyr_lookup_corr0_kernel<64, 0>" if variant == "fused" else "pyr_lookup_kernel"
+        agg = {}
+        for f in files:
+            for row in csv.DictReader(open(f)):
+                if want in row["Kernel_Name"]:
+                    n, v = agg.get(row["Counter_Name"], (0, 0.0))
+                    agg[row["Counter_Name"]] = (n + 1, v + float(row["Counter_Value"]))
+        c = {k: v / n for k, (n, v) in agg.items()}
+        if not all(k in c for k in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_128B_sum", "TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum")):
+            return None, "counters missing in the rocprofv3 output: %s" % sorted(c)
+        rd = c["TCC_EA0_RDREQ_128B_sum"] * 128 + (c["TCC_EA0_RDREQ_sum"] - c["TCC_EA0_RDREQ_128B_sum"]) * 64
+        wr = c["TCC_EA0_WRREQ_64B_sum"] * 64 + (c["TCC_EA0_WRREQ_sum"] - c["TCC_EA0_WRREQ_64B_sum"]) * 32
+        return (rd + wr) / (edges * 48 * 64), ("measured in this run: rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum "
+                                                 "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum -- scripts/bench_lookup.py --edges %d --flow reproj %s "
+                                                 "(per-dispatch average of %d launches; read %.3f GB + written %.3f GB)" % (
+                                                     edges, " ".join(flag), agg["TCC_EA0_RDREQ_sum"][0], rd / 1e9, wr / 1e9))
+    except subprocess.TimeoutExpired:
+        return None, "rocprofv3 --pmc pass exceeded %d s" % timeout_s
+    except Exception as exc:                                   # an informational field must never cost the bench line
+        return None, "rocprofv3 --pmc pass: %r" % (exc,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def reference_python_baseline(threads, timeout_s=300):
+    """The reference's OWN Python formulation (geom/ba.py:BA + modules/corr.py:CorrBlock + droid_net.py:UpdateModule,
+    unmodified, from oracle/_ref/ref_py.zip) timed on this host at BASELINE configs[1] = C2, beside the port's C3 figure:
+    north_star's "Python/CPU fallback".  Own process (oracle/time_reference_python.py): the reference binds the module
+    names `lietorch`, `torch_scatter`, `droid_backends`, which are the product's modules in this one."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "time_reference_python.py"), "--threads", str(max(1, threads))]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s,
+                           env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"skipped": "oracle/time_reference_python.py failed (rc %d): %s" % (r.returncode, r.stderr.strip()[-300:])}
+        return json.loads(lines[-1])
+    except subprocess.TimeoutExpired:
+        return {"skipped": "oracle/time_reference_python.py exceeded %d s" % timeout_s}
 
 
 def cpu_baseline(g, n_lookup_edges=64, n_update_edges=128, repeats=3):
@@ -174,7 +242,9 @@ def cpu_baseline(g, n_lookup_edges=64, n_update_edges=128, repeats=3):
         t_up1 = time.perf_counter() - t0
     per_ep1 = t_ba1 / (len(sub["ii"]) * ht * wd) + t_lk1 / (16 * ht * wd) + t_up1 / (16 * ht * wd)
     torch.set_num_threads(nthreads0)
-    return {"value": 1.0 / per_ep, "unit": "edge-pixels/s", "cores": max(th_ba, th_lk, th_up), "kind": "port",
+    ref_py = reference_python_baseline(th_up)
+    return {"reference_python_c2": ref_py,
+            "value": 1.0 / per_ep, "unit": "edge-pixels/s", "cores": max(th_ba, th_lk, th_up), "kind": "port",
             "sample": "oracle (numpy/torch-CPU, fp32) on a %d-core host, every leg at its fastest thread count, 1 warm-up + median of %d: "
                       "ba itrs=%d on the whole %d-keyframe / %d-edge graph (%.2fs, %d threads) + 4-level lookup of %d edges (%.3fs, %d threads) "
                       "+ update operator on %d edges (%.3fs, %d threads)" % (
@@ -571,12 +641,12 @@ def main():
         # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc, separate passes, gfx950
         # FETCH_SIZE correction; scripts/pmc_bench_lookup.sh), scaled to this rank's edge-pixels; None if not measured
         traffic = traffic_src = None
+        variant = "fused" if fused_lookup else "nhwc" if (upd is not None and corr is not None and not ref_layout) else "nchw"
         try:
             cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_lookup_pmc.json"))
             pmc = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))             # the latest round's passes
-            variant = "fused" if fused_lookup else "nhwc" if (upd is not None and corr is not None and not ref_layout) else "nchw"
             traffic = pmc[variant]["hbm_bytes_per_edge_pixel"] * E * HW
-            traffic_src = "profiles/%s (rocprofv3 --pmc passes of the same kernel at 4096 edges, committed; not re-measured in this run)" % cands[-1]
+            traffic_src = "profiles/%s (rocprofv3 --pmc passes of the same kernel at 4096 edges, committed; NOT re-measured in this run)" % cands[-1]
         except (OSError, KeyError, ValueError):
             pass
         out = {
@@ -632,6 +702,17 @@ def main():
             out["roofline_update_operator"] = {"error": repr(exc)}
         if not args.no_cpu_baseline and world == 1:        # rank 0 at N = 1 only (the other ranks would wait in teardown)
             out["cpu_baseline"] = cpu_baseline(g)
+        if world == 1 and not args.no_pmc and corr is not None:
+            # roofline.traffic measured IN THIS RUN: one rocprofv3 --pmc pass over the same kernel / flow / edge count in a
+            # child process, after everything is timed and the bench's own pyramid (105 GB at C3) is released
+            corr.pyramid = None
+            import gc
+            gc.collect(); torch.cuda.empty_cache()
+            per_ep, why = measure_lookup_traffic(variant, E)
+            if per_ep is not None:
+                out["roofline"]["traffic"], out["roofline"]["traffic_source"] = per_ep * E * HW, why
+            elif out["roofline"]["traffic_source"]:
+                out["roofline"]["traffic_source"] += " [in-run pass: %s]" % why
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

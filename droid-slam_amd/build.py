@@ -25,6 +25,14 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 HIP_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
              "-Wno-unused-result", "-ffp-contract=fast"]
+# DROID_HIP_ABLATION=1: also compile the prototype kernels (LDS-DMA / Winograd convolutions, first forms of the pyramid build
+# and alt-correlation kernels) and the timing ablations of the lookup that return wrong results by construction
+# (lookup_mode 2-5).  The shipped library is built WITHOUT it: those variants do not exist in it and dh_set_option refuses them.
+ABLATION = os.environ.get("DROID_HIP_ABLATION", "0") == "1"
+if ABLATION:
+    HIP_FLAGS.append("-DDH_ABLATION=1")
+    OBJ = os.path.join(HERE, "build", "ablation")        # own object directory: the two builds never mix objects
+MODE_STAMP = os.path.join(HERE, "build", ".lib_mode")    # which of the two builds libdroid_hip.so currently is
 
 
 def _run(cmd, verbose):
@@ -67,8 +75,11 @@ def build_lib(force=False, verbose=False):
             jobs.append([HIPCC] + HIP_FLAGS + ["-c", s, "-o", o])
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(lambda c: _run(c, verbose), jobs))
-    if force or jobs or _newer(LIB, objs):
+    mode = "ablation" if ABLATION else "release"
+    have = open(MODE_STAMP).read().strip() if os.path.exists(MODE_STAMP) else "release"
+    if force or jobs or _newer(LIB, objs) or have != mode:
         _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs, verbose)
+        open(MODE_STAMP, "w").write(mode)
     return LIB
 
 

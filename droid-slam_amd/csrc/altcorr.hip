@@ -199,6 +199,7 @@ __device__ __forceinline__ int wave_max_i(int v) {
   return v;
 }
 
+#ifdef DH_ABLATION   // first form of the MFMA alt-correlation kernel (1.4x slower, bit-identical): A/B only
 __global__ __launch_bounds__(AWPB * 64) void altcorr_mfma_kernel(
     const __half* __restrict__ f1, const __half* __restrict__ f2, const float* __restrict__ coords,
     const int64_t* __restrict__ us, const int64_t* __restrict__ vs, __half* __restrict__ corr,
@@ -351,6 +352,7 @@ __global__ __launch_bounds__(AWPB * 64) void altcorr_mfma_kernel(
     __builtin_amdgcn_wave_barrier();
   }
 }
+#endif  // DH_ABLATION
 
 // ---- second form of the MFMA kernel (default; DH_ALTCORR_V1=1 selects the first) ----------------------------------------
 // The first form spends its time waiting: a wave stages 64 targets x 256 B through 64 registers, then multiplies, then
@@ -617,12 +619,15 @@ extern "C" int dh_altcorr_fwd_nhwc_level(const void* fmap1, const void* fmap2, c
   if (M == 0) return DH_OK;
   if (!fmap1 || !fmap2 || !coords || !ii || !jj || !corr) return DH_ERR_ARG;
   const int nblk = (H / 8) * (W / 8);
+#ifdef DH_ABLATION
   if (opts().altcorr_v1) {
     const size_t lds = (size_t)AWPB * (64 * SF_LD + 64 * SC_LD) * sizeof(__half);
     hipLaunchKernelGGL(altcorr_mfma_kernel, dim3((nblk + AWPB - 1) / AWPB, M), dim3(AWPB * 64), lds, (hipStream_t)stream,
                        (const __half*)fmap1, (const __half*)fmap2, coords, ii, jj, (__half*)corr, H, W, H2, W2, nblk,
                        1.0f / (float)(1 << level), corr_stride_m);
-  } else {
+  } else
+#endif
+  {
     if (((uintptr_t)fmap2) % 16 || (long)H2 * W2 * AC * 2 >= (1L << 31)) return DH_ERR_ARG;      // 16-byte DMA pieces, 32-bit lane offsets
     hipLaunchKernelGGL(altcorr_mfma2_kernel, dim3((nblk + A2_WPB - 1) / A2_WPB, M), dim3(A2_WPB * 64), (size_t)A2_WPB * A2_WAVE_BYTES,
                        (hipStream_t)stream, (const __half*)fmap1, (const __half*)fmap2, coords, ii, jj, (__half*)corr, H, W, H2, W2, nblk,

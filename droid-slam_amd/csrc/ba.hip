@@ -1316,7 +1316,7 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(
     const float* __restrict__ Ei, const float* __restrict__ Ej, const float* __restrict__ dx,
     const int64_t* __restrict__ jj, const int* __restrict__ kx, const int* __restrict__ eoff,
     const int* __restrict__ eidx, const int* __restrict__ meta, int HW, int t0, int P,
-    float* __restrict__ dz_out, int n_dz_rows) {
+    float* __restrict__ dz_out, int n_dz_rows, int own_lo, int own_hi) {
   const int k = blockIdx.x;
   const int p = blockIdx.y * 256 + threadIdx.x;
   if (p >= HW) return;
@@ -1339,7 +1339,9 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(
       for (int a = 0; a < 6; ++a) s += Ej[((long)e * 6 + a) * HW + p] * dx[6 * r + a];
     }
   }
-  const float dz = meta[2] ? 0.f : Q[(long)k * HW + p] * (W[(long)k * HW + p] - s);      // flagged arguments: no update at all
+  // flagged arguments: no update at all; edge-sharded solver: only the owner of a frame moves its depths (a non-owner
+  // holds none of the frame's edges, its Q / w are the damping and the sensor prior alone)
+  const float dz = (meta[2] || f < own_lo || f >= own_hi) ? 0.f : Q[(long)k * HW + p] * (W[(long)k * HW + p] - s);
   disps[(long)f * HW + p] += dz;
   if (dz_out && k < n_dz_rows) dz_out[(long)k * HW + p] = dz;
 }
@@ -1352,6 +1354,53 @@ __global__ void ba_pose_retr_kernel(float* __restrict__ poses, const float* __re
   for (int a = 0; a < 6; ++a) xi[a] = dx[6 * i + a];
   SE3f T = load_pose(poses + 7 * (long)(t0 + i));
   store_pose(poses + 7 * (long)(t0 + i), retr(xi, T));
+}
+
+
+// ------------------------------------------------------------------------------------------ edge-sharded exchange
+// The reduced camera system of one rank's edges is non-zero only on the co-visible 6x6 blocks (lower triangle).  The
+// multi-GPU solver exchanges ONE contiguous fp64 buffer per Gauss-Newton iteration:
+//   [n_blocks][6][6] blocks (bp[b], bq[b]) | rhs [6P] | status[2]
+// status[0] = this rank's argument flag (meta[2] != 0), status[1] = a flag of the host (block pattern stale); both are
+// summed by the all-reduce, so every rank sees the same verdict and applies / skips the update together.
+__global__ __launch_bounds__(256) void ba_pack_blocks_kernel(
+    const double* __restrict__ H, int ld, int npad, int n, const int* __restrict__ bp, const int* __restrict__ bq,
+    int n_blocks, const int* __restrict__ meta, int host_flags, double* __restrict__ packed) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long nb36 = (long)n_blocks * 36;
+  if (i < nb36) {
+    const int b = (int)(i / 36), rc = (int)(i - (long)b * 36), r = rc / 6, c = rc - 6 * r;
+    packed[i] = H[(long)(6 * bp[b] + r) * ld + 6 * bq[b] + c];
+  } else if (i < nb36 + n) {
+    packed[i] = H[(long)npad * ld + (i - nb36)];
+  } else if (i == nb36 + n) {
+    packed[i] = meta[2] ? 1.0 : 0.0;
+  } else if (i == nb36 + n + 1) {
+    packed[i] = host_flags ? 1.0 : 0.0;
+  }
+}
+
+__global__ __launch_bounds__(256) void ba_unpack_blocks_kernel(
+    double* __restrict__ H, int ld, int npad, int n, const int* __restrict__ bp, const int* __restrict__ bq,
+    int n_blocks, int* __restrict__ meta, const double* __restrict__ packed) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long nb36 = (long)n_blocks * 36;
+  if (i < nb36) {
+    const int b = (int)(i / 36), rc = (int)(i - (long)b * 36), r = rc / 6, c = rc - 6 * r;
+    H[(long)(6 * bp[b] + r) * ld + 6 * bq[b] + c] = packed[i];
+  } else if (i < nb36 + n) {
+    H[(long)npad * ld + (i - nb36)] = packed[i];
+  } else if (i == nb36 + n) {
+    if (packed[nb36 + n] != 0.0 || packed[nb36 + n + 1] != 0.0) atomicOr(&meta[2], 4);   // some rank flagged: nobody updates
+  }
+}
+
+// dense exchange: the flags travel in a separate 2-element buffer
+__global__ void ba_flags_get_kernel(const int* __restrict__ meta, int host_flags, double* __restrict__ status) {
+  status[0] = meta[2] ? 1.0 : 0.0; status[1] = host_flags ? 1.0 : 0.0;
+}
+__global__ void ba_flags_set_kernel(int* __restrict__ meta, const double* __restrict__ status) {
+  if (status[0] != 0.0 || status[1] != 0.0) atomicOr(&meta[2], 4);
 }
 
 // ------------------------------------------------------------------------------------------ host
@@ -1415,7 +1464,7 @@ int run_build(const BaLayout& L, char* ws, const float* poses, const float* disp
 
 int run_finish(const BaLayout& L, char* ws, float* poses, float* disps, const int64_t* jj, int F, int HW,
                int t0, float lm, float ep, int motion_only, float* dx_out, float* dz_out, int n_dz_rows,
-               hipStream_t st) {
+               hipStream_t st, int own_lo = 0, int own_hi = 1 << 30) {
   double* H = (double*)(ws + L.H);
   double* x = (double*)(ws + L.x);
   double* Linv = (double*)(ws + L.Linv);
@@ -1468,7 +1517,7 @@ int run_finish(const BaLayout& L, char* ws, float* poses, float* disps, const in
     hipLaunchKernelGGL(ba_backsub_kernel, dim3(F, (HW + 255) / 256), dim3(256), 0, st, disps,
                        (const float*)(ws + L.Q), (const float*)(ws + L.W), (const float*)(ws + L.Ei),
                        (const float*)(ws + L.Ej), dxw, jj, (const int*)(ws + L.kx), (const int*)(ws + L.eoff),
-                       (const int*)(ws + L.eidx), meta, HW, t0, L.P, dz_out, n_dz_rows);
+                       (const int*)(ws + L.eidx), meta, HW, t0, L.P, dz_out, n_dz_rows, own_lo, own_hi);
     DH_LAUNCH_CHECK();
   }
   if (L.P > 0) {
@@ -1505,8 +1554,8 @@ extern "C" int dh_ba_system_shape(int t0, int t1, int* rows, int* cols) {
   return DH_OK;
 }
 
-extern "C" int dh_ba_build(const float* poses, const float* disps, const float* intrinsics, const float* disps_sens,
-                           const float* targets, const float* weights, const float* eta,
+static int ba_build_impl(int strict, const float* poses, const float* disps, const float* intrinsics, const float* disps_sens,
+                         const float* targets, const float* weights, const float* eta,
                            const int64_t* ii, const int64_t* jj,
                            int num_frames, int n_edges, int n_eta_rows, int ht, int wd,
                            int t0, int t1, int motion_only,
@@ -1528,13 +1577,93 @@ extern "C" int dh_ba_build(const float* poses, const float* disps, const float* 
   if (Hsys_out) *Hsys_out = (double*)(ws + L.H);
   if (bsys_out) *bsys_out = (double*)(ws + L.H) + (size_t)L.npad * L.ld;
   if (rc != DH_OK) return rc;
-  return strict_check(L, ws, st);                  // (the caller's all-reduce of the system follows: a natural sync point)
+  return strict ? strict_check(L, ws, st) : DH_OK;
 }
 
-extern "C" int dh_ba_finish(float* poses, float* disps, const int64_t* jj,
-                            int num_frames, int n_edges, int ht, int wd, int t0, int t1,
-                            float lm, float ep, int motion_only, float* dx_out, float* dz_out,
-                            void* workspace, size_t workspace_bytes, dh_stream_t stream) {
+extern "C" int dh_ba_build(const float* poses, const float* disps, const float* intrinsics, const float* disps_sens,
+                           const float* targets, const float* weights, const float* eta,
+                           const int64_t* ii, const int64_t* jj,
+                           int num_frames, int n_edges, int n_eta_rows, int ht, int wd,
+                           int t0, int t1, int motion_only,
+                           double** Hsys_out, double** bsys_out, void* workspace, size_t workspace_bytes,
+                           dh_stream_t stream) {
+  return ba_build_impl(1, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, num_frames, n_edges, n_eta_rows,
+                       ht, wd, t0, t1, motion_only, Hsys_out, bsys_out, workspace, workspace_bytes, stream);
+}
+
+// the edge-sharded solver's build: never synchronises -- a rank-local error before the collective would leave the other
+// ranks waiting in it; the argument flag travels with the exchanged buffer instead (dh_ba_pack_blocks / dh_ba_exchange_flags)
+extern "C" int dh_ba_build_shard(const float* poses, const float* disps, const float* intrinsics, const float* disps_sens,
+                                 const float* targets, const float* weights, const float* eta,
+                                 const int64_t* ii, const int64_t* jj,
+                                 int num_frames, int n_edges, int n_eta_rows, int ht, int wd,
+                                 int t0, int t1, int motion_only,
+                                 double** Hsys_out, double** bsys_out, void* workspace, size_t workspace_bytes,
+                                 dh_stream_t stream) {
+  return ba_build_impl(0, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, num_frames, n_edges, n_eta_rows,
+                       ht, wd, t0, t1, motion_only, Hsys_out, bsys_out, workspace, workspace_bytes, stream);
+}
+
+extern "C" size_t dh_ba_packed_len(int n_blocks, int t0, int t1) {
+  if (n_blocks < 0 || t0 < 0 || t1 < t0) return 0;
+  return (size_t)n_blocks * 36 + 6 * (size_t)(t1 - t0) + 2;
+}
+
+static int pack_args(int num_frames, int n_edges, int ht, int wd, int t0, int t1, int motion_only, const void* workspace,
+                     size_t workspace_bytes, const int32_t* bp, const int32_t* bq, int n_blocks, const void* packed, BaLayout* L) {
+  int rc = check_args(num_frames, n_edges, ht, wd, t0, t1);
+  if (rc != DH_OK) return rc;
+  if (!workspace || !packed || n_blocks < 0 || (n_blocks > 0 && (!bp || !bq))) return DH_ERR_ARG;
+  *L = make_layout(num_frames, n_edges, ht * wd, t0, t1, motion_only);
+  if (workspace_bytes < L->total || ((uintptr_t)workspace & 255)) return DH_ERR_WORKSPACE;
+  return DH_OK;
+}
+
+extern "C" int dh_ba_pack_blocks(const void* workspace, size_t workspace_bytes, int num_frames, int n_edges, int ht, int wd,
+                                 int t0, int t1, int motion_only, const int32_t* bp, const int32_t* bq, int n_blocks,
+                                 int host_flags, double* packed, dh_stream_t stream) {
+  BaLayout L;
+  int rc = pack_args(num_frames, n_edges, ht, wd, t0, t1, motion_only, workspace, workspace_bytes, bp, bq, n_blocks, packed, &L);
+  if (rc != DH_OK) return rc;
+  const char* ws = (const char*)workspace;
+  const long total = (long)n_blocks * 36 + L.n + 2;
+  hipLaunchKernelGGL(ba_pack_blocks_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const double*)(ws + L.H), L.ld, L.npad, L.n, bp, bq, n_blocks, (const int*)(ws + L.meta), host_flags, packed);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
+extern "C" int dh_ba_unpack_blocks(void* workspace, size_t workspace_bytes, int num_frames, int n_edges, int ht, int wd,
+                                   int t0, int t1, int motion_only, const int32_t* bp, const int32_t* bq, int n_blocks,
+                                   const double* packed, dh_stream_t stream) {
+  BaLayout L;
+  int rc = pack_args(num_frames, n_edges, ht, wd, t0, t1, motion_only, workspace, workspace_bytes, bp, bq, n_blocks, packed, &L);
+  if (rc != DH_OK) return rc;
+  char* ws = (char*)workspace;
+  const long total = (long)n_blocks * 36 + L.n + 1;
+  hipLaunchKernelGGL(ba_unpack_blocks_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (double*)(ws + L.H), L.ld, L.npad, L.n, bp, bq, n_blocks, (int*)(ws + L.meta), packed);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
+// dense exchange (no block pattern): get -> all-reduce(SUM) of status[2] -> set
+extern "C" int dh_ba_exchange_flags(void* workspace, size_t workspace_bytes, int num_frames, int n_edges, int ht, int wd,
+                                    int t0, int t1, int motion_only, int host_flags, double* status, int set, dh_stream_t stream) {
+  BaLayout L;
+  int rc = pack_args(num_frames, n_edges, ht, wd, t0, t1, motion_only, workspace, workspace_bytes, nullptr, nullptr, 0, status, &L);
+  if (rc != DH_OK) return rc;
+  char* ws = (char*)workspace;
+  if (set) hipLaunchKernelGGL(ba_flags_set_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (int*)(ws + L.meta), (const double*)status);
+  else hipLaunchKernelGGL(ba_flags_get_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const int*)(ws + L.meta), host_flags, status);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
+static int ba_finish_impl(float* poses, float* disps, const int64_t* jj,
+                          int num_frames, int n_edges, int ht, int wd, int t0, int t1,
+                          float lm, float ep, int motion_only, float* dx_out, float* dz_out,
+                          void* workspace, size_t workspace_bytes, dh_stream_t stream, int own_lo, int own_hi) {
   int rc = check_args(num_frames, n_edges, ht, wd, t0, t1);
   if (rc != DH_OK) return rc;
   if (!poses || !disps || !workspace) return DH_ERR_ARG;
@@ -1542,7 +1671,26 @@ extern "C" int dh_ba_finish(float* poses, float* disps, const int64_t* jj,
   if (workspace_bytes < L.total || ((uintptr_t)workspace & 255)) return DH_ERR_WORKSPACE;   // 16-byte operand loads, fp64 blocks
   if (n_edges > 0 && !jj) return DH_ERR_ARG;
   return run_finish(L, (char*)workspace, poses, disps, jj, num_frames, ht * wd, t0, lm, ep, motion_only,
-                    dx_out, dz_out, num_frames, (hipStream_t)stream);
+                    dx_out, dz_out, num_frames, (hipStream_t)stream, own_lo, own_hi);
+}
+
+extern "C" int dh_ba_finish(float* poses, float* disps, const int64_t* jj,
+                            int num_frames, int n_edges, int ht, int wd, int t0, int t1,
+                            float lm, float ep, int motion_only, float* dx_out, float* dz_out,
+                            void* workspace, size_t workspace_bytes, dh_stream_t stream) {
+  return ba_finish_impl(poses, disps, jj, num_frames, n_edges, ht, wd, t0, t1, lm, ep, motion_only, dx_out, dz_out,
+                        workspace, workspace_bytes, stream, 0, 1 << 30);
+}
+
+// dh_ba_finish for a rank that owns the depth maps of frames [own_lo, own_hi): the depths (and dz rows) of every other
+// frame stay untouched; poses are replicated and retracted by every rank
+extern "C" int dh_ba_finish_owned(float* poses, float* disps, const int64_t* jj,
+                                  int num_frames, int n_edges, int ht, int wd, int t0, int t1,
+                                  float lm, float ep, int motion_only, int own_lo, int own_hi, float* dx_out, float* dz_out,
+                                  void* workspace, size_t workspace_bytes, dh_stream_t stream) {
+  if (own_lo > own_hi) return DH_ERR_ARG;
+  return ba_finish_impl(poses, disps, jj, num_frames, n_edges, ht, wd, t0, t1, lm, ep, motion_only, dx_out, dz_out,
+                        workspace, workspace_bytes, stream, own_lo, own_hi);
 }
 
 extern "C" int dh_ba_ex(float* poses, float* disps, const float* intrinsics, const float* disps_sens, const float* alpha,

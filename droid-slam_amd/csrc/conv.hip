@@ -40,6 +40,7 @@ using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 
+using half2v = __attribute__((ext_vector_type(2))) _Float16;
 constexpr int BM = 256;            // pixels per workgroup
 constexpr int BK = 64;             // K chunk
 constexpr int LDT = BK + 8;        // LDS row stride (halves)
@@ -710,6 +711,7 @@ __device__ __attribute__((aligned(128))) uint4 g_zero_line[8];
 
 // VAR: 0 = product; timing ablations: 1 no DMA inside the loop, 2 no ds_read/MFMA inside the loop; and without DMA:
 // 5 no ds_read (MFMA + barrier), 6 no barrier (ds_read + MFMA), 7 no MFMA (ds_read + barrier)
+#ifdef DH_ABLATION   // opt-in LDS-DMA prototype (measured slower than conv3x3_halo2_kernel): not in release builds
 template <int EPI, int VAR = 0>
 __global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(ConvParams P) {
   extern __shared__ __half s_conv[];
@@ -871,6 +873,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(ConvParams P) {
 #undef DMA_WAIT_BARRIER
   conv_epilogue<EPI, 2, 2>(P, acc, M, m0, n0, wm0, wn0, lane, HW);
 }
+#endif  // DH_ABLATION
+
 
 // ---- 3x3, 128-cout tile, second form: weights by LDS-DMA, halo in 64-byte runs ----------------------------------------
 // The ablation of conv3x3_halo_kernel says its fetch path is the bound (no halo fetch 7.2 -> 5.2 ms, no weight fetch
@@ -1027,6 +1031,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
   else conv_epilogue<EPI, 2, 2>(P, acc, (long)P.N * HW, m0, n0, wm0, wn0, lane, HW);
 }
 
+#ifdef DH_ABLATION   // Winograd F(2,3) prototype (0.83-0.98x of the direct kernel): not in release builds
 // ---- 3x3 as Winograd F(2,3) along x (direct along y): PROTOTYPE, opt-in (weights_layout = DH_CONV_LAYOUT_WINO) -------------
 // One output row pair (x = 2p, 2p+1) needs the four input columns 2p-1 .. 2p+2:
 //     V0 = d0 - d2   V1 = d1 + d2   V2 = d2 - d1   V3 = d1 - d3            (input transform, per kernel row dy)
@@ -1047,7 +1052,6 @@ constexpr int WU_BYTES = 4 * 128 * 64;                    // 32,768: one (chunk,
 constexpr int WU_BUFS = 3;                               // weight groups are fetched TWO steps ahead (a step is only 16 MFMAs per wave)
 constexpr int WINO_LDS_BYTES = WV_BYTES + WU_BUFS * WU_BYTES;   // 147,456 (the staged epilogue tile needs 69,632)
 
-using half2v = __attribute__((ext_vector_type(2))) _Float16;
 __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) {
   return __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2v, a) - __builtin_bit_cast(half2v, b));
 }
@@ -1225,6 +1229,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(ConvParams P) {
   __syncthreads();
   staged_tile_store<EPI, 128>(P, sT, m0, n0, tid);
 }
+#endif  // DH_ABLATION
+
 
 // ---- 7x7 on 4 input channels (the flow encoder's first layer: motion features -> 128) -----------------------------------
 // In the generic loop this layer costs as much as a 128 -> 64 3x3 convolution: its K = 49 taps x 8 (4 real + 4 padded)
@@ -1449,6 +1455,7 @@ int launch_halo(const ConvParams& P, hipStream_t st) {
   return DH_OK;
 }
 
+#ifdef DH_ABLATION
 template <int EPI>
 int launch_dma(const ConvParams& P, hipStream_t st) {
   const long M = (long)P.N * P.H * P.W;
@@ -1470,6 +1477,8 @@ int launch_dma(const ConvParams& P, hipStream_t st) {
   DH_LAUNCH_CHECK();
   return DH_OK;
 }
+
+#endif  // DH_ABLATION
 
 template <int EPI>
 int launch_halo2(const ConvParams& P0, hipStream_t st) {
@@ -1500,6 +1509,7 @@ int launch_halo2(const ConvParams& P0, hipStream_t st) {
   return DH_OK;
 }
 
+#ifdef DH_ABLATION
 template <int EPI>
 bool wino_ok(const ConvParams& P) {
   if (!P.wt_halo || P.KH != 3 || P.KW != 3 || P.W != 64 || P.H % 4 || P.CoutPad % 128 || P.Ctot % H2CK) return false;
@@ -1529,6 +1539,8 @@ int launch_wino(const ConvParams& P0, hipStream_t st) {
   DH_LAUNCH_CHECK();
   return DH_OK;
 }
+
+#endif  // DH_ABLATION
 
 // halo2 layout of `weights_halo`: cout tile 128, channel count a multiple of 32 (DH_CONV_HALO2=0, read by both sides,
 // selects the 16-channel slabs of the first halo kernel instead)
@@ -1817,6 +1829,7 @@ extern "C" int dh_conv2d_nhwc_f16_ex2(const void* const* inputs, const int* in_c
   P.aux1 = (const __half*)aux1; P.aux1_stride = aux1_stride; P.red = red;
   hipStream_t st = (hipStream_t)stream;
   if (weights_layout == DH_CONV_LAYOUT_WINO) {              // prototype: F(2,3) along x; weights_halo = droid_amd.update.pack_conv_wino
+#ifdef DH_ABLATION
     switch (P.epi) {
       case EPI_LINEAR: if (!P.out_f32 && wino_ok<EPI_LINEAR>(P)) return launch_wino<EPI_LINEAR>(P, st); break;
       case EPI_RELU: if (wino_ok<EPI_RELU>(P)) return launch_wino<EPI_RELU>(P, st); break;
@@ -1825,8 +1838,10 @@ extern "C" int dh_conv2d_nhwc_f16_ex2(const void* const* inputs, const int* in_c
       case EPI_GRU_Q: if (wino_ok<EPI_GRU_Q>(P)) return launch_wino<EPI_GRU_Q>(P, st); break;
       default: break;
     }
-    return DH_ERR_UNSUPPORTED;
+#endif
+    return DH_ERR_UNSUPPORTED;                               // (release builds carry no prototype kernels: -DDH_ABLATION)
   }
+#ifdef DH_ABLATION
   if (dma_ok(P)) {
     switch (P.epi) {
       case EPI_LINEAR: return launch_dma<EPI_LINEAR>(P, st);
@@ -1837,6 +1852,7 @@ extern "C" int dh_conv2d_nhwc_f16_ex2(const void* const* inputs, const int* in_c
       default: break;
     }
   }
+#endif
   switch (P.epi) {
     case EPI_LINEAR: if (halo2_ok<EPI_LINEAR>(P)) return launch_halo2<EPI_LINEAR>(P, st); break;
     case EPI_RELU: if (halo2_ok<EPI_RELU>(P)) return launch_halo2<EPI_RELU>(P, st); break;

@@ -124,6 +124,7 @@ using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 
 __device__ __forceinline__ int wrap(int a, int n) { return a < 0 ? a + n : (a >= n ? a - n : a); }
 
+#ifdef DH_ABLATION   // first form of the build kernel, kept for A/B measurements (scripts/check_build_ab.py)
 // workgroup = 4 waves, one 8x8 source block of one edge; waves take target chunks of 64 pixels
 __global__ __launch_bounds__(256) void pyr_build_kernel(const __half* __restrict__ f1T, const __half* __restrict__ f2T,
                                                         __half* __restrict__ pyr, PyrDims D, long f1_stride_e,
@@ -231,6 +232,7 @@ __global__ __launch_bounds__(256) void pyr_build_kernel(const __half* __restrict
     for (int o = tid; o < n16; o += 256) z[o] = uint4{0u, 0u, 0u, 0u};
   }
 }
+#endif  // DH_ABLATION
 
 // ---- build, second form: row ring ------------------------------------------------------------------------------------
 // The chunk kernel above hands HBM 32-byte pieces (a 128-byte line per piece on the store path) and every wave reloads
@@ -955,10 +957,13 @@ extern "C" int dh_corr_pyramid_build(const void* fmap1, const void* fmap2, void*
   for (int l = 1; l < NLEV; ++l)
     hipLaunchKernelGGL(pyr_pool_kernel, dim3(D.h2[l] * D.w2[l], E), dim3(CH), 0, st, f2T, s2, D.tgt_off[l - 1],
                        D.tgt_off[l], D.h2[l - 1], D.w2[l - 1]);
+#ifdef DH_ABLATION
   if (opts().pyr_build_chunk) {                            // the first form of the build kernel (A/B measurements)
     hipLaunchKernelGGL(pyr_build_kernel, dim3(D.nblk, E), dim3(256), 0, st, (const __half*)f1T, (const __half*)f2T,
                        (__half*)pyramid, D, s1, s2);
-  } else {
+  } else
+#endif
+  {
     const size_t lds = (size_t)w * 1024 + (size_t)(w > 16 ? w : 16) * 256;       // row ring + one staged target row
     const dim3 grid(D.nblk, E);
     if (w == 64 && opts().pyr_build_waves == 8) {
@@ -991,12 +996,14 @@ int launch_lookup(const void* pyramid, const float* coords, void* out, int E, in
   const int mode = NHWC ? 0 : opts().lookup_mode;
   if (w == 64 && mode == 1)
     hipLaunchKernelGGL((pyr_lookup_kernel<64, NHWC, 1>), grid, block, lds, st, (const __half*)pyramid, coords, (__half*)out, D);
+#ifdef DH_ABLATION   // timing ablations with WRONG results: only in -DDH_ABLATION builds (options.hip refuses the modes otherwise)
   else if (w == 64 && mode == 2)
     hipLaunchKernelGGL((pyr_lookup_kernel<64, NHWC, 2>), grid, block, lds, st, (const __half*)pyramid, coords, (__half*)out, D);
   else if (w == 64 && mode == 3)
     hipLaunchKernelGGL((pyr_lookup_kernel<64, NHWC, 3>), grid, block, lds, st, (const __half*)pyramid, coords, (__half*)out, D);
   else if (w == 64 && mode == 4)
     hipLaunchKernelGGL((pyr_lookup_kernel<64, NHWC, 4>), grid, block, lds, st, (const __half*)pyramid, coords, (__half*)out, D);
+#endif
   else if (w == 64)
     hipLaunchKernelGGL((pyr_lookup_kernel<64, NHWC>), grid, block, lds, st, (const __half*)pyramid, coords, (__half*)out, D);
   else if (w == 32)
@@ -1042,13 +1049,17 @@ extern "C" int dh_corr_pyramid_lookup_corr0(const void* pyramid, const float* co
   const dim3 grid((unsigned)std::min<long>(n_strips, (long)cus * per_cu)), block(w * 8);
   hipStream_t st = (hipStream_t)stream;
   const int mode = opts().lookup_mode;                     // 2 / 3 / 5: timing ablations (wrong results); 6: synchronous twin (same results)
-  if (w == 64 && (mode == 2 || mode == 3 || mode == 5 || mode == 6)) {
 #define DH_FUSED_MODE(M_)                                                                                                      \
     { DH_LDS_OPTIN((&pyr_lookup_corr0_kernel<64, M_>), 160 * 1024);                                                            \
       hipLaunchKernelGGL((pyr_lookup_corr0_kernel<64, M_>), grid, block, lds, st, (const __half*)pyramid, coords, (const __half*)wpk, bias, (__half*)out, D, n_strips); }
-    if (mode == 2) DH_FUSED_MODE(2) else if (mode == 3) DH_FUSED_MODE(3) else if (mode == 5) DH_FUSED_MODE(5) else DH_FUSED_MODE(6)
+  if (w == 64 && mode == 6) DH_FUSED_MODE(6)               // the synchronous twin: same results (tests compare bit for bit)
+#ifdef DH_ABLATION   // timing ablations with WRONG results: only in -DDH_ABLATION builds
+  else if (w == 64 && mode == 2) DH_FUSED_MODE(2)
+  else if (w == 64 && mode == 3) DH_FUSED_MODE(3)
+  else if (w == 64 && mode == 5) DH_FUSED_MODE(5)
+#endif
 #undef DH_FUSED_MODE
-  } else if (w == 64) {
+  else if (w == 64) {
     DH_LDS_OPTIN((&pyr_lookup_corr0_kernel<64>), 160 * 1024);
     hipLaunchKernelGGL((pyr_lookup_corr0_kernel<64>), grid, block, lds, st, (const __half*)pyramid, coords, (const __half*)wpk, bias, (__half*)out, D, n_strips);
   } else if (w == 32) {

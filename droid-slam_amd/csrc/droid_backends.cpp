@@ -98,10 +98,10 @@ std::vector<torch::Tensor> ba_ex(torch::Tensor poses, torch::Tensor disps, torch
 // ---- split BA for the edge-sharded multi-GPU solver: build -> (all-reduce of `system`) -> finish ------
 // returns {workspace (opaque, keeps everything alive), system [(npad+48), npad] f64 view into it}: rows
 // 0..npad-1 = reduced camera matrix (6P x 6P in the top-left corner), row npad = right-hand side.
-std::vector<torch::Tensor> ba_build(torch::Tensor poses, torch::Tensor disps, torch::Tensor intrinsics,
-                                    torch::Tensor disps_sens, torch::Tensor targets, torch::Tensor weights,
-                                    torch::Tensor eta, torch::Tensor ii, torch::Tensor jj, const int t0, const int t1,
-                                    const bool motion_only) {
+static std::vector<torch::Tensor> ba_build_any(bool shard, torch::Tensor poses, torch::Tensor disps, torch::Tensor intrinsics,
+                                               torch::Tensor disps_sens, torch::Tensor targets, torch::Tensor weights,
+                                               torch::Tensor eta, torch::Tensor ii, torch::Tensor jj, const int t0, const int t1,
+                                               const bool motion_only) {
   CHECK_INPUT(targets); CHECK_INPUT(weights); CHECK_INPUT(poses); CHECK_INPUT(disps);
   CHECK_INPUT(intrinsics); CHECK_INPUT(disps_sens); CHECK_INPUT(ii); CHECK_INPUT(jj); CHECK_INPUT(eta);
   CHECK_F32(poses); CHECK_F32(disps); CHECK_F32(intrinsics); CHECK_F32(disps_sens);
@@ -113,10 +113,11 @@ std::vector<torch::Tensor> ba_build(torch::Tensor poses, torch::Tensor disps, to
   TORCH_CHECK(wsb > 0, "ba_build: invalid arguments");
   torch::Tensor ws = torch::empty({(int64_t)wsb}, poses.options().dtype(torch::kUInt8));
   double* H = nullptr; double* b = nullptr;
-  check_status(dh_ba_build(poses.data_ptr<float>(), disps.data_ptr<float>(), intrinsics.data_ptr<float>(),
-                           disps_sens.data_ptr<float>(), targets.data_ptr<float>(), weights.data_ptr<float>(),
-                           eta.data_ptr<float>(), ii.data_ptr<int64_t>(), jj.data_ptr<int64_t>(), F, E, K, ht, wd,
-                           t0, t1, motion_only ? 1 : 0, &H, &b, ws.data_ptr(), wsb, cur_stream()),
+  check_status((shard ? dh_ba_build_shard : dh_ba_build)(
+                   poses.data_ptr<float>(), disps.data_ptr<float>(), intrinsics.data_ptr<float>(),
+                   disps_sens.data_ptr<float>(), targets.data_ptr<float>(), weights.data_ptr<float>(),
+                   eta.data_ptr<float>(), ii.data_ptr<int64_t>(), jj.data_ptr<int64_t>(), F, E, K, ht, wd,
+                   t0, t1, motion_only ? 1 : 0, &H, &b, ws.data_ptr(), wsb, cur_stream()),
                "ba_build");
   int rows = 0, cols = 0;
   check_status(dh_ba_system_shape(t0, t1, &rows, &cols), "ba_system_shape");
@@ -124,21 +125,82 @@ std::vector<torch::Tensor> ba_build(torch::Tensor poses, torch::Tensor disps, to
   return {ws, sys};
 }
 
-std::vector<torch::Tensor> ba_finish(torch::Tensor poses, torch::Tensor disps, torch::Tensor jj, torch::Tensor ws,
-                                     const int n_eta_rows, const int t0, const int t1, const float lm, const float ep,
-                                     const bool motion_only) {
+std::vector<torch::Tensor> ba_build(torch::Tensor poses, torch::Tensor disps, torch::Tensor intrinsics,
+                                    torch::Tensor disps_sens, torch::Tensor targets, torch::Tensor weights,
+                                    torch::Tensor eta, torch::Tensor ii, torch::Tensor jj, const int t0, const int t1,
+                                    const bool motion_only) {
+  return ba_build_any(false, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1, motion_only);
+}
+
+// the edge-sharded solver's build (dh_ba_build_shard): no host synchronisation, the argument flag travels with the exchange
+std::vector<torch::Tensor> ba_build_shard(torch::Tensor poses, torch::Tensor disps, torch::Tensor intrinsics,
+                                          torch::Tensor disps_sens, torch::Tensor targets, torch::Tensor weights,
+                                          torch::Tensor eta, torch::Tensor ii, torch::Tensor jj, const int t0, const int t1,
+                                          const bool motion_only) {
+  return ba_build_any(true, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1, motion_only);
+}
+
+static std::vector<torch::Tensor> ba_finish_any(torch::Tensor poses, torch::Tensor disps, torch::Tensor jj, torch::Tensor ws,
+                                                const int n_eta_rows, const int t0, const int t1, const float lm, const float ep,
+                                                const bool motion_only, const int own_lo, const int own_hi) {
   CHECK_INPUT(poses); CHECK_INPUT(disps); CHECK_INPUT(jj); CHECK_INPUT(ws); CHECK_F32(poses); CHECK_F32(disps);
   CHECK_I64(jj);
   const int F = (int)disps.size(0), ht = (int)disps.size(1), wd = (int)disps.size(2), E = (int)jj.size(0);
   const int P = t1 - t0;
   torch::Tensor dx = torch::zeros({P > 0 ? P : 0, 6}, poses.options());
   torch::Tensor dz = torch::zeros({F, ht * wd}, poses.options());
-  check_status(dh_ba_finish(poses.data_ptr<float>(), disps.data_ptr<float>(), jj.data_ptr<int64_t>(), F, E, ht, wd,
-                            t0, t1, lm, ep, motion_only ? 1 : 0, dx.data_ptr<float>(),
-                            motion_only ? nullptr : dz.data_ptr<float>(), ws.data_ptr(), (size_t)ws.numel(),
-                            cur_stream()),
+  check_status(dh_ba_finish_owned(poses.data_ptr<float>(), disps.data_ptr<float>(), jj.data_ptr<int64_t>(), F, E, ht, wd,
+                                  t0, t1, lm, ep, motion_only ? 1 : 0, own_lo, own_hi, dx.data_ptr<float>(),
+                                  motion_only ? nullptr : dz.data_ptr<float>(), ws.data_ptr(), (size_t)ws.numel(),
+                                  cur_stream()),
                "ba_finish");
   return {dx, dz.narrow(0, 0, std::min(n_eta_rows, F))};
+}
+
+std::vector<torch::Tensor> ba_finish(torch::Tensor poses, torch::Tensor disps, torch::Tensor jj, torch::Tensor ws,
+                                     const int n_eta_rows, const int t0, const int t1, const float lm, const float ep,
+                                     const bool motion_only) {
+  return ba_finish_any(poses, disps, jj, ws, n_eta_rows, t0, t1, lm, ep, motion_only, 0, 1 << 30);
+}
+
+std::vector<torch::Tensor> ba_finish_owned(torch::Tensor poses, torch::Tensor disps, torch::Tensor jj, torch::Tensor ws,
+                                           const int n_eta_rows, const int t0, const int t1, const float lm, const float ep,
+                                           const bool motion_only, const int own_lo, const int own_hi) {
+  return ba_finish_any(poses, disps, jj, ws, n_eta_rows, t0, t1, lm, ep, motion_only, own_lo, own_hi);
+}
+
+// packed exchange of the co-visible 6x6 blocks (dh_ba_pack_blocks / dh_ba_unpack_blocks): `packed` f64
+// [36 * n_blocks + 6 (t1 - t0) + 2], bp / bq int32 block rows / columns; disps / jj only give the sizes
+void ba_pack_blocks(torch::Tensor ws, torch::Tensor disps, torch::Tensor jj, const int t0, const int t1, const bool motion_only,
+                    torch::Tensor bp, torch::Tensor bq, const int host_flags, torch::Tensor packed) {
+  CHECK_INPUT(ws); CHECK_INPUT(bp); CHECK_INPUT(bq); CHECK_INPUT(packed);
+  TORCH_CHECK(bp.scalar_type() == torch::kInt32 && bq.scalar_type() == torch::kInt32 && bp.numel() == bq.numel(), "ba_pack_blocks: bp / bq int32, same length");
+  TORCH_CHECK(packed.scalar_type() == torch::kFloat64 && (size_t)packed.numel() >= dh_ba_packed_len((int)bp.numel(), t0, t1), "ba_pack_blocks: packed buffer");
+  check_status(dh_ba_pack_blocks(ws.data_ptr(), (size_t)ws.numel(), (int)disps.size(0), (int)jj.size(0), (int)disps.size(1), (int)disps.size(2),
+                                 t0, t1, motion_only ? 1 : 0, bp.data_ptr<int32_t>(), bq.data_ptr<int32_t>(), (int)bp.numel(), host_flags,
+                                 packed.data_ptr<double>(), cur_stream()),
+               "ba_pack_blocks");
+}
+
+void ba_unpack_blocks(torch::Tensor ws, torch::Tensor disps, torch::Tensor jj, const int t0, const int t1, const bool motion_only,
+                      torch::Tensor bp, torch::Tensor bq, torch::Tensor packed) {
+  CHECK_INPUT(ws); CHECK_INPUT(bp); CHECK_INPUT(bq); CHECK_INPUT(packed);
+  TORCH_CHECK(bp.scalar_type() == torch::kInt32 && bq.scalar_type() == torch::kInt32 && bp.numel() == bq.numel(), "ba_unpack_blocks: bp / bq int32, same length");
+  TORCH_CHECK(packed.scalar_type() == torch::kFloat64 && (size_t)packed.numel() >= dh_ba_packed_len((int)bp.numel(), t0, t1), "ba_unpack_blocks: packed buffer");
+  check_status(dh_ba_unpack_blocks(ws.data_ptr(), (size_t)ws.numel(), (int)disps.size(0), (int)jj.size(0), (int)disps.size(1), (int)disps.size(2),
+                                   t0, t1, motion_only ? 1 : 0, bp.data_ptr<int32_t>(), bq.data_ptr<int32_t>(), (int)bp.numel(),
+                                   packed.data_ptr<double>(), cur_stream()),
+               "ba_unpack_blocks");
+}
+
+// dense exchange: status f64 [2]; set = false reads this rank's flags into it, set = true applies the all-reduced ones
+void ba_exchange_flags(torch::Tensor ws, torch::Tensor disps, torch::Tensor jj, const int t0, const int t1, const bool motion_only,
+                       const int host_flags, torch::Tensor status, const bool set) {
+  CHECK_INPUT(ws); CHECK_INPUT(status);
+  TORCH_CHECK(status.scalar_type() == torch::kFloat64 && status.numel() >= 2, "ba_exchange_flags: status f64 [2]");
+  check_status(dh_ba_exchange_flags(ws.data_ptr(), (size_t)ws.numel(), (int)disps.size(0), (int)jj.size(0), (int)disps.size(1), (int)disps.size(2),
+                                    t0, t1, motion_only ? 1 : 0, host_flags, status.data_ptr<double>(), set ? 1 : 0, cur_stream()),
+               "ba_exchange_flags");
 }
 
 // ---- geometry (droid.cpp:125-171, 228-242) ------------------------------------------------------
@@ -615,6 +677,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("ba_ex", &ba_ex, "bundle adjustment with a per-pixel depth-prior weight");
   m.def("ba_build", &ba_build, "per-rank reduced camera system (split BA)");
   m.def("ba_finish", &ba_finish, "damp + solve + back-substitute + retract (split BA)");
+  m.def("ba_build_shard", &ba_build_shard, "ba_build without a host synchronisation (edge-sharded BA)");
+  m.def("ba_finish_owned", &ba_finish_owned, "ba_finish that only moves the depths of frames [own_lo, own_hi)");
+  m.def("ba_pack_blocks", &ba_pack_blocks, "co-visible 6x6 blocks + rhs + flags -> one contiguous f64 buffer");
+  m.def("ba_unpack_blocks", &ba_unpack_blocks, "all-reduced buffer -> system + flags");
+  m.def("ba_exchange_flags", &ba_exchange_flags, "argument / pattern flags of the dense exchange");
   m.def("altcorr_forward_nhwc_levels", &altcorr_forward_nhwc_levels, "all pyramid levels of the on-the-fly correlation into one [M,49L,H,W] tensor");
   m.def("altcorr_forward_nhwc", &altcorr_forward_nhwc, "on-the-fly correlation on the fp16 MFMA, channel-last features");
   m.def("corr_volume_build", &corr_volume_build, "all-pairs volume in the reference layout (any image size)");

@@ -125,15 +125,18 @@ __global__ __launch_bounds__(256) void depth_filter_kernel(
     Vec3 R = rot(T.q, {X, Y, 1.f});
     const float x = R.x + di * T.t.x, y = R.y + di * T.t.y, z = R.z + di * T.t.z;
     const float uj = fx * (x / z) + cx, vj = fy * (y / z) + cy, dj = di / z;
-    const float fu = floorf(uj), fv = floorf(vj);
-    if (!(fu >= 0.f && fv >= 0.f && fu < (float)(wd - 1) && fv < (float)(ht - 1))) continue;
-    const int u0 = (int)fu, v0 = (int)fv;
+    // the reference converts floor() to int first and compares integers (droid_kernels.cu:760-763): a NaN coordinate
+    // converts to 0 on this hardware and passes, +-inf saturates and fails -- same conversion here
+    const int u0 = (int)floorf(uj), v0 = (int)floorf(vj);
+    if (!(u0 >= 0 && v0 >= 0 && u0 < wd - 1 && v0 < ht - 1)) continue;
     const float* dn = disps + (long)j * HW;
     const float d00 = dn[v0 * wd + u0], d01 = dn[v0 * wd + u0 + 1];
     const float d10 = dn[(v0 + 1) * wd + u0], d11 = dn[(v0 + 1) * wd + u0 + 1];
-    const float idj = 1.f / dj;
-    if (fabsf(idj - 1.f / d00) < t || fabsf(idj - 1.f / d01) < t || fabsf(idj - 1.f / d10) < t ||
-        fabsf(idj - 1.f / d11) < t)
+    // the reference's test is written with double literals, `abs(1.0/dj - 1.0/d00) < t` (droid_kernels.cu:775-778):
+    // reciprocals, difference and comparison are fp64; in fp32 the count differs on ~0.2 % of the pixels
+    const double idj = 1.0 / (double)dj, td = (double)t;
+    if (fabs(idj - 1.0 / (double)d00) < td || fabs(idj - 1.0 / (double)d01) < td || fabs(idj - 1.0 / (double)d10) < td ||
+        fabs(idj - 1.0 / (double)d11) < td)
       count += 1.f;
   }
   counter[(long)m * HW + p] = count;

@@ -31,9 +31,29 @@ Options& opts() {
     v.lookup_fused = env_int("DH_LOOKUP_FUSED", 1);
     v.altcorr_v1 = env_int("DH_ALTCORR_V1", 0);
     v.conv_wino = env_int("DH_CONV_WINO", 0);
+#ifndef DH_ABLATION
+    // release build: the prototype / timing-ablation kernels are not compiled in; a stray environment variable cannot
+    // select a variant that returns wrong results (lookup_mode 2-5) or does not exist
+    if (v.lookup_mode != 1 && v.lookup_mode != 6) v.lookup_mode = 0;
+    v.conv_dma = 0; v.dma_var = 0; v.pyr_build_chunk = 0; v.altcorr_v1 = 0; v.conv_wino = 0;
+#endif
     return v;
   }();
   return o;
+}
+
+// values a release build accepts for the switches whose other settings need -DDH_ABLATION
+static bool allowed(const char* name, int value) {
+#ifdef DH_ABLATION
+  (void)name; (void)value;
+  return true;
+#else
+  if (!strcmp(name, "lookup_mode")) return value == 0 || value == 1 || value == 6;      // 1: nt tap loads, 6: synchronous twin -- same results
+  if (!strcmp(name, "conv_dma") || !strcmp(name, "dma_var") || !strcmp(name, "pyr_build_chunk") || !strcmp(name, "altcorr_v1") ||
+      !strcmp(name, "conv_wino"))
+    return value == 0;
+  return true;
+#endif
 }
 
 static int* slot(const char* name) {
@@ -66,6 +86,7 @@ static int g_options_epoch = 0;
 extern "C" int dh_set_option(const char* name, int value) {
   int* s = dh::slot(name);
   if (!s) return DH_ERR_ARG;
+  if (!dh::allowed(name, value)) return DH_ERR_UNSUPPORTED;
   if (*s != value) ++g_options_epoch;
   *s = value;
   return DH_OK;
@@ -74,6 +95,14 @@ extern "C" int dh_set_option(const char* name, int value) {
 extern "C" int dh_options_epoch(void) { return g_options_epoch; }
 
 extern "C" int dh_get_option(const char* name, int* value) {
+  if (name && value && !strcmp(name, "ablation_build")) {       // read-only: 1 when compiled with -DDH_ABLATION
+#ifdef DH_ABLATION
+    *value = 1;
+#else
+    *value = 0;
+#endif
+    return DH_OK;
+  }
   int* s = dh::slot(name);
   if (!s || !value) return DH_ERR_ARG;
   *value = *s;

@@ -5,10 +5,14 @@ Same constructor / call interface as ``CorrBlock`` and ``AltCorrBlock`` of the r
 Inference only (no autograd): the hot path runs under ``torch.no_grad()`` in the reference as well
 (droid_slam/droid.py:62, droid_backend.py:24).
 
-``CorrBlock``     materialised 4-level pyramid in the reference layout
-                  ``[E, h1, w1, h2/2^l, w2/2^l]``; lookup = droid_backends.corr_index_forward per level.
-``AltCorrBlock``  on-the-fly correlation from pooled feature pyramids; lookup =
-                  droid_backends.altcorr_forward per level.
+``CorrBlock``     materialised 4-level pyramid in the MI355X layout of csrc/corr_pyramid.hip (8x8 source blocks,
+                  x-adjacent displacement pairs, one record of 25.6 MB per edge at 48x64; h % 8 == 0, w in {16, 32, 64});
+                  built on the MFMA (droid_backends.corr_pyramid_build), one launch looks up all four levels
+                  (corr_pyramid_lookup), optionally fused with the correlation encoder's first layer (lookup_corr0).
+``CorrBlockRef``  the reference layout ``[E, h1, w1, h2/2^l, w2/2^l]`` for any image size; lookup =
+                  droid_backends.corr_index_forward per level (FactorGraph takes it when CorrBlock.supported(ht, wd) is false).
+``AltCorrBlock``  on-the-fly correlation from pooled feature pyramids; lookup = the MFMA alt-correlation kernel per level
+                  (droid_backends.altcorr_forward_nhwc_levels; altcorr_forward for the reference's tensor layout).
 """
 import torch
 import torch.nn.functional as F

@@ -7,20 +7,24 @@ targets/weights (and correlation volumes / GRU state) and is the only rank that 
 depths of its frames; poses are replicated (28 B per frame).
 
 Per Gauss-Newton iteration:
-    build    every rank reduces ITS edges to a partial reduced camera system  (droid_backends.ba_build)
+    build    every rank reduces ITS edges to a partial reduced camera system  (droid_backends.ba_build_shard)
     exchange ONE all-reduce (sum, fp64) of [A - S | v - b_S] over RCCL/xGMI   (torch.distributed) -- of its NON-ZERO
-             6x6 blocks only: after `set_graph` the co-visible lower-triangular blocks + the rhs are packed into one
-             contiguous buffer (512 keyframes / 4096 edges: 6 MB instead of the dense 77 MB; xGMI rings are per-link bound)
-    finish   every rank damps + solves redundantly (no broadcast), back-substitutes the depths of its own
-             frames and retracts the replicated poses                         (droid_backends.ba_finish)
-At the end the owned depth maps are exchanged with one all-reduce of the depth increments so that every
-rank leaves with the full, identical `disps` buffer (what depth_video.ba's callers expect).
+             6x6 blocks only: after `set_graph` the co-visible lower-triangular blocks + the rhs + two status words are
+             packed into one contiguous buffer by a kernel (droid_backends.ba_pack_blocks / ba_unpack_blocks; 512
+             keyframes / 4096 edges: 3.2 MB instead of the dense 77 MB; xGMI rings are per-link bound)
+    finish   every rank damps + solves redundantly (no broadcast), back-substitutes the depths of the frames it OWNS
+             and retracts the replicated poses                                (droid_backends.ba_finish_owned)
+At the end every rank zeroes the depth maps it does not own and one all-reduce of `disps` leaves all ranks with the full,
+identical buffer (what depth_video.ba's callers expect).  No host synchronisation ahead of a collective: a rank's
+argument flag and a stale block pattern travel as the two status words of the exchanged buffer.
 
 Reduction order differs from the single-GPU run, so results agree to fp32 tolerance, not bitwise.
 """
 import numpy as np
 import torch
 import torch.distributed as dist
+
+from ._cache import tensor_cache_key
 
 
 def shard_edges_by_source_frame(ii, world):
@@ -90,9 +94,16 @@ def reduced_system_pattern(ii_all, jj_all, t0, t1):
 
 
 class DistBA:
-    """ba() with the droid_backends.ba contract, applied to this rank's edge shard."""
+    """ba() with the droid_backends.ba contract, applied to this rank's edge shard.
 
-    def __init__(self, world=None, frame_lo=0, frame_hi=1 << 30, group=None, backend=None):
+    Hot path per Gauss-Newton iteration: ba_build_shard -> ba_pack_blocks -> ONE all-reduce -> ba_unpack_blocks ->
+    ba_finish_owned, all stream-ordered launches on the device: no host synchronisation, no tensor copies, no indexing
+    kernels of torch.  The argument flag of every rank and the host's "pattern is stale" flag travel inside the reduced
+    buffer, so all ranks apply or skip an update together; the host reads the two status words ONCE, after the last
+    iteration, and then raises (bad arguments) or repeats the call with the dense exchange (stale pattern) on every rank."""
+
+    def __init__(self, world=None, frame_lo=0, frame_hi=1 << 30, group=None, backend=None, always_reduce=False):
+        self.always_reduce = always_reduce      # issue the collectives even in a group of one (exercises RCCL on a single GPU)
         self.world = dist.get_world_size(group) if (world is None and dist.is_initialized()) else (world or 1)
         self.group = group
         self.frame_lo, self.frame_hi = frame_lo, frame_hi
@@ -102,18 +113,19 @@ class DistBA:
         self._pattern = None            # (t0, t1, p, q) after set_graph
         self._pattern_keys = None
         self._covered = None
-        self._flat = None
+        self._blocks = None             # (device, bp int32, bq int32, packed buffer f64)
+        self._status = None
         self.last_exchange_bytes = 0
         self.last_exchange_packed = False
 
     def set_graph(self, ii_all, jj_all, t0, t1):
         """global edge list -> the all-reduce moves only the co-visible blocks (see reduced_system_pattern).  Without it
-        the whole dense system is reduced.  Call it again whenever the global edge list changes: ba() verifies that the
-        blocks of its local edges lie inside the pattern and falls back to the dense exchange (on every rank) if not."""
+        the whole dense system is reduced.  Call it again whenever the global edge list changes: a rank whose local edges
+        touch a block outside the pattern marks the exchanged buffer, and the call is repeated densely on every rank."""
         p, q = reduced_system_pattern(ii_all, jj_all, t0, t1)
         self._pattern = (int(t0), int(t1), p, q)
         self._pattern_keys = np.unique(p * (int(t1) - int(t0)) + q)
-        self._flat = None
+        self._blocks = None
         self._covered = None
 
     def _local_blocks_covered(self, ii, jj, t0, t1):
@@ -121,7 +133,6 @@ class DistBA:
         edge tensors (identity + version), so the host-side check runs once per edge list, not once per call."""
         if self._pattern is None or self._pattern[:2] != (int(t0), int(t1)):
             return False
-        from .update import tensor_cache_key
         key = tensor_cache_key(ii, jj)
         if key is not None and self._covered is not None and self._covered[0] == key:
             return self._covered[1]
@@ -130,61 +141,71 @@ class DistBA:
         self._covered = (key, ok, ii, jj)                    # (tensors kept alive: their addresses are in the key)
         return ok
 
-    def _flat_index(self, system, t0, t1):
-        ld = system.shape[1]
-        if self._flat is None or self._flat[0] != (ld, system.device):
-            _, _, p, q = self._pattern
-            r = np.arange(6)
-            off = ((6 * p[:, None, None] + r[None, :, None]) * ld + 6 * q[:, None, None] + r[None, None, :]).reshape(-1)
-            self._flat = ((ld, system.device), torch.as_tensor(off, dtype=torch.long, device=system.device))
-        return self._flat[1]
+    def _block_buffers(self, device):
+        if self._blocks is None or self._blocks[0] != device:
+            t0, t1, p, q = self._pattern
+            bp = torch.as_tensor(p.astype(np.int32), device=device); bq = torch.as_tensor(q.astype(np.int32), device=device)
+            buf = torch.zeros(36 * len(p) + 6 * (t1 - t0) + 2, dtype=torch.float64, device=device)
+            self._blocks = (device, bp, bq, buf)
+        return self._blocks[1:]
 
     def set_owned_frames(self, lo, hi):
         self.frame_lo, self.frame_hi = int(lo), int(hi)
 
     def _allreduce(self, t):
-        if self.world > 1:
+        if self.world > 1 or self.always_reduce:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def _iterate(self, packed, stale, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1,
+                 iterations, lm, ep, motion_only, lo, hi):
+        """-> (dx, dz, status): status = device tensor [2] (f64), summed over ranks: [argument flags, stale patterns]"""
+        be = self.be
+        dx = dz = None
+        status = None
+        for _ in range(iterations):
+            ws, system = be.ba_build_shard(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1, motion_only)
+            if packed:
+                bp, bq, buf = self._block_buffers(disps.device)
+                be.ba_pack_blocks(ws, disps, jj, t0, t1, motion_only, bp, bq, stale, buf)
+                self._allreduce(buf)
+                be.ba_unpack_blocks(ws, disps, jj, t0, t1, motion_only, bp, bq, buf)
+                status = buf[-2:]
+                self.last_exchange_bytes = buf.numel() * buf.element_size()
+            else:
+                if self._status is None or self._status.device != disps.device:
+                    self._status = torch.zeros(2, dtype=torch.float64, device=disps.device)
+                status = self._status
+                be.ba_exchange_flags(ws, disps, jj, t0, t1, motion_only, 0, status, False)
+                self._allreduce(system)
+                self._allreduce(status)
+                be.ba_exchange_flags(ws, disps, jj, t0, t1, motion_only, 0, status, True)
+                self.last_exchange_bytes = system.numel() * system.element_size()
+            dx, dz = be.ba_finish_owned(poses, disps, jj, ws, eta.shape[0], t0, t1, lm, ep, motion_only, lo, hi)
+        return dx, dz, status
 
     def ba(self, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1,
            iterations=2, lm=1e-4, ep=0.1, motion_only=False):
         F = disps.shape[0]
         lo, hi = max(0, self.frame_lo), min(F, self.frame_hi)
-        disps_in = disps.clone()
-        dx = dz = None
-        packed = False
-        if self.world > 1 and self._pattern is not None:
-            # the packed exchange is only valid if EVERY rank's blocks lie inside the pattern (a stale pattern after the edge
-            # list changed would silently drop blocks): one 4-byte MAX-reduce per call makes the decision collective
-            bad = torch.tensor([0 if self._local_blocks_covered(ii, jj, t0, t1) else 1], dtype=torch.int32, device=disps.device)
-            dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=self.group)
-            packed = int(bad.item()) == 0
+        args = (poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1, iterations, lm, ep, motion_only, lo, hi)
+        packed = self._pattern is not None and self._pattern[:2] == (int(t0), int(t1))
+        # host-side and cached per edge list; a stale pattern is reported THROUGH the exchange, never by a rank-local decision
+        stale = 0 if (not packed or self._local_blocks_covered(ii, jj, t0, t1)) else 1
+        dx, dz, status = self._iterate(packed, stale, *args)
+        flags = status.cpu().tolist() if status is not None else [0.0, 0.0]     # the call's one synchronisation
+        if packed and flags[1] != 0:
+            # some rank's blocks are not in the pattern: no rank has applied an update; all repeat with the dense exchange
+            packed = False
+            dx, dz, status = self._iterate(False, 0, *args)
+            flags = status.cpu().tolist() if status is not None else [0.0, 0.0]
         self.last_exchange_packed = packed
-        for _ in range(iterations):
-            before = disps.clone() if not motion_only else None
-            ws, system = self.be.ba_build(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj,
-                                          t0, t1, motion_only)
-            if packed:
-                # packed exchange: lower-triangular 6x6 blocks + rhs row (the factorisation reads the lower triangle only)
-                n = 6 * (t1 - t0)
-                idx = self._flat_index(system, t0, t1)
-                flat = system.view(-1)
-                rhs_row = system.shape[1]                                    # the rhs is row npad of [npad + NB, npad]
-                buf = torch.cat([flat[idx], system[rhs_row, :n]])
-                self._allreduce(buf)
-                flat[idx] = buf[:idx.numel()]
-                system[rhs_row, :n] = buf[idx.numel():]
-                self.last_exchange_bytes = buf.numel() * buf.element_size()
-            else:
-                self._allreduce(system)
-                self.last_exchange_bytes = system.numel() * system.element_size()
-            dx, dz = self.be.ba_finish(poses, disps, jj, ws, eta.shape[0], t0, t1, lm, ep, motion_only)
-            if not motion_only:
-                # only the owner of a frame updates its depth map
-                disps[:lo] = before[:lo]
-                disps[hi:] = before[hi:]
-        if not motion_only and self.world > 1:
-            delta = disps - disps_in
-            self._allreduce(delta)
-            disps.copy_(disps_in + delta)
+        if not motion_only and (self.world > 1 or self.always_reduce):
+            # every frame's depth map has exactly one owner: zero the others' and sum (no copies of the buffer)
+            disps[:lo].zero_(); disps[hi:].zero_()
+            self._allreduce(disps)
+        if flags[0] != 0:
+            strict = getattr(self.be, "get_option", lambda name: 1)("ba_strict")
+            if strict:
+                raise RuntimeError("DistBA.ba: an edge index outside the frame buffer or an eta without one row per depth block "
+                                   "on %d rank(s); no rank has applied an update" % int(flags[0]))
         return dx, dz

@@ -18,7 +18,7 @@ import torch
 
 import droid_backends as db
 from .corr import CorrBlock, CorrBlockRef, AltCorrBlock
-from .update import tensor_cache_key
+from ._cache import tensor_cache_key
 
 
 class FactorGraph:
@@ -182,14 +182,17 @@ class FactorGraph:
 
     # ---- global BA (factor_graph.py:266-330) --------------------------------------------------------------------------
     def _pyramid_fits(self, E, ht, wd):
-        """True if the materialised pyramid of all E edges plus the full-batch activations of the update operator fit into
-        the HBM that is free right now (288 GB per MI355X: 512 keyframes / 4096 edges at 48x64 need 105 + ~40 GB)"""
+        """Deterministic rule of update_lowmem(corr="auto"): a function of the problem size and the DEVICE (its total HBM), not
+        of what happens to be free at call time -- two runs of the same sequence take the same path and round the same way.
+        The materialised pyramid of all E edges plus the full-batch activations of the update operator (~3.5 KB per
+        edge-pixel) must fit into 60 % of the device memory (288 GB per MI355X: 512 keyframes / 4096 edges at 48x64 need
+        105 + 44 GB).  If the build then runs out of memory anyway (other tenants of the device), update_lowmem falls back to
+        the alt-correlation loop."""
         if not CorrBlock.supported(ht, wd):
             return False
-        free, _ = torch.cuda.mem_get_info(self.device)
-        free += torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)    # cached by torch, reusable
-        need = E * CorrBlock.bytes_per_edge(ht, wd) + E * ht * wd * 3584                               # + ~3.5 KB of activations per edge-pixel
-        return need < 0.9 * free
+        total = torch.cuda.get_device_properties(self.device).total_memory
+        need = E * CorrBlock.bytes_per_edge(ht, wd) + E * ht * wd * 3584
+        return need < 0.6 * total
 
     def _ba_global(self, tb, wb, itrs, use_inactive, EP, t):
         ii, jj = self.ii, self.jj
@@ -209,34 +212,60 @@ class FactorGraph:
           "pyramid"  the 4-level pyramid of every edge is built ONCE for the whole call (fmaps do not change during it) and
                      each step is one full-batch lookup + update operator, like update(): the build is amortised over the
                      steps and the lookup is HBM-bound instead of recomputing 8x8 x 128-channel dot products per step;
-          "auto"     "pyramid" when it fits into the free HBM (105 GB for 4096 edges at 48x64), else "alt".
+          "auto"     "pyramid" when pyramid + activations fit into 60 % of the DEVICE's memory (a rule of E, ht, wd and the
+                     device only: deterministic across runs; 105 + 44 GB for 4096 edges at 48x64), else "alt"; an
+                     out-of-memory error during the build also falls back to "alt".
+        Both paths skip the edges the reference's chunk loop never visits (source frame beyond the last chunk).
         The pyramid is dropped when the call returns."""
         v = self.video
         t = v.counter.value
         num, rig, ch, ht, wd = v.fmaps.shape
-        if corr == "pyramid" or (corr == "auto" and self._pyramid_fits(len(self.ii), ht, wd)):
-            c = (self.ii == self.jj).long() if rig > 1 else torch.zeros_like(self.ii)
-            block = CorrBlock(v.fmaps[self.ii, 0][None], v.fmaps[self.jj, c][None])
-            for _ in range(steps):
-                coords1 = v.reproject(self.ii, self.jj)[0][0]
-                feats, corr0 = self._pyramid_features(block, coords1)
-                dw, damping, upmask, uniq = self._operator(self._net, coords1, self.target[0].contiguous(), feats, self.ii, corr0)
-                target, weight, tb, wb = db.ba_inputs(coords1, dw)
-                self.target, self.weight = target[None], weight[None]
-                self.damping[uniq] = damping
-                if self.upsample:
-                    v.upsample(uniq, upmask)
-                self._ba_global(tb, wb, itrs, use_inactive, EP, t)
-            return
-        corr_op = AltCorrBlock(v.fmaps.view(1, num * rig, ch, ht, wd))
         s = self.chunk_frames
+        # the reference's chunk loop (factor_graph.py:284-287) runs over source frames [ii.min(), jj.max()] in steps of s: edges
+        # whose source frame lies beyond the last chunk are never visited and keep their previous hidden state / target /
+        # weight.  Both correlation paths reproduce that, so they are equivalent up to fp16 rounding of the features.
+        lo, hi = int(self.ii.min().item()), int(self.jj.max().item()) + 1
+        limit = lo + (hi - lo + s - 1) // s * s
+        all_visited = int(self.ii.max().item()) < limit
+        if corr == "pyramid" or (corr == "auto" and self._pyramid_fits(len(self.ii), ht, wd)):
+            sel = None if all_visited else torch.nonzero(self.ii < limit)[:, 0]
+            ii_v, jj_v = (self.ii, self.jj) if sel is None else (self.ii[sel], self.jj[sel])
+            c = (ii_v == jj_v).long() if rig > 1 else torch.zeros_like(ii_v)
+            try:
+                block = CorrBlock(v.fmaps[ii_v, 0][None], v.fmaps[jj_v, c][None])
+            except torch.cuda.OutOfMemoryError:
+                if corr == "pyramid":
+                    raise
+                block = None                                        # "auto": fall through to the alt-correlation loop
+                torch.cuda.empty_cache()
+            if block is not None:
+                for _ in range(steps):
+                    coords_all = v.reproject(self.ii, self.jj)[0][0]
+                    if sel is None:
+                        coords1, net, target_prev = coords_all, self._net, self.target[0].contiguous()
+                    else:
+                        coords1, net, target_prev = coords_all[sel].contiguous(), self._net[sel].contiguous(), self.target[0][sel].contiguous()
+                    feats, corr0 = self._pyramid_features(block, coords1)
+                    dw, damping, upmask, uniq = self._operator(net, coords1, target_prev, feats, ii_v, corr0)
+                    target, weight, tb, wb = db.ba_inputs(coords1, dw)
+                    if sel is not None:                                 # unvisited edges keep what they had
+                        self._net[sel] = net
+                        t_all, w_all = self.target[0].clone(), self.weight[0].clone()
+                        t_all[sel] = target; w_all[sel] = weight
+                        target, weight = t_all, w_all
+                        tb = target.permute(0, 3, 1, 2).contiguous(); wb = weight.permute(0, 3, 1, 2).contiguous()
+                    self.target, self.weight = target[None], weight[None]
+                    self.damping[uniq] = damping
+                    if self.upsample:
+                        v.upsample(uniq, upmask)
+                    self._ba_global(tb, wb, itrs, use_inactive, EP, t)
+                return
+        corr_op = AltCorrBlock(v.fmaps.view(1, num * rig, ch, ht, wd))
         for _ in range(steps):
             coords1 = v.reproject(self.ii, self.jj)[0][0]
             target_prev = self.target[0].contiguous()
-            lo, hi = int(self.ii.min().item()), int(self.jj.max().item()) + 1
-            if int(self.ii.max().item()) >= lo + (hi - lo + s - 1) // s * s:
-                # the reference's chunk loop (factor_graph.py:284-287) stops at jj.max(): edges whose source frame lies beyond
-                # it are not visited and keep their previous target / weight
+            if not all_visited:
+                # edges beyond the last chunk are not visited and keep their previous target / weight (see above)
                 target = target_prev.clone(); weight = self.weight[0].clone()
                 tb = target.permute(0, 3, 1, 2).contiguous(); wb = weight.permute(0, 3, 1, 2).contiguous()
             else:                                                       # every edge is written below

@@ -16,6 +16,8 @@ import torch.nn.functional as F
 
 import droid_backends
 
+from ._cache import tensor_cache_key
+
 EPI_LINEAR, EPI_RELU, EPI_SIGMOID, EPI_GRU_ZR, EPI_GRU_Q, EPI_GLO, EPI_SOFTPLUS_001, EPI_HEADS, EPI_HEADS0 = range(9)
 COR_PLANES = 4 * 49
 COR_NHWC = 224           # channel-last correlation features: 4 levels x (49 + 7 zero channels)
@@ -53,17 +55,6 @@ def empty_state_dict(dtype=torch.float32):
         sd[k + ".weight"] = torch.zeros(co, ci, ks, ks, dtype=dtype)
         sd[k + ".bias"] = torch.zeros(co, dtype=dtype)
     return sd
-
-
-def tensor_cache_key(*tensors):
-    """identity + version of tensors a cached derivation depends on, or None when no key can be formed (tensors created
-    under torch.inference_mode() carry no version counter: their derivations are then recomputed on every call)"""
-    key = []
-    for t in tensors:
-        if t.is_inference():
-            return None
-        key.append((t.data_ptr(), t._version, t.numel(), t.device))
-    return tuple(key)
 
 
 def _round_up(v, m):

@@ -196,6 +196,41 @@ int dh_ba_finish(float* poses, float* disps, const int64_t* jj,
                  float lm, float ep, int motion_only, float* dx_out, float* dz_out,
                  void* workspace, size_t workspace_bytes, dh_stream_t stream);
 
+/* Edge-sharded solver (north_star: "global BA partitioned by edge batches across the 8 GPUs of one node with RCCL
+ * all-reduce of the 6x6 pose Hessian blocks and residuals"; the reference has no such path -- its ba is droid.cpp:93-122).
+ * Per Gauss-Newton iteration a rank calls
+ *   dh_ba_build_shard   = dh_ba_build WITHOUT the ba_strict host synchronisation (a rank-local error ahead of the collective
+ *                         would leave the other ranks waiting in it);
+ *   dh_ba_pack_blocks   the n_blocks lower-triangular 6x6 blocks (bp[b], bq[b]) of its partial system, the rhs and two
+ *                       status words -> packed f64 [36 n_blocks + 6 P + 2]; status[0] = this rank's argument flag,
+ *                       status[1] = host_flags != 0 (the host's "block pattern is stale");
+ *   (one RCCL all-reduce, SUM, of `packed`)
+ *   dh_ba_unpack_blocks writes blocks and rhs back; a non-zero status word of ANY rank turns the iteration into a no-op
+ *                       update on EVERY rank (the host reads the two words once, after the last iteration, and raises /
+ *                       falls back on all ranks together);
+ *   dh_ba_finish_owned  = dh_ba_finish, moving only the depths of the frames [own_lo, own_hi) this rank owns.
+ * Dense fallback (no pattern): all-reduce the whole system and a 2-word status buffer filled / applied by
+ * dh_ba_exchange_flags(set = 0 / 1). */
+int dh_ba_build_shard(const float* poses, const float* disps, const float* intrinsics, const float* disps_sens,
+                      const float* targets, const float* weights, const float* eta,
+                      const int64_t* ii, const int64_t* jj,
+                      int num_frames, int n_edges, int n_eta_rows, int ht, int wd,
+                      int t0, int t1, int motion_only,
+                      double** Hsys_out, double** bsys_out, void* workspace, size_t workspace_bytes, dh_stream_t stream);
+size_t dh_ba_packed_len(int n_blocks, int t0, int t1);
+int dh_ba_pack_blocks(const void* workspace, size_t workspace_bytes, int num_frames, int n_edges, int ht, int wd,
+                      int t0, int t1, int motion_only, const int32_t* bp, const int32_t* bq, int n_blocks,
+                      int host_flags, double* packed, dh_stream_t stream);
+int dh_ba_unpack_blocks(void* workspace, size_t workspace_bytes, int num_frames, int n_edges, int ht, int wd,
+                        int t0, int t1, int motion_only, const int32_t* bp, const int32_t* bq, int n_blocks,
+                        const double* packed, dh_stream_t stream);
+int dh_ba_exchange_flags(void* workspace, size_t workspace_bytes, int num_frames, int n_edges, int ht, int wd,
+                         int t0, int t1, int motion_only, int host_flags, double* status, int set, dh_stream_t stream);
+int dh_ba_finish_owned(float* poses, float* disps, const int64_t* jj,
+                       int num_frames, int n_edges, int ht, int wd, int t0, int t1,
+                       float lm, float ep, int motion_only, int own_lo, int own_hi, float* dx_out, float* dz_out,
+                       void* workspace, size_t workspace_bytes, dh_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Encoder glue (csrc/norm.hip): the normalisation / residual steps of the feature and context encoders
  * (reference droid_slam/modules/extractor.py:6-50,120-198), whose convolutions go through dh_conv2d_nhwc_f16.

@@ -2,7 +2,7 @@
 """Generate tests/golden/graph_c2_python.npz and graph_stereo_python.npz by running the REFERENCE's own factor_graph.py +
 depth_video.py + modules/corr.py + droid_net.py, unmodified, on CPU (build container only: needs /root/reference):
 
-    python tests/golden/make_graph_scale_golden.py
+    python tests/golden/make_graph_scale_golden.py [stereo] [c2] [tum] [c3]
 
 Same replacements as make_graph_golden.py (droid_backends -> oracle-backed shim, lietorch / torch_scatter shims, the two
 hard-coded "cuda" devices); the update operator runs under torch.autocast(fp16) like under factor_graph.py's decorators.
@@ -31,6 +31,7 @@ from droid_amd.weights import fill_deterministic
 from golden_inputs import graph_scenario, C2_SAMPLE_EDGES, stereo_scenario
 
 ref_dv, ref_fg, ref_net = base.ref_dv, base.ref_fg, base.ref_net
+import modules.corr as ref_corr                    # reference (already imported by factor_graph.py)
 
 
 def update_operator(seed):
@@ -136,6 +137,111 @@ def scenario_tum_size():
     print("graph_tum_size: %d edges; |dpose| %.3e %.3e" % (len(out["ii"]), np.abs(out["U1_poses"] - S["poses"]).max(), np.abs(out["U2_poses"] - S["poses"]).max()))
 
 
+# --------------------------------------------------------------------------------------------- C3 (the headline size)
+class _ChunkedCorrBlock:
+    """The reference's OWN modules/corr.py CorrBlock, instantiated per 64-edge chunk inside __call__ instead of once for all
+    edges: 4096 all-pairs pyramids are 103 GB in fp16, the build container has 62 GB of RAM.  A correlation volume and its
+    lookup are per-edge independent (corr.py:23-50), so the concatenated result is what CorrBlock(fmap1, fmap2)(coords)
+    returns.  Only the constructor name `CorrBlock` in factor_graph.py's namespace is rebound; factor_graph.py itself runs
+    unmodified."""
+    CHUNK = 64
+
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=3):
+        self.fmap1, self.fmap2, self.num_levels, self.radius = fmap1, fmap2, num_levels, radius
+
+    def __call__(self, coords):
+        outs = []
+        for s in range(0, self.fmap1.shape[1], self.CHUNK):
+            blk = ref_corr.CorrBlock(self.fmap1[:, s:s + self.CHUNK], self.fmap2[:, s:s + self.CHUNK], self.num_levels, self.radius)
+            outs.append(blk(coords[:, s:s + self.CHUNK]))
+            del blk
+        return torch.cat(outs, dim=1)
+
+    def cat(self, other):
+        self.fmap1 = torch.cat([self.fmap1, other.fmap1], 1); self.fmap2 = torch.cat([self.fmap2, other.fmap2], 1)
+        return self
+
+    def __getitem__(self, index):
+        self.fmap1, self.fmap2 = self.fmap1[:, index], self.fmap2[:, index]
+        return self
+
+
+def update_operator_by_frame_groups(seed, frames_per_group=32):
+    """The reference's UpdateModule (droid_net.py:78-143) under fp16 autocast, evaluated on groups of WHOLE source frames:
+    its convolutions are per-edge, GraphAgg's scatter_mean (droid_net.py:62-67) is per source frame and returns rows in
+    sorted-unique order, so groups of ascending frame ranges concatenate to the full-batch result; the full batch of 4096
+    edges needs ~60 GB of fp16 activations on the host."""
+    m = ref_net.UpdateModule()
+    fill_deterministic(m, seed=seed)
+    m.agg.eta[2] = base._SoftplusF32()
+    m.eval()
+
+    def update_op(net, inp, corr, flow, ii, jj):
+        frames = torch.unique(ii)
+        E = ii.shape[0]
+        net_o = torch.empty_like(net)
+        delta_o = weight_o = None
+        etas, ups = [], []
+        for s in range(0, len(frames), frames_per_group):
+            grp = frames[s:s + frames_per_group]
+            sel = torch.nonzero((ii >= grp[0]) & (ii <= grp[-1]))[:, 0]
+            with torch.no_grad(), torch.autocast("cpu", dtype=torch.float16):
+                n, d, w, eta, up = m(net[:, sel], inp[:, sel], corr[:, sel], flow[:, sel], ii[sel], jj[sel])
+            if delta_o is None:
+                delta_o = torch.empty((1, E) + tuple(d.shape[2:]), dtype=d.dtype)
+                weight_o = torch.empty((1, E) + tuple(w.shape[2:]), dtype=w.dtype)
+            net_o[:, sel] = n.to(net_o.dtype); delta_o[:, sel] = d; weight_o[:, sel] = w
+            etas.append(eta); ups.append(up)
+        return net_o, delta_o, weight_o, torch.cat(etas, 1), torch.cat(ups, 1)
+    return update_op
+
+
+def scenario_c3():
+    """BASELINE configs[2] at FULL size (the configuration bench.py times): 512 keyframes / 4096 edges / 48x64,
+    droid_amd.synthetic.make_graph("C3", with_features=True); FactorGraph.add_factors on all edges, then two
+    FactorGraph.update iterations (factor_graph.py:214-263).  Kept per iteration: poses and damping of every frame, depths
+    of every 8th frame + per-frame depth means of all frames; target / weight of C3_SAMPLE_EDGES (64 edges spread over the
+    graph) and their hidden state at every 4th pixel in x and y; per-edge means of |target - coords0|, weight and
+    |hidden state| for ALL 4096 edges."""
+    from golden_inputs import C3_SAMPLE_EDGES, C3_SAMPLE_FRAMES
+    g = syn.make_graph("C3", with_features=True)
+    N, ht, wd = g["n_frames"], g["ht"], g["wd"]
+    video = ref_dv.DepthVideo(image_size=[8 * ht, 8 * wd], buffer=N + 2, stereo=False, device="cpu")
+    video.poses[:N] = torch.as_tensor(g["poses"]); video.disps[:N] = torch.as_tensor(g["disps"])
+    video.intrinsics[:N] = torch.as_tensor(g["intrinsics"])
+    video.fmaps[:N] = torch.as_tensor(g["fmaps"]); video.nets[:N] = torch.as_tensor(g["nets"]); video.inps[:N] = torch.as_tensor(g["inps"])
+    video.counter.value = N
+    out = {}
+    ref_fg.CorrBlock = _ChunkedCorrBlock
+    try:
+        with torch.no_grad():
+            fg = ref_fg.FactorGraph(video, update_operator_by_frame_groups(1234), device="cpu", corr_impl="volume", max_factors=-1, upsample=False)
+            fg.add_factors(torch.as_tensor(g["ii"]), torch.as_tensor(g["jj"]))
+            assert len(fg.ii) == len(g["ii"]) == 4096
+            out["ii"], out["jj"] = fg.ii.numpy().copy(), fg.jj.numpy().copy()
+            sample = torch.as_tensor(C3_SAMPLE_EDGES); fr = np.asarray(C3_SAMPLE_FRAMES)
+            for k in (1, 2):
+                t = time.time()
+                fg.update(t0=1, t1=None, itrs=2, use_inactive=False)
+                print("C3 update %d: %.1f s" % (k, time.time() - t), flush=True)
+                tag = "U%d" % k
+                out[tag + "_poses"] = video.poses[:N].numpy().copy()
+                d = video.disps[:N].numpy()
+                out[tag + "_disps_f"] = d[fr].copy(); out[tag + "_disps_mean"] = d.reshape(N, -1).mean(1).copy()
+                out[tag + "_damping_f"] = fg.damping[:N].numpy()[fr].copy()
+                out[tag + "_damping_mean"] = fg.damping[:N].numpy().reshape(N, -1).mean(1).copy()
+                tgt, wgt, net = fg.target[0], fg.weight[0], fg.net[0]
+                out[tag + "_target_s"] = tgt[sample].numpy().copy(); out[tag + "_weight_s"] = wgt[sample].numpy().astype(np.float16)
+                out[tag + "_net_s"] = net[sample][:, :, ::4, ::4].float().numpy().astype(np.float16)
+                out[tag + "_flow_mean"] = (tgt - fg.coords0).abs().mean(dim=(1, 2, 3)).numpy().copy()
+                out[tag + "_weight_mean"] = wgt.mean(dim=(1, 2, 3)).numpy().copy()
+                out[tag + "_net_absmean"] = torch.stack([net[s:s + 256].float().abs().mean(dim=(1, 2, 3)) for s in range(0, net.shape[0], 256)]).reshape(-1).numpy().copy()
+    finally:
+        ref_fg.CorrBlock = ref_corr.CorrBlock
+    np.savez_compressed(os.path.join(HERE, "graph_c3_python.npz"), **out)
+    print("graph_c3: |dpose| %.3e %.3e" % (np.abs(out["U1_poses"] - g["poses"]).max(), np.abs(out["U2_poses"] - g["poses"]).max()))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["stereo", "c2", "tum"]
     if "tum" in which:
@@ -144,3 +250,5 @@ if __name__ == "__main__":
         scenario_stereo()
     if "c2" in which:
         scenario_c2()
+    if "c3" in which:                          # not in the default list: ~62 GB host RAM, tens of minutes
+        scenario_c3()

@@ -56,6 +56,11 @@ def encoder_inputs():
 # edges of the C2 graph (512 edges) whose full hidden state / target / weight is kept in graph_c2_python.npz
 C2_SAMPLE_EDGES = [0, 1, 2, 3, 254, 255, 256, 257, 508, 509, 510, 511]
 
+# edges of the C3 graph (4096 edges) whose target / weight / subsampled hidden state is kept in graph_c3_python.npz: every
+# 65th edge (hits temporal and loop-closure edges, all strips of the lookup, all frame groups of the update operator)
+C3_SAMPLE_EDGES = list(range(0, 4096, 65))[:63] + [4095]
+C3_SAMPLE_FRAMES = list(range(0, 512, 8))
+
 
 def stereo_scenario(n_frames=6):
     """Six stereo keyframes at 16 x 64: feature maps of both cameras, stereo self-edges (i, i) followed by the temporal

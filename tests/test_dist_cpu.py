@@ -1,6 +1,6 @@
 """world_size-2 gloo test of the edge-sharded BA host logic (droid_amd/dist_ba.py) on CPU.
 
-The per-rank numerics (dh_ba_build / dh_ba_finish) need a GPU; here they are replaced by an injected backend that
+The per-rank numerics (dh_ba_build_shard / dh_ba_pack_blocks / dh_ba_unpack_blocks / dh_ba_finish_owned) need a GPU; here they are replaced by an injected backend that
 computes the same two halves with the oracle, so what is exercised is exactly what runs between the kernels on
 a multi-GPU node: the partition by source frame, the eta row mapping, the all-reduce of the reduced camera system,
 owner-only depth updates and the final exchange of depth increments.  Sharded result == unsharded oracle.
@@ -33,19 +33,51 @@ class OracleBackend:
         system[:n] = torch.from_numpy(info["H"]); system[n] = torch.from_numpy(info["b"])
         return dict(info=info, system=system, t0=t0, t1=t1), system
 
-    def ba_finish(self, poses, disps, jj, ws, n_eta_rows, t0, t1, lm, ep, motion_only):
+    def ba_build_shard(self, *a):                      # droid_backends.ba_build_shard: ba_build without the host check
+        return self.ba_build(*a)
+
+    @staticmethod
+    def _block_index(bp, bq):
+        r = torch.arange(6)
+        return 6 * bp.long()[:, None, None] + r[None, :, None], 6 * bq.long()[:, None, None] + r[None, None, :]
+
+    def ba_pack_blocks(self, ws, disps, jj, t0, t1, motion_only, bp, bq, host_flags, packed):
+        system, n, nb = ws["system"], 6 * (t1 - t0), len(bp)
+        rows, cols = self._block_index(bp, bq)
+        packed[:36 * nb] = system[rows, cols].reshape(-1)
+        packed[36 * nb:36 * nb + n] = system[n]
+        packed[36 * nb + n] = 0.0
+        packed[36 * nb + n + 1] = float(host_flags != 0)
+
+    def ba_unpack_blocks(self, ws, disps, jj, t0, t1, motion_only, bp, bq, packed):
+        system, n, nb = ws["system"], 6 * (t1 - t0), len(bp)
+        rows, cols = self._block_index(bp, bq)
+        system[rows, cols] = packed[:36 * nb].reshape(nb, 6, 6)
+        system[n] = packed[36 * nb:36 * nb + n]
+        ws["flag"] = bool(packed[36 * nb + n] != 0 or packed[36 * nb + n + 1] != 0)
+
+    def ba_exchange_flags(self, ws, disps, jj, t0, t1, motion_only, host_flags, status, set):
+        if set:
+            ws["flag"] = bool((status != 0).any())
+        else:
+            status[0] = 0.0; status[1] = float(host_flags != 0)
+
+    def ba_finish_owned(self, poses, disps, jj, ws, n_eta_rows, t0, t1, lm, ep, motion_only, own_lo, own_hi):
         from oracle import ba as oba
         info, system = ws["info"], ws["system"]
         n = 6 * (t1 - t0)
-        x, ok = oba.solve_damped(system[:n].numpy().copy(), system[n].numpy().copy(), lm, ep)
         P = t1 - t0
+        HW = info["Q"].shape[1]
+        if ws.get("flag"):                                  # some rank flagged: nobody updates
+            return torch.zeros(P, 6, dtype=torch.float64), torch.zeros(len(info["kx"]), HW, dtype=torch.float64)
+        x, ok = oba.solve_damped(system[:n].numpy().copy(), system[n].numpy().copy(), lm, ep)
         dx = x.reshape(P, 6).astype(np.float32).astype(np.float64)
         prel = info["jj_exp"] - t0
         use = (prel > 0) & (prel < P)
-        HW = info["Q"].shape[1]
         dw = np.zeros((len(prel), HW))
         dw[use] = np.einsum("nip,ni->np", info["Erow"][use], dx[prel[use]])
         dz = info["Q"] * (info["w"] - oba._segsum(dw, info["ii_exp"], info["kx"]))
+        dz[(info["kx"] < own_lo) | (info["kx"] >= own_hi)] = 0.0          # only the owner of a frame moves its depths
         pn = poses.numpy().astype(np.float64)
         oba._retract_poses(pn, dx, t0, t1, np.float64)
         poses.copy_(torch.from_numpy(pn).to(poses.dtype))

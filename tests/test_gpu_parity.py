@@ -364,6 +364,97 @@ def test_raw_c_abi_call(db):
     assert np.abs(out.cpu().numpy() - ocorr.corr_index_forward(vol, coords, 3)).max() < 2e-5
 
 
+def _capi():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = ctypes.CDLL(os.path.join(root, "droid-slam_amd", "libdroid_hip.so"))
+    lib.dh_ba_workspace_bytes.restype = ctypes.c_size_t
+    lib.dh_corr_pyramid_bytes.restype = ctypes.c_size_t
+    lib.dh_corr_pyramid_workspace_bytes.restype = ctypes.c_size_t
+    return lib
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def test_raw_c_abi_ba_on_a_side_stream(db):
+    """dh_ba (droid.cpp:93-122's replacement) through ctypes: raw device pointers, caller-allocated workspace of
+    dh_ba_workspace_bytes, a NON-default stream -- equal to droid_backends.ba (the torch binding) bit for bit."""
+    lib = _capi()
+    g = syn.make_graph("C1")
+    F, ht, wd = g["disps"].shape
+    E, t0, t1 = len(g["ii"]), 1, g["n_frames"]
+    K = g["eta"].shape[0]
+    want_p, want_d = dev(g["poses"]), dev(g["disps"])
+    wdx, wdz = db.ba(want_p, want_d, dev(g["intrinsics"]), dev(g["disps_sens"]), dev(g["targets"]), dev(g["weights"]), dev(g["eta"]),
+                     dev(g["ii"]), dev(g["jj"]), t0, t1, 2, g["lm"], g["ep"], False)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    poses, disps = dev(g["poses"]), dev(g["disps"])
+    intr, sens, tg, wt, eta, ii, jj = (dev(g[k]) for k in ("intrinsics", "disps_sens", "targets", "weights", "eta", "ii", "jj"))
+    wsb = lib.dh_ba_workspace_bytes(F, E, ht, wd, t0, t1, 0)
+    assert wsb > 0
+    ws = torch.empty(wsb + 256, dtype=torch.uint8, device="cuda")
+    off = (-ws.data_ptr()) % 256
+    dx = torch.zeros(t1 - t0, 6, device="cuda"); dz = torch.zeros(K, ht * wd, device="cuda")
+    torch.cuda.synchronize()
+    # a mis-aligned or short workspace is refused before anything is launched
+    assert lib.dh_ba(_p(poses), _p(disps), _p(intr), _p(sens), _p(tg), _p(wt), _p(eta), _p(ii), _p(jj), F, E, K, ht, wd, t0, t1, 2,
+                     ctypes.c_float(g["lm"]), ctypes.c_float(g["ep"]), 0, _p(dx), _p(dz), ctypes.c_void_p(ws.data_ptr() + off), ctypes.c_size_t(wsb - 1),
+                     ctypes.c_void_p(side.cuda_stream)) != 0
+    rc = lib.dh_ba(_p(poses), _p(disps), _p(intr), _p(sens), _p(tg), _p(wt), _p(eta), _p(ii), _p(jj), F, E, K, ht, wd, t0, t1, 2,
+                   ctypes.c_float(g["lm"]), ctypes.c_float(g["ep"]), 0, _p(dx), _p(dz), ctypes.c_void_p(ws.data_ptr() + off), ctypes.c_size_t(wsb),
+                   ctypes.c_void_p(side.cuda_stream))
+    assert rc == 0
+    side.synchronize()
+    assert torch.equal(poses, want_p) and torch.equal(disps, want_d) and torch.equal(dx, wdx) and torch.equal(dz, wdz)
+
+
+def test_raw_c_abi_altcorr_and_fused_lookup_on_a_side_stream(db):
+    """dh_altcorr_fwd (droid.cpp:198-204's replacement) and dh_corr_pyramid_build + dh_corr_pyramid_lookup_corr0 through
+    ctypes on a non-default stream == the torch binding's results"""
+    from droid_amd.update import pack_corr0_fused
+    lib = _capi()
+    rng = np.random.default_rng(9)
+    side = torch.cuda.Stream()
+    # ---- altcorr_forward: fmap1 [B,N,C,H,W], fmap2 [B,N,C,H2,W2], coords [B,M,2,H,W], ii, jj [M] -> [B,M,7,7,H,W]
+    B, N, C, H, W, M = 1, 3, 128, 8, 16, 5
+    f1 = dev(rng.standard_normal((B, N, C, H, W)).astype(np.float32)); f2 = dev(rng.standard_normal((B, N, C, H, W)).astype(np.float32))
+    coords = dev(np.stack([rng.uniform(-2, W + 1, (B, M, H, W)), rng.uniform(-2, H + 1, (B, M, H, W))], 2).astype(np.float32))
+    ii = dev(rng.integers(0, N, M)); jj = dev(rng.integers(0, N, M))
+    want, = db.altcorr_forward(f1, f2, coords, ii, jj, 3)
+    want = want.contiguous()
+    torch.cuda.synchronize()
+    out = torch.zeros(B, M, 7, 7, H, W, device="cuda")
+    torch.cuda.synchronize()
+    rc = lib.dh_altcorr_fwd(_p(f1), _p(f2), _p(coords), _p(ii), _p(jj), _p(out), 1, B, N, N, C, H, W, H, W, M, 3, ctypes.c_void_p(side.cuda_stream))
+    assert rc == 0
+    side.synchronize()
+    # the binding returns the reference's permuted view [B,M,H,W,7,7] -> compare in the C ABI's own layout
+    w = want if want.shape == out.shape else want.permute(0, 1, 4, 5, 2, 3).contiguous()
+    assert torch.equal(out, w)
+    # ---- pyramid build + the fused lookup
+    E, h, wd = 3, 16, 64
+    g1 = dev(rng.standard_normal((E, 128, h, wd)).astype(np.float16)); g2 = dev(rng.standard_normal((E, 128, h, wd)).astype(np.float16))
+    yy, xx = np.meshgrid(np.arange(h, dtype=np.float32), np.arange(wd, dtype=np.float32), indexing="ij")
+    cc = dev(np.stack([np.stack([xx + 2.3 * (e + 1) + 0.07 * yy, yy - 1.4 * e + 0.02 * xx], -1) for e in range(E)]).astype(np.float32))
+    wgt = dev((0.05 * rng.standard_normal((128, 196))).astype(np.float32)); bias = dev((0.3 * rng.standard_normal(128)).astype(np.float32))
+    wpk = pack_corr0_fused(wgt)
+    want_pyr = db.corr_pyramid_build(g1, g2)
+    want_c0 = db.corr_pyramid_lookup_corr0(want_pyr, cc, wpk, bias)
+    torch.cuda.synchronize()
+    nbytes = lib.dh_corr_pyramid_bytes(E, h, wd); wsb = lib.dh_corr_pyramid_workspace_bytes(E, h, wd)
+    assert nbytes == want_pyr.numel() * 2
+    pyr = torch.zeros(nbytes // 2, dtype=torch.float16, device="cuda"); wsp = torch.empty(max(wsb, 1), dtype=torch.uint8, device="cuda")
+    c0 = torch.zeros(E, h, wd, 128, dtype=torch.float16, device="cuda")
+    torch.cuda.synchronize()
+    st = ctypes.c_void_p(side.cuda_stream)
+    assert lib.dh_corr_pyramid_build(_p(g1), _p(g2), _p(pyr), _p(wsp), ctypes.c_size_t(wsb), E, 128, h, wd, st) == 0
+    assert lib.dh_corr_pyramid_lookup_corr0(_p(pyr), _p(cc), _p(wpk), _p(bias), _p(c0), E, h, wd, st) == 0
+    side.synchronize()
+    assert torch.equal(pyr, want_pyr.reshape(-1)) and torch.equal(c0, want_c0)
+
+
 # ------------------------------------------------------------------------------------------ sharded BA
 def test_sharded_ba_equals_single_gpu(db):
     """Edge-sharded BA emulated on one GPU: per-shard ba_build, summed systems (what the RCCL
@@ -464,11 +555,12 @@ def test_native_pyramid_build_kernels_are_bit_identical(db, option):
     for (E, h, w) in [(3, 48, 64), (2, 16, 32), (2, 8, 16), (1, 24, 64)]:
         f1 = torch.randn(E, 128, h, w, device="cuda").half()
         f2 = torch.randn(E, 128, h, w, device="cuda").half()
-        option("pyr_build_chunk", 1)
-        a = db.corr_pyramid_build(f1, f2)
-        option("pyr_build_chunk", 0)
         b = db.corr_pyramid_build(f1, f2)
-        assert torch.equal(a, b)
+        if db.get_option("ablation_build"):              # the chunk kernel exists only in a -DDH_ABLATION build
+            option("pyr_build_chunk", 1)
+            a = db.corr_pyramid_build(f1, f2)
+            option("pyr_build_chunk", 0)
+            assert torch.equal(a, b)
         option("pyr_build_waves", 4)                     # w = 64: the four-wave form of the row-ring kernel (8 waves is the default)
         c = db.corr_pyramid_build(f1, f2)
         option("pyr_build_waves", 8)
@@ -587,6 +679,8 @@ def test_update_operator_vs_reference_module_under_autocast(db, golden_dir, shar
 @pytest.mark.parametrize("halo,dma,halo2", [("1", "0", "1"), ("1", "0", "0"), ("1", "1", "1"), ("0", "0", "1")])
 def test_conv2d_nhwc_matches_torch_conv(db, option, halo, dma, halo2):
     # all four main loops: halo2 (DMA weights, the default for 128-cout tiles), halo-tile, opt-in LDS-DMA, generic (fallback)
+    if dma == "1" and not db.get_option("ablation_build"):
+        pytest.skip("the LDS-DMA prototype kernel is only part of a -DDH_ABLATION build (DROID_HIP_ABLATION=1)")
     option("conv_halo", halo)
     option("conv_dma", dma)
     option("conv_halo2", halo2)
@@ -920,6 +1014,8 @@ def test_conv_winograd_prototype(db):
     kernel on the same operands: multi-segment input, two cout tiles, image borders, relu epilogue; and the two gate
     convolutions of the update operator (accumulator start values through the transform's null space, GRU epilogues)
     against the autocast oracle at the operator's 2^-9."""
+    if not db.get_option("ablation_build"):
+        pytest.skip("the Winograd prototype kernel is only part of a -DDH_ABLATION build (DROID_HIP_ABLATION=1)")
     from oracle import update as oupd
     from droid_amd.update import pack_conv, pack_conv_halo, pack_conv_wino, EPI_RELU, LAYOUT_WINO, UpdateModule
     from droid_amd.weights import deterministic_state_dict

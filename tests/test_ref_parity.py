@@ -61,19 +61,45 @@ def _ba(mod, g, poses, disps, eta, t0, t1, itrs, lm, ep, mo):
     return p.cpu().numpy(), d.cpu().numpy(), r[0].cpu().numpy(), (None if mo else r[1].cpu().numpy())
 
 
-def _check(got, want, mo=False):
+def _oracle64(g, poses, disps, eta, t0, t1, lm, ep, mo, iters=1, **kw):
+    """one Gauss-Newton iteration of the fp64 oracle from the given state -> (poses, disps, dx, dz)"""
+    from oracle import ba as oba
+    p = np.array(poses, dtype=np.float64, order="C"); d = np.array(disps, dtype=np.float64, order="C")
+    dx, dz = oba.ba(p, d, g["intrinsics"], g["disps_sens"], g["targets"], g["weights"], eta, g["ii"], g["jj"], t0, t1, iters, lm, ep, mo,
+                    dtype=np.float64, **kw)
+    return p, d, dx, dz
+
+
+def _check(got, want, mo=False, exact=None):
+    """HIP vs the reference's ba from the same state.  Depths / depth steps: SURVEY 8c's rel 1e-3 everywhere; 99.5 % within
+    1e-4.  Pixels beyond 1e-3 (near-epipole pixels: Jz -> 0 by cancellation, the step r/Jz amplifies the last bits of two
+    fp32 evaluations in different summation orders) are allowed ONLY when `exact` -- a callable returning the fp64
+    oracle's result from the same state -- shows the reference's own fp32 result to be as far from the exact one: on the
+    set of those pixels the HIP error against fp64 must stay within 2x the reference's error against fp64 (max and mean),
+    and no pixel may exceed 1e-2."""
     p, d, dx, dz = got
     rp, rd, rdx, rdz = want
     assert np.linalg.norm(dx - rdx) <= 1e-3 * np.linalg.norm(rdx) + 1e-7
     assert np.abs(p[:, :3] - rp[:, :3]).max() <= 1e-4
     assert _rot_angle(p[:, 3:].astype(np.float64), rp[:, 3:].astype(np.float64)).max() <= 1e-4
-    if not mo:
-        # near-epipole pixels (Jz -> 0 by cancellation) get huge ill-conditioned depth steps r/Jz: fp32 vs fp32 in a
-        # different summation order agrees to ~1e-3 relative there, tightly everywhere else
-        e = np.abs(dz - rdz) / np.maximum(1.0, np.abs(rdz))
-        assert np.quantile(e, 0.995) <= 1e-4 and e.max() <= 1e-2
-        e = np.abs(d - rd) / np.maximum(1.0, np.abs(rd))
-        assert np.quantile(e, 0.995) <= 1e-4 and e.max() <= 1e-2
+    if mo:
+        return
+    x64 = None
+    for name, a, b, k in (("dz", dz, rdz, 3), ("disps", d, rd, 1)):
+        e = np.abs(a - b) / np.maximum(1.0, np.abs(b))
+        assert np.quantile(e, 0.995) <= 1e-4, "%s: q99.5 %g" % (name, np.quantile(e, 0.995))
+        tail = e > 1e-3
+        if not tail.any():
+            continue
+        assert e.max() <= 1e-2 and tail.mean() <= 1e-3, "%s: max %g, %d pixels beyond 1e-3" % (name, e.max(), int(tail.sum()))
+        assert exact is not None, "%s: %d pixels beyond rel 1e-3 (max %g) and no fp64 oracle to judge them" % (name, int(tail.sum()), e.max())
+        if x64 is None:
+            x64 = exact()
+        o = np.asarray(x64[k], dtype=np.float64).reshape(a.shape)
+        eh = np.abs(a - o)[tail] / np.maximum(1.0, np.abs(o[tail]))
+        er = np.abs(b - o)[tail] / np.maximum(1.0, np.abs(o[tail]))
+        assert eh.max() <= 2.0 * er.max() + 1e-6 and eh.mean() <= 2.0 * er.mean() + 1e-6, \
+            "%s tail (%d pixels): HIP vs fp64 max %g mean %g, reference vs fp64 max %g mean %g" % (name, int(tail.sum()), eh.max(), eh.mean(), er.max(), er.mean())
 
 
 def _per_iteration(db, ref, g, eta, t0, t1, iters, lm, ep, mo=False):
@@ -84,7 +110,7 @@ def _per_iteration(db, ref, g, eta, t0, t1, iters, lm, ep, mo=False):
     for k in range(1, iters + 1):
         got = _ba(db, g, g["poses"], g["disps"], eta, t0, t1, k, lm, ep, mo)
         want = _ba(mod, g, sp, sd, eta, t0, t1, 1, lm, ep, mo)
-        _check(got, want, mo)
+        _check(got, want, mo, exact=lambda sp=sp, sd=sd: _oracle64(g, sp, sd, eta, t0, t1, lm, ep, mo, threads=16))
         sp, sd = got[0], got[1]
 
 
@@ -137,7 +163,7 @@ def test_ba_failure_in_the_first_iteration_only_vs_reference(db, ref):
     two = _ba(db, g, g["poses"], g["disps"], g["eta"], 1, 6, 2, 1e-4, -0.14, False)
     two_ref = _ba(ref[0], g, g["poses"], g["disps"], g["eta"], 1, 6, 2, 1e-4, -0.14, False)
     assert np.abs(two_ref[2]).max() > 0 and np.abs(two[2]).max() > 0
-    _check(two, two_ref)
+    _check(two, two_ref, exact=lambda: _oracle64(g, g["poses"], g["disps"], g["eta"], 1, 6, 1e-4, -0.14, False, iters=2))
 
 
 def test_ba_bad_indices_and_eta_rows_raise_and_apply_no_update(db):
@@ -194,7 +220,8 @@ def test_ba_ex_per_pixel_depth_prior(db, ref):
     alpha = torch.full_like(d, 0.05)
     r = db.ba_ex(p, d, dev(g["intrinsics"]), dev(g["disps_sens"]), alpha, dev(g["targets"]), dev(g["weights"]), dev(eta),
                  dev(g["ii"]), dev(g["jj"]), 1, 6, 1, 1e-5, 1e-2, False)
-    _check((p.cpu().numpy(), d.cpu().numpy(), r[0].cpu().numpy(), r[1].cpu().numpy()), want)
+    _check((p.cpu().numpy(), d.cpu().numpy(), r[0].cpu().numpy(), r[1].cpu().numpy()), want,
+           exact=lambda: _oracle64(g, g["poses"], g["disps"], eta, 1, 6, 1e-5, 1e-2, False))
     amap = np.random.default_rng(1).uniform(0.0, 0.3, g["disps"].shape).astype(np.float32)
     p, d = dev(g["poses"]), dev(g["disps"])
     r = db.ba_ex(p, d, dev(g["intrinsics"]), dev(g["disps_sens"]), dev(amap), dev(g["targets"]), dev(g["weights"]), dev(eta),
@@ -212,7 +239,7 @@ def test_ba_config_c5_size_vs_reference(db, ref):
     g = syn.make_graph("C5")
     got = _ba(db, g, g["poses"], g["disps"], g["eta"], 1, g["n_frames"], 1, g["lm"], g["ep"], False)
     want = _ba(ref[0], g, g["poses"], g["disps"], g["eta"], 1, g["n_frames"], 1, g["lm"], g["ep"], False)
-    _check(got, want)
+    _check(got, want, exact=lambda: _oracle64(g, g["poses"], g["disps"], g["eta"], 1, g["n_frames"], g["lm"], g["ep"], False, threads=32))
 
 
 # ------------------------------------------------------------------------------------------ assembled system
@@ -331,4 +358,21 @@ def test_geometry_kernels_vs_reference(db, ref):
     assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item()
     ix = dev(np.arange(8)); th = dev(np.full(8, 0.05, dtype=np.float32))
     a, b = db.depth_filter(poses, disps, intr, ix, th), ref[0].depth_filter(poses, disps, intr, ix, th)
-    assert (a != b).float().mean().item() < 2e-3      # threshold comparisons may flip on fp32 rounding of the distance
+    assert torch.equal(a, b)                          # integer counts: equality
+
+
+@pytest.mark.parametrize("thresh", [0.005, 0.05, 0.5])
+def test_depth_filter_counts_equal_reference(db, ref, thresh):
+    """depth_filter returns integer counts (droid_kernels.cu:670-786): the bar is equality.  The kernel follows the
+    reference's arithmetic -- fp32 relative pose / transform / projection in the reference's operation order, then the
+    consistency test in fp64 as its double literals make it (`abs(1.0/dj - 1.0/d00) < t`).  C2: 64 frames, every frame
+    as centre (first / last frames have out-of-range neighbours), estimated (not ground-truth) poses and depths."""
+    g = syn.make_graph("C2")
+    rng = np.random.default_rng(5)
+    disps = (g["disps_gt"] * (1.0 + 0.02 * rng.standard_normal(g["disps_gt"].shape))).astype(np.float32)
+    poses, disps, intr = dev(g["poses"]), dev(disps), dev(g["intrinsics"])
+    ix = dev(np.arange(g["n_frames"])); th = dev(np.full(g["n_frames"], thresh, dtype=np.float32))
+    a, b = db.depth_filter(poses, disps, intr, ix, th), ref[0].depth_filter(poses, disps, intr, ix, th)
+    torch.cuda.synchronize()
+    assert 0.02 < (b > 0).float().mean().item() and b.max().item() >= 2     # the test is not vacuous
+    assert torch.equal(a, b), "depth_filter counts differ on %d of %d pixels" % (int((a != b).sum().item()), a.numel())
