@@ -25,14 +25,19 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 HIP_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
              "-Wno-unused-result", "-ffp-contract=fast"]
-# DROID_HIP_ABLATION=1: also compile the prototype kernels (LDS-DMA / Winograd convolutions, first forms of the pyramid build
-# and alt-correlation kernels) and the timing ablations of the lookup that return wrong results by construction
-# (lookup_mode 2-5).  The shipped library is built WITHOUT it: those variants do not exist in it and dh_set_option refuses them.
+# DROID_HIP_ABLATION=1: a SECOND, separate build under droid-slam_amd/ablation/ that also carries the prototype kernels
+# (LDS-DMA / Winograd convolutions, first forms of the pyramid build and alt-correlation kernels) and the timing ablations
+# that return wrong results by construction (lookup_mode 2-5, conv_abl).  The shipped library next to this file is built
+# WITHOUT -DDH_ABLATION: those variants do not exist in it and dh_set_option refuses them.  Measurement scripts pick the
+# ablation build by putting droid-slam_amd/ablation first on sys.path (scripts/conv_power.py --ablation).
 ABLATION = os.environ.get("DROID_HIP_ABLATION", "0") == "1"
 if ABLATION:
     HIP_FLAGS.append("-DDH_ABLATION=1")
-    OBJ = os.path.join(HERE, "build", "ablation")        # own object directory: the two builds never mix objects
-MODE_STAMP = os.path.join(HERE, "build", ".lib_mode")    # which of the two builds libdroid_hip.so currently is
+    OUTDIR = os.path.join(HERE, "ablation")
+    OBJ = os.path.join(HERE, "build", "ablation")
+    os.makedirs(OUTDIR, exist_ok=True)
+    LIB = os.path.join(OUTDIR, "libdroid_hip.so")
+    EXT = os.path.join(OUTDIR, "droid_backends.so")
 
 
 def _run(cmd, verbose):
@@ -75,11 +80,8 @@ def build_lib(force=False, verbose=False):
             jobs.append([HIPCC] + HIP_FLAGS + ["-c", s, "-o", o])
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(lambda c: _run(c, verbose), jobs))
-    mode = "ablation" if ABLATION else "release"
-    have = open(MODE_STAMP).read().strip() if os.path.exists(MODE_STAMP) else "release"
-    if force or jobs or _newer(LIB, objs) or have != mode:
+    if force or jobs or _newer(LIB, objs):
         _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs, verbose)
-        open(MODE_STAMP, "w").write(mode)
     return LIB
 
 
@@ -159,7 +161,7 @@ def build_ext(force=False, verbose=False):
           "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DTORCH_EXTENSION_NAME=droid_backends",
           "-DTORCH_API_INCLUDE_EXTENSION_H", "-D_GLIBCXX_USE_CXX11_ABI=%d" % abi,
           "-Wno-deprecated-declarations"] + inc, verbose)
-    _run([cxx, "-shared", "-o", EXT, obj, "-L" + tlib, "-L" + HERE,
+    _run([cxx, "-shared", "-o", EXT, obj, "-L" + tlib, "-L" + os.path.dirname(LIB),
           "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch", "-ltorch_python", "-ldroid_hip",
           "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + tlib], verbose)
     return EXT

@@ -897,7 +897,10 @@ constexpr int H2A_BYTES = HPIX * H2CK * 2;               // 25,344: halo [396 px
 constexpr int H2B_BYTES = 3 * 128 * H2CK * 2;            // 24,576: one (chunk, dy) weight group
 constexpr int H2_LDS_BYTES = H2A_BYTES + 2 * H2B_BYTES;  // 74,496 (the staged epilogue tile needs 69,632)
 
-template <int EPI, bool STAGED = true, bool CINIT = false>
+// ABL (only instantiated != 0 in -DDH_ABLATION builds, option "conv_abl", WRONG results by construction): timing / power
+// attribution of the main loop.  bit 0: fragment reads only in the first step (operands stay in registers); bit 1: no weight
+// DMA after the first two groups; bit 2: no halo fetch after the first chunk; bit 3: no epilogue; bit 4: no MFMAs.
+template <int EPI, bool STAGED = true, bool CINIT = false, int ABL = 0>
 __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
   extern __shared__ __half s_conv[];
   char* const lds = reinterpret_cast<char*>(s_conv);
@@ -974,6 +977,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
     }                                                                                                                \
   }
 
+  half8 abl_af[2] = {}, abl_bf[2] = {};                  // (ABL != 0 only: operands that outlive a step)
   H2_FETCH_A(0)
   H2_DMA_B(0)
   for (int c = 0; c < nchunks; ++c) {
@@ -993,10 +997,10 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
       // this wave's DMA pieces of group `step` (issued a step ago) have landed, its halo stores are done; then the barrier.
       // At dy == 1 the halo loads of the next chunk, issued AFTER those pieces one step ago, may stay in flight (vector
       // memory operations complete in order): they get two steps to land instead of one.
-      if (dy == 1 && c + 1 < nchunks) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (dy == 1 && c + 1 < nchunks && !(ABL & 4)) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if (step + 1 < nsteps) H2_DMA_B(step + 1)           // into the buffer last read in step - 1
-      if (dy == 0 && c + 1 < nchunks) H2_FETCH_A(c + 1)
+      if (step + 1 < nsteps && (!(ABL & 2) || step < 1)) H2_DMA_B(step + 1)           // into the buffer last read in step - 1
+      if (dy == 0 && c + 1 < nchunks && !(ABL & 4)) H2_FETCH_A(c + 1)
       const char* const Bcur = lds + H2A_BYTES + (step & 1) * H2B_BYTES;
       int pl_o = pl;
       asm volatile("" : "+v"(pl_o));                      // opaque: the 18 tap addresses are cheap to form, expensive to keep
@@ -1010,15 +1014,31 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          half8 af[2], bf[2];
+          if constexpr (ABL == 0) {
+            half8 af[2], bf[2];
 #pragma unroll
-          for (int a = 0; a < 2; ++a) af[a] = *reinterpret_cast<const half8*>(lds + a_row[a] + (((ks * 2) ^ a_x[a]) << 4));
+            for (int a = 0; a < 2; ++a) af[a] = *reinterpret_cast<const half8*>(lds + a_row[a] + (((ks * 2) ^ a_x[a]) << 4));
 #pragma unroll
-          for (int b = 0; b < 2; ++b) bf[b] = *reinterpret_cast<const half8*>(Bcur + dx * (128 * 64) + b_row[b] + (((ks * 2) ^ b_x[b]) << 4));
+            for (int b = 0; b < 2; ++b) bf[b] = *reinterpret_cast<const half8*>(Bcur + dx * (128 * 64) + b_row[b] + (((ks * 2) ^ b_x[b]) << 4));
 #pragma unroll
-          for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+              for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+          } else {
+            if (!(ABL & 1) || step == 0) {                  // (uniform branch: the reads of step 0 stay, the rest reuse the registers)
+#pragma unroll
+              for (int a = 0; a < 2; ++a) abl_af[a] = *reinterpret_cast<const half8*>(lds + a_row[a] + (((ks * 2) ^ a_x[a]) << 4));
+#pragma unroll
+              for (int b = 0; b < 2; ++b) abl_bf[b] = *reinterpret_cast<const half8*>(Bcur + dx * (128 * 64) + b_row[b] + (((ks * 2) ^ b_x[b]) << 4));
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+              for (int b = 0; b < 2; ++b) {
+                if (ABL & 16) asm volatile("" : "+v"(acc[a][b]) : "v"(abl_af[a]), "v"(abl_bf[b]));       // operands stay live, no matrix instruction
+                else acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(abl_af[a], abl_bf[b], acc[a][b], 0, 0, 0);
+              }
+          }
         }
       }
     }
@@ -1026,6 +1046,17 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
 #undef H2_FETCH_A
 #undef H2_DMA_B
 #undef GLDS16S
+  if constexpr ((ABL & 8) != 0) {                        // no epilogue: one never-taken store keeps the accumulators live
+    float sum = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sum += acc[a][b][q];
+    if (sum == 1.2345678e30f) reinterpret_cast<__half*>(P.out)[0] = __float2half(sum);
+    return;
+  }
   if constexpr (EPI == EPI_HEADS0) staged_heads0_epilogue(P, acc, s_conv, m0, n0, wm0, wn0, tid);
   else if constexpr (STAGED) staged_epilogue<EPI, 2, 128>(P, acc, s_conv, m0, n0, wm0, wn0, tid, HW);
   else conv_epilogue<EPI, 2, 2>(P, acc, (long)P.N * HW, m0, n0, wm0, wn0, lane, HW);
@@ -1503,6 +1534,20 @@ int launch_halo2(const ConvParams& P0, hipStream_t st) {
       return DH_OK;
     }
   }
+#ifdef DH_ABLATION
+  if constexpr (EPI == EPI_RELU) {                        // timing / power attribution (scripts/conv_power.py): wrong results
+    const int abl = opts().conv_abl;
+#define H2_ABL(v_)                                                                                                   \
+    if (abl == v_) {                                                                                                 \
+      DH_LDS_OPTIN((&conv3x3_halo2_kernel<EPI_RELU, true, false, v_>), 80 * 1024);                                   \
+      hipLaunchKernelGGL((conv3x3_halo2_kernel<EPI_RELU, true, false, v_>), grid, dim3(512), H2_LDS_BYTES, st, P);   \
+      DH_LAUNCH_CHECK();                                                                                             \
+      return DH_OK;                                                                                                  \
+    }
+    H2_ABL(1) H2_ABL(2) H2_ABL(4) H2_ABL(6) H2_ABL(7) H2_ABL(8) H2_ABL(15) H2_ABL(16) H2_ABL(22)
+#undef H2_ABL
+  }
+#endif
   DH_LDS_OPTIN((&conv3x3_halo2_kernel<EPI>), 80 * 1024);
   hipLaunchKernelGGL((conv3x3_halo2_kernel<EPI>), grid, dim3(512), H2_LDS_BYTES, st, P);
   DH_LAUNCH_CHECK();

@@ -103,8 +103,11 @@ __global__ __launch_bounds__(256) void pyr_transpose_kernel(const __half* __rest
 }
 
 // pooled level l from level l-1 of the channel-last pyramid (rows = target pixels)
+// (h_valid, w_valid): cells of the output level beyond them are stored as zeros -- the image-on-a-canvas mode of
+// dh_corr_pyramid_build_canvas, where avg_pool2d's floor (corr.py:36: 30x40 -> 15x20 -> 7x10 -> 3x5) must not pool the
+// canvas' zero padding into a level's last row / column
 __global__ __launch_bounds__(128) void pyr_pool_kernel(__half* __restrict__ f2T, long stride_e, int row_in, int row_out,
-                                                       int h_in, int w_in) {
+                                                       int h_in, int w_in, int h_valid, int w_valid) {
   const int e = blockIdx.y;
   const int q = blockIdx.x;                      // output pixel
   const int w_out = w_in >> 1;
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(128) void pyr_pool_kernel(__half* __restrict__ f2T,
   const long r00 = ((long)(2 * y) * w_in + 2 * x) * CH + c;
   const float s = __half2float(in[r00]) + __half2float(in[r00 + CH]) + __half2float(in[r00 + (long)w_in * CH]) +
                   __half2float(in[r00 + (long)w_in * CH + CH]);
-  f2T[(long)e * stride_e + (long)(row_out + q) * CH + c] = __float2half(0.25f * s);
+  f2T[(long)e * stride_e + (long)(row_out + q) * CH + c] = (y < h_valid && x < w_valid) ? __float2half(0.25f * s) : __float2half(0.f);
 }
 
 // ---------------------------------------------------------------------------------------- build
@@ -942,6 +945,16 @@ extern "C" size_t dh_corr_pyramid_workspace_bytes(int E, int h, int w) {
 
 extern "C" int dh_corr_pyramid_build(const void* fmap1, const void* fmap2, void* pyramid, void* workspace,
                                      size_t workspace_bytes, int E, int C, int h, int w, dh_stream_t stream) {
+  return dh_corr_pyramid_build_canvas(fmap1, fmap2, pyramid, workspace, workspace_bytes, E, C, h, w, h, w, stream);
+}
+
+// An image of h_real x w_real (any size <= the canvas) on a canvas of h x w that satisfies the layout's constraints: the
+// caller passes canvas-sized features, zero outside the image.  Level l of the image's pyramid has (h_real >> l) x (w_real >> l)
+// cells (avg_pool2d floors, corr.py:36); the canvas levels carry zeros beyond them, which is what a lookup outside a
+// reference-layout volume reads (correlation_kernels.cu:48 within_bounds).
+extern "C" int dh_corr_pyramid_build_canvas(const void* fmap1, const void* fmap2, void* pyramid, void* workspace,
+                                            size_t workspace_bytes, int E, int C, int h, int w, int h_real, int w_real, dh_stream_t stream) {
+  if (h_real <= 0 || w_real <= 0 || h_real > h || w_real > w) return DH_ERR_ARG;
   if (E < 0 || C != CH || !dims_ok(h, w)) return C != CH && E >= 0 && dims_ok(h, w) ? DH_ERR_UNSUPPORTED : DH_ERR_ARG;
   if (E == 0) return DH_OK;
   if (!fmap1 || !fmap2 || !pyramid || !workspace) return DH_ERR_ARG;
@@ -956,7 +969,7 @@ extern "C" int dh_corr_pyramid_build(const void* fmap1, const void* fmap2, void*
   hipLaunchKernelGGL(pyr_transpose_kernel, dim3((HW + 63) / 64, E), dim3(256), 0, st, (const __half*)fmap2, f2T, HW, s2, 0);
   for (int l = 1; l < NLEV; ++l)
     hipLaunchKernelGGL(pyr_pool_kernel, dim3(D.h2[l] * D.w2[l], E), dim3(CH), 0, st, f2T, s2, D.tgt_off[l - 1],
-                       D.tgt_off[l], D.h2[l - 1], D.w2[l - 1]);
+                       D.tgt_off[l], D.h2[l - 1], D.w2[l - 1], h_real >> l, w_real >> l);
 #ifdef DH_ABLATION
   if (opts().pyr_build_chunk) {                            // the first form of the build kernel (A/B measurements)
     hipLaunchKernelGGL(pyr_build_kernel, dim3(D.nblk, E), dim3(256), 0, st, (const __half*)f1T, (const __half*)f2T,

@@ -380,7 +380,9 @@ torch::Tensor altcorr_forward_nhwc_levels(torch::Tensor fmap1, std::vector<torch
 }
 
 // ---- MI355X-native correlation pyramid (own layout; droid_amd.corr.CorrBlock) ----------------------------
-torch::Tensor corr_pyramid_build(torch::Tensor fmap1, torch::Tensor fmap2) {
+// h_real / w_real > 0: the features are an h_real x w_real image, zero-padded to the canvas size of the tensors
+// (dh_corr_pyramid_build_canvas); 0 = the tensors ARE the image
+torch::Tensor corr_pyramid_build(torch::Tensor fmap1, torch::Tensor fmap2, const int h_real, const int w_real) {
   CHECK_INPUT(fmap1); CHECK_INPUT(fmap2);
   TORCH_CHECK(fmap1.scalar_type() == torch::kFloat16 && fmap2.scalar_type() == torch::kFloat16, "fmaps must be float16");
   TORCH_CHECK(fmap1.dim() == 4 && fmap1.sizes() == fmap2.sizes(), "corr_pyramid_build: fmaps [E,C,h,w] of equal shape");
@@ -393,8 +395,8 @@ torch::Tensor corr_pyramid_build(torch::Tensor fmap1, torch::Tensor fmap2) {
   torch::Tensor ws = torch::empty({(int64_t)wsb}, fmap1.options().dtype(torch::kUInt8));
   for (int s = 0; s < E; s += chunk) {
     const int n = std::min(chunk, E - s);
-    check_status(dh_corr_pyramid_build(fmap1[s].data_ptr(), fmap2[s].data_ptr(), pyr[s].data_ptr(), ws.data_ptr(), wsb,
-                                       n, C, h, w, cur_stream()),
+    check_status(dh_corr_pyramid_build_canvas(fmap1[s].data_ptr(), fmap2[s].data_ptr(), pyr[s].data_ptr(), ws.data_ptr(), wsb,
+                                              n, C, h, w, h_real > 0 ? h_real : h, w_real > 0 ? w_real : w, cur_stream()),
                  "corr_pyramid_build");
   }
   return pyr;
@@ -526,6 +528,13 @@ void conv2d_nhwc(std::vector<torch::Tensor> inputs, torch::Tensor weight, c10::o
 }
 
 // ---- factor-graph side kernels (droid_amd.factor_graph / droid_amd.depth_video) ---------------------------------
+// zero the canvas pixels outside the h x w image, in place (dh_canvas_mask_f16)
+void canvas_mask_(torch::Tensor x, const int h, const int w) {
+  CHECK_INPUT(x);
+  TORCH_CHECK(x.scalar_type() == torch::kFloat16 && x.dim() == 4, "canvas_mask_: [N,Hc,Wc,C] float16");
+  check_status(dh_canvas_mask_f16(x.data_ptr(), (int)x.size(0), (int)x.size(1), (int)x.size(2), (int)x.size(3), h, w, cur_stream()), "canvas_mask_");
+}
+
 torch::Tensor motion_features(torch::Tensor coords1, torch::Tensor target) {
   CHECK_INPUT(coords1); CHECK_INPUT(target); CHECK_F32(coords1); CHECK_F32(target);
   TORCH_CHECK(coords1.dim() == 4 && coords1.size(3) == 2 && target.sizes() == coords1.sizes(), "motion_features: [E,h,w,2]");
@@ -686,7 +695,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("altcorr_forward_nhwc", &altcorr_forward_nhwc, "on-the-fly correlation on the fp16 MFMA, channel-last features");
   m.def("corr_volume_build", &corr_volume_build, "all-pairs volume in the reference layout (any image size)");
   m.def("corr_volume_pool", &corr_volume_pool, "2x2 average pooling of the last two dims of a reference-layout volume");
-  m.def("corr_pyramid_build", &corr_pyramid_build, "all-pairs correlation pyramid, MI355X layout");
+  m.def("corr_pyramid_build", &corr_pyramid_build, "all-pairs correlation pyramid, MI355X layout", py::arg("fmap1"), py::arg("fmap2"),
+        py::arg("h_real") = 0, py::arg("w_real") = 0);
   m.def("corr_pyramid_lookup", &corr_pyramid_lookup, "fused 4-level lookup on the MI355X pyramid");
   m.def("corr_pyramid_lookup_nhwc", &corr_pyramid_lookup_nhwc, "fused 4-level lookup, channel-last output for the update operator");
   m.def("corr_pyramid_lookup_corr0", &corr_pyramid_lookup_corr0, "4-level lookup fused with the correlation encoder's first layer (1x1, 196 -> 128, ReLU)");
@@ -698,6 +708,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         py::arg("epilogue"), py::arg("out"), py::arg("out_stride"), py::arg("gterm"), py::arg("aux0"), py::arg("aux1"), py::arg("red"),
         py::arg("cinit") = py::none(), py::arg("cinit_idx") = py::none(), py::arg("cinit_off") = 0, py::arg("out_raw_f32") = false,
         py::arg("weights_layout") = 0);
+  m.def("canvas_mask_", &canvas_mask_, "zero the canvas pixels outside the h x w image (fp16 NHWC, in place)");
   m.def("motion_features", &motion_features, "cat(coords1 - coords0, target - coords1).clamp(-64, 64) as fp16 NHWC");
   m.def("ba_inputs", &ba_inputs, "target = coords1 + delta, weight; also in ba's [E,2,h,w] layout");
   m.def("cvx_upsample", &cvx_upsample, "convex 8x upsampling of depth maps");

@@ -151,7 +151,29 @@ __global__ __launch_bounds__(256) void prox_nms_kernel(float* __restrict__ d, co
   if (tid == 0) out_count[0] = count;
 }
 
+// an h x w image kept on an Hc x Wc canvas (channel-last fp16): zero every pixel outside the image.  The update operator's
+// production convolutions are specialised to 64-pixel rows and four-row tiles; other image sizes run on a zero-padded canvas
+// and every activation that feeds a 3x3 layer has its padding re-zeroed, so that the layer sees the zero border the
+// reference's padded convolution sees (droid_net.py:83-108: nn.Conv2d(..., padding=1)).
+__global__ __launch_bounds__(256) void canvas_mask_kernel(__half* __restrict__ x, long npieces, int Hc, int Wc, int cpieces, int h, int w) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= npieces) return;
+  const long pix = i / cpieces;
+  const int col = (int)(pix % Wc), row = (int)((pix / Wc) % Hc);
+  if (row >= h || col >= w) reinterpret_cast<uint4*>(x)[i] = uint4{0u, 0u, 0u, 0u};
+}
+
 }  // namespace
+
+extern "C" int dh_canvas_mask_f16(void* x, int N, int Hc, int Wc, int C, int h, int w, dh_stream_t stream) {
+  if (N < 0 || Hc <= 0 || Wc <= 0 || C <= 0 || C % 8 || h <= 0 || w <= 0 || h > Hc || w > Wc) return DH_ERR_ARG;
+  if (N == 0 || (h == Hc && w == Wc)) return DH_OK;
+  if (!x || ((uintptr_t)x & 15)) return DH_ERR_ARG;
+  const long n = (long)N * Hc * Wc * (C / 8);
+  hipLaunchKernelGGL(canvas_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (__half*)x, n, Hc, Wc, C / 8, h, w);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
 
 extern "C" int dh_motion_features(const float* coords1, const float* target, void* flow, int E, int ht, int wd, dh_stream_t stream) {
   if (E < 0 || ht <= 0 || wd <= 0) return DH_ERR_ARG;

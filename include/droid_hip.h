@@ -128,6 +128,12 @@ size_t dh_corr_pyramid_bytes(int E, int h, int w);
 size_t dh_corr_pyramid_workspace_bytes(int E, int h, int w);
 int dh_corr_pyramid_build(const void* fmap1, const void* fmap2, void* pyramid, void* workspace,
                           size_t workspace_bytes, int E, int C, int h, int w, dh_stream_t stream);
+/* an h_real x w_real image (any size that fits) on an h x w canvas that satisfies the layout (h % 8 == 0, w in {16,32,64}):
+ * fmap1 / fmap2 are canvas-sized and ZERO outside the image; pooled levels are cut at (h_real >> l) x (w_real >> l) as
+ * avg_pool2d floors them (reference modules/corr.py:36: 30x40 -> 15x20 -> 7x10 -> 3x5).  Lookups then run on the canvas
+ * (coords of canvas pixels outside the image are don't-cares, their outputs are to be dropped). */
+int dh_corr_pyramid_build_canvas(const void* fmap1, const void* fmap2, void* pyramid, void* workspace,
+                                 size_t workspace_bytes, int E, int C, int h, int w, int h_real, int w_real, dh_stream_t stream);
 int dh_corr_pyramid_lookup(const void* pyramid, const float* coords, void* out,
                            int E, int h, int w, dh_stream_t stream);
 /* same lookup written channel-last for the update operator of this library (dh_conv2d_nhwc_f16):
@@ -258,6 +264,10 @@ int dh_norm_act_nhwc_f16(const void* x, const void* residual, void* y, float* st
  *     (i,j) is written as (i,j),(j,i) to out_edges [2*max_new][2] i64 and suppresses its neighbourhood; stops at
  *     dist > thresh, when n_es0 + 2*accepted > max_factors (max_factors > 0), or at max_new; out_count[0] = accepted. */
 int dh_motion_features(const float* coords1, const float* target, void* flow, int E, int ht, int wd, dh_stream_t stream);
+/* x [N,Hc,Wc,C] f16 channel-last (C % 8 == 0, 16-byte aligned): zero the pixels outside the h x w image in the canvas' top-left
+ * corner.  Image sizes outside the production tiling (w != 64 or h % 4 != 0; TUM's 30x40, ...) run the update operator
+ * (reference droid_net.py:78-143) on a zero-padded canvas with this mask between the layers. */
+int dh_canvas_mask_f16(void* x, int N, int Hc, int Wc, int C, int h, int w, dh_stream_t stream);
 int dh_ba_inputs(const float* coords1, const float* dw, float* target, float* weight, float* target_ba, float* weight_ba,
                  int E, int ht, int wd, dh_stream_t stream);
 int dh_cvx_upsample(const float* disp, const void* mask, float* out, int K, int ht, int wd, dh_stream_t stream);

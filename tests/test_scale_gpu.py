@@ -281,6 +281,59 @@ def test_composed_update_at_c2_matches_reference_factor_graph(db, golden_dir):
     _free()
 
 
+def test_composed_update_at_c3_matches_reference_factor_graph(db, golden_dir, c3):
+    """BASELINE configs[2] at FULL size -- the configuration bench.py times: FactorGraph.add_factors on the 4096 edges of the
+    seeded C3 graph (105 GB pyramid) + two FactorGraph.update iterations through the product path (fused lookup, frame-level
+    context, on-device BA) against the golden written by the reference's unmodified factor_graph.py:214-263 on CPU
+    (tests/golden/make_graph_scale_golden.py c3: fp16-autocast update operator, fp64 geometry / BA from the oracle).  Kept in
+    the golden: poses and damping means of all 512 frames, depths of every 8th frame + per-frame depth means, target / weight
+    and the 4x4-subsampled hidden state of 64 edges spread over the graph, per-edge means of flow magnitude / confidence /
+    |hidden state| for ALL 4096 edges (a wrong edge anywhere in the batch shows there)."""
+    from droid_amd.factor_graph import FactorGraph
+    from droid_amd.update import UpdateModule
+    from droid_amd.weights import deterministic_state_dict
+    from golden_inputs import C3_SAMPLE_EDGES, C3_SAMPLE_FRAMES
+    path = os.path.join(golden_dir, "graph_c3_python.npz")
+    assert os.path.exists(path), "tests/golden/graph_c3_python.npz missing (python tests/golden/make_graph_scale_golden.py c3)"
+    G = np.load(path)
+    g = c3
+    N, ht, wd = g["n_frames"], g["ht"], g["wd"]
+    video = _video(N, ht, wd, g["poses"], g["disps"], np.tile(g["intrinsics"], (N, 1)), g["fmaps"][:, 0], g["nets"], g["inps"])
+    upd = UpdateModule("cuda").load_state_dict(deterministic_state_dict(_SD(), seed=1234))
+    fg = FactorGraph(video, upd, corr_impl="volume", max_factors=-1, upsample=False)
+    fg.add_factors(torch.as_tensor(g["ii"]), torch.as_tensor(g["jj"]))
+    assert np.array_equal(fg.ii.cpu().numpy(), G["ii"]) and np.array_equal(fg.jj.cpu().numpy(), G["jj"]) and len(fg.ii) == 4096
+    sample = torch.as_tensor(C3_SAMPLE_EDGES).cuda(); fr = np.asarray(C3_SAMPLE_FRAMES)
+    yy, xx = np.meshgrid(np.arange(ht, dtype=np.float32), np.arange(wd, dtype=np.float32), indexing="ij")
+    coords0 = torch.as_tensor(np.stack([xx, yy], -1)).cuda()
+    c = lambda t: t.float().cpu().numpy()
+    for k, scale in ((1, 1.0), (2, 3.0)):
+        fg.update(t0=1, t1=None, itrs=2, use_inactive=False)
+        torch.cuda.synchronize()
+        tag = "U%d" % k
+        p, rp = c(video.poses)[:N], G[tag + "_poses"]
+        assert np.abs(p[:, :3] - rp[:, :3]).max() <= 2e-3 * scale
+        assert _rot_angle(p[:, 3:].astype(np.float64), rp[:, 3:].astype(np.float64)).max() <= 2e-3 * scale
+        d = c(video.disps)[:N]
+        e = np.abs(d[fr] - G[tag + "_disps_f"]) / np.maximum(1.0, np.abs(G[tag + "_disps_f"]))
+        assert np.quantile(e, 0.99) <= 1e-2 * scale and e.max() <= 0.2 * scale
+        assert np.abs(d.reshape(N, -1).mean(1) - G[tag + "_disps_mean"]).max() <= 2e-3 * scale
+        dm = c(fg.damping)[:N]
+        assert np.abs(dm[fr] - G[tag + "_damping_f"]).max() <= 2.0 ** -8 * np.abs(G[tag + "_damping_f"]).max() * scale + 1e-6
+        assert np.abs(dm.reshape(N, -1).mean(1) - G[tag + "_damping_mean"]).max() <= 2.0 ** -9 * np.abs(G[tag + "_damping_mean"]).max() * scale + 1e-7
+        assert np.abs(c(fg.net[0][sample][:, :, ::4, ::4]) - G[tag + "_net_s"].astype(np.float32)).max() <= 2.0 ** -8 * scale
+        tg, rtg = c(fg.target[0][sample]), G[tag + "_target_s"]
+        assert np.quantile(np.abs(tg - rtg), 0.999) <= 2e-2 * scale and np.abs(tg - rtg).max() <= 0.5 * scale
+        assert np.abs(c(fg.weight[0][sample]) - G[tag + "_weight_s"].astype(np.float32)).max() <= 2.0 ** -8 * scale
+        fm = c((fg.target[0] - coords0).abs().mean(dim=(1, 2, 3)))
+        assert np.abs(fm - G[tag + "_flow_mean"]).max() <= 2e-3 * scale * max(1.0, np.abs(G[tag + "_flow_mean"]).max())
+        assert np.abs(c(fg.weight[0].mean(dim=(1, 2, 3))) - G[tag + "_weight_mean"]).max() <= 2.0 ** -10 * scale
+        nm = torch.cat([fg.net[0][s:s + 256].float().abs().mean(dim=(1, 2, 3)) for s in range(0, 4096, 256)])
+        assert np.abs(c(nm) - G[tag + "_net_absmean"]).max() <= 2.0 ** -10 * scale
+    del fg, video, upd
+    _free()
+
+
 def test_composed_stereo_update_matches_reference_factor_graph(db, golden_dir):
     """DepthVideo(stereo=True): pyramid from fmaps[jj, c] (c = 1 on stereo self-edges, factor_graph.py:128-133), stereo edges
     in the BA (droid_kernels.cu:228-238), two composed update iterations with upsampling vs the reference golden"""
