@@ -91,7 +91,8 @@ def measure_lookup_traffic(variant, edges, timeout_s=240):
                            env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp")
         files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
         if r.returncode != 0 or not files:
-            return None, "rocprofv3 --pmc pass failed (rc %d): %s" % (r.returncode, r.stdout.strip()[-200:])
+            lines = [l for l in r.stdout.splitlines() if "simple_timer" not in l and l.strip()]
+            return None, "rocprofv3 --pmc pass failed (rc %d): %s" % (r.returncode, " | ".join(lines[-6:])[-600:])
         want = "pyr_lookup_corr0_kernel<64, 0>" if variant == "fused" else "pyr_lookup_kernel"
         agg = {}
         for f in files:
@@ -708,7 +709,9 @@ def main():
             corr.pyramid = None
             import gc
             gc.collect(); torch.cuda.empty_cache()
-            per_ep, why = measure_lookup_traffic(variant, E)
+            # (bytes per edge-pixel do not depend on the edge count once the pyramid is far beyond the caches; 1024 edges =
+            # 26 GB keep the child process clear of whatever this process still holds)
+            per_ep, why = measure_lookup_traffic(variant, min(E, 1024))
             if per_ep is not None:
                 out["roofline"]["traffic"], out["roofline"]["traffic_source"] = per_ep * E * HW, why
             elif out["roofline"]["traffic_source"]:

@@ -105,7 +105,12 @@ class AltCorrBlock:
 class CorrBlock:
     """MI355X-native pyramid: built on the fp16 MFMA in the displacement-skewed, 8x8-block interleaved
     layout of csrc/corr_pyramid.hip and looked up by ONE fused kernel over the 4 levels.  Same interface as
-    the reference CorrBlock (corr.py:23-60): CorrBlock(fmap1, fmap2), block(coords), cat, __getitem__."""
+    the reference CorrBlock (corr.py:23-60): CorrBlock(fmap1, fmap2), block(coords), cat, __getitem__.
+
+    The layout needs h % 8 == 0 and w in {16, 32, 64}.  Any other image size up to 64 columns (TUM's 30x40, 40x64, ...) is
+    kept on a zero-padded CANVAS of the next such size: the pooled levels are cut at (h >> l) x (w >> l) like avg_pool2d's
+    floor (corr.py:36), so a lookup reads exactly the values / zeros it reads from the reference's volumes; coordinates of
+    canvas pixels outside the image point far outside every level, and their outputs are cropped away."""
 
     def __init__(self, fmap1, fmap2, num_levels=4, radius=3):
         assert num_levels == 4 and radius == 3, "the fused pyramid is specialised to 4 levels / radius 3"
@@ -113,35 +118,60 @@ class CorrBlock:
         assert batch == 1
         self.num_levels, self.radius = num_levels, radius
         self.ht, self.wd = ht, wd
-        self.pyramid = droid_backends.corr_pyramid_build(fmap1[0].half().contiguous(), fmap2[0].half().contiguous())
+        self.hc, self.wc = self.canvas(ht, wd)
+        f1, f2 = fmap1[0].half(), fmap2[0].half()
+        if (self.hc, self.wc) != (ht, wd):
+            pad = (0, self.wc - wd, 0, self.hc - ht)
+            self.pyramid = droid_backends.corr_pyramid_build(F.pad(f1, pad).contiguous(), F.pad(f2, pad).contiguous(), ht, wd)
+        else:
+            self.pyramid = droid_backends.corr_pyramid_build(f1.contiguous(), f2.contiguous())
+
+    @staticmethod
+    def canvas(ht, wd):
+        """size of the pyramid's canvas for an ht x wd image, or None if it has none (more than 64 columns)"""
+        if wd > 64:
+            return None
+        return (ht + 7) // 8 * 8, (16 if wd <= 16 else 32 if wd <= 32 else 64)
 
     @staticmethod
     def supported(ht, wd):
-        return ht % 8 == 0 and wd in (16, 32, 64)
+        return CorrBlock.canvas(ht, wd) is not None
 
     @staticmethod
     def bytes_per_edge(ht, wd):
         """size of one edge's record (csrc/corr_pyramid.hip make_dims: per level and 8x8 source block (h2 + 1 zero row) x w2
-        displacement cells x 64 pixels, fp16) = dh_corr_pyramid_bytes(1, ht, wd)"""
+        displacement cells x 64 pixels, fp16) = dh_corr_pyramid_bytes(1, canvas of (ht, wd))"""
+        ht, wd = CorrBlock.canvas(ht, wd)
         nblk = (ht // 8) * (wd // 8)
         return sum(nblk * ((ht >> l) + 1) * (wd >> l) * 64 * 2 for l in range(4))
 
+    def _coords(self, coords):
+        """[1,E,h,w,2] -> [E,hc,wc,2] contiguous; canvas pixels outside the image look at (-1e4, -1e4): every tap outside"""
+        batch, num, ht, wd, _ = coords.shape
+        assert (ht, wd) == (self.ht, self.wd)
+        c = coords.reshape(batch * num, ht, wd, 2)
+        if (self.hc, self.wc) != (ht, wd):
+            c = F.pad(c, (0, 0, 0, self.wc - wd, 0, self.hc - ht), value=-1.0e4)
+        return c.contiguous()
+
     def __call__(self, coords):
         batch, num, ht, wd, _ = coords.shape
-        out = droid_backends.corr_pyramid_lookup(self.pyramid, coords.reshape(batch * num, ht, wd, 2).contiguous())
-        return out.view(batch, num, -1, ht, wd)
+        out = droid_backends.corr_pyramid_lookup(self.pyramid, self._coords(coords))
+        return out[:, :, :ht, :wd].reshape(batch, num, -1, ht, wd)
 
     def lookup_nhwc(self, coords):
         """[1,E,h,w,2] -> [4,E,h,w,56] level-planar channel-last features for droid_amd.update.UpdateModule.forward_nhwc"""
         batch, num, ht, wd, _ = coords.shape
-        return droid_backends.corr_pyramid_lookup_nhwc(self.pyramid, coords.reshape(batch * num, ht, wd, 2).contiguous())
+        out = droid_backends.corr_pyramid_lookup_nhwc(self.pyramid, self._coords(coords))
+        return out if (self.hc, self.wc) == (ht, wd) else out[:, :, :ht, :wd].contiguous()
 
     def lookup_corr0(self, coords, update_op):
         """[1,E,h,w,2] -> [E,h,w,128] f16: the lookup and the first layer of the update operator's correlation encoder
         (Conv2d(196,128,1) + ReLU, droid_net.py:96-100) in one kernel; pass it to UpdateModule.forward_nhwc(corr0=...)"""
         batch, num, ht, wd, _ = coords.shape
         wpk, bias = update_op.params["corr0_fused"]
-        return droid_backends.corr_pyramid_lookup_corr0(self.pyramid, coords.reshape(batch * num, ht, wd, 2).contiguous(), wpk, bias)
+        out = droid_backends.corr_pyramid_lookup_corr0(self.pyramid, self._coords(coords), wpk, bias)
+        return out if (self.hc, self.wc) == (ht, wd) else out[:, :ht, :wd].contiguous()
 
     def cat(self, other):
         self.pyramid = torch.cat([self.pyramid, other.pyramid], 0)

@@ -22,7 +22,7 @@ from ._cache import tensor_cache_key
 
 
 class FactorGraph:
-    def __init__(self, video, update_op, device="cuda", corr_impl="volume", max_factors=-1, upsample=False, chunk_frames=8):
+    def __init__(self, video, update_op, device="cuda", corr_impl="volume", max_factors=-1, upsample=False, chunk_frames=8, native_corr=None):
         self.video = video
         self.update_op = update_op
         self.device = video.device if hasattr(video, "device") else torch.device(device)
@@ -43,7 +43,9 @@ class FactorGraph:
         self.ii_bad = torch.zeros(0, **lt); self.jj_bad = torch.zeros(0, **lt)
         self.target_inac = torch.zeros(1, 0, ht, wd, 2, device=self.device)
         self.weight_inac = torch.zeros(1, 0, ht, wd, 2, device=self.device)
-        self._native_corr = CorrBlock.supported(ht, wd)
+        # the MI355X pyramid (any image up to 64 columns wide: sizes outside its layout sit on a zero-padded canvas, see
+        # droid_amd.corr.CorrBlock); native_corr=False forces the reference-layout volumes (CorrBlockRef), the only form for wider images
+        self._native_corr = CorrBlock.supported(ht, wd) if native_corr is None else (bool(native_corr) and CorrBlock.supported(ht, wd))
 
     # ---- reference-shaped views of the channel-last state ---------------------------------------------------------
     @property

@@ -210,10 +210,13 @@ class _Conv:
 class UpdateModule:
     """Weight-compatible, inference-only replacement of droid_net.UpdateModule."""
 
-    def __init__(self, device="cuda", share_inp_by_source_frame=False):
+    def __init__(self, device="cuda", share_inp_by_source_frame=False, canvas=True):
         self.device = torch.device(device)
         self.params = None
         self.last_dw = None
+        # image sizes outside the production tiling of csrc/conv.hip (64-pixel rows, four-row tiles) run on a zero-padded
+        # 64-column canvas through the SAME kernels (forward_nhwc); False = the generic implicit-GEMM loop on the image itself
+        self.canvas = canvas
         # forward() (the reference's interface, per-edge `inp`): treat edges with equal ii as sharing their context features
         self.share_inp_by_source_frame = share_inp_by_source_frame
 
@@ -322,7 +325,7 @@ class UpdateModule:
             self._seg_key, self._seg = key, (order, seg_off, ii)       # (ii kept alive: its address is part of the key)
         return self._seg[0], self._seg[1]
 
-    def forward_nhwc(self, net, inp, corr, flow, ii, inp_frames=None, inp_index=None, ctx=None, corr0=None):
+    def forward_nhwc(self, net, inp, corr, flow, ii, inp_frames=None, inp_index=None, ctx=None, corr0=None, _mask=None):
         """net [E,h,w,128] f16 (updated IN PLACE), corr = [E,196,h,w] f16 in the reference's layout (pixel counts that are a
         multiple of 128) or [4,E,h,w,56] f16, the level-planar channel-last output of
         droid_backends.corr_pyramid_lookup_nhwc (channel order: corr_channel_map), flow [E,h,w,8] f16 (4 + zero pad),
@@ -336,19 +339,25 @@ class UpdateModule:
         -> (net, delta [E,h,w,2] f32, weight [E,h,w,2] f32, eta [K,h,w] f32, upmask [K,h,w,576] f16)."""
         P = self.params
         E, h, w, _ = net.shape
+        if self.canvas and not (w == 64 and h % 4 == 0) and w <= 64 and _mask is None:
+            return self._forward_canvas(net, inp, corr, flow, ii, inp_frames, inp_index, corr0)
+        # canvas mode (_mask = (h_img, w_img)): the tensors are canvases; every activation that feeds a 3x3 layer gets the pixels
+        # outside the image zeroed again, which is the zero border the reference's padded convolutions see there
+        mk = (lambda t: t) if _mask is None else (lambda t: (droid_backends.canvas_mask_(t, _mask[0], _mask[1]), t)[1])
+        npix = float(h * w) if _mask is None else float(_mask[0] * _mask[1])
         if corr0 is not None:
             c0 = corr0
         elif corr.dim() == 4 and corr.shape[1] == COR_PLANES:      # reference layout [E,196,h,w] (see wants_reference_layout_corr)
             c0 = droid_backends.corr0_nchw(corr, P["corr0_nchw"][0], P["corr0_nchw"][1])
         else:
             c0 = P["corr0"]([corr[0], corr[1], corr[2], corr[3]], EPI_RELU)
-        c = P["corr2"]([c0], EPI_RELU)
-        f = P["flow2"]([P["flow0"]([flow], EPI_RELU)], EPI_RELU)
+        c = mk(P["corr2"]([mk(c0)], EPI_RELU))
+        f = mk(P["flow2"]([mk(P["flow0"]([flow], EPI_RELU))], EPI_RELU))
         # global context: mean over pixels of sigmoid(w(net)) * net, then three 128x128 GEMVs per edge
         red = torch.zeros(E, 128, dtype=torch.float32, device=net.device)
         P["gru_w"]([net], EPI_GLO, aux0=net, red=red)
-        gzr = droid_backends.glo_gemv(red, P["glo_zr_t"][0], P["glo_zr_t"][1], 1.0 / float(h * w))     # [E,256] z | r
-        gq = droid_backends.glo_gemv(red, P["glo_q_t"][0], P["glo_q_t"][1], 1.0 / float(h * w))        # [E,128]
+        gzr = droid_backends.glo_gemv(red, P["glo_zr_t"][0], P["glo_zr_t"][1], 1.0 / npix)     # [E,256] z | r
+        gq = droid_backends.glo_gemv(red, P["glo_q_t"][0], P["glo_q_t"][1], 1.0 / npix)        # [E,128]
         if inp is None and not (w == 64 and h % 4 == 0):
             inp = inp_frames[inp_index]        # image shape outside the production kernel: the reference's data flow
         if inp is not None:
@@ -360,27 +369,50 @@ class UpdateModule:
             zr = P["zr_e"]([net, c, f], EPI_GRU_ZR, gterm=gzr, aux0=net, cinit=ctx, cinit_idx=inp_index, cinit_off=0)
             P["q_e"]([zr[..., 128:], c, f], EPI_GRU_Q, out=net, gterm=gq, aux0=net, aux1=zr,
                      cinit=ctx, cinit_idx=inp_index, cinit_off=256)
-        if w == 64 and h % 4 == 0 and droid_backends.get_option("conv_halo") and droid_backends.get_option("conv_halo2"):
+        mk(net)
+        if _mask is None and w == 64 and h % 4 == 0 and droid_backends.get_option("conv_halo") and droid_backends.get_option("conv_halo2"):
             # heads: the 256-channel activations never leave the first layer's kernel (see csrc/conv.hip EPI_HEADS0)
             w2p, b4 = P["heads2_fused"]
             part = torch.empty(2, 9, E * h * w, 4, dtype=torch.float32, device=net.device)
             P["heads0"]([net], EPI_HEADS0, aux1=w2p, red=part)
             dw = droid_backends.heads_gather(part, b4, h, w)
         else:
-            hd = P["heads0"]([net], EPI_RELU)
+            hd = mk(P["heads0"]([net], EPI_RELU))       # (canvas mode: the second layer must see zeros outside the image, so no fusion)
             dw = torch.empty(E, h, w, 4, dtype=torch.float32, device=net.device)
             P["heads2"]([hd], EPI_HEADS, out=dw)
         self.last_dw = dw                        # (delta_x, delta_y, w_x, w_y) as one tensor for droid_backends.ba_inputs
         # GraphAgg: conv -> mean over the edges of each source frame -> conv -> eta / upmask
         x = P["agg1"]([net], EPI_RELU)
         order, seg_off = self.segments(ii)
-        xm = droid_backends.segment_mean(x, order, seg_off)
-        x2 = P["agg2"]([xm], EPI_RELU)
+        xm = mk(droid_backends.segment_mean(x, order, seg_off))
+        x2 = mk(P["agg2"]([xm], EPI_RELU))
         K = xm.shape[0]
         eta = torch.empty(K, h, w, 1, dtype=torch.float32, device=net.device)
         P["eta"]([x2], EPI_SOFTPLUS_001, out=eta)
         upmask = P["upmask"]([x2], EPI_LINEAR)
         return net, dw[..., :2], dw[..., 2:], eta[..., 0], upmask
+
+    def _forward_canvas(self, net, inp, corr, flow, ii, inp_frames, inp_index, corr0):
+        """forward_nhwc for an image that is not 64 pixels wide / a multiple of four rows high (TUM's 30x40, 16x32, ...): the
+        tensors are embedded into zero-padded canvases [.., ceil4(h), 64, C], the production kernels run on the canvases with
+        the padding re-zeroed between the layers (forward_nhwc, _mask), and the results are cropped.  Same arithmetic per
+        image pixel as on a 64-wide image; the hidden state is still updated in place."""
+        E, h, w, _ = net.shape
+        Hc, Wc = (h + 3) // 4 * 4, 64
+        pad = lambda t: None if t is None else F.pad(t, (0, 0, 0, Wc - w, 0, Hc - h)).contiguous()          # [N,h,w,C] -> [N,Hc,Wc,C]
+        crop = lambda t: t[:, :h, :w].contiguous()
+        net_c = pad(net)
+        if corr0 is not None:
+            corr_c, corr0_c = None, pad(corr0)
+        elif corr.dim() == 4 and corr.shape[1] == COR_PLANES:                         # [E,196,h,w]
+            corr_c, corr0_c = F.pad(corr, (0, Wc - w, 0, Hc - h)).contiguous(), None
+        else:                                                                         # [4,E,h,w,56]
+            corr_c, corr0_c = F.pad(corr, (0, 0, 0, Wc - w, 0, Hc - h)).contiguous(), None
+        n, delta, weight, eta, upmask = self.forward_nhwc(net_c, pad(inp), corr_c, pad(flow), ii, inp_frames=pad(inp_frames),
+                                                          inp_index=inp_index, ctx=None, corr0=corr0_c, _mask=(h, w))
+        net.copy_(n[:, :h, :w])
+        self.last_dw = crop(self.last_dw)
+        return net, self.last_dw[..., :2], self.last_dw[..., 2:], eta[:, :h, :w].contiguous(), crop(upmask)
 
     def corr_to_nhwc(self, corr):
         """[E,196,h,w] correlation features in the reference's channel order (level*49 + xoff*7 + yoff) -> the level-planar

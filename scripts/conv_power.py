@@ -26,6 +26,8 @@ ap.add_argument("--edges", type=int, default=1024)
 ap.add_argument("--seconds", type=float, default=1.5)
 ap.add_argument("--masks", default="0,1,2,4,6,7,8,15,16,22")
 ap.add_argument("--shapes", default="zr,c128")
+ap.add_argument("--fills", default="zero,randn")
+ap.add_argument("--quick", type=int, default=0, help="N > 0: N launches per case, no idle gaps, no sampler (for rocprofv3 --pmc passes)")
 ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "conv_power.json"))
 a = ap.parse_args()
 sys.path[:0] = [ROOT] + ([os.path.join(ROOT, "droid-slam_amd", "ablation")] if a.ablation else []) + [os.path.join(ROOT, "droid-slam_amd")]
@@ -54,54 +56,82 @@ def _hwmon_files():
 
 
 class Sampler(threading.Thread):
+    """socket power / shader clock while the kernels run.  Two sources side by side: `rocm-smi --showpower --showclocks --json`
+    (one process per sample, ~5 Hz) and the hwmon files (first session of round 4: the hwmon values did not follow the load at
+    100 Hz on the pool's boxes, so they are recorded but not trusted on their own)."""
+
     def __init__(self):
         super().__init__(daemon=True)
         self.power_f, self.clock_f = _hwmon_files()
-        self.source = "hwmon (%s, %s)" % (self.power_f, self.clock_f) if self.power_f else "rocm-smi --showpower --showclocks --json"
-        self.samples = []                 # (t, watts, sclk_mhz)
+        self.source = "rocm-smi --showpower --showclocks --json (+ hwmon %s, %s)" % (self.power_f, self.clock_f)
+        self.samples = []                 # (t, smi_watts, smi_sclk_mhz, hwmon_watts, hwmon_mhz)
         self.run_flag = True
+        self.raw_example = None
 
-    def _read(self):
-        if self.power_f:
-            try:
-                w = float(open(self.power_f).read()) * 1e-6
-                c = float(open(self.clock_f).read()) * 1e-6 if self.clock_f else None
-                return w, c
-            except (OSError, ValueError):
-                return None, None
+    def _hwmon(self):
+        try:
+            w = float(open(self.power_f).read()) * 1e-6 if self.power_f else None
+            c = float(open(self.clock_f).read()) * 1e-6 if self.clock_f else None
+            return w, c
+        except (OSError, ValueError):
+            return None, None
+
+    def _smi(self):
         try:
             r = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=5)
             d = json.loads(r.stdout)
-            card = d[sorted(d)[0]]
-            w = next((float(v) for k, v in card.items() if "ower" in k and "W" in k), None)
-            c = next((float(str(v).strip("()Mhz ").split()[-1].strip("()Mhz")) for k, v in card.items() if "sclk" in k.lower()), None)
+            card = d[sorted(k for k in d if k.startswith("card"))[0]]
+            if self.raw_example is None:
+                self.raw_example = card
+            w = c = None
+            for k, v in card.items():
+                kl = k.lower()
+                if w is None and "power" in kl and "(w)" in kl:
+                    try:
+                        w = float(v)
+                    except ValueError:
+                        pass
+                if c is None and "sclk" in kl and "level" not in kl.replace("clock level", "level"):
+                    digits = "".join(ch if (ch.isdigit() or ch == ".") else " " for ch in str(v)).split()
+                    if digits:
+                        c = float(digits[-1])
+            if c is None:
+                for k, v in card.items():
+                    if "sclk" in k.lower():
+                        digits = "".join(ch if (ch.isdigit() or ch == ".") else " " for ch in str(v)).split()
+                        if digits:
+                            c = float(digits[-1]); break
             return w, c
         except Exception:
             return None, None
 
     def run(self):
         while self.run_flag:
-            w, c = self._read()
-            self.samples.append((time.perf_counter(), w, c))
-            time.sleep(0.01 if self.power_f else 0.05)
+            t = time.perf_counter()
+            w, c = self._smi()
+            hw, hc = self._hwmon()
+            self.samples.append((0.5 * (t + time.perf_counter()), w, c, hw, hc))
 
     def window(self, t0, t1):
-        ws = [w for t, w, c in self.samples if t0 <= t <= t1 and w is not None]
-        cs = [c for t, w, c in self.samples if t0 <= t <= t1 and c is not None]
+        sel = [s_ for s_ in self.samples if t0 <= s_[0] <= t1]
         avg = lambda v: sum(v) / len(v) if v else None
-        return {"power_W_avg": avg(ws), "power_W_max": max(ws) if ws else None, "sclk_MHz_avg": avg(cs), "n_samples": len(ws)}
+        col = lambda i: [s_[i] for s_ in sel if s_[i] is not None]
+        return {"power_W_avg": avg(col(1)), "power_W_max": max(col(1)) if col(1) else None, "sclk_MHz_avg": avg(col(2)), "n_samples": len(col(1)),
+                "hwmon_power_W_avg": avg(col(3)), "hwmon_sclk_MHz_avg": avg(col(4))}
 
 
 sampler = Sampler()
-sampler.start()
+if not a.quick:
+    sampler.start()
 h, w = 48, 64
 SHAPES = {"zr": ("gates z|r 3x3 320->256", (128, 128, 64), 256), "c128": ("3x3 128->128", (128,), 128), "q": ("gate q 3x3 320->128", (128, 128, 64), 128)}
 results = {"device": torch.cuda.get_device_name(0), "library": os.path.dirname(db.__file__), "power_source": sampler.source,
+           "fills": a.fills,
            "edges": a.edges, "seconds_per_case": a.seconds, "cases": []}
 masks = [int(m) for m in a.masks.split(",")] if a.ablation else [0]
 for key in a.shapes.split(","):
     name, cins, cout = SHAPES[key]
-    for fill in ("zero", "randn"):
+    for fill in a.fills.split(","):
         torch.manual_seed(0)
         mk = torch.zeros if fill == "zero" else torch.randn
         xs = [mk(a.edges, h, w, c, device="cuda").half() for c in cins]
@@ -115,6 +145,11 @@ for key in a.shapes.split(","):
             if a.ablation:
                 db.set_option("conv_abl", m)
             run(); torch.cuda.synchronize()
+            if a.quick:
+                for _ in range(a.quick):
+                    run()
+                torch.cuda.synchronize()
+                continue
             time.sleep(0.4)                                   # idle: the first launches below start from boost clocks
             idle = sampler.window(time.perf_counter() - 0.3, time.perf_counter())
             evs = []
@@ -143,6 +178,9 @@ for key in a.shapes.split(","):
             db.set_option("conv_abl", 0)
         del xs, out
 sampler.run_flag = False
+results["rocm_smi_example"] = sampler.raw_example
+if a.quick:
+    sys.exit(0)
 os.makedirs(os.path.dirname(a.out), exist_ok=True)
 json.dump(results, open(a.out, "w"), indent=1)
 print("wrote", a.out)

@@ -234,7 +234,11 @@ def test_round3_entry_points_and_host_helpers(built):
     lib.dh_corr_pyramid_bytes.restype = ctypes.c_size_t
     for h, w in ((48, 64), (40, 64), (16, 16), (24, 32)):
         assert CorrBlock.bytes_per_edge(h, w) == lib.dh_corr_pyramid_bytes(1, h, w)
-    assert not CorrBlock.supported(30, 40) and CorrBlock.supported(40, 64)
+    assert CorrBlock.supported(40, 64) and CorrBlock.canvas(40, 64) == (40, 64) and CorrBlock.canvas(48, 64) == (48, 64)
+    # sizes outside the layout up to 64 columns sit on a zero-padded canvas; wider images have no native pyramid
+    assert CorrBlock.supported(30, 40) and CorrBlock.canvas(30, 40) == (32, 64) and CorrBlock.canvas(12, 16) == (16, 16)
+    assert not CorrBlock.supported(30, 80) and CorrBlock.canvas(60, 80) is None
+    assert CorrBlock.bytes_per_edge(30, 40) == CorrBlock.bytes_per_edge(32, 64)
 
 
 def test_reference_python_is_staged_as_an_archive_only():

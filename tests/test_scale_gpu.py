@@ -369,11 +369,16 @@ def test_composed_stereo_update_matches_reference_factor_graph(db, golden_dir):
         assert np.quantile(e, 0.99) <= 1e-2 * scale + 2.0 ** -10
 
 
-def test_composed_update_at_tum_image_size_matches_reference_factor_graph(db, golden_dir):
-    """30 x 40 at 1/8 resolution (TUM's 240 x 320, evaluation_scripts/test_tum.py): outside the pyramid layout and the
-    production convolution tiling, so the iteration runs on reference-layout volumes (hand-written build + floor pooling),
-    corr_index_forward per level, the generic convolution loop and per-edge context features; two composed update
-    iterations with upsampling against the reference's factor_graph.py golden"""
+@pytest.mark.parametrize("path", ["canvas", "fallback"])
+def test_composed_update_at_tum_image_size_matches_reference_factor_graph(db, golden_dir, path):
+    """30 x 40 at 1/8 resolution (TUM's 240 x 320, evaluation_scripts/test_tum.py): outside the pyramid layout (h % 8, w in
+    {16,32,64}) and the production convolution tiling (w == 64, h % 4).
+      canvas   (default): the PRODUCTION kernels on zero-padded canvases -- the MI355X pyramid on 32 x 64 with its pooled levels
+               cut at 15x20 / 7x10 / 3x5 like avg_pool2d's floor, the fused lookup, the update operator on 32 x 64 canvases with
+               the padding re-zeroed between the layers;
+      fallback the reference-layout volumes (hand-written build + floor pooling), corr_index_forward per level, the generic
+               convolution loop and per-edge context features.
+    Two composed update iterations with upsampling against the reference's factor_graph.py golden, same tolerances for both."""
     from droid_amd.corr import CorrBlock, CorrBlockRef
     from droid_amd.factor_graph import FactorGraph
     from droid_amd.update import UpdateModule
@@ -382,12 +387,15 @@ def test_composed_update_at_tum_image_size_matches_reference_factor_graph(db, go
     G = np.load(os.path.join(golden_dir, "graph_tum_size_python.npz"))
     S = graph_scenario(6, 30, 40)
     N, ht, wd = S["n_frames"], S["ht"], S["wd"]
-    assert not CorrBlock.supported(ht, wd)
+    assert CorrBlock.canvas(ht, wd) == (32, 64)
     video = _video(N, ht, wd, S["poses"], S["disps"], S["intrinsics"], S["fmaps"], S["nets"], S["inps"])
-    upd = UpdateModule("cuda").load_state_dict(deterministic_state_dict(_SD(), seed=S["weight_seed"]))
-    fg = FactorGraph(video, upd, corr_impl="volume", max_factors=-1, upsample=True)
+    upd = UpdateModule("cuda", canvas=(path == "canvas")).load_state_dict(deterministic_state_dict(_SD(), seed=S["weight_seed"]))
+    fg = FactorGraph(video, upd, corr_impl="volume", max_factors=-1, upsample=True, native_corr=(path == "canvas"))
     fg.add_neighborhood_factors(0, N, r=2)
-    assert isinstance(fg.corr, CorrBlockRef) and [tuple(v.shape[-2:]) for v in fg.corr.corr_pyramid] == [(30, 40), (15, 20), (7, 10), (3, 5)]
+    if path == "canvas":
+        assert isinstance(fg.corr, CorrBlock) and (fg.corr.hc, fg.corr.wc) == (32, 64)
+    else:
+        assert isinstance(fg.corr, CorrBlockRef) and [tuple(v.shape[-2:]) for v in fg.corr.corr_pyramid] == [(30, 40), (15, 20), (7, 10), (3, 5)]
     assert np.array_equal(fg.ii.cpu().numpy(), G["ii"]) and np.array_equal(fg.jj.cpu().numpy(), G["jj"])
     assert np.abs(fg.target[0].cpu().numpy() - G["target0"]).max() < 2e-4
     c = lambda t: t.float().cpu().numpy()
@@ -408,3 +416,50 @@ def test_composed_update_at_tum_image_size_matches_reference_factor_graph(db, go
         du, rdu = c(video.disps_up)[:N], G[tag + "_disps_up"].astype(np.float32)
         e = np.abs(du - rdu) / np.maximum(1.0, np.abs(rdu))
         assert np.quantile(e, 0.99) <= 1e-2 * scale + 2.0 ** -10
+
+
+@pytest.mark.parametrize("shape", [(30, 40), (12, 20), (44, 64), (16, 32), (21, 13)])
+def test_canvas_pyramid_and_operator_equal_the_general_paths(db, shape):
+    """image sizes outside the pyramid layout / the convolution tiling: (a) the canvas pyramid's lookup (CorrBlock) against the
+    reference-layout volumes with floor pooling (CorrBlockRef) on the same features and coordinates, windows leaving the image
+    on every side, 2^-9 of the samples' scale; the fused lookup + first encoder layer against that layer applied in fp32;
+    (b) the update operator on canvases against the generic convolution loop on the image itself: same fp16 layer boundaries,
+    so equal to a few fp16 ulp (the accumulation order inside a layer differs)."""
+    from droid_amd.corr import CorrBlock, CorrBlockRef
+    from droid_amd.update import UpdateModule, pack_corr0_fused
+    from droid_amd.weights import deterministic_state_dict
+    h, w = shape
+    E = 5
+    torch.manual_seed(h * 100 + w)
+    f1 = torch.randn(1, E, 128, h, w, device="cuda").half(); f2 = torch.randn(1, E, 128, h, w, device="cuda").half()
+    yy, xx = torch.meshgrid(torch.arange(h, device="cuda", dtype=torch.float32), torch.arange(w, device="cuda", dtype=torch.float32), indexing="ij")
+    base = torch.stack([xx, yy], -1)[None, None]
+    shift = torch.tensor([[-6.3, 2.2], [3.7, -4.1], [0.4, 0.6], [float(w) - 2.5, 1.0], [-1.5, float(h) - 3.2]], device="cuda").view(1, E, 1, 1, 2)
+    coords = (base + shift + 0.07 * yy[None, None, :, :, None]).contiguous()
+    blk, ref = CorrBlock(f1, f2), CorrBlockRef(f1, f2)
+    a, b = blk(coords).float(), ref(coords).float()
+    assert a.shape == b.shape == (1, E, 196, h, w)
+    scale = b.abs().max().item()
+    assert scale > 1.0 and (a - b).abs().max().item() <= 2.0 ** -9 * scale
+    upd = UpdateModule("cuda").load_state_dict(deterministic_state_dict(_SD(), seed=7))
+    c0 = blk.lookup_corr0(coords, upd).float()
+    w0, b0 = upd.params["corr0_nchw"]
+    lay = torch.relu(torch.einsum("ekhw,ck->ehwc", a[0], w0[:, :196].float()) + b0)
+    assert c0.shape == lay.shape and (c0 - lay).abs().max().item() <= 2.0 ** -8 * max(1.0, lay.abs().max().item())
+    # (b) operator: canvas vs generic loop
+    gen = UpdateModule("cuda", canvas=False); gen.params, gen.cmap = upd.params, upd.cmap
+    ii = torch.tensor([0, 0, 1, 2, 2], device="cuda")
+    net = torch.tanh(torch.randn(E, h, w, 128, device="cuda")).half()
+    inp_frames = torch.relu(torch.randn(3, h, w, 128, device="cuda")).half()
+    flow = torch.zeros(E, h, w, 8, device="cuda", dtype=torch.float16); flow[..., :4] = (4.0 * torch.randn(E, h, w, 4, device="cuda")).clamp(-64, 64).half()
+    corr_feat = blk(coords)[0].half().contiguous()
+    feats = lambda m: corr_feat if m.wants_reference_layout_corr(h, w) else m.corr_to_nhwc(corr_feat)
+    outs = []
+    for m in (upd, gen):
+        n = net.clone()
+        r = m.forward_nhwc(n, None, feats(m), flow, ii, inp_frames=inp_frames, inp_index=ii)
+        torch.cuda.synchronize()
+        outs.append([t.float().clone() for t in r])
+    for x, y, tol in zip(outs[0], outs[1], (2.0 ** -9, 2.0 ** -8, 2.0 ** -9, 2.0 ** -9, 2.0 ** -8)):
+        assert x.shape == y.shape
+        assert (x - y).abs().max().item() <= tol * max(1.0, y.abs().max().item())
