@@ -631,8 +631,20 @@ def main():
         per_rank = [None] * world
         dist.all_gather_object(per_rank, {"rank": rank, "device": torch.cuda.get_device_name(local), "local_rank": local,
                                           "edges": int(E), "frames": [int(bounds[rank]), int(min(bounds[rank + 1], N))]})
+        # what the collectives of one ba() cost on this transport, measured on their own (median of 5, every rank takes part):
+        # `itrs` all-reduces of the packed system + one of the depth maps; ms_per_global_ba minus this is the ranks' own work
+        def _ar_ms(t):
+            ts = []
+            for _ in range(5):
+                torch.cuda.synchronize(); dist.barrier()
+                t0 = time.perf_counter(); dist.all_reduce(t); torch.cuda.synchronize(); ts.append(1e3 * (time.perf_counter() - t0))
+            return sorted(ts)[2]
+        ar_sys = _ar_ms(torch.zeros(max(1, int(solver.last_exchange_bytes) // 8), dtype=torch.float64, device=dev))
+        ar_disps = _ar_ms(torch.zeros_like(disps0))
         dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": per_rank,
-                     "allreduce_bytes_per_gn_iteration": int(solver.last_exchange_bytes), "packed_exchange": bool(solver.last_exchange_packed)}
+                     "allreduce_bytes_per_gn_iteration": int(solver.last_exchange_bytes), "packed_exchange": bool(solver.last_exchange_packed),
+                     "ms_allreduce_system": ar_sys, "ms_allreduce_disps": ar_disps,
+                     "ms_collectives_per_global_ba": g["itrs"] * ar_sys + ar_disps}
     if rank == 0:
         ms = 1000.0 * elapsed / max(1, args.steps)
         ep_total = E_all * HW
