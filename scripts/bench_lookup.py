@@ -3,7 +3,7 @@
 usage: python scripts/bench_lookup.py [--edges 1024] [--reps 5] [--flow smooth|reproj|random] [--build-reps 0]"""
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "droid-slam_amd")]
+sys.path[:0] = [ROOT] + ([os.path.join(ROOT, "droid-slam_amd", "ablation")] if "--ablation" in sys.argv else []) + [os.path.join(ROOT, "droid-slam_amd")]
 import numpy as np, torch
 import droid_backends as db
 
@@ -14,6 +14,7 @@ ap.add_argument("--flow", default="reproj")
 ap.add_argument("--build-reps", type=int, default=0)
 ap.add_argument("--nhwc", action="store_true", help="channel-last variant (feeds the update operator)")
 ap.add_argument("--fused", action="store_true", help="also time corr_pyramid_lookup_corr0 (lookup + first encoder layer) against lookup + corr0_nchw")
+ap.add_argument("--ablation", action="store_true", help="load the -DDH_ABLATION build (droid-slam_amd/ablation/)")
 ap.add_argument("--modes", default="", help="comma list of lookup_mode values to time one after the other on the same pyramid "
                 "(0 product, 1 nt tap loads, 2 no output stores, 3 no tap loads -- 2 / 3 are timing ablations with wrong results)")
 a = ap.parse_args()
@@ -85,7 +86,7 @@ if a.fused:
     d = (o_f.float() - o_u.float()).abs().max().item()
     print("fused lookup+corr0: %.3f ms   unfused: lookup %.3f + corr0_nchw %.3f = %.3f ms   max |diff| %.3e (scale %.2f)  reads+writes 744 B/ep -> %.1f GB/s" % (
         t_f, t_l, t_c, t_l + t_c, d, o_u.float().abs().max().item(), 744.0 * E * h * w / t_f / 1e6))
-    for mode in (2, 3, 5, 6):
+    for mode in ((2, 3, 5, 6) if db.get_option("ablation_build") else (6,)):      # 2 / 3 / 5 exist only in a -DDH_ABLATION build
         db.set_option("lookup_mode", mode)
         tm, _ = timed(lambda: db.corr_pyramid_lookup_corr0(pyr, coords, wpk, bias))
         print("  fused, variant %d (%s): %.3f ms" % (mode, {2: "no output stores", 3: "no tap loads", 5: "a quarter of the MFMAs", 6: "synchronous twin: every tap batch waited for at issue (correct results)"}[mode], tm))
