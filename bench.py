@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--no-check", action="store_true", help="skip the untimed output check of the step (N = 1 only): the same "
                     "iteration through the reference-layout entry points (reference-layout volumes + corr_index_forward, the "
                     "reference interface of the update operator with per-edge context features, ba) from the same state")
+    ap.add_argument("--no-lowmem", action="store_true", help="do not add the update_lowmem line (child process) to the default line")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic in this run (rocprofv3 --pmc pass in a child process)")
     ap.add_argument("--no-sensitivity", action="store_true", help="skip the untimed flow-sensitivity runs of the lookup kernel")
     ap.add_argument("--lowmem", action="store_true", help="time FactorGraph.update_lowmem steps (the global-BA iteration, "
@@ -115,6 +116,22 @@ def measure_lookup_traffic(variant, edges, timeout_s=240):
         return None, "rocprofv3 --pmc pass: %r" % (exc,)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def lowmem_line(timeout_s=300):
+    """`bench.py --lowmem --steps 16 --warmup 1` in a child process -> its JSON line (ms_per_step of update_lowmem(steps=8) calls)"""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--lowmem", "--steps", "16", "--warmup", "1"]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"skipped": "bench.py --lowmem failed (rc %d): %s" % (r.returncode, r.stderr.strip()[-300:])}
+        d = json.loads(lines[-1])
+        return {k: d.get(k) for k in ("metric", "value", "unit", "ms_per_step", "steps", "config", "ms_altcorr_per_step", "ms_pyramid_build_per_call")
+                if k in d}
+    except subprocess.TimeoutExpired:
+        return {"skipped": "bench.py --lowmem exceeded %d s" % timeout_s}
 
 
 def reference_python_baseline(threads, timeout_s=300):
@@ -457,7 +474,18 @@ def main():
 
     # ---- correlation pyramid for this rank's edges (setup, untimed: built once per edge lifetime) ----
     c = (ii == jj).long() if rig > 1 else torch.zeros_like(ii)
-    corr = None if args.no_lookup else CorrBlock(fmaps[ii, 0][None], fmaps[jj, c][None])
+    ms_build = None
+    if args.no_lookup:
+        corr = None
+    else:
+        CorrBlock(fmaps[ii[:8], 0][None], fmaps[jj[:8], c[:8]][None])          # code objects, LDS opt-in, allocator
+        f1, f2 = fmaps[ii, 0][None], fmaps[jj, c][None]
+        torch.cuda.synchronize()
+        e0, e1 = _ev(), _ev()
+        e0.record(); corr = CorrBlock(f1, f2); e1.record()
+        torch.cuda.synchronize()
+        ms_build = e0.elapsed_time(e1)                        # all of this rank's edges: transposes, pooling, row-ring build kernel
+        del f1, f2
     torch.cuda.synchronize()
     torch.cuda.empty_cache()                              # (the per-edge feature gathers and the build workspace)
     # ---- ConvGRU update operator: random-init weights of the reference architecture (no droid.pth here) ----
@@ -676,6 +704,7 @@ def main():
                 "parallelism": "edge-sharded x%d" % world, "update_operator_chunks": len(chunk_slices),
                 "pyramid_GB": (corr.bytes() / 1e9 if corr is not None else 0.0)},
             "ms_per_global_ba": ba, "ms_corr_lookup": lk, "ms_update_operator": up,
+            "ms_pyramid_build": ms_build,                     # setup, outside the timed steps: once per edge lifetime (factor_graph.py:128-133)
             "roofline": {"kernel": "pyr_lookup_corr0_kernel<64> (1 launch = 4-level pyramid lookup of all edges + the 196 -> 128 layer that "
                          "consumes it; 744 B/ep = 2*(240 taps + 128 outputs) + 8)" if fused_lookup else
                          "pyr_lookup_kernel<64, %s> (1 launch = 4-level pyramid lookup of all edges)" % (
@@ -715,6 +744,13 @@ def main():
             out["roofline_update_operator"] = {"error": repr(exc)}
         if not args.no_cpu_baseline and world == 1:        # rank 0 at N = 1 only (the other ranks would wait in teardown)
             out["cpu_baseline"] = cpu_baseline(g)
+        if world == 1 and not args.no_lowmem and corr is not None and cfg.name == "C3":
+            # the global-BA iteration (FactorGraph.update_lowmem, factor_graph.py:266-330) on the same graph, as an extra key of
+            # the default line: own process (`bench.py --lowmem`), after this one's pyramid is released
+            corr.pyramid = None
+            import gc
+            gc.collect(); torch.cuda.empty_cache()
+            out["lowmem"] = lowmem_line()
         if world == 1 and not args.no_pmc and corr is not None:
             # roofline.traffic measured IN THIS RUN: one rocprofv3 --pmc pass over the same kernel / flow / edge count in a
             # child process, after everything is timed and the bench's own pyramid (105 GB at C3) is released
