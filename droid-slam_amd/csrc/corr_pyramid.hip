@@ -250,42 +250,31 @@ __global__ __launch_bounds__(256) void pyr_build_kernel(const __half* __restrict
 // one level of the ring build; NTL = 16-target tiles per target row (compile time: everything below stays in registers)
 // NT = threads of the workgroup: 256 (4 waves = 4 source row pairs, every wave all NTL target tiles) or 512 (8 waves: the
 // second four take the upper half of the target tiles -- twice the waves per CU on the same 80 KB of LDS)
-// NA = 2 (level 0 of the 8-wave form): a wave multiplies TWO 16-pixel source tiles (its own row pair and the sibling pair
-// wave ^ 1) with ONE 16-target tile instead of one source tile with two target tiles.  Same MFMAs, same results bit for bit, but
-// a B fragment read from LDS feeds two MFMAs: the target row's fragments are read by 2 instead of 4 source groups (the
-// kernel is LDS-bound: per level-0 step 64 -> 32 KB of fragment reads next to 16 KB staged, the 2-byte scatter and 8 KB read out).
 template <int NTL, int NT>
-__device__ __forceinline__ void ring_level(const half8 (&afrag)[4], const half8 (&afrag_sib)[4], const __half* __restrict__ trow0, __half* __restrict__ lbase,
+__device__ __forceinline__ void ring_level(const half8 (&afrag)[4], const __half* __restrict__ trow0, __half* __restrict__ lbase,
                                            unsigned char* __restrict__ ring, unsigned char* __restrict__ sB,
                                            int l, int h2, int w2, int by, int bx, int tid) {
   const int lane = tid & 63, wave = (tid >> 6) & 3, wt = tid >> 8;      // wave = source row pair, wt = target half (NT = 512)
-  constexpr bool A2 = (NT == 512 && NTL == 4);
-  constexpr int NA = A2 ? 2 : 1;                                         // source tiles per wave
-  constexpr int NTW = A2 ? 1 : ((NT == 512 && NTL >= 2) ? NTL / 2 : NTL);   // target tiles of this wave
+  constexpr int NTW = (NT == 512 && NTL >= 2) ? NTL / 2 : NTL;           // target tiles of this wave: wt * NTW .. + NTW
   const bool has_tiles = NT == 256 || NTL >= 2 || wt == 0;
-  const int nt0 = A2 ? 2 * wt + (wave & 1) : ((NT == 512 && NTL >= 2) ? wt * NTW : 0);
-  const int j = lane & 15, xq = ((lane >> 4) & 1) * 4;
+  const int nt0 = (NT == 512 && NTL >= 2) ? wt * NTW : 0;
+  const int j = lane & 15, yy = 2 * wave + (lane >> 5), xq = ((lane >> 4) & 1) * 4;     // pixel p_r = yy*8 + xq + r
   const int R = 8 >> l, ybase = (by * 8) >> l;
   const int rowbytes = w2 * 128;                                  // one displacement row: w2/2 pairs x 64 px x 4 B
   const int nsteps = h2 + R - 1;
-  int dd[NA];                                                     // source row offset inside the block, per source tile
-  // byte offset inside a ring row of the value (source tile a, target tile nt, register r) of this lane -- the same at every
-  // step -- or -1 for the padding columns of a row shorter than 16 targets
-  int soff[NA][NTW][4];
+  const int d = ((by * 8 + yy) >> l) - ybase;                      // this lane's source row offset inside the block
+  // byte offset inside a ring row of the value (tile nt, register r) of this lane -- the same at every step -- or -1
+  // for the padding columns of a row shorter than 16 targets
+  int soff[NTW][4];
 #pragma unroll
-  for (int a = 0; a < NA; ++a) {
-    const int yy = 2 * (wave ^ a) + (lane >> 5);                  // a = 0: own row pair, a = 1: the sibling pair
-    dd[a] = ((by * 8 + yy) >> l) - ybase;
+  for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-    for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int x2 = (nt0 + nt) * 16 + j, x1l = (bx * 8 + xq + r) >> l;
-        const int u = wrap(x2 - x1l, w2), up = u >> 1, p = yy * 8 + xq + r;
-        const int f = (up & 3) | ((up & 4) << 2);
-        soff[a][nt][r] = x2 < w2 ? ((up * 64 + (p ^ f)) << 2) + ((u & 1) << 1) : -1;
-      }
-  }
+    for (int r = 0; r < 4; ++r) {
+      const int x2 = (nt0 + nt) * 16 + j, x1l = (bx * 8 + xq + r) >> l;
+      const int u = wrap(x2 - x1l, w2), up = u >> 1, p = yy * 8 + xq + r;
+      const int f = (up & 3) | ((up & 4) << 2);
+      soff[nt][r] = x2 < w2 ? ((up * 64 + (p ^ f)) << 2) + ((u & 1) << 1) : -1;
+    }
   // B staging role: piece id = tid + 256*q -> (target id>>4, quad id&15), q < NTL.  Target rows are fetched THREE steps
   // ahead into registers.  (A __syncthreads() would drain vmcnt and with it the prefetch: the LDS traffic of a step only
   // needs lgkmcnt(0) + s_barrier.)
@@ -311,30 +300,25 @@ __device__ __forceinline__ void ring_level(const half8 (&afrag)[4], const half8 
     if (stages) { _Pragma("unroll") for (int q = 0; q < NQ; ++q) *reinterpret_cast<u32x4*>(sB + b_dst[q]) = breg[s_][q]; } \
     RING_BARRIER();                         /* target row staged; last step's completed row has been read out */    \
     RING_FETCH_B(k + 3, s_)                                                                                          \
-    f32x4 acc[NA][NTW];                                                                                              \
-    _Pragma("unroll") for (int a = 0; a < NA; ++a)                                                                   \
-      _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt) acc[a][nt] = f32x4{0.f, 0.f, 0.f, 0.f};                     \
+    const int v = k - d;                    /* displacement row this lane's pixels contribute to */                  \
+    const bool vok = v >= 0 && v < h2;                                                                               \
+    unsigned char* const rslot = ring + (v & (R - 1)) * rowbytes;                                                    \
+    f32x4 acc[NTW];                                                                                                  \
+    _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};                          \
     if (has_tiles) {                                                                                                 \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {        /* the tiles' accumulation chains interleaved */       \
       half8 b[NTW];                                                                                                  \
       _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt)                                                             \
         b[nt] = *reinterpret_cast<const half8*>(sB + ((nt0 + nt) * 16 + j) * 256 + (((ks * 4 + (lane >> 4)) ^ j) << 4)); \
-      _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt) {                                                           \
-        acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag[ks], b[nt], acc[0][nt], 0, 0, 0);                  \
-        if constexpr (NA == 2) acc[NA - 1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag_sib[ks], b[nt], acc[NA - 1][nt], 0, 0, 0); \
-      }                                                                                                              \
+      _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt)                                                             \
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag[ks], b[nt], acc[nt], 0, 0, 0);                        \
     }                                                                                                                \
     }                                                                                                                \
-    _Pragma("unroll") for (int a = 0; a < NA; ++a) {                                                                 \
-      const int v = k - dd[a];              /* displacement row this lane's pixels of source tile a contribute to */ \
-      const bool vok = v >= 0 && v < h2;                                                                             \
-      unsigned char* const rslot = ring + (v & (R - 1)) * rowbytes;                                                  \
-      if (vok && has_tiles) {                                                                                        \
-        _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt)                                                           \
-          _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                              \
-            if (NTL > 1 || soff[a][nt][r] >= 0)                                                                      \
-              *reinterpret_cast<__half*>(rslot + soff[a][nt][r]) = __float2half(acc[a][nt][r] * 0.0625f);            \
-      }                                                                                                              \
+    if (vok && has_tiles) {                                                                                          \
+      _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt)                                                             \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                                \
+          if (NTL > 1 || soff[nt][r] >= 0)                                                                           \
+            *reinterpret_cast<__half*>(rslot + soff[nt][r]) = __float2half(acc[nt][r] * 0.0625f);                    \
     }                                                                                                                \
     RING_BARRIER();                         /* scatter complete */                                                  \
     const int vdone = k - (R - 1);                                                                                   \
@@ -382,16 +366,12 @@ __global__ __launch_bounds__(NT) void pyr_build_ring_kernel(const __half* __rest
   constexpr int nbx = W / 8;
   const int by = sb / nbx, bx = sb - by * nbx;
   // A fragments of this wave's 16 source pixels (rows yy = 2*wave, 2*wave+1): lane holds A[i = lane&15][k = (lane>>4)*8..+8]
-  half8 afrag[4], afrag_sib[4];          // (the sibling row pair wave ^ 1: second source tile of level 0 in the 8-wave form)
+  half8 afrag[4];
   {
     const int p = wave * 16 + (lane & 15);
     const __half* row = f1T + (long)e * f1_stride_e + ((long)(by * 8 + (p >> 3)) * W + bx * 8 + (p & 7)) * CH;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) afrag[ks] = *reinterpret_cast<const half8*>(row + ks * 32 + (lane >> 4) * 8);
-    const int ps = (wave ^ 1) * 16 + (lane & 15);
-    const __half* rows = f1T + (long)e * f1_stride_e + ((long)(by * 8 + (ps >> 3)) * W + bx * 8 + (ps & 7)) * CH;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) afrag_sib[ks] = (W == 64 && NT == 512) ? *reinterpret_cast<const half8*>(rows + ks * 32 + (lane >> 4) * 8) : afrag[ks];
   }
   const __half* bbase = f2T + (long)e * f2_stride_e;
   __half* obase = pyr + (long)e * D.edge_elems;
@@ -400,7 +380,7 @@ __global__ __launch_bounds__(NT) void pyr_build_ring_kernel(const __half* __rest
   {                                                                                                                  \
     constexpr int w2 = W >> (l_);                                                                                    \
     constexpr int NTL = w2 >= 16 ? w2 / 16 : 1;                                                                      \
-    ring_level<NTL, NT>(afrag, afrag_sib, bbase + (long)D.tgt_off[l_] * CH, obase + D.lev_off[l_] + (long)sb * D.blk_elems[l_],     \
+    ring_level<NTL, NT>(afrag, bbase + (long)D.tgt_off[l_] * CH, obase + D.lev_off[l_] + (long)sb * D.blk_elems[l_],     \
                     ring, sB, l_, h >> (l_), w2, by, bx, tid);                                                       \
   }
   RING_LEVEL(0) RING_LEVEL(1) RING_LEVEL(2) RING_LEVEL(3)
