@@ -429,8 +429,12 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a ROCm device (no CPU fallback)"
     local = local % torch.cuda.device_count()            # (several ranks on one device only in the gloo self-test below)
     torch.cuda.set_device(local)
-    if world > 1:
+    # DH_BENCH_DIST1=1: the multi-rank code path (process group, DistBA, collectives, `dist` record) with ONE rank -- on the `nccl`
+    # backend this is RCCL executing the edge-sharded step on a single-GPU box
+    dist_on = world > 1 or os.environ.get("DH_BENCH_DIST1", "0") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         # RCCL ("nccl") is the product path; DH_BENCH_BACKEND=gloo exists to exercise the multi-rank code path on a box
         # with a single GPU (RCCL refuses two ranks on one device)
         dist.init_process_group(os.environ.get("DH_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
@@ -526,7 +530,7 @@ def main():
     target_prev = targets.permute(0, 2, 3, 1).contiguous()                # [E,h,w,2]
     torch.cuda.synchronize()
 
-    solver = DistBA(world) if world > 1 else None
+    solver = DistBA(world, always_reduce=(world == 1)) if dist_on else None
     if solver is not None:
         solver.set_owned_frames(bounds[rank], bounds[rank + 1])
         solver.set_graph(ii_all, jj_all, 1, N)              # all-reduce of the co-visible 6x6 blocks only (~6 MB instead of 77 MB)
@@ -592,7 +596,7 @@ def main():
         return coords1
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -608,7 +612,7 @@ def main():
         step(True)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -655,7 +659,7 @@ def main():
                 sens_out = {"skipped": "out of memory: %s" % str(exc)[:80]}
 
     dist_info = None
-    if world > 1:                                               # auditable record of the process group behind a multi-GPU line
+    if dist_on:                                                 # auditable record of the process group behind a multi-GPU line
         per_rank = [None] * world
         dist.all_gather_object(per_rank, {"rank": rank, "device": torch.cuda.get_device_name(local), "local_rank": local,
                                           "edges": int(E), "frames": [int(bounds[rank]), int(min(bounds[rank + 1], N))]})
@@ -765,7 +769,7 @@ def main():
             elif out["roofline"]["traffic_source"]:
                 out["roofline"]["traffic_source"] += " [in-run pass: %s]" % why
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -1131,9 +1131,15 @@ __global__ __launch_bounds__(256, 1) void chol_step_kernel(double* __restrict__ 
   int r, c;
   if (panel) { r = j + 2 + blockIdx.x; c = j + 1; }
   else {
-    const int u = blockIdx.x - nP, side = nP;          // block rows / columns j+2 .. j+1+side
-    r = j + 2 + u / side; c = j + 2 + u % side;
-    if (c > r || c >= nbk) return;
+    // block rows / columns j+2 .. j+1+nP, lower triangle only: u = rr (rr + 1) / 2 + cc, cc <= rr (a square grid would
+    // start nP^2 workgroups of which half return at once -- each still takes a 72-KB LDS slot from the ones that work)
+    const int u = blockIdx.x - nP;
+    int rr = (int)((sqrtf(8.f * (float)u + 1.f) - 1.f) * 0.5f);
+    while (rr * (rr + 1) / 2 > u) --rr;
+    while ((rr + 1) * (rr + 2) / 2 <= u) ++rr;
+    const int cc = u - rr * (rr + 1) / 2;
+    r = j + 2 + rr; c = j + 2 + cc;
+    if (c >= nbk) return;                              // (the rhs block row has no diagonal block)
   }
   const long r0 = (long)r * NB, c0 = (long)c * NB, d0 = (long)j * NB;
   double2 va[8], vb[8];
@@ -1499,9 +1505,9 @@ int run_finish(const BaLayout& L, char* ws, float* poses, float* disps, const in
       for (int j = 0; j + 1 < L.nbk; ++j) {
         const int nP = nbrows - j - 2;                   // block rows below the diagonal block of column j+1
         if (opts().chol_regpanel)
-          hipLaunchKernelGGL(chol_step_kernel<true>, dim3(nP + nP * nP), dim3(256), lds_panel + 256 * sizeof(double), st, H, L.ld, j, L.nbk, nP, meta, Ldiag);
+          hipLaunchKernelGGL(chol_step_kernel<true>, dim3(nP + nP * (nP + 1) / 2), dim3(256), lds_panel + 256 * sizeof(double), st, H, L.ld, j, L.nbk, nP, meta, Ldiag);
         else
-          hipLaunchKernelGGL(chol_step_kernel<false>, dim3(nP + nP * nP), dim3(256), lds_panel, st, H, L.ld, j, L.nbk, nP, meta, Ldiag);
+          hipLaunchKernelGGL(chol_step_kernel<false>, dim3(nP + nP * (nP + 1) / 2), dim3(256), lds_panel, st, H, L.ld, j, L.nbk, nP, meta, Ldiag);
         DH_LAUNCH_CHECK();
       }
     }

@@ -34,8 +34,8 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(chol_panel_kernel, dim3(nbk), dim3(256), lds, 0, H, ld, 0, meta, Ldiag);
     for (int j = 0; j + 1 < nbk; ++j) {
       const int nP = nbk + 1 - j - 2;
-      if (regp) hipLaunchKernelGGL(chol_step_kernel<true>, dim3(nP + nP * nP), dim3(256), lds + 2048, 0, H, ld, j, nbk, nP, meta, Ldiag);
-      else hipLaunchKernelGGL(chol_step_kernel<false>, dim3(nP + nP * nP), dim3(256), lds, 0, H, ld, j, nbk, nP, meta, Ldiag);
+      if (regp) hipLaunchKernelGGL(chol_step_kernel<true>, dim3(nP + nP * (nP + 1) / 2), dim3(256), lds + 2048, 0, H, ld, j, nbk, nP, meta, Ldiag);
+      else hipLaunchKernelGGL(chol_step_kernel<false>, dim3(nP + nP * (nP + 1) / 2), dim3(256), lds, 0, H, ld, j, nbk, nP, meta, Ldiag);
       if (j == 10 || j == 40) {
         hipMemcpyFromSymbol(ts, HIP_SYMBOL(g_chol_ts), sizeof(ts));
         if (rep == 2) {
