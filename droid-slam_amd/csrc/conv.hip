@@ -67,13 +67,13 @@ struct ConvParams {
 // contiguous run of pixel tiles [x * T, (x + 1) * T) and visits the cout tiles of a pixel tile back to back, so the halo
 // rows shared by vertically adjacent tiles, the second cout tile's re-read of the same activations and the accumulator
 // start values of a source frame's edges are L2 hits instead of trips to the other side of the fabric.
-__device__ __forceinline__ void xcd_decode(const ConvParams& P, long& m0, int& n0, int bn) {
+__device__ __forceinline__ void xcd_decode(const ConvParams& P, long& m0, int& n0, int bn, int bm = BM) {
   if (P.xcd_tiles > 0) {
     const unsigned id = blockIdx.x, xcd = id & 7, slot = id >> 3;
     const unsigned y = slot % (unsigned)P.ny, t = slot / (unsigned)P.ny;
-    m0 = ((long)xcd * P.xcd_tiles + t) * BM; n0 = (int)y * bn;
+    m0 = ((long)xcd * P.xcd_tiles + t) * bm; n0 = (int)y * bn;
   } else {
-    m0 = (long)blockIdx.x * BM; n0 = blockIdx.y * bn;
+    m0 = (long)blockIdx.x * bm; n0 = blockIdx.y * bn;
   }
 }
 
@@ -1062,6 +1062,155 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
   else conv_epilogue<EPI, 2, 2>(P, acc, (long)P.N * HW, m0, n0, wm0, wn0, lane, HW);
 }
 
+// ---- 3x3, 128-cout tile, THIRD form: 512-pixel tile (8 image rows), 128 x 64 per wave -- opt-in (option conv_halo3) -----------
+// Round 4's power measurements (profiles/r04_conv_power.json) put conv3x3_halo2_kernel on the socket's 1400 W cap with 31 % of the
+// dynamic energy outside the matrix cores: 11 % fragment reads from LDS, 12 % weight DMA + halo fetch, 5 % epilogue.  Under the cap
+// time is energy, so this form spends fewer bytes per flop with the SAME data flow (weights of a (32-channel chunk, kernel row) group
+// by LDS-DMA into two buffers, halo staged once per chunk through registers, same weight layout, same swizzles, same epilogues):
+//   * a wave owns image rows wrow and wrow + 4 of the 8-row tile x 64 couts = 4 x 2 accumulator tiles (128 registers): a weight
+//     fragment read from LDS feeds four MFMAs instead of two -- 0.75 fragment reads per MFMA instead of 1;
+//   * one weight group per 512 pixels instead of per 256: half the weight stream per pixel; halo 10 rows for 8 (1.25x) instead
+//     of 6 for 4 (1.5x).
+// Price: 128 accumulators + staging = ~200 registers -> ONE workgroup per CU (8 waves, 2 per SIMD, 91 KB of LDS): nothing overlaps
+// this workgroup's prologue / epilogue.  Needs H % 8 == 0.  The two 256-pixel halves go through the epilogues of the second form
+// one after the other.
+constexpr int H3ROWS = 10, H3PIX = H3ROWS * HCOLS;
+constexpr int H3A_BYTES = H3PIX * H2CK * 2;              // 42,240: halo [660 px][32 ch]
+constexpr int H3_LDS_BYTES = H3A_BYTES + 2 * H2B_BYTES;  // 91,392 (the staged epilogue tile needs 69,632)
+
+template <int EPI, bool STAGED = true, bool CINIT = false>
+__global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(ConvParams P) {
+  extern __shared__ __half s_conv[];
+  char* const lds = reinterpret_cast<char*>(s_conv);
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)s_conv;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wrow = wave & 3, wn0 = (wave >> 2) * 64, wm0 = wrow * 64;
+  long m0; int n0;
+  xcd_decode(P, m0, n0, 128, 512);
+  const int HW = P.H * P.W;
+  const int img = (int)(m0 / HW), y0 = (int)((m0 - (long)img * HW) / 64);
+  const int nchunks = P.Ctot / H2CK, nsteps = nchunks * 3;
+
+  // halo: the 10 x 64 interior is exactly 5 pieces per thread: piece id = tid + 512*i -> (row 2i + (tid >> 8), column (tid >> 2) & 63,
+  // 16-byte slot tid & 3); the first and last column (outside the 64-pixel-wide image for every tile) are zeroed once
+  constexpr int A_PIECES = 5;
+  const int aq = tid & 3, ax = (tid >> 2) & 63, ahy = tid >> 8;
+  const int a_pix0 = (img * P.H + y0 - 1 + ahy) * 64 + ax;
+  if (tid < 8 * H3ROWS) {                                // 20 edge pixels x 4 slots
+    const int hp = (tid >> 3) * HCOLS + ((tid >> 2) & 1) * (HCOLS - 1);
+    *reinterpret_cast<uint4*>(lds + hp * 64 + aq * 16) = uint4{0u, 0u, 0u, 0u};
+  }
+  const int b_voff = lane * 16;
+  const char* const bsrc = reinterpret_cast<const char*>(P.wt_halo) + (long)(n0 >> 7) * nsteps * H2B_BYTES;
+
+  const int pl = wrow * HCOLS + (lane & 31), kh = lane >> 5;
+  int b_row[2], b_x[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int r = wn0 + b * 32 + (lane & 31);
+    b_row[b] = r * 64; b_x[b] = ((r >> 2) & 3) ^ kh;
+  }
+
+  f32x16 acc[2][2][2];                                   // [tile half: image rows wrow / wrow + 4][32-pixel half of the row][32-cout half]
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if constexpr (CINIT) init_acc_tile<2, 2>(P, acc[h], m0 + h * 256, n0, wm0, wn0, lane, HW);
+    else zero_acc<2, 2>(acc[h]);
+  }
+
+  u32x4 ra[A_PIECES];
+#define H3_FETCH_A(chunk_)                                                                                           \
+  {                                                                                                                  \
+    int cs = (chunk_) * H2CK, sgi = 0;                                                                               \
+    _Pragma("unroll") for (int q = 0; q < MAXSEG - 1; ++q)                                                           \
+      if (sgi == q && q + 1 < P.nseg && cs >= P.segC[q]) { cs -= P.segC[q]; sgi = q + 1; }                          \
+    const __half* base = P.in[0]; int segs = P.segS[0];                                                              \
+    _Pragma("unroll") for (int q = 1; q < MAXSEG; ++q) if (sgi == q) { base = P.in[q]; segs = P.segS[q]; }           \
+    int pix0 = a_pix0;                                                                                               \
+    asm volatile("" : "+v"(pix0));                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < A_PIECES; ++i) {                                                           \
+      const bool ok = (unsigned)(y0 - 1 + ahy + 2 * i) < (unsigned)P.H;                                              \
+      ra[i] = *reinterpret_cast<const u32x4*>(base + (long)(ok ? pix0 + 128 * i : 0) * segs + cs + aq * 8);          \
+    }                                                                                                                \
+  }
+#define GLDS16S(sbase_, voff_, ldsaddr_)                                                                             \
+  {                                                                                                                  \
+    unsigned keep_;                                                                                                  \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep_) : "v"(voff_), "s"(sbase_), "s"(ldsaddr_) : "memory");                                \
+  }
+#define H3_DMA_B(step_)                                                                                              \
+  {                                                                                                                  \
+    _Pragma("unroll") for (int q = 0; q < 3; ++q) {                                                                  \
+      const unsigned long gaddr = (unsigned long)(bsrc + (long)(step_) * H2B_BYTES + (wave + 8 * q) * 1024);          \
+      const unsigned glo = __builtin_amdgcn_readfirstlane((unsigned)gaddr);                                          \
+      const unsigned ghi = __builtin_amdgcn_readfirstlane((unsigned)(gaddr >> 32));                                  \
+      const void* gs = reinterpret_cast<const void*>(((unsigned long)ghi << 32) | glo);                              \
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + H3A_BYTES + ((step_) & 1) * H2B_BYTES + (wave + 8 * q) * 1024); \
+      GLDS16S(gs, b_voff, dst)                                                                                       \
+    }                                                                                                                \
+  }
+
+  H3_FETCH_A(0)
+  H3_DMA_B(0)
+  for (int c = 0; c < nchunks; ++c) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave has finished the previous chunk's reads of the halo tile
+    int ahy_o = ahy, ax_o = ax;
+    asm volatile("" : "+v"(ahy_o), "+v"(ax_o));
+#pragma unroll
+    for (int i = 0; i < A_PIECES; ++i) {
+      const int hp = (2 * i + ahy_o) * HCOLS + ax_o + 1;
+      const uint32_t m = (unsigned)(y0 - 1 + ahy_o + 2 * i) < (unsigned)P.H ? 0xffffffffu : 0u;
+      *reinterpret_cast<u32x4*>(lds + hp * 64 + ((aq ^ ((hp >> 2) & 3)) << 4)) = ra[i] & m;
+    }
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int step = c * 3 + dy;
+      // as in the second form; the next chunk's 5 halo loads (issued after the DMA pieces one step ago) may stay in flight at dy == 1
+      if (dy == 1 && c + 1 < nchunks) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (step + 1 < nsteps) H3_DMA_B(step + 1)
+      if (dy == 0 && c + 1 < nchunks) H3_FETCH_A(c + 1)
+      const char* const Bcur = lds + H3A_BYTES + (step & 1) * H2B_BYTES;
+      int pl_o = pl;
+      asm volatile("" : "+v"(pl_o));
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          half8 bf[2];
+#pragma unroll
+          for (int b = 0; b < 2; ++b) bf[b] = *reinterpret_cast<const half8*>(Bcur + dx * (128 * 64) + b_row[b] + (((ks * 2) ^ b_x[b]) << 4));
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            half8 af[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+              const int p = pl_o + (4 * h + dy) * HCOLS + dx + a * 32;
+              af[a] = *reinterpret_cast<const half8*>(lds + p * 64 + (((ks * 2) ^ ((p >> 2) & 3) ^ kh) << 4));
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+              for (int b = 0; b < 2; ++b) acc[h][a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[h][a][b], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+#undef H3_FETCH_A
+#undef H3_DMA_B
+#undef GLDS16S
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if constexpr (EPI == EPI_HEADS0) staged_heads0_epilogue(P, acc[h], s_conv, m0 + h * 256, n0, wm0, wn0, tid);
+    else if constexpr (STAGED) staged_epilogue<EPI, 2, 128>(P, acc[h], s_conv, m0 + h * 256, n0, wm0, wn0, tid, HW);
+    else conv_epilogue<EPI, 2, 2>(P, acc[h], (long)P.N * HW, m0 + h * 256, n0, wm0, wn0, lane, HW);
+    if (h == 0) __syncthreads();                          // the staging tile is reused by the second half
+  }
+}
+
 #ifdef DH_ABLATION   // Winograd F(2,3) prototype (0.83-0.98x of the direct kernel): not in release builds
 // ---- 3x3 as Winograd F(2,3) along x (direct along y): PROTOTYPE, opt-in (weights_layout = DH_CONV_LAYOUT_WINO) -------------
 // One output row pair (x = 2p, 2p+1) needs the four input columns 2p-1 .. 2p+2:
@@ -1554,6 +1703,35 @@ int launch_halo2(const ConvParams& P0, hipStream_t st) {
   return DH_OK;
 }
 
+template <int EPI>
+int launch_halo3(const ConvParams& P0, hipStream_t st) {
+  ConvParams P = P0;
+  const long M = (long)P.N * P.H * P.W;
+  dim3 grid((unsigned)(M / 512), (unsigned)(P.CoutPad / 128));
+  P.ny = (int)grid.y;
+  if (opts().conv_xcd && grid.x % 8 == 0) { P.xcd_tiles = (int)(grid.x / 8); grid = dim3(grid.x * grid.y, 1); }
+  if constexpr (EPI == EPI_LINEAR) {
+    if (P.out_f32) {
+      DH_LDS_OPTIN((&conv3x3_halo3_kernel<EPI, false>), 96 * 1024);
+      hipLaunchKernelGGL((conv3x3_halo3_kernel<EPI, false>), grid, dim3(512), H3_LDS_BYTES, st, P);
+      DH_LAUNCH_CHECK();
+      return DH_OK;
+    }
+  }
+  if constexpr (EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q) {
+    if (P.cinit) {
+      DH_LDS_OPTIN((&conv3x3_halo3_kernel<EPI, true, true>), 96 * 1024);
+      hipLaunchKernelGGL((conv3x3_halo3_kernel<EPI, true, true>), grid, dim3(512), H3_LDS_BYTES, st, P);
+      DH_LAUNCH_CHECK();
+      return DH_OK;
+    }
+  }
+  DH_LDS_OPTIN((&conv3x3_halo3_kernel<EPI>), 96 * 1024);
+  hipLaunchKernelGGL((conv3x3_halo3_kernel<EPI>), grid, dim3(512), H3_LDS_BYTES, st, P);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
 #ifdef DH_ABLATION
 template <int EPI>
 bool wino_ok(const ConvParams& P) {
@@ -1898,6 +2076,17 @@ extern "C" int dh_conv2d_nhwc_f16_ex2(const void* const* inputs, const int* in_c
     }
   }
 #endif
+  if (opts().conv_halo3 && P.H % 8 == 0 && ((long)P.N * P.H * P.W) % 512 == 0) {       // opt-in: the 512-pixel-tile form of the same kernel
+    switch (P.epi) {
+      case EPI_LINEAR: if (halo2_ok<EPI_LINEAR>(P)) return launch_halo3<EPI_LINEAR>(P, st); break;
+      case EPI_RELU: if (halo2_ok<EPI_RELU>(P)) return launch_halo3<EPI_RELU>(P, st); break;
+      case EPI_SIGMOID: if (halo2_ok<EPI_SIGMOID>(P)) return launch_halo3<EPI_SIGMOID>(P, st); break;
+      case EPI_GRU_ZR: if (halo2_ok<EPI_GRU_ZR>(P)) return launch_halo3<EPI_GRU_ZR>(P, st); break;
+      case EPI_GRU_Q: if (halo2_ok<EPI_GRU_Q>(P)) return launch_halo3<EPI_GRU_Q>(P, st); break;
+      case EPI_HEADS0: if (halo2_ok<EPI_HEADS0>(P)) return launch_halo3<EPI_HEADS0>(P, st); break;
+      default: break;
+    }
+  }
   switch (P.epi) {
     case EPI_LINEAR: if (halo2_ok<EPI_LINEAR>(P)) return launch_halo2<EPI_LINEAR>(P, st); break;
     case EPI_RELU: if (halo2_ok<EPI_RELU>(P)) return launch_halo2<EPI_RELU>(P, st); break;

@@ -32,6 +32,7 @@ Options& opts() {
     v.altcorr_v1 = env_int("DH_ALTCORR_V1", 0);
     v.conv_wino = env_int("DH_CONV_WINO", 0);
     v.conv_abl = env_int("DH_CONV_ABL", 0);
+    v.conv_halo3 = env_int("DH_CONV_HALO3", 0);
 #ifndef DH_ABLATION
     // release build: the prototype / timing-ablation kernels are not compiled in; a stray environment variable cannot
     // select a variant that returns wrong results (lookup_mode 2-5) or does not exist
@@ -78,6 +79,7 @@ static int* slot(const char* name) {
   if (!strcmp(name, "altcorr_v1")) return &o.altcorr_v1;
   if (!strcmp(name, "conv_wino")) return &o.conv_wino;
   if (!strcmp(name, "conv_abl")) return &o.conv_abl;
+  if (!strcmp(name, "conv_halo3")) return &o.conv_halo3;
   return nullptr;
 }
 

@@ -27,6 +27,7 @@ ap.add_argument("--seconds", type=float, default=1.5)
 ap.add_argument("--masks", default="0,1,2,4,6,7,8,15,16,22")
 ap.add_argument("--shapes", default="zr,c128")
 ap.add_argument("--fills", default="zero,randn")
+ap.add_argument("--opt", action="append", default=[], help="library option name=value set before the runs (e.g. conv_halo3=1)")
 ap.add_argument("--quick", type=int, default=0, help="N > 0: N launches per case, no idle gaps, no sampler (for rocprofv3 --pmc passes)")
 ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "conv_power.json"))
 a = ap.parse_args()
@@ -36,6 +37,9 @@ import droid_backends as db
 from droid_amd.update import pack_conv, pack_conv_halo, EPI_RELU
 
 assert (db.get_option("ablation_build") == 1) == bool(a.ablation), db.__file__
+for kv in a.opt:
+    k_, v_ = kv.split("=")
+    db.set_option(k_, int(v_))
 
 
 # ---------------------------------------------------------------------------------------------- power / clock sampler
@@ -126,7 +130,7 @@ if not a.quick:
 h, w = 48, 64
 SHAPES = {"zr": ("gates z|r 3x3 320->256", (128, 128, 64), 256), "c128": ("3x3 128->128", (128,), 128), "q": ("gate q 3x3 320->128", (128, 128, 64), 128)}
 results = {"device": torch.cuda.get_device_name(0), "library": os.path.dirname(db.__file__), "power_source": sampler.source,
-           "fills": a.fills,
+           "fills": a.fills, "options": a.opt,
            "edges": a.edges, "seconds_per_case": a.seconds, "cases": []}
 masks = [int(m) for m in a.masks.split(",")] if a.ablation else [0]
 for key in a.shapes.split(","):

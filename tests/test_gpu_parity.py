@@ -1009,6 +1009,51 @@ def test_update_forward_leaves_a_channel_last_hidden_state_untouched(db):
     assert torch.equal(out1, out2)
 
 
+def test_conv_512_pixel_tile_form_is_bit_identical(db, option):
+    """conv3x3_halo3_kernel (option conv_halo3: 8-row / 512-pixel tile, 128 x 64 per wave, one workgroup per CU) runs the same
+    k order per output element as conv3x3_halo2_kernel: raw convolutions (relu, multi-segment input, two cout tiles, several
+    images, image borders) and the WHOLE update operator (gates with accumulator start values and GRU epilogues, fused heads)
+    must be equal bit for bit with the option on and off."""
+    from oracle import update as oupd
+    from droid_amd.update import pack_conv, pack_conv_halo, EPI_RELU, UpdateModule
+    from droid_amd.weights import deterministic_state_dict
+    torch.manual_seed(5)
+    for (n, h, cins, cout) in [(3, 8, (128, 128, 64), 256), (2, 16, (128,), 128), (1, 48, (32, 96), 128)]:
+        xs = [torch.randn(n, h, 64, c, device="cuda").half() for c in cins]
+        wgt = torch.randn(cout, sum(cins), 3, 3, device="cuda") / (sum(cins) * 9) ** 0.5
+        wp, bp = pack_conv(wgt, torch.randn(cout, device="cuda"))
+        wh = pack_conv_halo(wgt)
+        outs = []
+        for v in (0, 1):
+            option("conv_halo3", v)
+            out = torch.zeros(n, h, 64, cout, device="cuda", dtype=torch.float16)
+            db.conv2d_nhwc(xs, wp, wh, bp, 3, 3, cout, EPI_RELU, out, cout, None, None, None, None)
+            torch.cuda.synchronize()
+            outs.append(out)
+        ref = torch.nn.functional.conv2d(torch.cat(xs, -1).float().permute(0, 3, 1, 2), wgt.half().float(), bp[:cout], padding=1).permute(0, 2, 3, 1).clamp_min(0)
+        assert (outs[1].float() - ref).abs().max().item() <= 2.0 ** -8 * max(1.0, ref.abs().max().item())
+        assert torch.equal(outs[0], outs[1])
+
+    class _SD:
+        def state_dict(self):
+            return oupd.empty_state_dict()
+    mod = UpdateModule("cuda").load_state_dict(deterministic_state_dict(_SD(), seed=3))
+    E, h, w = 6, 16, 64
+    net = torch.tanh(torch.randn(E, h, w, 128, device="cuda")).half()
+    inp_frames = torch.relu(torch.randn(3, h, w, 128, device="cuda")).half()
+    c0 = torch.relu(torch.randn(E, h, w, 128, device="cuda")).half()
+    flow = torch.zeros(E, h, w, 8, device="cuda", dtype=torch.float16); flow[..., :4] = (4.0 * torch.randn(E, h, w, 4, device="cuda")).clamp(-64, 64).half()
+    ii = torch.tensor([0, 0, 1, 1, 2, 2], device="cuda")
+    res = []
+    for v in (0, 1):
+        option("conv_halo3", v)
+        r = mod.forward_nhwc(net.clone(), None, None, flow, ii, inp_frames=inp_frames, inp_index=ii, corr0=c0)
+        torch.cuda.synchronize()
+        res.append([t.clone() for t in r])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
 def test_conv_winograd_prototype(db):
     """conv3x3_wino_kernel (Winograd F(2,3) along x, opt-in prototype) against torch's fp32 convolution and against the direct
     kernel on the same operands: multi-segment input, two cout tiles, image borders, relu epilogue; and the two gate
