@@ -1062,6 +1062,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
   else conv_epilogue<EPI, 2, 2>(P, acc, (long)P.N * HW, m0, n0, wm0, wn0, lane, HW);
 }
 
+#ifdef DH_ABLATION   // 512-pixel-tile form: measured equal in energy, slower in time (profiles/r04_d_conv_halo3_ab.json): not in release builds
 // ---- 3x3, 128-cout tile, THIRD form: 512-pixel tile (8 image rows), 128 x 64 per wave -- opt-in (option conv_halo3) -----------
 // Round 4's power measurements (profiles/r04_conv_power.json) put conv3x3_halo2_kernel on the socket's 1400 W cap with 31 % of the
 // dynamic energy outside the matrix cores: 11 % fragment reads from LDS, 12 % weight DMA + halo fetch, 5 % epilogue.  Under the cap
@@ -1210,6 +1211,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(ConvParams P) {
     if (h == 0) __syncthreads();                          // the staging tile is reused by the second half
   }
 }
+
+#endif  // DH_ABLATION
 
 #ifdef DH_ABLATION   // Winograd F(2,3) prototype (0.83-0.98x of the direct kernel): not in release builds
 // ---- 3x3 as Winograd F(2,3) along x (direct along y): PROTOTYPE, opt-in (weights_layout = DH_CONV_LAYOUT_WINO) -------------
@@ -1703,6 +1706,7 @@ int launch_halo2(const ConvParams& P0, hipStream_t st) {
   return DH_OK;
 }
 
+#ifdef DH_ABLATION
 template <int EPI>
 int launch_halo3(const ConvParams& P0, hipStream_t st) {
   ConvParams P = P0;
@@ -1731,6 +1735,8 @@ int launch_halo3(const ConvParams& P0, hipStream_t st) {
   DH_LAUNCH_CHECK();
   return DH_OK;
 }
+
+#endif  // DH_ABLATION
 
 #ifdef DH_ABLATION
 template <int EPI>
@@ -2076,6 +2082,7 @@ extern "C" int dh_conv2d_nhwc_f16_ex2(const void* const* inputs, const int* in_c
     }
   }
 #endif
+#ifdef DH_ABLATION
   if (opts().conv_halo3 && P.H % 8 == 0 && ((long)P.N * P.H * P.W) % 512 == 0) {       // opt-in: the 512-pixel-tile form of the same kernel
     switch (P.epi) {
       case EPI_LINEAR: if (halo2_ok<EPI_LINEAR>(P)) return launch_halo3<EPI_LINEAR>(P, st); break;
@@ -2087,6 +2094,7 @@ extern "C" int dh_conv2d_nhwc_f16_ex2(const void* const* inputs, const int* in_c
       default: break;
     }
   }
+#endif
   switch (P.epi) {
     case EPI_LINEAR: if (halo2_ok<EPI_LINEAR>(P)) return launch_halo2<EPI_LINEAR>(P, st); break;
     case EPI_RELU: if (halo2_ok<EPI_RELU>(P)) return launch_halo2<EPI_RELU>(P, st); break;

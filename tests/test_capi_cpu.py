@@ -269,7 +269,7 @@ def test_shipped_library_is_a_release_build_without_wrong_result_modes(built):
         assert lib.dh_set_option(b"lookup_mode", mode) != 0
     for mode in (1, 6, 0):                                        # nt tap loads / the synchronous twin: same results
         assert lib.dh_set_option(b"lookup_mode", mode) == 0
-    for name in (b"conv_dma", b"conv_wino", b"pyr_build_chunk", b"altcorr_v1", b"dma_var"):
+    for name in (b"conv_dma", b"conv_wino", b"pyr_build_chunk", b"altcorr_v1", b"dma_var", b"conv_abl", b"conv_halo3"):
         assert lib.dh_set_option(name, 1) != 0 and lib.dh_set_option(name, 0) == 0
         assert lib.dh_get_option(name, ctypes.byref(v)) == 0 and v.value == 0
     # a stray environment variable is ignored as well (fresh process: the option store is initialised at first use)
@@ -282,6 +282,6 @@ def test_shipped_library_is_a_release_build_without_wrong_result_modes(built):
     # the prototype kernels are not in the code object
     syms = subprocess.run(["nm", "-D", "--defined-only", LIB], stdout=subprocess.PIPE, text=True).stdout
     blob = open(LIB, "rb").read()
-    for kern in (b"conv3x3_wino_kernel", b"conv3x3_dma_kernel", b"altcorr_mfma_kernel", b"pyr_build_kernel"):
+    for kern in (b"conv3x3_wino_kernel", b"conv3x3_dma_kernel", b"conv3x3_halo3_kernel", b"altcorr_mfma_kernel", b"pyr_build_kernel"):
         assert kern not in blob, kern
     assert b"conv3x3_halo2_kernel" in blob and b"pyr_build_ring_kernel" in blob and b"altcorr_mfma2_kernel" in blob

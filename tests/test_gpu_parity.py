@@ -1014,6 +1014,8 @@ def test_conv_512_pixel_tile_form_is_bit_identical(db, option):
     k order per output element as conv3x3_halo2_kernel: raw convolutions (relu, multi-segment input, two cout tiles, several
     images, image borders) and the WHOLE update operator (gates with accumulator start values and GRU epilogues, fused heads)
     must be equal bit for bit with the option on and off."""
+    if not db.get_option("ablation_build"):
+        pytest.skip("the 512-pixel-tile kernel is only part of a -DDH_ABLATION build (measured slower: profiles/r04_d_conv_halo3_ab.json)")
     from oracle import update as oupd
     from droid_amd.update import pack_conv, pack_conv_halo, EPI_RELU, UpdateModule
     from droid_amd.weights import deterministic_state_dict
