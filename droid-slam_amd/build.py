@@ -40,6 +40,12 @@ if ABLATION:
     EXT = os.path.join(OUTDIR, "droid_backends.so")
 
 
+# per-file flags.  corr_pyramid.hip: without the SLP vectoriser hipcc keeps the lookup's fp32 interpolation scalar and folds the fp16
+# operands / results into v_fma_mix_f32 / v_fma_mixlo_f16 instead of packing pairs into v_pk_*_f32 behind explicit conversions
+# (packed fp32 runs at half rate on this part: same flops, more instructions)
+FILE_FLAGS = {"corr_pyramid.hip": ["-fno-slp-vectorize"]}
+
+
 def _run(cmd, verbose):
     if verbose:
         print(" ".join(cmd), flush=True)
@@ -77,7 +83,7 @@ def build_lib(force=False, verbose=False):
         o = os.path.join(OBJ, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
         if force or _newer(o, [s] + hdrs):
-            jobs.append([HIPCC] + HIP_FLAGS + ["-c", s, "-o", o])
+            jobs.append([HIPCC] + HIP_FLAGS + FILE_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o])
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(lambda c: _run(c, verbose), jobs))
     if force or jobs or _newer(LIB, objs):
@@ -93,7 +99,7 @@ def audit_asm_loads(force=False, verbose=False):
     if not force and os.path.exists(stamp) and os.path.getmtime(stamp) >= max(os.path.getmtime(src), *map(os.path.getmtime, headers())):
         return
     asm = os.path.join(OBJ, "corr_pyramid.s")
-    _run([HIPCC] + HIP_FLAGS + ["-S", "--cuda-device-only", src, "-o", asm], verbose)
+    _run([HIPCC] + HIP_FLAGS + FILE_FLAGS.get("corr_pyramid.hip", []) + ["-S", "--cuda-device-only", src, "-o", asm], verbose)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "audit_asm_loads.py"), asm, "pyr_lookup_kernel"],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:

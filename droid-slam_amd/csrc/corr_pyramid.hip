@@ -691,7 +691,24 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 using half2f = __attribute__((ext_vector_type(2))) _Float16;
 
-template <int W, int MODE = 0>
+// t1 - t0 of two fp16 values that sit in halves H1 / H0 of packed registers, as ONE instruction: v_fma_mix_f32 takes fp16 operands
+// (either half) straight into an fp32 FMA, t1 * 1.0 + (-t0) is exact -- the same value v_cvt_f32_f16 x 2 + v_sub_f32 produce.
+// (hipcc folds conversions into v_fma_mix_f32 for the multiply-add of the interpolation by itself once its SLP vectoriser is off
+// for this file -- build.py -- but not for a bare subtraction.)
+template <int H1, int H0>
+__device__ __forceinline__ float sub_f16_halves(uint32_t p1, uint32_t p0) {
+  float d;
+  if constexpr (H1 == 0 && H0 == 0) asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(p1), "v"(p0));
+  else if constexpr (H1 == 1 && H0 == 0) asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[1,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(p1), "v"(p0));
+  else if constexpr (H1 == 0 && H0 == 1) asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(p1), "v"(p0));
+  else asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(p1), "v"(p0));
+  return d;
+}
+
+// MIX (option lookup_mix, default 1): the interpolation without fp16 -> fp32 / fp32 -> fp16 conversion instructions (the taps enter the
+// fp32 arithmetic as fp16 operands of v_fma_mix_f32, the samples leave it through v_fma_mixlo / mixhi_f16); 0 = the conversions
+// spelled out.  Same operations in the same order: bit-identical (tests/test_gpu_parity.py).
+template <int W, int MODE = 0, bool MIX = true>
 __global__ __launch_bounds__(W * 8, 1) void pyr_lookup_corr0_kernel(const __half* __restrict__ pyr, const float* __restrict__ coords,
                                                                     const __half* __restrict__ wpk, const float* __restrict__ bias,
                                                                     __half* __restrict__ out, PyrDims D, int n_strips) {
@@ -805,27 +822,44 @@ __global__ __launch_bounds__(W * 8, 1) void pyr_lookup_corr0_kernel(const __half
 #pragma unroll
     for (int jj = 0; jj < HALF_ROWS; ++jj) {
       const int j = half * HALF_ROWS + jj;
-      float t[WIN];
-#pragma unroll
-      for (int n = 0; n < WIN / 2; ++n) {
-        const uint32_t pr = __builtin_amdgcn_alignbit(T.raw[jj][n + 1], T.raw[jj][n], G.par16) & G.cmask[n];
-        t[2 * n] = (float)__builtin_bit_cast(_Float16, (unsigned short)(pr & 0xffffu));
-        t[2 * n + 1] = (float)__builtin_bit_cast(_Float16, (unsigned short)(pr >> 16));
-      }
       float c[OUTW];
+      if constexpr (MIX) {
+        uint32_t pr[WIN / 2];
 #pragma unroll
-      for (int a = 0; a < OUTW; ++a) c[a] = t[a] + dx * (t[a + 1] - t[a]);
+        for (int n = 0; n < WIN / 2; ++n) pr[n] = __builtin_amdgcn_alignbit(T.raw[jj][n + 1], T.raw[jj][n], G.par16) & G.cmask[n];
+        // c[a] = t[a] + dx * (t[a + 1] - t[a]); tap a = half (a & 1) of pr[a >> 1]
+#define DH_LERP_X(a_) { const float d_ = sub_f16_halves<((a_) + 1) & 1, (a_) & 1>(pr[((a_) + 1) >> 1], pr[(a_) >> 1]);                     \
+                        c[a_] = __builtin_fmaf(dx, d_, (float)__builtin_bit_cast(half2f, pr[(a_) >> 1])[(a_) & 1]); }
+        DH_LERP_X(0) DH_LERP_X(1) DH_LERP_X(2) DH_LERP_X(3) DH_LERP_X(4) DH_LERP_X(5) DH_LERP_X(6)
+#undef DH_LERP_X
+      } else {
+        float t[WIN];
+#pragma unroll
+        for (int n = 0; n < WIN / 2; ++n) {
+          const uint32_t pr = __builtin_amdgcn_alignbit(T.raw[jj][n + 1], T.raw[jj][n], G.par16) & G.cmask[n];
+          t[2 * n] = (float)__builtin_bit_cast(_Float16, (unsigned short)(pr & 0xffffu));
+          t[2 * n + 1] = (float)__builtin_bit_cast(_Float16, (unsigned short)(pr >> 16));
+        }
+#pragma unroll
+        for (int a = 0; a < OUTW; ++a) c[a] = t[a] + dx * (t[a + 1] - t[a]);
+      }
       if (j > 0) {
 #pragma unroll
         for (int a = 0; a < OUTW; ++a) {
           const float o = prev[a] + dy * (c[a] - prev[a]);
           const int ch = (j - 1) * OUTW + a;
-          const uint32_t hv = (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)o);
           if (ch == NCH_OUT - 1) {       // 13th k-step, k = l
-            *reinterpret_cast<unsigned short*>(fwr + FT_BYTES + l * 2) = (unsigned short)hv;
+            *reinterpret_cast<_Float16*>(fwr + FT_BYTES + l * 2) = (_Float16)o;
           } else {
             const int d = (ch >> 1) & 3;
-            if (ch & 1) piece[d] |= hv << 16; else piece[d] = hv;
+            if constexpr (MIX) {         // insert into the packed pair: v_fma_mixlo / mixhi_f16 write the half directly
+              half2f pk = __builtin_bit_cast(half2f, piece[d]);
+              pk[ch & 1] = (_Float16)o;
+              piece[d] = __builtin_bit_cast(uint32_t, pk);
+            } else {
+              const uint32_t hv = (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)o);
+              if (ch & 1) piece[d] |= hv << 16; else piece[d] = hv;
+            }
             if ((ch & 7) == 7) {
               const int q = ch >> 3, s = q >> 1, kh = q & 1;
               *reinterpret_cast<u32x4*>(fwr + (s * 4 + kh) * 512) = u32x4{piece[0], piece[1], piece[2], piece[3]};
@@ -1065,14 +1099,22 @@ extern "C" int dh_corr_pyramid_lookup_corr0(const void* pyramid, const float* co
 #define DH_FUSED_MODE(M_)                                                                                                      \
     { DH_LDS_OPTIN((&pyr_lookup_corr0_kernel<64, M_>), 160 * 1024);                                                            \
       hipLaunchKernelGGL((pyr_lookup_corr0_kernel<64, M_>), grid, block, lds, st, (const __half*)pyramid, coords, (const __half*)wpk, bias, (__half*)out, D, n_strips); }
-  if (w == 64 && mode == 6) DH_FUSED_MODE(6)               // the synchronous twin: same results (tests compare bit for bit)
+  const bool mix = opts().lookup_mix != 0;                  // 0: conversions spelled out (same results; A/B and the bit-identity test)
+  if (w == 64 && mode == 6 && mix) DH_FUSED_MODE(6)        // the synchronous twin: same results (tests compare bit for bit)
+  else if (w == 64 && mode == 6) {
+    DH_LDS_OPTIN((&pyr_lookup_corr0_kernel<64, 6, false>), 160 * 1024);
+    hipLaunchKernelGGL((pyr_lookup_corr0_kernel<64, 6, false>), grid, block, lds, st, (const __half*)pyramid, coords, (const __half*)wpk, bias, (__half*)out, D, n_strips);
+  }
 #ifdef DH_ABLATION   // timing ablations with WRONG results: only in -DDH_ABLATION builds
   else if (w == 64 && mode == 2) DH_FUSED_MODE(2)
   else if (w == 64 && mode == 3) DH_FUSED_MODE(3)
   else if (w == 64 && mode == 5) DH_FUSED_MODE(5)
 #endif
 #undef DH_FUSED_MODE
-  else if (w == 64) {
+  else if (w == 64 && !mix) {
+    DH_LDS_OPTIN((&pyr_lookup_corr0_kernel<64, 0, false>), 160 * 1024);
+    hipLaunchKernelGGL((pyr_lookup_corr0_kernel<64, 0, false>), grid, block, lds, st, (const __half*)pyramid, coords, (const __half*)wpk, bias, (__half*)out, D, n_strips);
+  } else if (w == 64) {
     DH_LDS_OPTIN((&pyr_lookup_corr0_kernel<64>), 160 * 1024);
     hipLaunchKernelGGL((pyr_lookup_corr0_kernel<64>), grid, block, lds, st, (const __half*)pyramid, coords, (const __half*)wpk, bias, (__half*)out, D, n_strips);
   } else if (w == 32) {

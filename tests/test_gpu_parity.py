@@ -839,6 +839,13 @@ def test_lookup_fused_with_first_encoder_layer(db, option):
             option("lookup_mode", 0)
             assert torch.equal(out, sync)
             del sync
+            # the interpolation through v_fma_mix_f32 / v_fma_mixlo_f16 (default) performs the same fp32 operations in the same
+            # order as the form with the fp16 <-> fp32 conversions spelled out: bit-identical
+            option("lookup_mix", 0)
+            plain = db.corr_pyramid_lookup_corr0(pyr, coords, wpk, bias)
+            option("lookup_mix", 1)
+            assert torch.equal(out, plain)
+            del plain
         del pyr, samples, out, ref
 
 
