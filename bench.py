@@ -94,7 +94,7 @@ def measure_lookup_traffic(variant, edges, timeout_s=240):
         if r.returncode != 0 or not files:
             lines = [l for l in r.stdout.splitlines() if "simple_timer" not in l and l.strip()]
             return None, "rocprofv3 --pmc pass failed (rc %d): %s" % (r.returncode, " | ".join(lines[-6:])[-600:])
-        want = "pyr_lookup_corr0_kernel<64, 0>" if variant == "fused" else "pyr_lookup_kernel"
+        want = "pyr_lookup_corr0_kernel<64, 0" if variant == "fused" else "pyr_lookup_kernel"      # (<W, MODE = 0, MIX>: not the twin <64, 6, ..>)
         agg = {}
         for f in files:
             for row in csv.DictReader(open(f)):

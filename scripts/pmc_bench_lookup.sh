@@ -19,7 +19,7 @@ for f in sorted(glob.glob("$OUT/*/run_counter_collection.csv")):
     tag = f.split("/")[-2].split("_")[0]
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
-        if ("pyr_lookup_corr0_kernel<64, 0>" in r["Kernel_Name"]) if tag == "fused" else ("pyr_lookup_kernel" in r["Kernel_Name"]):     # (not the timing ablations <64, 2 / 3 / 5>)
+        if ("pyr_lookup_corr0_kernel<64, 0" in r["Kernel_Name"]) if tag == "fused" else ("pyr_lookup_kernel" in r["Kernel_Name"]):     # (not the timing ablations <64, 2 / 3 / 5>)
             agg[r["Counter_Name"]][0] += 1; agg[r["Counter_Name"]][1] += float(r["Counter_Value"])
     for k, (n, v) in agg.items():
         res.setdefault(tag, {})[k] = v / n
