@@ -423,6 +423,7 @@ struct LevelGeom {                                  // per-lane addressing / wei
   int coloff[NPAIR];                                // byte offsets of the 5 cell pairs (lane included)
   uint32_t cmask[WIN / 2];                          // column validity of the aligned tap pairs (0xffff per tap)
   int Y0, y1l, par16;                               // first window row, own row at this level, 16 * (u0 & 1)
+  int v0;                                           // fused kernel: displacement row of window row 0, folded once into [0, 2 h2)
   float dx, dy;
 };
 struct HalfTaps { uint32_t raw[HALF_ROWS][NPAIR]; };
@@ -756,6 +757,13 @@ __global__ __launch_bounds__(W * 8, 1) void pyr_lookup_corr0_kernel(const __half
     if (part == 1) {
       G.Y0 = (int)fyf - RAD;
       G.y1l = y1 >> l;
+      {
+        // displacement row of window row r is (Y0 + r - y1l) mod h2.  Folded ONCE per level: for every window row inside the image
+        // v0 + r lies in [0, 2 h2), so the row needs one add and one unsigned min (request()) instead of a two-sided wrap with
+        // four compares / selects -- 32 window rows per block, and the kernel is bound by the instructions a wave issues
+        const int a0 = G.Y0 - G.y1l;
+        G.v0 = a0 + (a0 < 0 ? D.h2[l] : 0);
+      }
       G.base = pyr + (long)e * D.edge_elems + D.lev_off[l];
       G.sboff = (int)((long)sb * D.blk_elems[l] * 2);
       const int k0 = u0 >> 1;
@@ -778,10 +786,13 @@ __global__ __launch_bounds__(W * 8, 1) void pyr_lookup_corr0_kernel(const __half
     const int w2 = W >> l, h2 = D.h2[l];
 #pragma unroll
     for (int jj = 0; jj < HALF_ROWS; ++jj) {
-      const int y2 = G.Y0 + half * HALF_ROWS + jj;
-      const bool inside = (unsigned)y2 < (unsigned)h2;
-      // (select by mask: a branch per window row would cut the interpolation into basic blocks)
-      const int rowoff = inside ? wrap(y2 - G.y1l, h2) * (w2 * 128) + G.sboff : h2 * (w2 * 128);
+      const int r = half * HALF_ROWS + jj;
+      const bool inside = (unsigned)(G.Y0 + r) < (unsigned)h2;
+      const unsigned vr = (unsigned)(G.v0 + r);
+      const unsigned v = min(vr, vr - (unsigned)h2);          // (v0 + r) mod h2 for rows inside the image (see geom); w2 * 128 is a power of two
+      int own = (int)(v * (unsigned)(w2 * 128)) + G.sboff;
+      asm("" : "+v"(own));               // computed for every lane: hipcc would otherwise sink it under an exec-mask branch per window row
+      const int rowoff = inside ? own : h2 * (w2 * 128);      // else block 0's all-zero row
 #pragma unroll
       for (int m = 0; m < NPAIR; ++m)
         if (MODE == 3) asm volatile("v_mov_b32 %0, %1" : "=v"(T.raw[jj][m]) : "v"(rowoff + G.coloff[m]));
@@ -799,7 +810,7 @@ __global__ __launch_bounds__(W * 8, 1) void pyr_lookup_corr0_kernel(const __half
   };
 
   f32x16 acc[4][2];
-  uint32_t piece[4];                     // the 8 channels being packed (one 16-byte piece of a B operand)
+  uint32_t piece[4] = {0u, 0u, 0u, 0u};  // the 8 channels being packed (one 16-byte piece of a B operand)
   float prev[OUTW];
   // B operands of the level in the wave's tile: [k-step s][pixel tile nt][kh][32 pixels][8 channels] fp16; lane = pixel
   unsigned char* fwr = tile + (lane >> 5) * 1024 + (lane & 31) * 16;              // + (s * 4 + kh) * 512
@@ -852,10 +863,12 @@ __global__ __launch_bounds__(W * 8, 1) void pyr_lookup_corr0_kernel(const __half
             *reinterpret_cast<_Float16*>(fwr + FT_BYTES + l * 2) = (_Float16)o;
           } else {
             const int d = (ch >> 1) & 3;
-            if constexpr (MIX) {         // insert into the packed pair: v_fma_mixlo / mixhi_f16 write the half directly
-              half2f pk = __builtin_bit_cast(half2f, piece[d]);
-              pk[ch & 1] = (_Float16)o;
-              piece[d] = __builtin_bit_cast(uint32_t, pk);
+            if constexpr (MIX) {
+              // prev + dy * (c - prev) rounded to fp16 straight into its half of the packed pair: v_fma_mixlo / mixhi_f16 write one
+              // half of the destination and keep the other (hipcc picks mixlo into a temporary + v_or_b32_sdwa for the upper halves)
+              const float dd = c[a] - prev[a];
+              if (ch & 1) asm("v_fma_mixhi_f16 %0, %1, %2, %3" : "+v"(piece[d]) : "v"(dy), "v"(dd), "v"(prev[a]));
+              else asm("v_fma_mixlo_f16 %0, %1, %2, %3" : "+v"(piece[d]) : "v"(dy), "v"(dd), "v"(prev[a]));
             } else {
               const uint32_t hv = (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)o);
               if (ch & 1) piece[d] |= hv << 16; else piece[d] = hv;
