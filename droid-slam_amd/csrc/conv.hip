@@ -201,14 +201,14 @@ inline bool staged_epilogue_ok(const ConvParams& P) {
 
 // second phase of the staged epilogues: the workgroup walks the fp16 tile [256 px][BNT couts] in 16-byte pieces (8 couts of
 // one pixel), applies the gate algebra with 16-byte operand loads and stores a pixel's couts as one run
-template <int EPI, int BNT>
+template <int EPI, int BNT, int NT = 512>
 __device__ __forceinline__ void staged_tile_store(const ConvParams& P, const __half* __restrict__ sT, long m0, int n0, int tid) {
   constexpr int ELD = BNT + 8;
   constexpr int PPR = BNT / 8;
-  // 256 px x PPR pieces; thread -> (pixel row, piece): PPR consecutive lanes cover the couts of one pixel
+  // 256 px x PPR pieces; thread -> (pixel row, piece): PPR consecutive lanes cover the couts of one pixel (NT = threads of the workgroup)
 #pragma unroll
-  for (int it = 0; it < PPR / 2; ++it) {
-    const int id = tid + 512 * it, row = id / PPR, c8 = (id % PPR) * 8;
+  for (int it = 0; it < 256 * PPR / NT; ++it) {
+    const int id = tid + NT * it, row = id / PPR, c8 = (id % PPR) * 8;
     const int co = n0 + c8;
     if (co >= P.Cout) continue;
     const long pix = m0 + row;
@@ -243,7 +243,7 @@ __device__ __forceinline__ void staged_tile_store(const ConvParams& P, const __h
 }
 
 // TN = 32-cout accumulator tiles per wave, BNT = couts of the workgroup tile (128 or 64)
-template <int EPI, int TN, int BNT>
+template <int EPI, int TN, int BNT, int NT = 512>
 __device__ __forceinline__ void staged_epilogue(const ConvParams& P, f32x16 (&acc)[2][TN], __half* __restrict__ sT, long m0, int n0,
                                                 int wm0, int wn0, int tid, int HW) {
   constexpr int ELD = BNT + 8;            // LDS row stride of the staged tile (halves)
@@ -271,7 +271,7 @@ __device__ __forceinline__ void staged_epilogue(const ConvParams& P, f32x16 (&ac
       }
   }
   __syncthreads();
-  staged_tile_store<EPI, BNT>(P, sT, m0, n0, tid);
+  staged_tile_store<EPI, BNT, NT>(P, sT, m0, n0, tid);
 }
 
 // EPI_HEADS0: first layer of the delta | weight heads (3x3, 128 -> 256, relu) FUSED with the second layer's channel
@@ -1062,6 +1062,126 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
   else conv_epilogue<EPI, 2, 2>(P, acc, (long)P.N * HW, m0, n0, wm0, wn0, lane, HW);
 }
 
+#ifdef DH_ABLATION   // four-wave form of the second kernel (measurement variant, option conv_halo4)
+// ---- 3x3, 128-cout tile, the second form with FOUR waves of 64 x 128 instead of eight of 64 x 64 --------------------------------
+// Same tile (4 image rows x 64 columns x 128 couts), same LDS image and weight layout, still two workgroups per CU; a wave owns one
+// image row and all 128 couts: 2 x 4 accumulator tiles (128 registers), an activation fragment read from LDS feeds four MFMAs
+// (0.75 fragment reads per MFMA instead of 1), two waves per SIMD instead of four.
+template <int EPI, bool STAGED = true, bool CINIT = false>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(ConvParams P) {
+  extern __shared__ __half s_conv[];
+  char* const lds = reinterpret_cast<char*>(s_conv);
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)s_conv;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wrow = wave, wn0 = 0, wm0 = wrow * 64;
+  long m0; int n0;
+  xcd_decode(P, m0, n0, 128);
+  const int HW = P.H * P.W;
+  const int img = (int)(m0 / HW), y0 = (int)((m0 - (long)img * HW) / 64);
+  const int nchunks = P.Ctot / H2CK, nsteps = nchunks * 3;
+  // halo: 6 x 64 interior = 1536 pieces = 6 per thread: piece tid + 256 i -> (row i, column (tid >> 2) & 63, slot tid & 3)
+  constexpr int A_PIECES = 6;
+  const int aq = tid & 3, ax = (tid >> 2) & 63;
+  const int a_pix0 = (img * P.H + y0 - 1) * 64 + ax;
+  if (tid < 48) {
+    const int hp = (tid >> 3) * HCOLS + ((tid >> 2) & 1) * (HCOLS - 1);
+    *reinterpret_cast<uint4*>(lds + hp * 64 + aq * 16) = uint4{0u, 0u, 0u, 0u};
+  }
+  const int b_voff = lane * 16;
+  const char* const bsrc = reinterpret_cast<const char*>(P.wt_halo) + (long)(n0 >> 7) * nsteps * H2B_BYTES;
+  const int pl = wrow * HCOLS + (lane & 31), kh = lane >> 5;
+  int b_row[4], b_x[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int r = b * 32 + (lane & 31);
+    b_row[b] = r * 64; b_x[b] = ((r >> 2) & 3) ^ kh;
+  }
+  f32x16 acc[2][4];
+  if constexpr (CINIT) init_acc_tile<2, 4>(P, acc, m0, n0, wm0, wn0, lane, HW);
+  else zero_acc<2, 4>(acc);
+  u32x4 ra[A_PIECES];
+#define H4_FETCH_A(chunk_)                                                                                           \
+  {                                                                                                                  \
+    int cs = (chunk_) * H2CK, sgi = 0;                                                                               \
+    _Pragma("unroll") for (int q = 0; q < MAXSEG - 1; ++q)                                                           \
+      if (sgi == q && q + 1 < P.nseg && cs >= P.segC[q]) { cs -= P.segC[q]; sgi = q + 1; }                          \
+    const __half* base = P.in[0]; int segs = P.segS[0];                                                              \
+    _Pragma("unroll") for (int q = 1; q < MAXSEG; ++q) if (sgi == q) { base = P.in[q]; segs = P.segS[q]; }           \
+    int pix0 = a_pix0;                                                                                               \
+    asm volatile("" : "+v"(pix0));                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < A_PIECES; ++i) {                                                           \
+      const bool ok = (unsigned)(y0 - 1 + i) < (unsigned)P.H;                                                        \
+      ra[i] = *reinterpret_cast<const u32x4*>(base + (long)(ok ? pix0 + 64 * i : 0) * segs + cs + aq * 8);           \
+    }                                                                                                                \
+  }
+#define GLDS16S(sbase_, voff_, ldsaddr_)                                                                             \
+  {                                                                                                                  \
+    unsigned keep_;                                                                                                  \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep_) : "v"(voff_), "s"(sbase_), "s"(ldsaddr_) : "memory");                                \
+  }
+#define H4_DMA_B(step_)                                                                                              \
+  {                                                                                                                  \
+    _Pragma("unroll") for (int q = 0; q < 6; ++q) {                                                                  \
+      const unsigned long gaddr = (unsigned long)(bsrc + (long)(step_) * H2B_BYTES + (wave + 4 * q) * 1024);          \
+      const unsigned glo = __builtin_amdgcn_readfirstlane((unsigned)gaddr);                                          \
+      const unsigned ghi = __builtin_amdgcn_readfirstlane((unsigned)(gaddr >> 32));                                  \
+      const void* gs = reinterpret_cast<const void*>(((unsigned long)ghi << 32) | glo);                              \
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + H2A_BYTES + ((step_) & 1) * H2B_BYTES + (wave + 4 * q) * 1024); \
+      GLDS16S(gs, b_voff, dst)                                                                                       \
+    }                                                                                                                \
+  }
+  H4_FETCH_A(0)
+  H4_DMA_B(0)
+  for (int c = 0; c < nchunks; ++c) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    int ax_o = ax;
+    asm volatile("" : "+v"(ax_o));
+#pragma unroll
+    for (int i = 0; i < A_PIECES; ++i) {
+      const int hp = i * HCOLS + ax_o + 1;
+      const uint32_t m = (unsigned)(y0 - 1 + i) < (unsigned)P.H ? 0xffffffffu : 0u;
+      *reinterpret_cast<u32x4*>(lds + hp * 64 + ((aq ^ ((hp >> 2) & 3)) << 4)) = ra[i] & m;
+    }
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int step = c * 3 + dy;
+      if (dy == 1 && c + 1 < nchunks) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (step + 1 < nsteps) H4_DMA_B(step + 1)
+      if (dy == 0 && c + 1 < nchunks) H4_FETCH_A(c + 1)
+      const char* const Bcur = lds + H2A_BYTES + (step & 1) * H2B_BYTES;
+      int pl_o = pl;
+      asm volatile("" : "+v"(pl_o));
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          half8 af[2], bf[4];
+#pragma unroll
+          for (int a = 0; a < 2; ++a) {
+            const int p = pl_o + dy * HCOLS + dx + a * 32;
+            af[a] = *reinterpret_cast<const half8*>(lds + p * 64 + (((ks * 2) ^ ((p >> 2) & 3) ^ kh) << 4));
+          }
+#pragma unroll
+          for (int b = 0; b < 4; ++b) bf[b] = *reinterpret_cast<const half8*>(Bcur + dx * (128 * 64) + b_row[b] + (((ks * 2) ^ b_x[b]) << 4));
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+      }
+    }
+  }
+#undef H4_FETCH_A
+#undef H4_DMA_B
+#undef GLDS16S
+  if constexpr (STAGED) staged_epilogue<EPI, 4, 128, 256>(P, acc, s_conv, m0, n0, wm0, wn0, tid, HW);
+  else conv_epilogue<EPI, 2, 4>(P, acc, (long)P.N * HW, m0, n0, wm0, wn0, lane, HW);
+}
+#endif  // DH_ABLATION
+
 #ifdef DH_ABLATION   // 512-pixel-tile form: measured equal in energy, slower in time (profiles/r04_d_conv_halo3_ab.json): not in release builds
 // ---- 3x3, 128-cout tile, THIRD form: 512-pixel tile (8 image rows), 128 x 64 per wave -- opt-in (option conv_halo3) -----------
 // Round 4's power measurements (profiles/r04_conv_power.json) put conv3x3_halo2_kernel on the socket's 1400 W cap with 31 % of the
@@ -1708,6 +1828,29 @@ int launch_halo2(const ConvParams& P0, hipStream_t st) {
 
 #ifdef DH_ABLATION
 template <int EPI>
+int launch_halo4(const ConvParams& P0, hipStream_t st) {
+  ConvParams P = P0;
+  const long M = (long)P.N * P.H * P.W;
+  dim3 grid((unsigned)(M / BM), (unsigned)(P.CoutPad / 128));
+  P.ny = (int)grid.y;
+  if (opts().conv_xcd && grid.x % 8 == 0) { P.xcd_tiles = (int)(grid.x / 8); grid = dim3(grid.x * grid.y, 1); }
+  if constexpr (EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q) {
+    if (P.cinit) {
+      DH_LDS_OPTIN((&conv3x3_halo4_kernel<EPI, true, true>), 80 * 1024);
+      hipLaunchKernelGGL((conv3x3_halo4_kernel<EPI, true, true>), grid, dim3(256), H2_LDS_BYTES, st, P);
+      DH_LAUNCH_CHECK();
+      return DH_OK;
+    }
+  }
+  DH_LDS_OPTIN((&conv3x3_halo4_kernel<EPI>), 80 * 1024);
+  hipLaunchKernelGGL((conv3x3_halo4_kernel<EPI>), grid, dim3(256), H2_LDS_BYTES, st, P);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+#endif  // DH_ABLATION
+
+#ifdef DH_ABLATION
+template <int EPI>
 int launch_halo3(const ConvParams& P0, hipStream_t st) {
   ConvParams P = P0;
   const long M = (long)P.N * P.H * P.W;
@@ -2083,6 +2226,16 @@ extern "C" int dh_conv2d_nhwc_f16_ex2(const void* const* inputs, const int* in_c
   }
 #endif
 #ifdef DH_ABLATION
+  if (opts().conv_halo4 && !(P.epi == EPI_LINEAR && P.out_f32)) {                      // measurement variant: four 64 x 128 waves per workgroup
+    switch (P.epi) {
+      case EPI_LINEAR: if (halo2_ok<EPI_LINEAR>(P)) return launch_halo4<EPI_LINEAR>(P, st); break;
+      case EPI_RELU: if (halo2_ok<EPI_RELU>(P)) return launch_halo4<EPI_RELU>(P, st); break;
+      case EPI_SIGMOID: if (halo2_ok<EPI_SIGMOID>(P)) return launch_halo4<EPI_SIGMOID>(P, st); break;
+      case EPI_GRU_ZR: if (halo2_ok<EPI_GRU_ZR>(P)) return launch_halo4<EPI_GRU_ZR>(P, st); break;
+      case EPI_GRU_Q: if (halo2_ok<EPI_GRU_Q>(P)) return launch_halo4<EPI_GRU_Q>(P, st); break;
+      default: break;
+    }
+  }
   if (opts().conv_halo3 && P.H % 8 == 0 && ((long)P.N * P.H * P.W) % 512 == 0) {       // opt-in: the 512-pixel-tile form of the same kernel
     switch (P.epi) {
       case EPI_LINEAR: if (halo2_ok<EPI_LINEAR>(P)) return launch_halo3<EPI_LINEAR>(P, st); break;

@@ -7,6 +7,10 @@ PKG = os.path.join(ROOT, "droid-slam_amd")
 for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
+# DROID_HIP_TEST_ABLATION=1: run the suite against the -DDH_ABLATION build (droid-slam_amd/ablation/, built by
+# DROID_HIP_ABLATION=1 python droid-slam_amd/build.py): the tests of the prototype / measurement kernels then run instead of skipping
+if os.environ.get("DROID_HIP_TEST_ABLATION", "0") == "1":
+    sys.path.insert(0, os.path.join(PKG, "ablation"))
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 

@@ -1016,13 +1016,15 @@ def test_update_forward_leaves_a_channel_last_hidden_state_untouched(db):
     assert torch.equal(out1, out2)
 
 
-def test_conv_512_pixel_tile_form_is_bit_identical(db, option):
-    """conv3x3_halo3_kernel (option conv_halo3: 8-row / 512-pixel tile, 128 x 64 per wave, one workgroup per CU) runs the same
-    k order per output element as conv3x3_halo2_kernel: raw convolutions (relu, multi-segment input, two cout tiles, several
-    images, image borders) and the WHOLE update operator (gates with accumulator start values and GRU epilogues, fused heads)
-    must be equal bit for bit with the option on and off."""
+@pytest.mark.parametrize("variant", ["conv_halo3", "conv_halo4"])
+def test_conv_512_pixel_tile_form_is_bit_identical(db, option, variant):
+    """conv3x3_halo3_kernel (option conv_halo3: 8-row / 512-pixel tile, 128 x 64 per wave, one workgroup per CU) and
+    conv3x3_halo4_kernel (conv_halo4: the production tile with four 64 x 128 waves) run the same k order per output element as
+    conv3x3_halo2_kernel: raw convolutions (relu, multi-segment input, two cout tiles, several images, image borders) and the
+    WHOLE update operator (gates with accumulator start values and GRU epilogues, fused heads) must be equal bit for bit with
+    the option on and off."""
     if not db.get_option("ablation_build"):
-        pytest.skip("the 512-pixel-tile kernel is only part of a -DDH_ABLATION build (measured slower: profiles/r04_d_conv_halo3_ab.json)")
+        pytest.skip("measurement kernels of the -DDH_ABLATION build (DROID_HIP_TEST_ABLATION=1 runs them; profiles/r04_d_conv_halo3_ab.json)")
     from oracle import update as oupd
     from droid_amd.update import pack_conv, pack_conv_halo, EPI_RELU, UpdateModule
     from droid_amd.weights import deterministic_state_dict
@@ -1034,7 +1036,7 @@ def test_conv_512_pixel_tile_form_is_bit_identical(db, option):
         wh = pack_conv_halo(wgt)
         outs = []
         for v in (0, 1):
-            option("conv_halo3", v)
+            option(variant, v)
             out = torch.zeros(n, h, 64, cout, device="cuda", dtype=torch.float16)
             db.conv2d_nhwc(xs, wp, wh, bp, 3, 3, cout, EPI_RELU, out, cout, None, None, None, None)
             torch.cuda.synchronize()
@@ -1055,7 +1057,7 @@ def test_conv_512_pixel_tile_form_is_bit_identical(db, option):
     ii = torch.tensor([0, 0, 1, 1, 2, 2], device="cuda")
     res = []
     for v in (0, 1):
-        option("conv_halo3", v)
+        option(variant, v)
         r = mod.forward_nhwc(net.clone(), None, None, flow, ii, inp_frames=inp_frames, inp_index=ii, corr0=c0)
         torch.cuda.synchronize()
         res.append([t.clone() for t in r])
