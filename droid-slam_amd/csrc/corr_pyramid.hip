@@ -709,7 +709,11 @@ __device__ __forceinline__ float sub_f16_halves(uint32_t p1, uint32_t p0) {
 // MIX (option lookup_mix, default 1): the interpolation without fp16 -> fp32 / fp32 -> fp16 conversion instructions (the taps enter the
 // fp32 arithmetic as fp16 operands of v_fma_mix_f32, the samples leave it through v_fma_mixlo / mixhi_f16); 0 = the conversions
 // spelled out.  Same operations in the same order: bit-identical (tests/test_gpu_parity.py).
-template <int W, int MODE = 0, bool MIX = true>
+// FILL (option lookup_fill): how the 40 tap registers of a lane are refilled.  0 = two half-level batches of 4 window rows: a batch is
+// requested again (for the next level) when all of its rows are interpolated, so during an interpolation phase only the other batch is
+// in flight.  1 = by window row: row r of the next level is requested as soon as row r of this level is interpolated, 35 of the 40
+// registers are in flight at every wait.  Same loads, same arithmetic in the same order: bit-identical.
+template <int W, int MODE = 0, bool MIX = true, int FILL = 0>
 __global__ __launch_bounds__(W * 8, 1) void pyr_lookup_corr0_kernel(const __half* __restrict__ pyr, const float* __restrict__ coords,
                                                                     const __half* __restrict__ wpk, const float* __restrict__ bias,
                                                                     __half* __restrict__ out, PyrDims D, int n_strips) {
@@ -782,31 +786,25 @@ __global__ __launch_bounds__(W * 8, 1) void pyr_lookup_corr0_kernel(const __half
       }
     }
   };
-  auto request = [&](int l, const LevelGeom& G, int half, HalfTaps& T) {
+  auto request_row = [&](int l, const LevelGeom& G, int r, uint32_t (&raw)[NPAIR]) {
     const int w2 = W >> l, h2 = D.h2[l];
+    const bool inside = (unsigned)(G.Y0 + r) < (unsigned)h2;
+    const unsigned vr = (unsigned)(G.v0 + r);
+    const unsigned v = min(vr, vr - (unsigned)h2);          // (v0 + r) mod h2 for rows inside the image (see geom); w2 * 128 is a power of two
+    int own = (int)(v * (unsigned)(w2 * 128)) + G.sboff;
+    asm("" : "+v"(own));               // computed for every lane: hipcc would otherwise sink it under an exec-mask branch per window row
+    const int rowoff = inside ? own : h2 * (w2 * 128);      // else block 0's all-zero row
 #pragma unroll
-    for (int jj = 0; jj < HALF_ROWS; ++jj) {
-      const int r = half * HALF_ROWS + jj;
-      const bool inside = (unsigned)(G.Y0 + r) < (unsigned)h2;
-      const unsigned vr = (unsigned)(G.v0 + r);
-      const unsigned v = min(vr, vr - (unsigned)h2);          // (v0 + r) mod h2 for rows inside the image (see geom); w2 * 128 is a power of two
-      int own = (int)(v * (unsigned)(w2 * 128)) + G.sboff;
-      asm("" : "+v"(own));               // computed for every lane: hipcc would otherwise sink it under an exec-mask branch per window row
-      const int rowoff = inside ? own : h2 * (w2 * 128);      // else block 0's all-zero row
-#pragma unroll
-      for (int m = 0; m < NPAIR; ++m)
-        if (MODE == 3) asm volatile("v_mov_b32 %0, %1" : "=v"(T.raw[jj][m]) : "v"(rowoff + G.coloff[m]));
-        else asm volatile("global_load_dword %0, %1, %2" : "=v"(T.raw[jj][m]) : "v"(rowoff + G.coloff[m]), "s"(G.base));
-    }
-    // MODE 6 = the synchronous twin of the product kernel: every batch is waited for where it is issued, so no register is ever
+    for (int m = 0; m < NPAIR; ++m)
+      if (MODE == 3) asm volatile("v_mov_b32 %0, %1" : "=v"(raw[m]) : "v"(rowoff + G.coloff[m]));
+      else asm volatile("global_load_dword %0, %1, %2" : "=v"(raw[m]) : "v"(rowoff + G.coloff[m]), "s"(G.base));
+    // MODE 6 = the synchronous twin of the product kernel: every request is waited for where it is issued, so no register is ever
     // in flight across compiler-scheduled code.  Same arithmetic in the same order -> the test suite requires bit-identical
     // output from MODE 0, which is how the product binary's explicit vmcnt bookkeeping is checked on real launches.
     if (MODE == 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
-  auto landed = [&](HalfTaps& T) {
-#pragma unroll
-    for (int jj = 0; jj < HALF_ROWS; ++jj)
-      asm volatile("" : "+v"(T.raw[jj][0]), "+v"(T.raw[jj][1]), "+v"(T.raw[jj][2]), "+v"(T.raw[jj][3]), "+v"(T.raw[jj][4]));
+  auto landed_row = [&](uint32_t (&raw)[NPAIR]) {
+    asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]));
   };
 
   f32x16 acc[4][2];
@@ -828,16 +826,19 @@ __global__ __launch_bounds__(W * 8, 1) void pyr_lookup_corr0_kernel(const __half
       acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[mt][nt], 0, 0, 0);
     }
   };
-  auto consume = [&](int l, const LevelGeom& G, const HalfTaps& T, int half) {
+  auto consume_row = [&](int l, const LevelGeom& G, const uint32_t (&raw)[NPAIR], int j) {
     const float dx = G.dx, dy = G.dy;
-#pragma unroll
-    for (int jj = 0; jj < HALF_ROWS; ++jj) {
-      const int j = half * HALF_ROWS + jj;
+    if (MODE == 7) {                       // timing ablation (wrong results): the taps are touched, nothing is interpolated
+      piece[j & 3] ^= raw[0] ^ raw[1] ^ raw[2] ^ raw[3] ^ raw[4];
+      if (j == WIN - 1) *reinterpret_cast<u32x4*>(fwr) = u32x4{piece[0], piece[1], piece[2], piece[3]};
+      return;
+    }
+    {
       float c[OUTW];
       if constexpr (MIX) {
         uint32_t pr[WIN / 2];
 #pragma unroll
-        for (int n = 0; n < WIN / 2; ++n) pr[n] = __builtin_amdgcn_alignbit(T.raw[jj][n + 1], T.raw[jj][n], G.par16) & G.cmask[n];
+        for (int n = 0; n < WIN / 2; ++n) pr[n] = __builtin_amdgcn_alignbit(raw[n + 1], raw[n], G.par16) & G.cmask[n];
         // c[a] = t[a] + dx * (t[a + 1] - t[a]); tap a = half (a & 1) of pr[a >> 1]
 #define DH_LERP_X(a_) { const float d_ = sub_f16_halves<((a_) + 1) & 1, (a_) & 1>(pr[((a_) + 1) >> 1], pr[(a_) >> 1]);                     \
                         c[a_] = __builtin_fmaf(dx, d_, (float)__builtin_bit_cast(half2f, pr[(a_) >> 1])[(a_) & 1]); }
@@ -847,7 +848,7 @@ __global__ __launch_bounds__(W * 8, 1) void pyr_lookup_corr0_kernel(const __half
         float t[WIN];
 #pragma unroll
         for (int n = 0; n < WIN / 2; ++n) {
-          const uint32_t pr = __builtin_amdgcn_alignbit(T.raw[jj][n + 1], T.raw[jj][n], G.par16) & G.cmask[n];
+          const uint32_t pr = __builtin_amdgcn_alignbit(raw[n + 1], raw[n], G.par16) & G.cmask[n];
           t[2 * n] = (float)__builtin_bit_cast(_Float16, (unsigned short)(pr & 0xffffu));
           t[2 * n + 1] = (float)__builtin_bit_cast(_Float16, (unsigned short)(pr >> 16));
         }
@@ -886,9 +887,10 @@ __global__ __launch_bounds__(W * 8, 1) void pyr_lookup_corr0_kernel(const __half
   };
 
   LevelGeom G, R;                        // G: interpolation part of the current level; R: request part of the level in flight
-  HalfTaps A, B;
+  uint32_t T[WIN][NPAIR];                // the taps of one level: window row r in T[r] (FILL 0: rows 0..3 and 4..7 are the two batches)
   geom(0, R, 1);
-  request(0, R, 0, A); request(0, R, 1, B);
+#pragma unroll
+  for (int r = 0; r < WIN; ++r) request_row(0, R, r, T[r]);
   bool first = true;
   for (;;) {
     const int next = strip + gridDim.x;
@@ -907,22 +909,58 @@ __global__ __launch_bounds__(W * 8, 1) void pyr_lookup_corr0_kernel(const __half
 #pragma unroll
     for (int l = 0; l < NLEV; ++l) {
       const bool more = l + 1 < NLEV;
-      // issue order: ... A_l B_l [16 stores of the previous block, l == 0 only] [next coords, after B_1's request]
-      if (l == 0 && !first && MODE != 2) wait_vm<BATCH + F_STORES>(); else wait_vm<BATCH>();
-      landed(A);
-      geom(l, G, 2);
-      consume(l, G, A, 0);                 // channels 0..20
-      if (more) { geom(l + 1, R, 1); request(l + 1, R, 0, A); }
-      else if (has_next) {
-        cur ^= 1; e = en; by = byn;
-        geom(0, R, 1); request(0, R, 0, A);
-      }
-      if (l == 0 && !first && MODE != 2) wait_vm<BATCH + F_STORES>(); else if (more || has_next) wait_vm<BATCH>(); else wait_vm<0>();
-      landed(B);
-      consume(l, G, B, 1);                 // channels 21..48
-      if (more || has_next) request(more ? l + 1 : 0, R, 1, B);      // (before the MFMAs: the batch has their time to land)
+      if constexpr (FILL == 0) {
+        // issue order: ... A_l B_l [16 stores of the previous block, l == 0 only] [next coords, after B_1's request]
+        if (l == 0 && !first && MODE != 2) wait_vm<BATCH + F_STORES>(); else wait_vm<BATCH>();
 #pragma unroll
-      for (int s = 0; s < 3; ++s) { unit(l * 3 + s, 0); unit(l * 3 + s, 1); }
+        for (int r = 0; r < HALF_ROWS; ++r) landed_row(T[r]);
+        geom(l, G, 2);
+#pragma unroll
+        for (int r = 0; r < HALF_ROWS; ++r) consume_row(l, G, T[r], r);       // channels 0..20
+        if (more) geom(l + 1, R, 1);
+        else if (has_next) { cur ^= 1; e = en; by = byn; geom(0, R, 1); }
+        if (more || has_next) {
+#pragma unroll
+          for (int r = 0; r < HALF_ROWS; ++r) request_row(more ? l + 1 : 0, R, r, T[r]);
+        }
+        if (l == 0 && !first && MODE != 2) wait_vm<BATCH + F_STORES>(); else if (more || has_next) wait_vm<BATCH>(); else wait_vm<0>();
+#pragma unroll
+        for (int r = HALF_ROWS; r < WIN; ++r) landed_row(T[r]);
+#pragma unroll
+        for (int r = HALF_ROWS; r < WIN; ++r) consume_row(l, G, T[r], r);     // channels 21..48
+        if (more || has_next) {                                              // (before the MFMAs: the batch has their time to land)
+#pragma unroll
+          for (int r = HALF_ROWS; r < WIN; ++r) request_row(more ? l + 1 : 0, R, r, T[r]);
+        }
+      } else {
+        // issue order: ... rows 0..7 of level 0 [16 stores of the previous block] | (1,0) .. (1,7) [2 coordinate DMAs] | (2,r) | (3,r) |
+        // (0',r): row r of the next level is issued right after row r of this level is interpolated, so the requests younger than
+        // (l, r) are rows r+1..7 of level l and rows 0..r-1 of the next: 35, plus the 16 stores while level 0 of a later block is
+        // waited for.  (The two coordinate DMAs sit between (1,7) and (2,0): waiting for 35 instead of 37 at level 1 is on the
+        // safe side.)  Last block of the workgroup, last level: nothing follows, rows r+1..7 only.
+        geom(l, G, 2);
+        if (more) geom(l + 1, R, 1);
+        else if (has_next) { cur ^= 1; e = en; by = byn; geom(0, R, 1); }
+#pragma unroll
+        for (int r = 0; r < WIN; ++r) {
+          constexpr int YOUNGER = (WIN - 1) * NPAIR;
+          if (more || has_next) { if (l == 0 && !first && MODE != 2) wait_vm<YOUNGER + F_STORES>(); else wait_vm<YOUNGER>(); }
+          else {
+            switch (r) {                   // (r is a constant after unrolling)
+              case 0: wait_vm<7 * NPAIR>(); break; case 1: wait_vm<6 * NPAIR>(); break; case 2: wait_vm<5 * NPAIR>(); break;
+              case 3: wait_vm<4 * NPAIR>(); break; case 4: wait_vm<3 * NPAIR>(); break; case 5: wait_vm<2 * NPAIR>(); break;
+              case 6: wait_vm<NPAIR>(); break; default: wait_vm<0>(); break;
+            }
+          }
+          landed_row(T[r]);
+          consume_row(l, G, T[r], r);
+          if (more || has_next) request_row(more ? l + 1 : 0, R, r, T[r]);
+        }
+      }
+      if (MODE != 7) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) { unit(l * 3 + s, 0); unit(l * 3 + s, 1); }
+      }
       if (l == 0 && has_next) {           // the next block's coordinates: LDS-DMA, no registers held across the levels
         const int voff = ((byn * 8 + yy) * W + bx * 8 + xx) * 8;
         const float* cbase = coords + (long)en * HW * 2;
@@ -1108,29 +1146,26 @@ extern "C" int dh_corr_pyramid_lookup_corr0(const void* pyramid, const float* co
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(160 * 1024 / lds, (size_t)(16 / (w / 8))));   // LDS and 2 waves / SIMD
   const dim3 grid((unsigned)std::min<long>(n_strips, (long)cus * per_cu)), block(w * 8);
   hipStream_t st = (hipStream_t)stream;
-  const int mode = opts().lookup_mode;                     // 2 / 3 / 5: timing ablations (wrong results); 6: synchronous twin (same results)
-#define DH_FUSED_MODE(M_)                                                                                                      \
-    { DH_LDS_OPTIN((&pyr_lookup_corr0_kernel<64, M_>), 160 * 1024);                                                            \
-      hipLaunchKernelGGL((pyr_lookup_corr0_kernel<64, M_>), grid, block, lds, st, (const __half*)pyramid, coords, (const __half*)wpk, bias, (__half*)out, D, n_strips); }
+  const int mode = opts().lookup_mode;                     // 2 / 3 / 5 / 7: timing ablations (wrong results); 6: synchronous twin (same results)
   const bool mix = opts().lookup_mix != 0;                  // 0: conversions spelled out (same results; A/B and the bit-identity test)
-  if (w == 64 && mode == 6 && mix) DH_FUSED_MODE(6)        // the synchronous twin: same results (tests compare bit for bit)
-  else if (w == 64 && mode == 6) {
-    DH_LDS_OPTIN((&pyr_lookup_corr0_kernel<64, 6, false>), 160 * 1024);
-    hipLaunchKernelGGL((pyr_lookup_corr0_kernel<64, 6, false>), grid, block, lds, st, (const __half*)pyramid, coords, (const __half*)wpk, bias, (__half*)out, D, n_strips);
-  }
+  const bool rows = opts().lookup_fill != 0;                // 1: tap registers refilled window row by window row (same results)
+#define DH_FUSED(M_, X_, F_)                                                                                                   \
+    { DH_LDS_OPTIN((&pyr_lookup_corr0_kernel<64, M_, X_, F_>), 160 * 1024);                                                    \
+      hipLaunchKernelGGL((pyr_lookup_corr0_kernel<64, M_, X_, F_>), grid, block, lds, st, (const __half*)pyramid, coords, (const __half*)wpk, bias, (__half*)out, D, n_strips); }
+  if (w == 64 && mode == 6 && mix) DH_FUSED(6, true, 0)   // the synchronous twin: same results (tests compare bit for bit)
+  else if (w == 64 && mode == 6) DH_FUSED(6, false, 0)
 #ifdef DH_ABLATION   // timing ablations with WRONG results: only in -DDH_ABLATION builds
-  else if (w == 64 && mode == 2) DH_FUSED_MODE(2)
-  else if (w == 64 && mode == 3) DH_FUSED_MODE(3)
-  else if (w == 64 && mode == 5) DH_FUSED_MODE(5)
+  else if (w == 64 && mode == 2) DH_FUSED(2, true, 0)
+  else if (w == 64 && mode == 3) DH_FUSED(3, true, 0)
+  else if (w == 64 && mode == 5) DH_FUSED(5, true, 0)
+  else if (w == 64 && mode == 7 && rows) DH_FUSED(7, true, 1)
+  else if (w == 64 && mode == 7) DH_FUSED(7, true, 0)
 #endif
-#undef DH_FUSED_MODE
-  else if (w == 64 && !mix) {
-    DH_LDS_OPTIN((&pyr_lookup_corr0_kernel<64, 0, false>), 160 * 1024);
-    hipLaunchKernelGGL((pyr_lookup_corr0_kernel<64, 0, false>), grid, block, lds, st, (const __half*)pyramid, coords, (const __half*)wpk, bias, (__half*)out, D, n_strips);
-  } else if (w == 64) {
-    DH_LDS_OPTIN((&pyr_lookup_corr0_kernel<64>), 160 * 1024);
-    hipLaunchKernelGGL((pyr_lookup_corr0_kernel<64>), grid, block, lds, st, (const __half*)pyramid, coords, (const __half*)wpk, bias, (__half*)out, D, n_strips);
-  } else if (w == 32) {
+  else if (w == 64 && !mix) DH_FUSED(0, false, 0)
+  else if (w == 64 && rows) DH_FUSED(0, true, 1)
+  else if (w == 64) DH_FUSED(0, true, 0)
+#undef DH_FUSED
+  else if (w == 32) {
     DH_LDS_OPTIN((&pyr_lookup_corr0_kernel<32>), 160 * 1024);
     hipLaunchKernelGGL((pyr_lookup_corr0_kernel<32>), grid, block, lds, st, (const __half*)pyramid, coords, (const __half*)wpk, bias, (__half*)out, D, n_strips);
   } else {

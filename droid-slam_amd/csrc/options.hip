@@ -30,6 +30,7 @@ Options& opts() {
     v.lookup_mode = env_int("DH_LOOKUP_MODE", 0);
     v.lookup_fused = env_int("DH_LOOKUP_FUSED", 1);
     v.lookup_mix = env_int("DH_LOOKUP_MIX", 1);
+    v.lookup_fill = env_int("DH_LOOKUP_FILL", 0);
     v.altcorr_v1 = env_int("DH_ALTCORR_V1", 0);
     v.conv_wino = env_int("DH_CONV_WINO", 0);
     v.conv_abl = env_int("DH_CONV_ABL", 0);
@@ -79,6 +80,7 @@ static int* slot(const char* name) {
   if (!strcmp(name, "lookup_mode")) return &o.lookup_mode;
   if (!strcmp(name, "lookup_fused")) return &o.lookup_fused;
   if (!strcmp(name, "lookup_mix")) return &o.lookup_mix;
+  if (!strcmp(name, "lookup_fill")) return &o.lookup_fill;
   if (!strcmp(name, "altcorr_v1")) return &o.altcorr_v1;
   if (!strcmp(name, "conv_wino")) return &o.conv_wino;
   if (!strcmp(name, "conv_abl")) return &o.conv_abl;
