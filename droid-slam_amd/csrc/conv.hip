@@ -280,8 +280,9 @@ __device__ __forceinline__ void staged_epilogue(const ConvParams& P, f32x16 (&ac
 // vector, which this workgroup has just computed: the relu'd fp16 tile is parked in LDS as for the other staged epilogues,
 // multiplied on the MFMA with the 36 (padded to 64) x 128 weight slice of this cout tile, and the fp32 partial products
 // [cout tile][pixel][36] are all that leaves the kernel -- the 256-channel head activations (6.4 GB at 4096 edges) are
-// never written nor re-read with a halo by a second convolution; heads_gather_kernel sums the 9 shifted partials.
-// P.aux1 = W2 packed [CoutPad/128][64][128] f16 (n = tap*4 + output), P.red = partials [CoutPad/128][9 taps][M][4] f32.
+// never written nor re-read with a halo by a second convolution; the taps whose source pixel lies in this tile are summed here,
+// heads_gather_kernel adds the rows that the tiles above and below contribute.
+// P.aux1 = W2 packed [CoutPad/128][64][128] f16 (n = tap*4 + output), P.red = partials [CoutPad/128][M/256 tiles][6 rows][64][4] f32.
 __device__ __forceinline__ void staged_heads0_epilogue(const ConvParams& P, f32x16 (&acc)[2][2], __half* __restrict__ sT, long m0, int n0,
                                                        int wm0, int wn0, int tid) {
   constexpr int ELD = 128 + 8;
@@ -333,36 +334,49 @@ __device__ __forceinline__ void staged_heads0_epilogue(const ConvParams& P, f32x
       }
   }
   __syncthreads();
-  const long M = (long)P.N * P.H * P.W;
+  // The tile is four full image rows (W = 64, m0 a multiple of 256, H a multiple of 4): the x-neighbours of every pixel and up to three
+  // of its y-neighbours are in this tile.  Sum the taps whose source pixel is here before anything leaves the CU: six rows of
+  // o-partials (output rows -1 .. 4 relative to the tile) instead of nine planes of four rows -- 6 KB instead of 36 KB per tile.
+  const long ntm = ((long)P.N * P.H * P.W) >> 8;     // pixel tiles
+  if (tid < 6 * 64) {
+    const int ro = (tid >> 6) - 1, x = tid & 63;
+    float4 acc4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int it = 0; it < 5; ++it) {
-    const int piece = tid + 512 * it;               // 9 taps x 256 pixels
-    if (piece < 9 * 256) {
-      const int t = piece >> 8, px = piece & 255;
-      const float4 v = *reinterpret_cast<const float4*>(sD + t * PLD + px * 4);
-      *reinterpret_cast<float4*>(P.red + (((long)tile * 9 + t) * M + m0 + px) * 4) = v;
+    for (int ty = 0; ty < 3; ++ty) {
+      const int sr = ro + ty - 1;                    // o(y, x) += P_t(y + ty - 1, x + tx - 1)
+      if ((unsigned)sr >= 4u) continue;
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx) {
+        const int sx = x + tx - 1;
+        if ((unsigned)sx >= 64u) continue;
+        const float4 v = *reinterpret_cast<const float4*>(sD + (ty * 3 + tx) * PLD + (sr * 64 + sx) * 4);
+        acc4.x += v.x; acc4.y += v.y; acc4.z += v.z; acc4.w += v.w;
+      }
     }
+    *reinterpret_cast<float4*>(P.red + (((long)tile * ntm + (m0 >> 8)) * 384 + tid) * 4) = acc4;
   }
 }
 
-// o(p) = bias + sum over cout tiles and taps of P_t(p + t - 1) (zero outside the image), then the heads' activation
-// (delta_x, delta_y raw; sigmoid on the two confidence outputs), values rounded to fp16 like the convolution it replaces
+// o(p) = bias + sum over cout tiles of (own tile's row partial + the row the tile above / below contributes, same image), then the
+// heads' activation (delta_x, delta_y raw; sigmoid on the two confidence outputs), values rounded to fp16 like the convolution it
+// replaces.  part = [cout tiles][pixel tiles of 4 rows][6 output rows: -1 .. 4][64][4] f32 (staged_heads0_epilogue); W = 64.
 __global__ __launch_bounds__(256) void heads_gather_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ dw,
-                                                           long M, int ntiles, int H, int W) {
+                                                           long M, int ntiles, int H) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= M) return;
-  const int HW = H * W;
-  const int r = (int)(i % HW), y = r / W, x = r - y * W;
+  const long pt = i >> 8, ntm = M >> 8;
+  const int ry = (int)(i & 255) >> 6, x = (int)i & 63;
+  const int y = (int)((i >> 6) % H);
   float o[4] = {bias[0], bias[1], bias[2], bias[3]};
-#pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-    if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) continue;
-    const long q = i + (long)(t / 3 - 1) * W + (t % 3 - 1);
-    for (int tl = 0; tl < ntiles; ++tl) {
-      const float4 v = *reinterpret_cast<const float4*>(part + (((long)tl * 9 + t) * M + q) * 4);
-      o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w;
-    }
+  auto add = [&](long tile_, int row_) {
+    const float4 v = *reinterpret_cast<const float4*>(part + ((tile_ * 6 + row_) * 64 + x) * 4);
+    o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w;
+  };
+  for (int tl = 0; tl < ntiles; ++tl) {
+    const long t0 = (long)tl * ntm + pt;
+    add(t0, ry + 1);
+    if (ry == 0 && y > 0) add(t0 - 1, 5);
+    if (ry == 3 && y < H - 1) add(t0 + 1, 0);
   }
   float4 res;
   res.x = round_h(o[0]); res.y = round_h(o[1]);
@@ -2343,10 +2357,11 @@ extern "C" int dh_glo_gemv(const float* red, const float* wt, const float* bias,
 
 extern "C" int dh_heads_gather(const float* partials, const float* bias4, float* dw, int N, int H, int W, int n_cout_tiles, dh_stream_t stream) {
   if (N < 0 || H <= 0 || W <= 0 || n_cout_tiles < 1) return DH_ERR_ARG;
+  if (W != 64 || H % 4) return DH_ERR_UNSUPPORTED;           // the partials are per tile of four full 64-pixel rows (EPI_HEADS0)
   if (N == 0) return DH_OK;
   if (!partials || !bias4 || !dw) return DH_ERR_ARG;
   const long M = (long)N * H * W;
-  hipLaunchKernelGGL(heads_gather_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partials, bias4, dw, M, n_cout_tiles, H, W);
+  hipLaunchKernelGGL(heads_gather_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partials, bias4, dw, M, n_cout_tiles, H);
   DH_LAUNCH_CHECK();
   return DH_OK;
 }

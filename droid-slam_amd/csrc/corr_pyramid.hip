@@ -709,7 +709,7 @@ __device__ __forceinline__ float sub_f16_halves(uint32_t p1, uint32_t p0) {
 // MIX (option lookup_mix, default 1): the interpolation without fp16 -> fp32 / fp32 -> fp16 conversion instructions (the taps enter the
 // fp32 arithmetic as fp16 operands of v_fma_mix_f32, the samples leave it through v_fma_mixlo / mixhi_f16); 0 = the conversions
 // spelled out.  Same operations in the same order: bit-identical (tests/test_gpu_parity.py).
-// FILL (option lookup_fill): how the 40 tap registers of a lane are refilled.  0 = two half-level batches of 4 window rows: a batch is
+// FILL (option lookup_fill, -DDH_ABLATION builds): how the 40 tap registers of a lane are refilled.  0 = two half-level batches of 4 window rows: a batch is
 // requested again (for the next level) when all of its rows are interpolated, so during an interpolation phase only the other batch is
 // in flight.  1 = by window row: row r of the next level is requested as soon as row r of this level is interpolated, 35 of the 40
 // registers are in flight at every wait.  Same loads, same arithmetic in the same order: bit-identical.
@@ -1148,7 +1148,7 @@ extern "C" int dh_corr_pyramid_lookup_corr0(const void* pyramid, const float* co
   hipStream_t st = (hipStream_t)stream;
   const int mode = opts().lookup_mode;                     // 2 / 3 / 5 / 7: timing ablations (wrong results); 6: synchronous twin (same results)
   const bool mix = opts().lookup_mix != 0;                  // 0: conversions spelled out (same results; A/B and the bit-identity test)
-  const bool rows = opts().lookup_fill != 0;                // 1: tap registers refilled window row by window row (same results)
+  const bool rows = opts().lookup_fill != 0;                // 1: tap registers refilled window row by window row (same results; -DDH_ABLATION builds)
 #define DH_FUSED(M_, X_, F_)                                                                                                   \
     { DH_LDS_OPTIN((&pyr_lookup_corr0_kernel<64, M_, X_, F_>), 160 * 1024);                                                    \
       hipLaunchKernelGGL((pyr_lookup_corr0_kernel<64, M_, X_, F_>), grid, block, lds, st, (const __half*)pyramid, coords, (const __half*)wpk, bias, (__half*)out, D, n_strips); }
@@ -1160,9 +1160,9 @@ extern "C" int dh_corr_pyramid_lookup_corr0(const void* pyramid, const float* co
   else if (w == 64 && mode == 5) DH_FUSED(5, true, 0)
   else if (w == 64 && mode == 7 && rows) DH_FUSED(7, true, 1)
   else if (w == 64 && mode == 7) DH_FUSED(7, true, 0)
+  else if (w == 64 && rows && mix) DH_FUSED(0, true, 1)    // measured: 1.874 vs 1.865 ms (profiles/r04_j_lookup_fill_ab.txt) -> A/B builds only
 #endif
   else if (w == 64 && !mix) DH_FUSED(0, false, 0)
-  else if (w == 64 && rows) DH_FUSED(0, true, 1)
   else if (w == 64) DH_FUSED(0, true, 0)
 #undef DH_FUSED
   else if (w == 32) {

@@ -589,9 +589,10 @@ std::vector<torch::Tensor> proximity_nms(torch::Tensor dist, torch::Tensor edges
 
 torch::Tensor heads_gather(torch::Tensor partials, torch::Tensor bias4, int64_t H, int64_t W) {
   CHECK_INPUT(partials); CHECK_INPUT(bias4); CHECK_F32(partials); CHECK_F32(bias4);
-  TORCH_CHECK(partials.dim() == 4 && partials.size(1) == 9 && partials.size(3) == 4 && bias4.numel() >= 4 && partials.size(2) % (H * W) == 0,
-              "heads_gather: partials [tiles,9,N*H*W,4]");
-  const int N = (int)(partials.size(2) / (H * W));
+  TORCH_CHECK(partials.dim() == 5 && partials.size(2) == 6 && partials.size(3) == 64 && partials.size(4) == 4 && bias4.numel() >= 4 && W == 64 &&
+              H % 4 == 0 && (partials.size(1) * 4) % H == 0,
+              "heads_gather: partials [cout tiles, N*H/4 pixel tiles, 6, 64, 4] f32 of images with 64 columns");
+  const int N = (int)(partials.size(1) * 4 / H);
   torch::Tensor dw = torch::empty({N, H, W, 4}, partials.options());
   check_status(dh_heads_gather(partials.data_ptr<float>(), bias4.data_ptr<float>(), dw.data_ptr<float>(), N, (int)H, (int)W,
                                (int)partials.size(0), cur_stream()), "heads_gather");

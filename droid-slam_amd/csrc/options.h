@@ -19,7 +19,7 @@ struct Options {
   int pyr_build_waves;  // DH_PYR_BUILD_WAVES (8): waves per workgroup of the row-ring build kernel at w = 64 (4 = the first form)
   int lookup_mode;      // DH_LOOKUP_MODE (0): pyramid lookup variant: 1 = nt tap loads; 2 / 3 = timing ablations (no stores / no loads, wrong results); fused kernel: also 5 (a quarter of the MFMAs) and 6 = synchronous twin (every tap batch waited for at issue; same results, used by the tests)
   int lookup_fused;     // DH_LOOKUP_FUSED (1): read by the host side (droid_amd.factor_graph, bench.py): lookup and the correlation encoder's first layer in one kernel (dh_corr_pyramid_lookup_corr0); 0 = dh_corr_pyramid_lookup + dh_corr0_nchw_f16
-  int lookup_fill;      // DH_LOOKUP_FILL (0): fused lookup refills its tap registers 0 = by half level (two batches of 4 window rows), 1 = window row by window row; same results
+  int lookup_fill;      // DH_LOOKUP_FILL (0): fused lookup refills its tap registers 0 = by half level (two batches of 4 window rows), 1 = window row by window row (-DDH_ABLATION builds); same results
   int lookup_mix;       // DH_LOOKUP_MIX (1): fused lookup interpolates through v_fma_mix_f32 / v_fma_mixlo_f16 (no conversion instructions); 0 = conversions spelled out, same results
   int altcorr_v1;       // DH_ALTCORR_V1 (0): first form of the MFMA alt-correlation kernel (register staging) for A/B runs
   int conv_wino;        // DH_CONV_WINO (0): read by the host packer only (droid_amd.update): gate convolutions through the Winograd F(2,3) prototype

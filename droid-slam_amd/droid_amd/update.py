@@ -373,7 +373,7 @@ class UpdateModule:
         if _mask is None and w == 64 and h % 4 == 0 and droid_backends.get_option("conv_halo") and droid_backends.get_option("conv_halo2"):
             # heads: the 256-channel activations never leave the first layer's kernel (see csrc/conv.hip EPI_HEADS0)
             w2p, b4 = P["heads2_fused"]
-            part = torch.empty(2, 9, E * h * w, 4, dtype=torch.float32, device=net.device)
+            part = torch.empty(2, E * h // 4, 6, 64, 4, dtype=torch.float32, device=net.device)     # per tile of four rows: output rows -1 .. 4
             P["heads0"]([net], EPI_HEADS0, aux1=w2p, red=part)
             dw = droid_backends.heads_gather(part, b4, h, w)
         else:

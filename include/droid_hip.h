@@ -294,8 +294,8 @@ int dh_proximity_nms(float* dist, const float* sorted, const int64_t* order, con
  *     6 0.01*softplus, 7 (delta_x, delta_y, sigmoid w_x, sigmoid w_y),
  *     8 first head layer fused with the second layer's channel contraction (3x3, W == 64, H % 4 == 0, Cout = CoutPad a
  *       multiple of 128; DH_ERR_UNSUPPORTED otherwise): aux1 = second-layer weights packed [CoutPad/128][64][128] f16
- *       (row = tap*4 + output, 36 used), red = partial products [CoutPad/128][9][N*H*W][4] f32, `out` unused; finish with
- *       dh_heads_gather
+ *       (row = tap*4 + output, 36 used), red = partial sums [CoutPad/128][N*H/4 tiles of four rows][6][64][4] f32 (what the
+ *       tile's pixels contribute to the output rows -1 .. 4 relative to the tile), `out` unused; finish with dh_heads_gather
  *   gterm [N,CoutPad] f32 or NULL: per-image additive term (the ConvGRU's 1x1 global-context convolutions).
  */
 int dh_conv2d_nhwc_f16(const void* const* inputs, const int* in_channels, const int* in_strides, int n_inputs,
@@ -304,9 +304,9 @@ int dh_conv2d_nhwc_f16(const void* const* inputs, const int* in_channels, const 
                        void* out, int out_is_f32, int out_stride,
                        const float* gterm, const void* aux0, int aux0_stride, const void* aux1, int aux1_stride,
                        float* red, dh_stream_t stream);
-/* dw [N,H,W,4] f32 = (delta_x, delta_y, sigmoid w_x, sigmoid w_y) from the partial products of epilogue 8:
- * bias4 + sum over cout tiles and the 9 taps of partials[tile][tap][pixel + tap][c], zero outside the image
- * (= the heads' second 3x3 convolution, reference droid_slam/droid_net.py:95-106). */
+/* dw [N,H,W,4] f32 = (delta_x, delta_y, sigmoid w_x, sigmoid w_y) from the partial sums of epilogue 8: bias4 + over the cout
+ * tiles the pixel's own four-row tile's row + the row the tile above / below contributes (same image)
+ * (= the heads' second 3x3 convolution, reference droid_slam/droid_net.py:95-106).  W == 64, H % 4 == 0, else DH_ERR_UNSUPPORTED. */
 int dh_heads_gather(const float* partials, const float* bias4, float* dw, int N, int H, int W, int n_cout_tiles, dh_stream_t stream);
 /* The same convolution with accumulator start values:  acc(image n, pixel r, cout) starts from
  *   cinit[(cinit_idx[n] * H*W + r) * cinit_stride + cinit_off + cout]   (fp32; cinit_idx [N] i64)

@@ -846,14 +846,14 @@ def test_lookup_fused_with_first_encoder_layer(db, option):
             option("lookup_mix", 1)
             assert torch.equal(out, plain)
             del plain
-            # the other refill schedule of the tap registers (window row by window row / by half level): the same loads and the same
-            # arithmetic under different vmcnt bookkeeping
-            fill0 = db.get_option("lookup_fill")
-            option("lookup_fill", 1 - fill0)
-            other = db.corr_pyramid_lookup_corr0(pyr, coords, wpk, bias)
-            option("lookup_fill", fill0)
-            assert torch.equal(out, other)
-            del other
+            # the other refill schedule of the tap registers (window row by window row instead of by half level): the same loads and
+            # the same arithmetic under different vmcnt bookkeeping
+            if db.get_option("ablation_build"):              # (DROID_HIP_TEST_ABLATION=1; the release build has one schedule)
+                option("lookup_fill", 1)
+                other = db.corr_pyramid_lookup_corr0(pyr, coords, wpk, bias)
+                option("lookup_fill", 0)
+                assert torch.equal(out, other)
+                del other
         del pyr, samples, out, ref
 
 
