@@ -92,7 +92,7 @@ if a.fused:
         print("  fused, variant %d (%s): %.3f ms" % (mode, {2: "no output stores", 3: "no tap loads", 5: "a quarter of the MFMAs", 6: "synchronous twin: every tap batch waited for at issue (correct results)"}[mode], tm))
     db.set_option("lookup_mode", 0)
     # refill schedule of the tap registers (lookup_fill 0 = by half level, 1 = by window row), alternating in one process
-    for rep in range(3):
+    for rep in range(3 if db.get_option("ablation_build") else 0):       # (lookup_fill 1 exists in -DDH_ABLATION builds only)
         for fill in (0, 1):
             db.set_option("lookup_fill", fill)
             tm, o_x = timed(lambda: db.corr_pyramid_lookup_corr0(pyr, coords, wpk, bias))
@@ -103,7 +103,8 @@ if a.fused:
                 db.set_option("lookup_mode", 0)
                 line += "   [variant 7, taps loaded but neither interpolated nor multiplied: %.3f ms]" % t7
             print(line)
-    db.set_option("lookup_fill", 0)
+    if db.get_option("ablation_build"):
+        db.set_option("lookup_fill", 0)
     for rep in range(2):
         t_f2, _ = timed(lambda: db.corr_pyramid_lookup_corr0(pyr, coords, wpk, bias))
         t_l2, _ = timed(lambda: db.corr_pyramid_lookup(pyr, coords))
