@@ -6,7 +6,8 @@ Inference only (no autograd): the hot path runs under ``torch.no_grad()`` in the
 (droid_slam/droid.py:62, droid_backend.py:24).
 
 ``CorrBlock``     materialised 4-level pyramid in the MI355X layout of csrc/corr_pyramid.hip (8x8 source blocks,
-                  x-adjacent displacement pairs, one record of 25.6 MB per edge at 48x64; h % 8 == 0, w in {16, 32, 64});
+                  x-adjacent displacement pairs, one record of 25.6 MB per edge at 48x64; any image with at most 64 columns or at
+                  most 64 rows, on a canvas with h % 8 == 0, w in {16, 32, 64});
                   built on the MFMA (droid_backends.corr_pyramid_build), one launch looks up all four levels
                   (corr_pyramid_lookup), optionally fused with the correlation encoder's first layer (lookup_corr0).
 ``CorrBlockRef``  the reference layout ``[E, h1, w1, h2/2^l, w2/2^l]`` for any image size; lookup =
@@ -110,7 +111,10 @@ class CorrBlock:
     The layout needs h % 8 == 0 and w in {16, 32, 64}.  Any other image size up to 64 columns (TUM's 30x40, 40x64, ...) is
     kept on a zero-padded CANVAS of the next such size: the pooled levels are cut at (h >> l) x (w >> l) like avg_pool2d's
     floor (corr.py:36), so a lookup reads exactly the values / zeros it reads from the reference's volumes; coordinates of
-    canvas pixels outside the image point far outside every level, and their outputs are cropped away."""
+    canvas pixels outside the image point far outside every level, and their outputs are cropped away.  An image with more
+    than 64 columns but at most 64 rows (41x73 from a 16:9 video, 60x80) is kept TRANSPOSED on such a canvas: the correlation
+    of transposed features at transposed coordinates is the transposed volume, the 7x7 window comes out with its axes swapped
+    and is swapped back (or, for lookup_corr0, meets weights with the window swapped: UpdateModule.transposed_twin)."""
 
     def __init__(self, fmap1, fmap2, num_levels=4, radius=3):
         assert num_levels == 4 and radius == 3, "the fused pyramid is specialised to 4 levels / radius 3"
@@ -119,7 +123,10 @@ class CorrBlock:
         self.num_levels, self.radius = num_levels, radius
         self.ht, self.wd = ht, wd
         self.hc, self.wc = self.canvas(ht, wd)
+        self.transposed = self.is_transposed(ht, wd)
         f1, f2 = fmap1[0].half(), fmap2[0].half()
+        if self.transposed:
+            f1, f2, ht, wd = f1.transpose(-1, -2), f2.transpose(-1, -2), wd, ht
         if (self.hc, self.wc) != (ht, wd):
             pad = (0, self.wc - wd, 0, self.hc - ht)
             self.pyramid = droid_backends.corr_pyramid_build(F.pad(f1, pad).contiguous(), F.pad(f2, pad).contiguous(), ht, wd)
@@ -127,8 +134,15 @@ class CorrBlock:
             self.pyramid = droid_backends.corr_pyramid_build(f1.contiguous(), f2.contiguous())
 
     @staticmethod
+    def is_transposed(ht, wd):
+        return wd > 64 and ht <= 64
+
+    @staticmethod
     def canvas(ht, wd):
-        """size of the pyramid's canvas for an ht x wd image, or None if it has none (more than 64 columns)"""
+        """size of the pyramid's canvas for an ht x wd image (of the transposed image if is_transposed(ht, wd)), or None if it has
+        none (more than 64 columns AND more than 64 rows)"""
+        if CorrBlock.is_transposed(ht, wd):
+            ht, wd = wd, ht
         if wd > 64:
             return None
         return (ht + 7) // 8 * 8, (16 if wd <= 16 else 32 if wd <= 32 else 64)
@@ -146,10 +160,13 @@ class CorrBlock:
         return sum(nblk * ((ht >> l) + 1) * (wd >> l) * 64 * 2 for l in range(4))
 
     def _coords(self, coords):
-        """[1,E,h,w,2] -> [E,hc,wc,2] contiguous; canvas pixels outside the image look at (-1e4, -1e4): every tap outside"""
+        """[1,E,h,w,2] -> [E,hc,wc,2] contiguous (of the transposed image: pixel (x, y) looks at (y', x')); canvas pixels outside
+        the image look at (-1e4, -1e4): every tap outside"""
         batch, num, ht, wd, _ = coords.shape
         assert (ht, wd) == (self.ht, self.wd)
         c = coords.reshape(batch * num, ht, wd, 2)
+        if self.transposed:
+            c, ht, wd = c.transpose(1, 2).flip(-1), wd, ht
         if (self.hc, self.wc) != (ht, wd):
             c = F.pad(c, (0, 0, 0, self.wc - wd, 0, self.hc - ht), value=-1.0e4)
         return c.contiguous()
@@ -157,20 +174,29 @@ class CorrBlock:
     def __call__(self, coords):
         batch, num, ht, wd, _ = coords.shape
         out = droid_backends.corr_pyramid_lookup(self.pyramid, self._coords(coords))
+        if self.transposed:           # [E, level, xoff' = yoff, yoff' = xoff, x, y] -> [E, level, xoff, yoff, y, x]
+            out = out[:, :, :wd, :ht].reshape(batch * num, 4, 7, 7, wd, ht).permute(0, 1, 3, 2, 5, 4)
+            return out.reshape(batch, num, -1, ht, wd)
         return out[:, :, :ht, :wd].reshape(batch, num, -1, ht, wd)
 
     def lookup_nhwc(self, coords):
         """[1,E,h,w,2] -> [4,E,h,w,56] level-planar channel-last features for droid_amd.update.UpdateModule.forward_nhwc"""
         batch, num, ht, wd, _ = coords.shape
         out = droid_backends.corr_pyramid_lookup_nhwc(self.pyramid, self._coords(coords))
+        if self.transposed:           # channel = yoff' * 7 + xoff' = xoff * 7 + yoff  ->  yoff * 7 + xoff
+            k = torch.arange(56, device=out.device)
+            perm = torch.where(k < 49, (k % 7) * 7 + k // 7, k)
+            return out[:, :, :wd, :ht].transpose(2, 3)[..., perm].contiguous()
         return out if (self.hc, self.wc) == (ht, wd) else out[:, :, :ht, :wd].contiguous()
 
     def lookup_corr0(self, coords, update_op):
         """[1,E,h,w,2] -> [E,h,w,128] f16: the lookup and the first layer of the update operator's correlation encoder
         (Conv2d(196,128,1) + ReLU, droid_net.py:96-100) in one kernel; pass it to UpdateModule.forward_nhwc(corr0=...)"""
         batch, num, ht, wd, _ = coords.shape
-        wpk, bias = update_op.params["corr0_fused"]
+        wpk, bias = (update_op.transposed_twin() if self.transposed else update_op).params["corr0_fused"]
         out = droid_backends.corr_pyramid_lookup_corr0(self.pyramid, self._coords(coords), wpk, bias)
+        if self.transposed:
+            return out[:, :wd, :ht].transpose(1, 2).contiguous()
         return out if (self.hc, self.wc) == (ht, wd) else out[:, :ht, :wd].contiguous()
 
     def cat(self, other):

@@ -219,11 +219,13 @@ class UpdateModule:
         self.canvas = canvas
         # forward() (the reference's interface, per-edge `inp`): treat edges with equal ii as sharing their context features
         self.share_inp_by_source_frame = share_inp_by_source_frame
+        self._sd, self._twin = None, None      # the loaded tensors, kept for transposed_twin()
 
     # ---- parameters ----------------------------------------------------------------------------
     def load_state_dict(self, sd, prefix=""):
         """sd: reference names ('gru.convz.weight', ...), optionally prefixed (e.g. 'update.')."""
         g = lambda n: sd[prefix + n].to(self.device)
+        self._sd, self._twin = {k: sd[prefix + k + s_] for k in PARAM_SHAPES for s_ in (".weight", ".bias")}, None
         P = {}
         conv = lambda name, cin_pad=None: _Conv(*pack_conv(g(name + ".weight"), g(name + ".bias"), cin_pad),
                                                 PARAM_SHAPES[name][2], PARAM_SHAPES[name][0],
@@ -341,6 +343,8 @@ class UpdateModule:
         E, h, w, _ = net.shape
         if self.canvas and not (w == 64 and h % 4 == 0) and w <= 64 and _mask is None:
             return self._forward_canvas(net, inp, corr, flow, ii, inp_frames, inp_index, corr0)
+        if self.canvas and w > 64 and h <= 64 and _mask is None:
+            return self._forward_transposed(net, inp, corr, flow, ii, inp_frames, inp_index, corr0)
         # canvas mode (_mask = (h_img, w_img)): the tensors are canvases; every activation that feeds a 3x3 layer gets the pixels
         # outside the image zeroed again, which is the zero border the reference's padded convolutions see there
         mk = (lambda t: t) if _mask is None else (lambda t: (droid_backends.canvas_mask_(t, _mask[0], _mask[1]), t)[1])
@@ -413,6 +417,47 @@ class UpdateModule:
         net.copy_(n[:, :h, :w])
         self.last_dw = crop(self.last_dw)
         return net, self.last_dw[..., :2], self.last_dw[..., 2:], eta[:, :h, :w].contiguous(), crop(upmask)
+
+    # ---- images wider than 64 columns but at most 64 rows high (41x73 from a 16:9 video, 60x80, ...) -------------------------
+    def transposed_twin(self):
+        """The same operator for the TRANSPOSED image: every k x k kernel transposed (a convolution commutes with swapping the two
+        image axes when its taps are swapped too; 1x1 layers and all channel meanings are untouched) and the 7x7 lookup window of
+        corr_encoder.0's input channels transposed (a pyramid built from transposed features delivers window sample (xoff, yoff)
+        where the original delivers (yoff, xoff)).  An h x w image with w > 64 >= h then runs as the w x h image on the 64-column
+        canvases of the production kernels."""
+        if self._twin is None:
+            sd = {}
+            for k, v in self._sd.items():
+                if k.endswith(".weight") and v.dim() == 4 and v.shape[-1] > 1:
+                    v = v.transpose(-1, -2)
+                elif k == "corr_encoder.0.weight":
+                    v = v.reshape(128, 4, 7, 7).transpose(2, 3).reshape(128, COR_PLANES, 1, 1)
+                sd[k] = v.contiguous()
+            self._twin = UpdateModule(self.device, share_inp_by_source_frame=self.share_inp_by_source_frame, canvas=True).load_state_dict(sd)
+        return self._twin
+
+    @staticmethod
+    def transpose_corr(corr):
+        """correlation features of the image -> those of the transposed image (image axes and window axes swapped):
+        [E,196,h,w] (channel = level*49 + xoff*7 + yoff) or the level-planar [4,E,h,w,56] (channel = yoff*7 + xoff, 49..55 pad)"""
+        if corr.dim() == 4:
+            E, _, h, w = corr.shape
+            return corr.reshape(E, 4, 7, 7, h, w).permute(0, 1, 3, 2, 5, 4).reshape(E, COR_PLANES, w, h).contiguous()
+        k = torch.arange(56, device=corr.device)
+        perm = torch.where(k < 49, (k % 7) * 7 + k // 7, k)
+        return corr.transpose(2, 3)[..., perm].contiguous()
+
+    def _forward_transposed(self, net, inp, corr, flow, ii, inp_frames, inp_index, corr0):
+        """forward_nhwc for an image with more than 64 columns and at most 64 rows: run the transposed twin on the transposed tensors
+        (it embeds them into [.., ceil4(w), 64, C] canvases, _forward_canvas) and transpose the results back."""
+        twin = self.transposed_twin()
+        t = lambda x: None if x is None else x.transpose(1, 2).contiguous()                 # [N,h,w,C] <-> [N,w,h,C]
+        corr_t = None if (corr is None or corr0 is not None) else self.transpose_corr(corr)
+        n, _, _, eta, upmask = twin.forward_nhwc(t(net), t(inp), corr_t, t(flow), ii, inp_frames=t(inp_frames), inp_index=inp_index,
+                                                 corr0=t(corr0))
+        net.copy_(n.transpose(1, 2))
+        self.last_dw = t(twin.last_dw)
+        return net, self.last_dw[..., :2], self.last_dw[..., 2:], eta.transpose(1, 2).contiguous(), t(upmask)
 
     def corr_to_nhwc(self, corr):
         """[E,196,h,w] correlation features in the reference's channel order (level*49 + xoff*7 + yoff) -> the level-planar

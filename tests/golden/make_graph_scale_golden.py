@@ -2,7 +2,7 @@
 """Generate tests/golden/graph_c2_python.npz and graph_stereo_python.npz by running the REFERENCE's own factor_graph.py +
 depth_video.py + modules/corr.py + droid_net.py, unmodified, on CPU (build container only: needs /root/reference):
 
-    python tests/golden/make_graph_scale_golden.py [stereo] [c2] [tum] [c3]
+    python tests/golden/make_graph_scale_golden.py [stereo] [c2] [tum] [wide] [c3]
 
 Same replacements as make_graph_golden.py (droid_backends -> oracle-backed shim, lietorch / torch_scatter shims, the two
 hard-coded "cuda" devices); the update operator runs under torch.autocast(fp16) like under factor_graph.py's decorators.
@@ -137,6 +137,35 @@ def scenario_tum_size():
     print("graph_tum_size: %d edges; |dpose| %.3e %.3e" % (len(out["ii"]), np.abs(out["U1_poses"] - S["poses"]).max(), np.abs(out["U2_poses"] - S["poses"]).max()))
 
 
+WIDE_SAMPLE_EDGES = [0, 5, 13]
+
+
+def scenario_wide():
+    """scenario W: 5 keyframes at 41 x 73 (a 16:9 video at the reference's demo resolution, demo.py:33-40: 1080p -> 328 x 584):
+    more than 64 columns, so the HIP path keeps the image TRANSPOSED on its 64-column canvases (CorrBlock.transposed,
+    UpdateModule.transposed_twin).  Two update iterations with upsampling; hidden state / target / weight of three edges and
+    per-edge means of all edges."""
+    S = graph_scenario(5, 41, 73)
+    N, ht, wd = S["n_frames"], S["ht"], S["wd"]
+    video = ref_dv.DepthVideo(image_size=[8 * ht, 8 * wd], buffer=N + 2, stereo=False, device="cpu")
+    video.poses[:N] = torch.as_tensor(S["poses"]); video.disps[:N] = torch.as_tensor(S["disps"])
+    video.intrinsics[:N] = torch.as_tensor(S["intrinsics"])
+    video.fmaps[:N, 0] = torch.as_tensor(S["fmaps"]); video.nets[:N] = torch.as_tensor(S["nets"]); video.inps[:N] = torch.as_tensor(S["inps"])
+    video.counter.value = N
+    out = {}
+    with torch.no_grad():
+        fg = ref_fg.FactorGraph(video, update_operator(S["weight_seed"]), device="cpu", corr_impl="volume", max_factors=-1, upsample=True)
+        fg.add_neighborhood_factors(0, N, r=2)
+        out["ii"], out["jj"] = fg.ii.numpy().copy(), fg.jj.numpy().copy()
+        out["target0_s"] = fg.target[0][WIDE_SAMPLE_EDGES].numpy().copy()
+        for k in (1, 2):
+            fg.update(t0=1, t1=None, itrs=2, use_inactive=False)
+            snap(out, "U%d" % k, video, fg, N, sample=WIDE_SAMPLE_EDGES)
+            out["U%d_disps_up" % k] = video.disps_up[:N].numpy().astype(np.float16)
+    np.savez_compressed(os.path.join(HERE, "graph_wide_python.npz"), **out)
+    print("graph_wide: %d edges; |dpose| %.3e %.3e" % (len(out["ii"]), np.abs(out["U1_poses"] - S["poses"]).max(), np.abs(out["U2_poses"] - S["poses"]).max()))
+
+
 # --------------------------------------------------------------------------------------------- C3 (the headline size)
 class _ChunkedCorrBlock:
     """The reference's OWN modules/corr.py CorrBlock, instantiated per 64-edge chunk inside __call__ instead of once for all
@@ -246,6 +275,8 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["stereo", "c2", "tum"]
     if "tum" in which:
         scenario_tum_size()
+    if "wide" in which:
+        scenario_wide()
     if "stereo" in which:
         scenario_stereo()
     if "c2" in which:

@@ -418,13 +418,63 @@ def test_composed_update_at_tum_image_size_matches_reference_factor_graph(db, go
         assert np.quantile(e, 0.99) <= 1e-2 * scale + 2.0 ** -10
 
 
-@pytest.mark.parametrize("shape", [(30, 40), (12, 20), (44, 64), (16, 32), (21, 13)])
+def test_composed_update_at_16_9_image_size_matches_reference_factor_graph(db, golden_dir):
+    """41 x 73 at 1/8 resolution (a 1080p video through the reference's demo.py resize: 328 x 584): more than 64 columns, at most 64
+    rows -> the image is kept TRANSPOSED on the 64-column canvases of the production kernels (CorrBlock.transposed: pyramid of the
+    transposed features, window axes swapped back; UpdateModule.transposed_twin: every k x k kernel transposed).  Two composed update
+    iterations with upsampling against the golden of the reference's unmodified factor_graph.py
+    (tests/golden/make_graph_scale_golden.py wide); tolerances of the TUM-size test."""
+    from droid_amd.corr import CorrBlock
+    from droid_amd.factor_graph import FactorGraph
+    from droid_amd.update import UpdateModule
+    from droid_amd.weights import deterministic_state_dict
+    from golden_inputs import graph_scenario
+    G = np.load(os.path.join(golden_dir, "graph_wide_python.npz"))
+    S = graph_scenario(5, 41, 73)
+    N, ht, wd = S["n_frames"], S["ht"], S["wd"]
+    sample = [0, 5, 13]
+    assert CorrBlock.is_transposed(ht, wd) and CorrBlock.canvas(ht, wd) == (80, 64)
+    video = _video(N, ht, wd, S["poses"], S["disps"], S["intrinsics"], S["fmaps"], S["nets"], S["inps"])
+    upd = UpdateModule("cuda").load_state_dict(deterministic_state_dict(_SD(), seed=S["weight_seed"]))
+    fg = FactorGraph(video, upd, corr_impl="volume", max_factors=-1, upsample=True)
+    fg.add_neighborhood_factors(0, N, r=2)
+    assert isinstance(fg.corr, CorrBlock) and fg.corr.transposed and (fg.corr.hc, fg.corr.wc) == (80, 64)
+    assert np.array_equal(fg.ii.cpu().numpy(), G["ii"]) and np.array_equal(fg.jj.cpu().numpy(), G["jj"])
+    c = lambda t: t.float().cpu().numpy()
+    assert np.abs(c(fg.target[0])[sample] - G["target0_s"]).max() < 2e-4
+    for k, scale in ((1, 1.0), (2, 2.0)):
+        fg.update(t0=1, t1=None, itrs=2, use_inactive=False)
+        torch.cuda.synchronize()
+        tag = "U%d" % k
+        p, rp = c(video.poses)[:N], G[tag + "_poses"]
+        assert np.abs(p[:, :3] - rp[:, :3]).max() <= 2e-3 * scale
+        assert _rot_angle(p[:, 3:].astype(np.float64), rp[:, 3:].astype(np.float64)).max() <= 2e-3 * scale
+        d, rd = c(video.disps)[:N], G[tag + "_disps"]
+        e = np.abs(d - rd) / np.maximum(1.0, np.abs(rd))
+        assert np.quantile(e, 0.99) <= 1e-2 * scale and e.max() <= 0.1 * scale
+        assert np.abs(c(fg.net[0])[sample] - G[tag + "_net_s"].astype(np.float32)).max() <= 2.0 ** -8 * scale
+        tg, rtg = c(fg.target[0])[sample], G[tag + "_target_s"]
+        assert np.quantile(np.abs(tg - rtg), 0.999) <= 2e-2 * scale and np.abs(tg - rtg).max() <= 0.5 * scale
+        assert np.abs(c(fg.weight[0])[sample] - G[tag + "_weight_s"]).max() <= 2.0 ** -8 * scale
+        # every edge through its means (the sample holds three of the 14)
+        yy, xx = torch.meshgrid(torch.arange(ht, device="cuda", dtype=torch.float32), torch.arange(wd, device="cuda", dtype=torch.float32), indexing="ij")
+        grid = torch.stack([xx, yy], -1)                                     # pops.coords_grid (factor_graph.py:38)
+        assert np.abs(c((fg.target[0] - grid).abs().mean(dim=(1, 2, 3))) - G[tag + "_flow_mean"]).max() <= 2e-3 * scale * max(1.0, G[tag + "_flow_mean"].max())
+        assert np.abs(c(fg.weight[0].mean(dim=(1, 2, 3))) - G[tag + "_weight_mean"]).max() <= 2.0 ** -9 * scale
+        du, rdu = c(video.disps_up)[:N], G[tag + "_disps_up"].astype(np.float32)
+        e = np.abs(du - rdu) / np.maximum(1.0, np.abs(rdu))
+        assert np.quantile(e, 0.99) <= 1e-2 * scale + 2.0 ** -10
+
+
+@pytest.mark.parametrize("shape", [(30, 40), (12, 20), (44, 64), (16, 32), (21, 13), (41, 73), (60, 80), (32, 72), (64, 96)])
 def test_canvas_pyramid_and_operator_equal_the_general_paths(db, shape):
     """image sizes outside the pyramid layout / the convolution tiling: (a) the canvas pyramid's lookup (CorrBlock) against the
     reference-layout volumes with floor pooling (CorrBlockRef) on the same features and coordinates, windows leaving the image
     on every side, 2^-9 of the samples' scale; the fused lookup + first encoder layer against that layer applied in fp32;
     (b) the update operator on canvases against the generic convolution loop on the image itself: same fp16 layer boundaries,
-    so equal to a few fp16 ulp (the accumulation order inside a layer differs)."""
+    so equal to a few fp16 ulp (the accumulation order inside a layer differs).  Shapes with more than 64 columns (41x73 = a
+    16:9 video at the reference's demo resolution, 60x80, ...) run TRANSPOSED on the canvases (CorrBlock.transposed,
+    UpdateModule.transposed_twin): same comparisons, plus the operator fed by the fused lookup."""
     from droid_amd.corr import CorrBlock, CorrBlockRef
     from droid_amd.update import UpdateModule, pack_corr0_fused
     from droid_amd.weights import deterministic_state_dict
@@ -460,6 +510,12 @@ def test_canvas_pyramid_and_operator_equal_the_general_paths(db, shape):
         r = m.forward_nhwc(n, None, feats(m), flow, ii, inp_frames=inp_frames, inp_index=ii)
         torch.cuda.synchronize()
         outs.append([t.float().clone() for t in r])
-    for x, y, tol in zip(outs[0], outs[1], (2.0 ** -9, 2.0 ** -8, 2.0 ** -9, 2.0 ** -9, 2.0 ** -8)):
-        assert x.shape == y.shape
-        assert (x - y).abs().max().item() <= tol * max(1.0, y.abs().max().item())
+    # the same call fed by the fused lookup (corr0 = lookup + first encoder layer in the lookup kernel)
+    n = net.clone()
+    r = upd.forward_nhwc(n, None, None, flow, ii, inp_frames=inp_frames, inp_index=ii, corr0=blk.lookup_corr0(coords, upd))
+    torch.cuda.synchronize()
+    outs.append([t.float().clone() for t in r])
+    for k in (0, 2):
+        for x, y, tol in zip(outs[k], outs[1], (2.0 ** -9, 2.0 ** -8, 2.0 ** -9, 2.0 ** -9, 2.0 ** -8)):
+            assert x.shape == y.shape
+            assert (x - y).abs().max().item() <= (tol if k == 0 else 4 * tol) * max(1.0, y.abs().max().item()), (k, shape)
