@@ -225,7 +225,7 @@ class UpdateModule:
     def load_state_dict(self, sd, prefix=""):
         """sd: reference names ('gru.convz.weight', ...), optionally prefixed (e.g. 'update.')."""
         g = lambda n: sd[prefix + n].to(self.device)
-        self._sd, self._twin = {k: sd[prefix + k + s_] for k in PARAM_SHAPES for s_ in (".weight", ".bias")}, None
+        self._sd, self._twin = {k + s_: sd[prefix + k + s_] for k in PARAM_SHAPES for s_ in (".weight", ".bias")}, None
         P = {}
         conv = lambda name, cin_pad=None: _Conv(*pack_conv(g(name + ".weight"), g(name + ".bias"), cin_pad),
                                                 PARAM_SHAPES[name][2], PARAM_SHAPES[name][0],
