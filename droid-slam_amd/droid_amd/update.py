@@ -178,6 +178,21 @@ def _halo_layout_options():
     return droid_backends.get_option("conv_dma"), droid_backends.get_option("conv_halo2")
 
 
+def transposed_state_dict(sd):
+    """parameters (reference names) of the update operator of the TRANSPOSED image: k x k kernels transposed, the 7 x 7 lookup window of
+    corr_encoder.0's 196 input channels (level*49 + xoff*7 + yoff) transposed; everything else unchanged.  With T = swapping the two
+    image axes (and the window axes of the correlation features): operator(sd)(x) == T(operator(transposed_state_dict(sd))(T(x)))
+    (tests/test_transposed_cpu.py checks the identity on the oracle)."""
+    out = {}
+    for k, v in sd.items():
+        if k.endswith(".weight") and v.dim() == 4 and v.shape[-1] > 1:
+            v = v.transpose(-1, -2)
+        elif k.endswith("corr_encoder.0.weight"):
+            v = v.reshape(128, 4, 7, 7).transpose(2, 3).reshape(128, COR_PLANES, 1, 1)
+        out[k] = v.contiguous()
+    return out
+
+
 class _Conv:
     def __init__(self, wp, bp, k, cout, wh=None, layout=LAYOUT_AUTO):
         self.w, self.b, self.k, self.cout, self.wh, self.layout = wp, bp, k, cout, wh, layout
@@ -426,14 +441,8 @@ class UpdateModule:
         where the original delivers (yoff, xoff)).  An h x w image with w > 64 >= h then runs as the w x h image on the 64-column
         canvases of the production kernels."""
         if self._twin is None:
-            sd = {}
-            for k, v in self._sd.items():
-                if k.endswith(".weight") and v.dim() == 4 and v.shape[-1] > 1:
-                    v = v.transpose(-1, -2)
-                elif k == "corr_encoder.0.weight":
-                    v = v.reshape(128, 4, 7, 7).transpose(2, 3).reshape(128, COR_PLANES, 1, 1)
-                sd[k] = v.contiguous()
-            self._twin = UpdateModule(self.device, share_inp_by_source_frame=self.share_inp_by_source_frame, canvas=True).load_state_dict(sd)
+            self._twin = UpdateModule(self.device, share_inp_by_source_frame=self.share_inp_by_source_frame,
+                                      canvas=True).load_state_dict(transposed_state_dict(self._sd))
         return self._twin
 
     @staticmethod
