@@ -1619,6 +1619,69 @@ __global__ __launch_bounds__(512, 4) void conv7x7_c4_kernel(ConvParams P) {
   staged_epilogue<EPI, 2, 128>(P, acc, s_conv, m0, 0, wm0, wn0, tid, HW);
 }
 
+// ---- 1x1 on 128 input channels with many outputs (GraphAgg's upmask head: 128 -> 576 on the source frames, droid_net.py:62) -------
+// The generic loop runs this shape as 5 independent cout tiles per pixel tile, each with a two-chunk main loop between a cold
+// prologue and a full epilogue (0.80 ms at 512 frames for 2.2 GB of traffic).  Here the pixel tile's activations [256 px][128 ch] are
+// staged ONCE and stay in LDS while the workgroup walks the 64-cout tiles (576 = 9 tiles, no padding tile): per tile a 16 KB weight
+// slab (next tile's slab fetched into registers under the MFMAs), 16 MFMAs per wave (64 px x 32 couts) and the staged 16-byte-piece
+// store of the other kernels, whose stores drain under the next tile.  LDS: 69.6 (A) + 17.4 (B) + 36.9 (staged tile) KB.  Measured at 512
+// frames: 0.60-0.68 ms against 0.80-0.86 ms (a persistent form that prefetches the next pixel tile: 0.66-0.73 ms, not kept).
+constexpr int K1_LD = 128 + 8;
+constexpr int K1_A_BYTES = BM * K1_LD * 2, K1_B_BYTES = 64 * K1_LD * 2, K1_T_BYTES = BM * (64 + 8) * 2;
+constexpr int K1_LDS_BYTES = K1_A_BYTES + K1_B_BYTES + K1_T_BYTES;
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void conv1x1_c128_kernel(ConvParams P) {
+  extern __shared__ __half s_conv[];
+  __half* sA = s_conv;
+  __half* sB = s_conv + K1_A_BYTES / 2;
+  __half* sT = s_conv + (K1_A_BYTES + K1_B_BYTES) / 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave & 3) * 64, wn0 = (wave >> 2) * 32;
+  const long m0 = (long)blockIdx.x * BM;
+  const int HW = P.H * P.W;
+  uint4 ra[8], rb[2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int id = tid + 512 * i;
+    ra[i] = *reinterpret_cast<const uint4*>(P.in[0] + (m0 + (id >> 4)) * P.segS[0] + (id & 15) * 8);
+  }
+  auto fetch_b = [&](int n0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int id = tid + 512 * i, row = id >> 4;
+      rb[i] = n0 + row < P.CoutPad ? *reinterpret_cast<const uint4*>(P.wt + (long)(n0 + row) * P.Kpad + (id & 15) * 8) : uint4{0u, 0u, 0u, 0u};
+    }
+  };
+  fetch_b(0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int id = tid + 512 * i;
+    *reinterpret_cast<uint4*>(sA + (id >> 4) * K1_LD + (id & 15) * 8) = ra[i];
+  }
+  const int p = lane & 31, kh = lane >> 5;
+  for (int n0 = 0; n0 < P.CoutPad; n0 += 64) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {          // (the previous cout tile's B fragments are read: two barriers in its epilogue)
+      const int id = tid + 512 * i;
+      *reinterpret_cast<uint4*>(sB + (id >> 4) * K1_LD + (id & 15) * 8) = rb[i];
+    }
+    __syncthreads();                       // A (first cout tile) and B staged
+    if (n0 + 64 < P.CoutPad) fetch_b(n0 + 64);          // the next cout tile's slab under the MFMAs
+    f32x16 acc[2][1];
+    zero_acc<2, 1>(acc);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const half8 bf = *reinterpret_cast<const half8*>(sB + (wn0 + p) * K1_LD + ks * 16 + kh * 8);
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const half8 af = *reinterpret_cast<const half8*>(sA + (wm0 + a * 32 + p) * K1_LD + ks * 16 + kh * 8);
+        acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[a][0], 0, 0, 0);
+      }
+    }
+    staged_epilogue<EPI, 1, 64>(P, acc, sT, m0, n0, wm0, wn0, tid, HW);      // (its first barrier: the previous tile's pieces are read)
+  }
+}
+
 // ---- global-context reduction of the ConvGRU as its own kernel: red[n][c] += sum_px sigmoid(W net + b)[c] * net[c] --------
 // (reference gru.py:23-24).  A 128 x 128 1x1 convolution is a streaming problem (3.2 GB of hidden state at 4096 edges
 // against 0.4 TFLOP), and in the generic loop a workgroup never has more than one 32 KB chunk in flight and re-reads the
@@ -1971,6 +2034,25 @@ bool c7_ok(const ConvParams& P) {
   return staged_epilogue_ok<EPI_RELU>(P);
 }
 
+// compute units of the current device (grid size of the persistent kernels); queried once per device: hipGetDeviceProperties takes milliseconds
+int device_cus() {
+  static int cu_count[64];
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+    if (!cu_count[dev]) { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cu_count[dev] = n; }
+    if (cu_count[dev]) cus = cu_count[dev];
+  }
+  return cus;
+}
+
+// 1x1, one 128-channel input, at least four 64-cout tiles (fewer: the generic loop's independent tiles fill the chip better)
+bool k1_ok(const ConvParams& P) {
+  if (!opts().conv_halo || P.KH != 1 || P.KW != 1 || P.nseg != 1 || P.Ctot != 128 || P.Kpad != 128 || P.segS[0] % 8) return false;
+  if (P.epi != EPI_LINEAR && P.epi != EPI_RELU) return false;
+  if (P.cinit || P.gterm || P.CoutPad < 256 || P.CoutPad % 64 || ((long)P.N * P.H * P.W) % BM || ((uintptr_t)P.in[0]) % 16) return false;
+  return P.epi == EPI_LINEAR ? staged_epilogue_ok<EPI_LINEAR>(P) : staged_epilogue_ok<EPI_RELU>(P);
+}
+
 bool glo_ok(const ConvParams& P) {
   if (!opts().conv_halo || P.epi != EPI_GLO || P.KH != 1 || P.KW != 1 || P.nseg != 1 || P.segC[0] != 128) return false;
   if (P.Cout != 128 || P.CoutPad != 128 || P.Kpad != 128 || P.cinit) return false;
@@ -2281,6 +2363,18 @@ extern "C" int dh_conv2d_nhwc_f16_ex2(const void* const* inputs, const int* in_c
       default: break;
     }
   }
+  if (k1_ok(P)) {
+    const dim3 grid((unsigned)((long)P.N * P.H * P.W / BM));
+    if (P.epi == EPI_LINEAR) {
+      DH_LDS_OPTIN((&conv1x1_c128_kernel<EPI_LINEAR>), 160 * 1024);
+      hipLaunchKernelGGL((conv1x1_c128_kernel<EPI_LINEAR>), grid, dim3(512), K1_LDS_BYTES, st, P);
+    } else {
+      DH_LDS_OPTIN((&conv1x1_c128_kernel<EPI_RELU>), 160 * 1024);
+      hipLaunchKernelGGL((conv1x1_c128_kernel<EPI_RELU>), grid, dim3(512), K1_LDS_BYTES, st, P);
+    }
+    DH_LAUNCH_CHECK();
+    return DH_OK;
+  }
   if (glo_ok(P)) {
     DH_LDS_OPTIN(&glo_reduce_kernel, 80 * 1024);
     hipLaunchKernelGGL(glo_reduce_kernel, dim3((unsigned)((long)P.N * P.H * P.W / BM)), dim3(512), BM * GLD * 2, st, P);
@@ -2330,14 +2424,8 @@ extern "C" int dh_corr0_nchw_f16(const void* x, const void* wp, const float* bia
   if (E == 0) return DH_OK;
   if (!x || !wp || !bias || !out) return DH_ERR_ARG;
   DH_LDS_OPTIN(&corr0_nchw_kernel, C0_LDS_BYTES);
-  static int cu_count[64];                                // per device, queried once (hipGetDeviceProperties takes milliseconds)
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
-    if (!cu_count[dev]) { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cu_count[dev] = n; }
-    if (cu_count[dev]) cus = cu_count[dev];
-  }
   const long ntiles = (long)E * (HW / C0_TILE);
-  const unsigned grid = (unsigned)std::min<long>(ntiles, cus);
+  const unsigned grid = (unsigned)std::min<long>(ntiles, device_cus());
   hipLaunchKernelGGL(corr0_nchw_kernel, dim3(grid), dim3(512), C0_LDS_BYTES, (hipStream_t)stream, (const __half*)x, (const __half*)wp,
                      bias, (__half*)out, E, HW);
   DH_LAUNCH_CHECK();

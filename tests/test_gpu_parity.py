@@ -694,6 +694,7 @@ def test_conv2d_nhwc_matches_torch_conv(db, option, halo, dma, halo2):
     cases += [(2, 8, 64, c) for c in [((128, 64, 64), 128, 3), ((256,), 256, 3), ((64,), 256, 3), ((256,), 4, 3), ((128,), 1, 3), ((128,), 64, 3),
                                       ((128, 128, 128, 64), 256, 3), ((96, 32), 128, 3), ((160, 96), 128, 3)]]
     cases += [(3, 12, 64, ((64, 128), 128, 3))]
+    cases += [(2, 8, 64, ((128,), 576, 1)), (1, 4, 64, ((128,), 320, 1))]      # conv1x1_c128_kernel: 9 / 5 cout tiles of 64 over a resident pixel tile
     for (N, H, W, (cins, cout, k)) in cases:
         xs = [torch.randn(N, H, W, c, device="cuda").half() for c in cins]
         wgt = torch.randn(cout, sum(cins), k, k, device="cuda") / (sum(cins) * k * k) ** 0.5
