@@ -235,9 +235,13 @@ def test_round3_entry_points_and_host_helpers(built):
     for h, w in ((48, 64), (40, 64), (16, 16), (24, 32)):
         assert CorrBlock.bytes_per_edge(h, w) == lib.dh_corr_pyramid_bytes(1, h, w)
     assert CorrBlock.supported(40, 64) and CorrBlock.canvas(40, 64) == (40, 64) and CorrBlock.canvas(48, 64) == (48, 64)
-    # sizes outside the layout up to 64 columns sit on a zero-padded canvas; wider images have no native pyramid
+    # sizes outside the layout up to 64 columns sit on a zero-padded canvas; wider images up to 64 rows sit on it TRANSPOSED;
+    # more than 64 in both dimensions: no native pyramid
     assert CorrBlock.supported(30, 40) and CorrBlock.canvas(30, 40) == (32, 64) and CorrBlock.canvas(12, 16) == (16, 16)
-    assert not CorrBlock.supported(30, 80) and CorrBlock.canvas(60, 80) is None
+    assert CorrBlock.supported(30, 80) and CorrBlock.is_transposed(30, 80) and CorrBlock.canvas(30, 80) == (80, 32)
+    assert CorrBlock.canvas(60, 80) == (80, 64) and CorrBlock.canvas(41, 73) == (80, 64) and not CorrBlock.is_transposed(64, 64)
+    assert CorrBlock.bytes_per_edge(41, 73) == lib.dh_corr_pyramid_bytes(1, 80, 64)
+    assert not CorrBlock.supported(72, 80) and CorrBlock.canvas(65, 65) is None
     assert CorrBlock.bytes_per_edge(30, 40) == CorrBlock.bytes_per_edge(32, 64)
 
 
