@@ -11,6 +11,8 @@ kept NHWC fp16 between layers, the 448-channel GRU input is never concatenated, 
 single launches.  torch is used only for allocation, the per-edge 128-vector "global context" GEMVs and the
 scatter-mean over source frames (index_add_), i.e. plumbing.  There is no CPU path.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -222,6 +224,35 @@ class _Conv:
         return out
 
 
+class _Fork:
+    """`with _Fork(side, main) as b: ...` runs the block on the side stream after everything already enqueued on the caller's stream;
+    `b.join(t, ...)` makes the caller's stream wait for the block and tells the allocator that it reads the tensors.  side = None: the
+    block runs inline on the caller's stream."""
+
+    def __init__(self, side, main):
+        self.side, self.main, self.done, self.ctx = side, main, None, None
+
+    def __enter__(self):
+        if self.side is not None:
+            self.side.wait_event(self.main.record_event())
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.side is not None:
+            self.done = self.side.record_event()
+            self.ctx.__exit__(*exc)
+        return False
+
+    def join(self, *tensors):
+        if self.side is not None:
+            self.main.wait_event(self.done)
+            for t in tensors:
+                if t is not None:
+                    t.record_stream(self.main)
+
+
 class UpdateModule:
     """Weight-compatible, inference-only replacement of droid_net.UpdateModule."""
 
@@ -235,6 +266,12 @@ class UpdateModule:
         # forward() (the reference's interface, per-edge `inp`): treat edges with equal ii as sharing their context features
         self.share_inp_by_source_frame = share_inp_by_source_frame
         self._sd, self._twin = None, None      # the loaded tensors, kept for transposed_twin()
+        # DH_UPDATE_STREAMS=1 (opt-in): the independent branches of the operator (flow encoder / global context + context term next to
+        # the correlation encoder; GraphAgg next to the heads) on two side streams, so that the HBM- and latency-bound kernels among
+        # them run under the MFMA-bound ones.  Measured at C3 (profiles/r04_r_update_streams_ab.txt): 48.22 vs 48.39 ms per operator
+        # call -- the step is bound by the socket's power, and a joule costs the same on any stream; off by default.
+        self.streams = os.environ.get("DH_UPDATE_STREAMS", "0") == "1"
+        self._side = None
 
     # ---- parameters ----------------------------------------------------------------------------
     def load_state_dict(self, sd, prefix=""):
@@ -364,31 +401,50 @@ class UpdateModule:
         # outside the image zeroed again, which is the zero border the reference's padded convolutions see there
         mk = (lambda t: t) if _mask is None else (lambda t: (droid_backends.canvas_mask_(t, _mask[0], _mask[1]), t)[1])
         npix = float(h * w) if _mask is None else float(_mask[0] * _mask[1])
+        main, side = torch.cuda.current_stream(net.device), (None, None)
+        if self.streams and net.is_cuda and E * h * w >= (1 << 18):          # (small problems are launch-bound: nothing to overlap)
+            if self._side is None:
+                self._side = (torch.cuda.Stream(device=net.device), torch.cuda.Stream(device=net.device))
+            side = self._side
         if corr0 is not None:
             c0 = corr0
         elif corr.dim() == 4 and corr.shape[1] == COR_PLANES:      # reference layout [E,196,h,w] (see wants_reference_layout_corr)
             c0 = droid_backends.corr0_nchw(corr, P["corr0_nchw"][0], P["corr0_nchw"][1])
         else:
             c0 = P["corr0"]([corr[0], corr[1], corr[2], corr[3]], EPI_RELU)
-        c = mk(P["corr2"]([mk(c0)], EPI_RELU))
-        f = mk(P["flow2"]([mk(P["flow0"]([flow], EPI_RELU))], EPI_RELU))
-        # global context: mean over pixels of sigmoid(w(net)) * net, then three 128x128 GEMVs per edge
-        red = torch.zeros(E, 128, dtype=torch.float32, device=net.device)
-        P["gru_w"]([net], EPI_GLO, aux0=net, red=red)
-        gzr = droid_backends.glo_gemv(red, P["glo_zr_t"][0], P["glo_zr_t"][1], 1.0 / npix)     # [E,256] z | r
-        gq = droid_backends.glo_gemv(red, P["glo_q_t"][0], P["glo_q_t"][1], 1.0 / npix)        # [E,128]
         if inp is None and not (w == 64 and h % 4 == 0):
             inp = inp_frames[inp_index]        # image shape outside the production kernel: the reference's data flow
+        with _Fork(side[0], main) as fb:       # flow encoder
+            f = mk(P["flow2"]([mk(P["flow0"]([flow], EPI_RELU))], EPI_RELU))
+        with _Fork(side[1], main) as gb:
+            # global context: mean over pixels of sigmoid(w(net)) * net, then three 128x128 GEMVs per edge
+            red = torch.zeros(E, 128, dtype=torch.float32, device=net.device)
+            P["gru_w"]([net], EPI_GLO, aux0=net, red=red)
+            gzr = droid_backends.glo_gemv(red, P["glo_zr_t"][0], P["glo_zr_t"][1], 1.0 / npix)     # [E,256] z | r
+            gq = droid_backends.glo_gemv(red, P["glo_q_t"][0], P["glo_q_t"][1], 1.0 / npix)        # [E,128]
+            if inp is None and ctx is None:
+                ctx = self.context_term(inp_frames)
+        c = mk(P["corr2"]([mk(c0)], EPI_RELU))
+        fb.join(f)
+        gb.join(gzr, gq, ctx)
         if inp is not None:
             zr = P["zr"]([net, inp, c, f], EPI_GRU_ZR, gterm=gzr, aux0=net)             # [E,h,w,256] = z | r*net
             P["q"]([zr[..., 128:], inp, c, f], EPI_GRU_Q, out=net, gterm=gq, aux0=net, aux1=zr)
         else:
-            if ctx is None:
-                ctx = self.context_term(inp_frames)
             zr = P["zr_e"]([net, c, f], EPI_GRU_ZR, gterm=gzr, aux0=net, cinit=ctx, cinit_idx=inp_index, cinit_off=0)
             P["q_e"]([zr[..., 128:], c, f], EPI_GRU_Q, out=net, gterm=gq, aux0=net, aux1=zr,
                      cinit=ctx, cinit_idx=inp_index, cinit_off=256)
         mk(net)
+        with _Fork(side[0], main) as ab:
+            # GraphAgg: conv -> mean over the edges of each source frame -> conv -> eta / upmask
+            x = P["agg1"]([net], EPI_RELU)
+            order, seg_off = self.segments(ii)
+            xm = mk(droid_backends.segment_mean(x, order, seg_off))
+            x2 = mk(P["agg2"]([xm], EPI_RELU))
+            K = xm.shape[0]
+            eta = torch.empty(K, h, w, 1, dtype=torch.float32, device=net.device)
+            P["eta"]([x2], EPI_SOFTPLUS_001, out=eta)
+            upmask = P["upmask"]([x2], EPI_LINEAR)
         if _mask is None and w == 64 and h % 4 == 0 and droid_backends.get_option("conv_halo") and droid_backends.get_option("conv_halo2"):
             # heads: the 256-channel activations never leave the first layer's kernel (see csrc/conv.hip EPI_HEADS0)
             w2p, b4 = P["heads2_fused"]
@@ -400,15 +456,7 @@ class UpdateModule:
             dw = torch.empty(E, h, w, 4, dtype=torch.float32, device=net.device)
             P["heads2"]([hd], EPI_HEADS, out=dw)
         self.last_dw = dw                        # (delta_x, delta_y, w_x, w_y) as one tensor for droid_backends.ba_inputs
-        # GraphAgg: conv -> mean over the edges of each source frame -> conv -> eta / upmask
-        x = P["agg1"]([net], EPI_RELU)
-        order, seg_off = self.segments(ii)
-        xm = mk(droid_backends.segment_mean(x, order, seg_off))
-        x2 = mk(P["agg2"]([xm], EPI_RELU))
-        K = xm.shape[0]
-        eta = torch.empty(K, h, w, 1, dtype=torch.float32, device=net.device)
-        P["eta"]([x2], EPI_SOFTPLUS_001, out=eta)
-        upmask = P["upmask"]([x2], EPI_LINEAR)
+        ab.join(eta, upmask)
         return net, dw[..., :2], dw[..., 2:], eta[..., 0], upmask
 
     def _forward_canvas(self, net, inp, corr, flow, ii, inp_frames, inp_index, corr0):
