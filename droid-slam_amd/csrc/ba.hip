@@ -41,16 +41,30 @@ constexpr int GS = 10;            // slots per Gram chunk: 10*6 + 1 (w) = 61 <= 
 constexpr int GCOLS = 64;
 constexpr float ALPHA_PRIOR = 0.05f;   // src/droid_kernels.cu:1405
 
+constexpr int FLOW_HDR = 32;        // ints ahead of the ready flags in BaLayout::flow (ticket counter and watchdog word on their own line)
+
 struct BaLayout {
   size_t kmap, kx, eoff, cursor, eidx, meta;          // int32 arrays
   size_t Q, W, Ei, Ej, Hpart;                          // f32
   size_t H, x, Linv, Ldiag;                            // f64
+  size_t flow;                                         // int32: ticket counter, watchdog word, one ready flag per block of L (dataflow Cholesky)
   size_t dx;                                           // f32 [P,6]
   size_t total;
   int P, n, nbk, npad, ld, NS, Kmax;
 };
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// compute units of the current device (grid of the persistent Cholesky); queried once per device
+inline int device_cus() {
+  static int cu_count[64];
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+    if (!cu_count[dev]) { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cu_count[dev] = n; }
+    if (cu_count[dev]) cus = cu_count[dev];
+  }
+  return cus;
+}
 
 BaLayout make_layout(int F, int E, int HW, int t0, int t1, int motion_only) {
   BaLayout L{};
@@ -81,6 +95,7 @@ BaLayout make_layout(int F, int E, int HW, int t0, int t1, int motion_only) {
   L.Linv = take(sizeof(double) * (size_t)L.nbk * NB * NB);
   L.Ldiag = take(sizeof(double) * (size_t)L.nbk * NB * NB);
   L.dx = take(sizeof(float) * (size_t)(L.P > 0 ? L.P : 1) * 6);
+  L.flow = take(sizeof(int) * (FLOW_HDR + (size_t)(L.nbk + 1) * (L.nbk > 0 ? L.nbk : 1)));
   L.total = off;
   return L;
 }
@@ -641,9 +656,11 @@ __global__ __launch_bounds__(256, DIAG ? 4 : 2) void ba_gram_kernel(
 
 // ------------------------------------------------------------------------------------------ solve
 // (also clears the Cholesky failure flag: SparseBlock::solve judges every iteration on its own, droid_kernels.cu:1201-1221)
-__global__ void ba_damp_kernel(double* __restrict__ H, int ld, int n, int npad, double lm, double ep, int* __restrict__ meta) {
+__global__ void ba_damp_kernel(double* __restrict__ H, int ld, int n, int npad, double lm, double ep, int* __restrict__ meta,
+                               int* __restrict__ flow, int nflow) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) meta[1] = 0;
+  for (int k = i; k < nflow; k += gridDim.x * blockDim.x) flow[k] = 0;      // ticket counter and ready flags of chol_flow_kernel
   if (i >= npad) return;
   if (i < n) { const double d = H[(long)i * ld + i]; H[(long)i * ld + i] = d + ep + lm * d; }
   else H[(long)i * ld + i] = 1.0;
@@ -1241,6 +1258,131 @@ __global__ __launch_bounds__(256, 1) void chol_step_kernel(double* __restrict__ 
   DH_TS(4);
 }
 
+#ifdef DH_ABLATION
+// ---- dataflow schedule (chol_lookahead = 2, -DDH_ABLATION builds): ONE persistent launch for the whole factorisation -------------
+// The look-ahead schedule pays a kernel boundary per block column: 47 dependent launches of 18-33 us at 512 keyframes, of which the
+// panel itself is a third.  Here the launches' implicit grid barriers are replaced by one ready flag per block of L.  A task = one
+// block (r, c) below the diagonal (the rhs block row included), LEFT-looking: it takes A_rc and A_cc, applies
+// A_rc -= L_rj L_cj^T and A_cc -= L_cj L_cj^T for j = 0 .. c-1 AS THE FLAGS OF (r, j) AND (c, j) COME UP (same updates in the same
+// order as the launches apply them: identical factors), then runs the stacked panel factorisation of the look-ahead step and raises
+// its own flag.  Workgroups draw tasks from a ticket counter in column-major order, so everything a task waits for belongs to a ticket
+// drawn earlier by a workgroup that is running: no deadlock whatever the number of resident workgroups.  flow[0] = ticket counter,
+// flow[1] = watchdog word (a wait that does not end raises it, which ends every wait and fails the factorisation like a bad pivot
+// instead of hanging the device), flow[FLOW_HDR + r * nbk + c] = 1 when L_rc is in H.  Polls and flag stores are read-modify-writes
+// (executed at the memory side: never served from one XCD's own L2); `zero` = 0, a kernel argument the compiler cannot fold.
+// All LDS is dynamic (the task word sits behind the panel): the panel's 16-byte accesses need the dynamic base at offset 0 -- a 4-byte
+// static __shared__ word in front of it made the first version of this kernel hang the queue.
+// Measured at 512 keyframes (profiles/r04_w_chol_dataflow.txt): results identical to the look-ahead schedule bit for bit, 3.67 vs 3.51 ms
+// per global BA -- a release / acquire pair across the eight L2s per block column costs what a kernel boundary costs.  Not faster
+// yet: the acquires could be batched (one per group of finished columns) and the next update's blocks prefetched.
+__global__ __launch_bounds__(256, 1) void chol_flow_kernel(double* __restrict__ H, int ld, int nbk, int* __restrict__ meta,
+                                                           double* __restrict__ Ldiag, int* __restrict__ flow, int zero) {
+  extern __shared__ double s_chol[];
+  double* sA = s_chol;                    // L_rj, later rows 64..127 of the stacked panel
+  double* sB = sA + NB * LDB;             // L_cj
+  double* const xch = s_chol + 2 * NB * LDB;
+  volatile int* s_task = reinterpret_cast<volatile int*>(xch + 256);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ntasks = nbk * (nbk + 1) / 2;
+  int* const flags = flow + FLOW_HDR;
+  for (int round = 0; round <= ntasks; ++round) {
+    if (tid == 0) s_task[0] = atomicAdd(&flow[0], 1);
+    __syncthreads();
+    const int t = s_task[0];
+    __syncthreads();                        // (the task word is rewritten by the next round)
+    if (t >= ntasks) return;
+    int c = 0, rem = t;
+    while (c < nbk && rem >= nbk - c) { rem -= nbk - c; ++c; }       // column c has the block rows c+1 .. nbk (nbk = the rhs row)
+    const int r = c + 1 + rem;
+    const long r0 = (long)r * NB, c0 = (long)c * NB;
+    double cur[4][4], curd[4][4];           // A_rc and A_cc in the accumulator layout of mfma_abt_64
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        cur[nt][q] = H[(r0 + wave * 16 + (lane >> 4) + 4 * q) * ld + c0 + nt * 16 + (lane & 15)];
+        curd[nt][q] = H[(c0 + wave * 16 + (lane >> 4) + 4 * q) * ld + c0 + nt * 16 + (lane & 15)];
+      }
+    for (int j = 0; j < c; ++j) {
+      if (tid == 0) {
+        int spins = 0;
+        while (atomicAdd(&flags[r * nbk + j], zero) == 0 || atomicAdd(&flags[c * nbk + j], zero) == 0) {
+          __builtin_amdgcn_s_sleep(2);
+          if ((++spins & 63) == 0 && (spins > (1 << 16) || atomicAdd(&flow[1], zero) != 0)) { atomicExch(&flow[1], 1); meta[1] = 1; break; }
+        }
+      }
+      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the two blocks were written by other workgroups (other XCDs, other L2s)
+      const long d0 = (long)j * NB;
+      double2 va[8], vb[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int o = tid + 256 * q;
+        va[q] = *reinterpret_cast<const double2*>(H + (r0 + (o >> 5)) * ld + d0 + (o & 31) * 2);
+        vb[q] = *reinterpret_cast<const double2*>(H + (c0 + (o >> 5)) * ld + d0 + (o & 31) * 2);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int o = tid + 256 * q;
+        *reinterpret_cast<double2*>(sA + (o >> 5) * LDB + (o & 31) * 2) = va[q];
+        *reinterpret_cast<double2*>(sB + (o >> 5) * LDB + (o & 31) * 2) = vb[q];
+      }
+      __syncthreads();
+      f64x4 acc[4], accd[4];
+      mfma_abt_64<false>(sA, sB, wave, lane, acc);
+      // A_cc -= L_cj L_cj^T, lower tiles only, spread 2 / 2 / 3 / 3 over the waves (see chol_step_kernel)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) accd[nt] = f64x4{0.0, 0.0, 0.0, 0.0};
+      if (wave == 0) {
+        accd[0] = mfma_abt_tile(sB, sB, 0, 0, lane);
+        const f64x4 t30 = mfma_abt_tile(sB, sB, 3, 0, lane);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xch[q * 64 + lane] = t30[q];
+      } else if (wave == 1) {
+        accd[0] = mfma_abt_tile(sB, sB, 1, 0, lane); accd[1] = mfma_abt_tile(sB, sB, 1, 1, lane);
+      } else if (wave == 2) {
+        accd[0] = mfma_abt_tile(sB, sB, 2, 0, lane); accd[1] = mfma_abt_tile(sB, sB, 2, 1, lane); accd[2] = mfma_abt_tile(sB, sB, 2, 2, lane);
+      } else {
+        accd[1] = mfma_abt_tile(sB, sB, 3, 1, lane); accd[2] = mfma_abt_tile(sB, sB, 3, 2, lane); accd[3] = mfma_abt_tile(sB, sB, 3, 3, lane);
+      }
+      __syncthreads();                      // every wave has read both operand blocks (next j / the panel may overwrite them)
+      if (wave == 3) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) accd[0][q] = xch[q * 64 + lane];
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { curd[nt][q] -= accd[nt][q]; cur[nt][q] -= acc[nt][q]; }
+    }
+    f64x4 top[4], bot[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { top[nt][q] = curd[nt][q]; bot[nt][q] = cur[nt][q]; }
+    double* P = s_chol;                     // [128][LDB]: A_cc over A_rc, both fully updated
+    const bool ok = chol_panel128_regs(P, top, bot, tid);
+    if (!ok && tid == 0) meta[1] = 1;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int o = tid + 256 * q;
+      *reinterpret_cast<double2*>(H + (r0 + (o >> 5)) * ld + c0 + (o & 31) * 2) = *reinterpret_cast<const double2*>(P + (NB + (o >> 5)) * LDB + (o & 31) * 2);
+    }
+    if (r == c + 1) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int o = tid + 256 * q;
+        *reinterpret_cast<double2*>(Ldiag + (long)c * NB * NB + (o >> 5) * NB + (o & 31) * 2) = *reinterpret_cast<const double2*>(P + (o >> 5) * LDB + (o & 31) * 2);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");    // the block is on its way to memory before the flag
+    __syncthreads();                                      // (also: the panel is read, the next task may overwrite it)
+    if (tid == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); atomicExch(&flags[r * nbk + c], 1); }
+  }
+}
+
+#endif  // DH_ABLATION
+
 // back substitution of L^T x = y (y = row `brow` of H) in groups of BG block rows per launch:
 // every workgroup solves the group's triangular system itself (x_g = W_g^T (y_g - sum_{g' > g in group} L_g'g^T x_g')),
 // workgroup 0 publishes x, workgroup 1 + q applies the group's contribution to y_q for its own q < group start.
@@ -1477,8 +1619,9 @@ int run_finish(const BaLayout& L, char* ws, float* poses, float* disps, const in
   int* meta = (int*)(ws + L.meta);
   float* dxw = (float*)(ws + L.dx);
   if (L.P > 0) {
+    int* flow = (int*)(ws + L.flow);
     hipLaunchKernelGGL(ba_damp_kernel, dim3((L.npad + 255) / 256), dim3(256), 0, st, H, L.ld, L.n, L.npad,
-                       (double)lm, (double)ep, meta);
+                       (double)lm, (double)ep, meta, flow, FLOW_HDR + (L.nbk + 1) * L.nbk);
     const int nbrows = L.nbk + 1;                        // + rhs block row
     DH_LDS_OPTIN(&chol_panel_kernel, 72 * 1024);
     DH_LDS_OPTIN(&chol_inverse_kernel, 80 * 1024);
@@ -1491,6 +1634,15 @@ int run_finish(const BaLayout& L, char* ws, float* poses, float* disps, const in
     const size_t lds_upd = sizeof(double) * 2 * NB * LDB;
     const bool two_launch = opts().chol_lookahead == 0;
     double* Ldiag = (double*)(ws + L.Ldiag);
+#ifdef DH_ABLATION
+    if (opts().chol_lookahead == 2) {                    // dataflow schedule: one persistent launch (A/B builds: measured 3.67 vs 3.51 ms per global BA)
+      DH_LDS_OPTIN(&chol_flow_kernel, 72 * 1024);
+      const int ntasks = L.nbk * (L.nbk + 1) / 2;
+      hipLaunchKernelGGL(chol_flow_kernel, dim3(std::min(ntasks, 2 * device_cus())), dim3(256), lds_panel + 256 * sizeof(double) + 16, st,
+                         H, L.ld, L.nbk, meta, Ldiag, flow, 0);
+      DH_LAUNCH_CHECK();
+    } else
+#endif
     if (two_launch) {                                    // reference schedule: panel, then the whole trailing update
       for (int j = 0; j < L.nbk; ++j) {
         const int m = nbrows - j - 1;

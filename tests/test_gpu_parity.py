@@ -279,6 +279,16 @@ def test_ba_cholesky_schedules_agree(db, option):
     got = _run_ba(db, g, 1, 64, 2, g["lm"], g["ep"])
     for a, b in zip(got, ref):
         assert np.allclose(a, b, rtol=0, atol=1e-7)
+    if db.get_option("ablation_build"):
+        # the dataflow schedule of the -DDH_ABLATION build (chol_lookahead = 2: one persistent launch, ready flags instead of kernel
+        # boundaries) applies the same updates in the same order as well: identical results, also at 47 block columns (C3)
+        for cfg, t1 in ((g, 64), (syn.make_graph("C3"), 512)):
+            option("chol_lookahead", 1)
+            a = _run_ba(db, cfg, 1, t1, 2, cfg["lm"], cfg["ep"])
+            option("chol_lookahead", 2)
+            b = _run_ba(db, cfg, 1, t1, 2, cfg["lm"], cfg["ep"])
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y)
 
 
 def test_ba_cholesky_failure_gives_zero_update(db):
