@@ -1381,6 +1381,149 @@ __global__ __launch_bounds__(256, 1) void chol_flow_kernel(double* __restrict__ 
   }
 }
 
+// ---- dataflow schedule, second form (chol_lookahead = 3): WRITTEN IN ROUND 4 AFTER THE GPU BUDGET WAS SPENT -- COMPILES, NOT YET RUN.
+// What the measurement of the first form asks for: an update costs ~9 us there (acquire fence, two cold 32-KB block
+// loads through registers, 110 MFMAs, three barriers) whether or not its operands have been ready for a long time.  Here
+//   * ONE acquire and ONE vector read of the flags (wave 0, a lane per column) per GROUP of columns whose blocks are already flagged;
+//   * the operand blocks arrive by LDS-DMA (global_load_lds_dwordx4, one 512-byte matrix row per half-wave instruction into the
+//     padded LDS rows): no staging registers, and the next update's blocks land in the second LDS buffer under this update's MFMAs.
+// Same updates in the same order as the other schedules (tests/test_gpu_parity.py compares bit for bit once it has been run).
+__global__ __launch_bounds__(256, 1) void chol_flow_dma_kernel(double* __restrict__ H, int ld, int nbk, int* __restrict__ meta,
+                                                               double* __restrict__ Ldiag, int* __restrict__ flow, int zero) {
+  extern __shared__ double s_chol[];
+  constexpr int BUF = 2 * NB * LDB;                                  // doubles per operand buffer: L_rj over L_cj
+  double* const xch = s_chol + 2 * BUF;
+  volatile int* s_task = reinterpret_cast<volatile int*>(xch + 256);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ntasks = nbk * (nbk + 1) / 2;
+  int* const flags = flow + FLOW_HDR;
+  const unsigned lds0 = (unsigned)(uintptr_t)s_chol;
+  for (int round = 0; round <= ntasks; ++round) {
+    if (tid == 0) s_task[0] = atomicAdd(&flow[0], 1);
+    __syncthreads();
+    const int t = s_task[0];
+    __syncthreads();
+    if (t >= ntasks) return;
+    int c = 0, rem = t;
+    while (c < nbk && rem >= nbk - c) { rem -= nbk - c; ++c; }
+    const int r = c + 1 + rem;
+    const long r0 = (long)r * NB, c0 = (long)c * NB;
+    double cur[4][4], curd[4][4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        cur[nt][q] = H[(r0 + wave * 16 + (lane >> 4) + 4 * q) * ld + c0 + nt * 16 + (lane & 15)];
+        curd[nt][q] = H[(c0 + wave * 16 + (lane >> 4) + 4 * q) * ld + c0 + nt * 16 + (lane & 15)];
+      }
+    // blocks (r, j) and (c, j) -> buffer `b`: wave w moves rows 16 w .. 16 w + 15 of both, one row (512 B = 32 lanes x 16 B) per instruction
+    auto dma = [&](int j, int b) {
+      const long d0 = (long)j * NB;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const long blk0 = half ? c0 : r0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = wave * 16 + i;
+          const unsigned long gaddr = (unsigned long)(H + (blk0 + row) * ld + d0);
+          const unsigned glo = __builtin_amdgcn_readfirstlane((unsigned)gaddr);
+          const unsigned ghi = __builtin_amdgcn_readfirstlane((unsigned)(gaddr >> 32));
+          const void* gs = reinterpret_cast<const void*>(((unsigned long)ghi << 32) | glo);
+          const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(((long)b * BUF + (long)half * NB * LDB + (long)row * LDB) * sizeof(double)));
+          if (lane < 32) {
+            unsigned keep_;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep_) : "v"(lane * 16), "s"(gs), "s"(dst) : "memory");
+          }
+        }
+      }
+    };
+    auto wait_for = [&](int j) {
+      int spins = 0;
+      while (atomicAdd(&flags[r * nbk + j], zero) == 0 || atomicAdd(&flags[c * nbk + j], zero) == 0) {
+        __builtin_amdgcn_s_sleep(2);
+        if ((++spins & 63) == 0 && (spins > (1 << 16) || atomicAdd(&flow[1], zero) != 0)) { atomicExch(&flow[1], 1); meta[1] = 1; break; }
+      }
+    };
+    int b = 0;
+    for (int j = 0; j < c;) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (wave == 0) {
+        const int jj = j + lane;
+        const bool up = jj < c && __hip_atomic_load(&flags[r * nbk + jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 &&
+                        __hip_atomic_load(&flags[c * nbk + jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        const unsigned long long m = __ballot(up);
+        int n = m == ~0ull ? 64 : __builtin_ctzll(~m);                    // leading columns whose blocks are flagged
+        if (lane == 0) {
+          if (n == 0) { wait_for(j); n = 1; }
+          s_task[1] = n;
+        }
+      }
+      __syncthreads();
+      const int k = s_task[1];
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                  // (after a wait: the blocks flagged meanwhile)
+      dma(j, b);
+      for (int u = 0; u < k; ++u) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's rows of update u are in LDS ...
+        __syncthreads();                                                  // ... and every other wave's
+        if (u + 1 < k) dma(j + u + 1, b ^ 1);                             // the next update's blocks land under the MFMAs
+        const double* sA = s_chol + (long)b * BUF;
+        const double* sB = sA + NB * LDB;
+        f64x4 acc[4], accd[4];
+        mfma_abt_64<false>(sA, sB, wave, lane, acc);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) accd[nt] = f64x4{0.0, 0.0, 0.0, 0.0};
+        if (wave == 0) {
+          accd[0] = mfma_abt_tile(sB, sB, 0, 0, lane);
+          const f64x4 t30 = mfma_abt_tile(sB, sB, 3, 0, lane);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) xch[q * 64 + lane] = t30[q];
+        } else if (wave == 1) {
+          accd[0] = mfma_abt_tile(sB, sB, 1, 0, lane); accd[1] = mfma_abt_tile(sB, sB, 1, 1, lane);
+        } else if (wave == 2) {
+          accd[0] = mfma_abt_tile(sB, sB, 2, 0, lane); accd[1] = mfma_abt_tile(sB, sB, 2, 1, lane); accd[2] = mfma_abt_tile(sB, sB, 2, 2, lane);
+        } else {
+          accd[1] = mfma_abt_tile(sB, sB, 3, 1, lane); accd[2] = mfma_abt_tile(sB, sB, 3, 2, lane); accd[3] = mfma_abt_tile(sB, sB, 3, 3, lane);
+        }
+        __syncthreads();                      // every wave has read buffer b (and xch is written)
+        if (wave == 3) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) accd[0][q] = xch[q * 64 + lane];
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { curd[nt][q] -= accd[nt][q]; cur[nt][q] -= acc[nt][q]; }
+        b ^= 1;
+      }
+      j += k;
+    }
+    f64x4 top[4], bot[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { top[nt][q] = curd[nt][q]; bot[nt][q] = cur[nt][q]; }
+    double* P = s_chol;                       // [128][LDB] = operand buffer 0 (every wave is past its last read of both buffers)
+    const bool ok = chol_panel128_regs(P, top, bot, tid);
+    if (!ok && tid == 0) meta[1] = 1;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int o = tid + 256 * q;
+      *reinterpret_cast<double2*>(H + (r0 + (o >> 5)) * ld + c0 + (o & 31) * 2) = *reinterpret_cast<const double2*>(P + (NB + (o >> 5)) * LDB + (o & 31) * 2);
+    }
+    if (r == c + 1) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int o = tid + 256 * q;
+        *reinterpret_cast<double2*>(Ldiag + (long)c * NB * NB + (o >> 5) * NB + (o & 31) * 2) = *reinterpret_cast<const double2*>(P + (o >> 5) * LDB + (o & 31) * 2);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (tid == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); atomicExch(&flags[r * nbk + c], 1); }
+  }
+}
+
 #endif  // DH_ABLATION
 
 // back substitution of L^T x = y (y = row `brow` of H) in groups of BG block rows per launch:
@@ -1635,11 +1778,16 @@ int run_finish(const BaLayout& L, char* ws, float* poses, float* disps, const in
     const bool two_launch = opts().chol_lookahead == 0;
     double* Ldiag = (double*)(ws + L.Ldiag);
 #ifdef DH_ABLATION
-    if (opts().chol_lookahead == 2) {                    // dataflow schedule: one persistent launch (A/B builds: measured 3.67 vs 3.51 ms per global BA)
-      DH_LDS_OPTIN(&chol_flow_kernel, 72 * 1024);
+    if (opts().chol_lookahead >= 2) {                    // dataflow schedule: one persistent launch (A/B builds: measured 3.67 vs 3.51 ms per global BA)
       const int ntasks = L.nbk * (L.nbk + 1) / 2;
-      hipLaunchKernelGGL(chol_flow_kernel, dim3(std::min(ntasks, 2 * device_cus())), dim3(256), lds_panel + 256 * sizeof(double) + 16, st,
-                         H, L.ld, L.nbk, meta, Ldiag, flow, 0);
+      const dim3 grid(std::min(ntasks, 2 * device_cus()));
+      if (opts().chol_lookahead == 3) {                  // second form (LDS-DMA operands, grouped acquires): not yet run on a device
+        DH_LDS_OPTIN(&chol_flow_dma_kernel, 140 * 1024);
+        hipLaunchKernelGGL(chol_flow_dma_kernel, grid, dim3(256), 2 * lds_panel + 256 * sizeof(double) + 16, st, H, L.ld, L.nbk, meta, Ldiag, flow, 0);
+      } else {
+        DH_LDS_OPTIN(&chol_flow_kernel, 72 * 1024);
+        hipLaunchKernelGGL(chol_flow_kernel, grid, dim3(256), lds_panel + 256 * sizeof(double) + 16, st, H, L.ld, L.nbk, meta, Ldiag, flow, 0);
+      }
       DH_LAUNCH_CHECK();
     } else
 #endif
