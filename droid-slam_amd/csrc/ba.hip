@@ -1381,13 +1381,14 @@ __global__ __launch_bounds__(256, 1) void chol_flow_kernel(double* __restrict__ 
   }
 }
 
-// ---- dataflow schedule, second form (chol_lookahead = 3): WRITTEN IN ROUND 4 AFTER THE GPU BUDGET WAS SPENT -- COMPILES, NOT YET RUN.
+// ---- dataflow schedule, second form (chol_lookahead = 3; measured: 3.70 ms per global BA against 3.66 for the first form, 3.47 look-ahead)
 // What the measurement of the first form asks for: an update costs ~9 us there (acquire fence, two cold 32-KB block
 // loads through registers, 110 MFMAs, three barriers) whether or not its operands have been ready for a long time.  Here
 //   * ONE acquire and ONE vector read of the flags (wave 0, a lane per column) per GROUP of columns whose blocks are already flagged;
 //   * the operand blocks arrive by LDS-DMA (global_load_lds_dwordx4, one 512-byte matrix row per half-wave instruction into the
 //     padded LDS rows): no staging registers, and the next update's blocks land in the second LDS buffer under this update's MFMAs.
-// Same updates in the same order as the other schedules (tests/test_gpu_parity.py compares bit for bit once it has been run).
+// Same updates in the same order as the other schedules: results identical bit for bit (scripts/bench_chol.py; profiles/r04_zz_chol_schedules_ab.txt).
+// It is not faster: the time is the chain through flag, acquire, cold loads, MFMAs, panel, store and release, not the early updates.
 __global__ __launch_bounds__(256, 1) void chol_flow_dma_kernel(double* __restrict__ H, int ld, int nbk, int* __restrict__ meta,
                                                                double* __restrict__ Ldiag, int* __restrict__ flow, int zero) {
   extern __shared__ double s_chol[];
@@ -1781,7 +1782,7 @@ int run_finish(const BaLayout& L, char* ws, float* poses, float* disps, const in
     if (opts().chol_lookahead >= 2) {                    // dataflow schedule: one persistent launch (A/B builds: measured 3.67 vs 3.51 ms per global BA)
       const int ntasks = L.nbk * (L.nbk + 1) / 2;
       const dim3 grid(std::min(ntasks, 2 * device_cus()));
-      if (opts().chol_lookahead == 3) {                  // second form (LDS-DMA operands, grouped acquires): not yet run on a device
+      if (opts().chol_lookahead == 3) {                  // second form (LDS-DMA operands, grouped acquires)
         DH_LDS_OPTIN(&chol_flow_dma_kernel, 140 * 1024);
         hipLaunchKernelGGL(chol_flow_dma_kernel, grid, dim3(256), 2 * lds_panel + 256 * sizeof(double) + 16, st, H, L.ld, L.nbk, meta, Ldiag, flow, 0);
       } else {

@@ -8,7 +8,7 @@ struct Options {
   int debug;            // DH_DEBUG=1: print HIP errors to stderr
   int gram_strips;      // DH_GRAM_STRIPS (0 = automatic): pixel strips per depth block in the Schur-complement kernel
   int chol_regpanel;    // DH_CHOL_REGPANEL (1): look-ahead step keeps the unfinished panel in MFMA accumulator registers; 0 = LDS panel
-  int chol_lookahead;   // DH_CHOL_LOOKAHEAD (1): one fused launch per block column of the Cholesky; 0 = two launches; 2 / 3 (-DDH_ABLATION builds) = dataflow schedule, one persistent launch (3: LDS-DMA operands, grouped acquires; not yet run)
+  int chol_lookahead;   // DH_CHOL_LOOKAHEAD (1): one fused launch per block column of the Cholesky; 0 = two launches; 2 / 3 (-DDH_ABLATION builds) = dataflow schedule, one persistent launch (3: LDS-DMA operands, grouped acquires)
   int conv_epi_staged;  // DH_CONV_EPI_STAGED (1): LDS-staged convolution epilogues
   int conv_halo;        // DH_CONV_HALO (1): 3x3 halo-tile kernels; 0 = generic loop only
   int conv_halo2;       // DH_CONV_HALO2 (1): weights by LDS-DMA for 128-cout tiles; 0 = first halo kernel

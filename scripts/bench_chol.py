@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """A/B of the Cholesky schedules inside droid_backends.ba (option chol_lookahead: 0 two launches per block column, 1 the look-ahead
 step = default, 2 the dataflow schedule of the -DDH_ABLATION build, 3 its second form with LDS-DMA operands and grouped acquires --
-written at the end of round 4, not yet run: select it explicitly with --modes 1,2,3 and run it under `timeout`): results compared bit
+select it with --modes 1,2,3): results compared bit
 for bit with the default schedule, median time of a global BA (itrs = 2) per configuration.
     python scripts/bench_chol.py [--ablation] [--modes 1,2] [--configs C2,C3] [--reps 7]"""
 import argparse, os, sys

@@ -285,10 +285,11 @@ def test_ba_cholesky_schedules_agree(db, option):
         for cfg, t1 in ((g, 64), (syn.make_graph("C3"), 512)):
             option("chol_lookahead", 1)
             a = _run_ba(db, cfg, 1, t1, 2, cfg["lm"], cfg["ep"])
-            option("chol_lookahead", 2)
-            b = _run_ba(db, cfg, 1, t1, 2, cfg["lm"], cfg["ep"])
-            for x, y in zip(a, b):
-                assert np.array_equal(x, y)
+            for mode in (2, 3):             # 3: grouped acquires, operand blocks by LDS-DMA
+                option("chol_lookahead", mode)
+                b = _run_ba(db, cfg, 1, t1, 2, cfg["lm"], cfg["ep"])
+                for x, y in zip(a, b):
+                    assert np.array_equal(x, y), mode
 
 
 def test_ba_cholesky_failure_gives_zero_update(db):
