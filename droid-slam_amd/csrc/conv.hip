@@ -1194,6 +1194,129 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(ConvParams P) {
   if constexpr (STAGED) staged_epilogue<EPI, 4, 128, 256>(P, acc, s_conv, m0, n0, wm0, wn0, tid, HW);
   else conv_epilogue<EPI, 2, 4>(P, acc, (long)P.N * HW, m0, n0, wm0, wn0, lane, HW);
 }
+
+// ---- 3x3, 64-cout tile in the SECOND form (option conv_halo64): the flow encoder's 128 -> 64 layer ----------------------------------
+// That layer runs in the first-generation halo kernel (conv3x3_halo_kernel<.., 64>: eight waves of 64 px x 32 couts, weights staged
+// through registers) at 0.80-0.90 PFLOP/s where the 128-cout layers reach 1.0-1.1 on the same operands.  This is conv3x3_halo4_kernel
+// with half the couts: four waves, a wave owns one image row and all 64 couts (2 x 2 accumulator tiles, the production wave tile), the
+// (32-channel chunk, kernel row) weight groups arrive by LDS-DMA into two 12-KB buffers -- 50 KB of LDS, three workgroups per CU.
+// Weights: the conv3x3_halo2_kernel layout of the layer padded to 128 couts (droid_amd.update.pack_conv_halo under this option); a
+// (chunk, dy) group there is 3 x 128 rows of 64 bytes, of which this kernel fetches rows 0 .. 63 of every dx.
+constexpr int H64B_BYTES = 3 * 64 * H2CK * 2;                 // 12,288: one (chunk, dy) weight group, 64 couts
+constexpr int H64_LDS_BYTES = H2A_BYTES + 2 * H64B_BYTES;     // 49,920 (the staged epilogue tile needs 36,864)
+template <int EPI>
+__global__ __launch_bounds__(256, 3) void conv3x3_halo64_kernel(ConvParams P) {
+  extern __shared__ __half s_conv[];
+  char* const lds = reinterpret_cast<char*>(s_conv);
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)s_conv;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wrow = wave, wn0 = 0, wm0 = wrow * 64;
+  long m0; int n0;
+  xcd_decode(P, m0, n0, 64);
+  const int HW = P.H * P.W;
+  const int img = (int)(m0 / HW), y0 = (int)((m0 - (long)img * HW) / 64);
+  const int nchunks = P.Ctot / H2CK, nsteps = nchunks * 3;
+  constexpr int A_PIECES = 6;
+  const int aq = tid & 3, ax = (tid >> 2) & 63;
+  const int a_pix0 = (img * P.H + y0 - 1) * 64 + ax;
+  if (tid < 48) {
+    const int hp = (tid >> 3) * HCOLS + ((tid >> 2) & 1) * (HCOLS - 1);
+    *reinterpret_cast<uint4*>(lds + hp * 64 + aq * 16) = uint4{0u, 0u, 0u, 0u};
+  }
+  const int b_voff = lane * 16;
+  const char* const bsrc = reinterpret_cast<const char*>(P.wt_halo);           // one 128-cout tile in the halo2 layout
+  const int pl = wrow * HCOLS + (lane & 31), kh = lane >> 5;
+  int b_row[2], b_x[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int r = b * 32 + (lane & 31);
+    b_row[b] = r * 64; b_x[b] = ((r >> 2) & 3) ^ kh;
+  }
+  f32x16 acc[2][2];
+  zero_acc<2, 2>(acc);
+  u32x4 ra[A_PIECES];
+#define H64_FETCH_A(chunk_)                                                                                          \
+  {                                                                                                                  \
+    int cs = (chunk_) * H2CK, sgi = 0;                                                                               \
+    _Pragma("unroll") for (int q = 0; q < MAXSEG - 1; ++q)                                                           \
+      if (sgi == q && q + 1 < P.nseg && cs >= P.segC[q]) { cs -= P.segC[q]; sgi = q + 1; }                          \
+    const __half* base = P.in[0]; int segs = P.segS[0];                                                              \
+    _Pragma("unroll") for (int q = 1; q < MAXSEG; ++q) if (sgi == q) { base = P.in[q]; segs = P.segS[q]; }           \
+    int pix0 = a_pix0;                                                                                               \
+    asm volatile("" : "+v"(pix0));                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < A_PIECES; ++i) {                                                           \
+      const bool ok = (unsigned)(y0 - 1 + i) < (unsigned)P.H;                                                        \
+      ra[i] = *reinterpret_cast<const u32x4*>(base + (long)(ok ? pix0 + 64 * i : 0) * segs + cs + aq * 8);           \
+    }                                                                                                                \
+  }
+#define GLDS16S(sbase_, voff_, ldsaddr_)                                                                             \
+  {                                                                                                                  \
+    unsigned keep_;                                                                                                  \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep_) : "v"(voff_), "s"(sbase_), "s"(ldsaddr_) : "memory");                                \
+  }
+  // 12 pieces of 1 KB per group: piece p = wave + 4 q -> dx = p >> 2, rows 16 (p & 3) .. of that dx
+#define H64_DMA_B(step_)                                                                                             \
+  {                                                                                                                  \
+    _Pragma("unroll") for (int q = 0; q < 3; ++q) {                                                                  \
+      const int pc = wave + 4 * q;                                                                                   \
+      const unsigned long gaddr = (unsigned long)(bsrc + (long)(step_) * H2B_BYTES + (pc >> 2) * 8192 + (pc & 3) * 1024); \
+      const unsigned glo = __builtin_amdgcn_readfirstlane((unsigned)gaddr);                                          \
+      const unsigned ghi = __builtin_amdgcn_readfirstlane((unsigned)(gaddr >> 32));                                  \
+      const void* gs = reinterpret_cast<const void*>(((unsigned long)ghi << 32) | glo);                              \
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + H2A_BYTES + ((step_) & 1) * H64B_BYTES + (pc >> 2) * 4096 + (pc & 3) * 1024); \
+      GLDS16S(gs, b_voff, dst)                                                                                       \
+    }                                                                                                                \
+  }
+  H64_FETCH_A(0)
+  H64_DMA_B(0)
+  for (int c = 0; c < nchunks; ++c) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    int ax_o = ax;
+    asm volatile("" : "+v"(ax_o));
+#pragma unroll
+    for (int i = 0; i < A_PIECES; ++i) {
+      const int hp = i * HCOLS + ax_o + 1;
+      const uint32_t m = (unsigned)(y0 - 1 + i) < (unsigned)P.H ? 0xffffffffu : 0u;
+      *reinterpret_cast<u32x4*>(lds + hp * 64 + ((aq ^ ((hp >> 2) & 3)) << 4)) = ra[i] & m;
+    }
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int step = c * 3 + dy;
+      // (vmcnt: the group of this step was requested one step ago; at dy == 1 the six halo loads of the next chunk are younger)
+      if (dy == 1 && c + 1 < nchunks) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (step + 1 < nsteps) H64_DMA_B(step + 1)
+      if (dy == 0 && c + 1 < nchunks) H64_FETCH_A(c + 1)
+      const char* const Bcur = lds + H2A_BYTES + (step & 1) * H64B_BYTES;
+      int pl_o = pl;
+      asm volatile("" : "+v"(pl_o));
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          half8 af[2], bf[2];
+#pragma unroll
+          for (int a = 0; a < 2; ++a) {
+            const int p = pl_o + dy * HCOLS + dx + a * 32;
+            af[a] = *reinterpret_cast<const half8*>(lds + p * 64 + (((ks * 2) ^ ((p >> 2) & 3) ^ kh) << 4));
+          }
+#pragma unroll
+          for (int b = 0; b < 2; ++b) bf[b] = *reinterpret_cast<const half8*>(Bcur + dx * (64 * 64) + b_row[b] + (((ks * 2) ^ b_x[b]) << 4));
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+      }
+    }
+  }
+#undef H64_FETCH_A
+#undef H64_DMA_B
+#undef GLDS16S
+  staged_epilogue<EPI, 2, 64, 256>(P, acc, s_conv, m0, n0, wm0, wn0, tid, HW);
+}
 #endif  // DH_ABLATION
 
 #ifdef DH_ABLATION   // 512-pixel-tile form: measured equal in energy, slower in time (profiles/r04_d_conv_halo3_ab.json): not in release builds
@@ -1924,6 +2047,27 @@ int launch_halo4(const ConvParams& P0, hipStream_t st) {
   DH_LAUNCH_CHECK();
   return DH_OK;
 }
+
+// conv3x3_halo64_kernel: 3x3, Cout <= 64 = CoutPad, W == 64, H % 4 == 0, 32-channel segments, fp16 output through the staged epilogue;
+// `weights_halo` must be the halo2 layout of the layer padded to 128 couts (the packer follows the same option)
+inline bool halo64_ok(const ConvParams& P) {
+  if (!opts().conv_halo64 || !opts().conv_halo || !P.wt_halo || P.KH != 3 || P.KW != 3 || P.W != 64 || P.H % 4 || P.CoutPad != 64) return false;
+  if (P.Ctot % H2CK || P.cinit || P.out_f32 || P.gterm) return false;
+  for (int i = 0; i < P.nseg; ++i) if (P.segC[i] % H2CK) return false;
+  return P.epi == EPI_RELU ? staged_epilogue_ok<EPI_RELU>(P) : (P.epi == EPI_LINEAR && staged_epilogue_ok<EPI_LINEAR>(P));
+}
+
+template <int EPI>
+int launch_halo64(const ConvParams& P0, hipStream_t st) {
+  ConvParams P = P0;
+  const long M = (long)P.N * P.H * P.W;
+  dim3 grid((unsigned)(M / BM), 1);
+  P.ny = 1;
+  if (opts().conv_xcd && grid.x % 8 == 0) P.xcd_tiles = (int)(grid.x / 8);
+  hipLaunchKernelGGL((conv3x3_halo64_kernel<EPI>), grid, dim3(256), H64_LDS_BYTES, st, P);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
 #endif  // DH_ABLATION
 
 #ifdef DH_ABLATION
@@ -2322,6 +2466,7 @@ extern "C" int dh_conv2d_nhwc_f16_ex2(const void* const* inputs, const int* in_c
   }
 #endif
 #ifdef DH_ABLATION
+  if (halo64_ok(P)) return P.epi == EPI_RELU ? launch_halo64<EPI_RELU>(P, st) : launch_halo64<EPI_LINEAR>(P, st);
   if (opts().conv_halo4 && !(P.epi == EPI_LINEAR && P.out_f32)) {                      // measurement variant: four 64 x 128 waves per workgroup
     switch (P.epi) {
       case EPI_LINEAR: if (halo2_ok<EPI_LINEAR>(P)) return launch_halo4<EPI_LINEAR>(P, st); break;

@@ -107,6 +107,8 @@ def pack_conv_halo(weight):
     if kh != 3 or kw != 3 or ctot % 32:
         return None
     cp = _round_up(cout, 32)                # CoutPad of pack_conv
+    if cp == 64 and droid_backends.get_option("conv_halo64") and droid_backends.get_option("conv_halo2"):
+        cp = 128                            # conv3x3_halo64_kernel (-DDH_ABLATION builds) reads the halo2 layout of the layer padded to 128 couts
     w = torch.zeros(cp, ctot, 9, dtype=torch.float32, device=weight.device)
     w[:cout] = weight.float().reshape(cout, ctot, 9)
     if _dma_layout(cp, ctot):
@@ -177,7 +179,7 @@ def pack_conv_7x7_c4(weight):
 
 def _halo_layout_options():
     """the options that decide the layout of `weights_halo` (csrc/conv.hip dma_layout / halo2_layout)"""
-    return droid_backends.get_option("conv_dma"), droid_backends.get_option("conv_halo2")
+    return droid_backends.get_option("conv_dma"), droid_backends.get_option("conv_halo2"), droid_backends.get_option("conv_halo64")
 
 
 def transposed_state_dict(sd):
@@ -207,7 +209,7 @@ class _Conv:
         epoch = droid_backends.options_epoch()
         if epoch != self._epoch:
             if self.wh is not None and self.layout == LAYOUT_AUTO and _halo_layout_options() != self._layout:
-                raise RuntimeError("conv weights were packed for (conv_dma, conv_halo2) = %s, the options now say %s: "
+                raise RuntimeError("conv weights were packed for (conv_dma, conv_halo2, conv_halo64) = %s, the options now say %s: "
                                    "call load_state_dict again after changing them" % (self._layout, _halo_layout_options()))
             self._epoch = epoch
 

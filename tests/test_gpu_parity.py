@@ -718,6 +718,35 @@ def test_conv2d_nhwc_matches_torch_conv(db, option, halo, dma, halo2):
         assert (out.float() - ref).abs().max() <= 1e-2 * max(1.0, ref.abs().max().item())
 
 
+def test_conv_64_cout_layer_in_the_second_kernel_form(db, option):
+    """conv3x3_halo64_kernel (-DDH_ABLATION build, option conv_halo64): the flow encoder's 128 -> 64 layer as four waves of 64 px x 64
+    couts with LDS-DMA weights, against torch's fp32 convolution and against the production kernel (different accumulation order:
+    one fp16 ulp), image borders and two segments included"""
+    if not db.get_option("ablation_build"):
+        pytest.skip("conv3x3_halo64_kernel is only part of a -DDH_ABLATION build (DROID_HIP_TEST_ABLATION=1)")
+    from droid_amd.update import pack_conv, pack_conv_halo, EPI_LINEAR, EPI_RELU
+    torch.manual_seed(1)
+    for (N, H, W, cins, cout) in [(2, 8, 64, (128,), 64), (3, 12, 64, (64, 64), 64), (8, 48, 64, (128,), 64), (1, 4, 64, (32, 96), 48)]:
+        xs = [torch.randn(N, H, W, c, device="cuda").half() for c in cins]
+        wgt = torch.randn(cout, sum(cins), 3, 3, device="cuda") / (sum(cins) * 9) ** 0.5
+        bias = torch.randn(cout, device="cuda")
+        wp, bp = pack_conv(wgt, bias)
+        x = torch.cat(xs, -1).float().permute(0, 3, 1, 2)
+        ref = torch.nn.functional.conv2d(x, wgt.half().float(), bias, padding=1).permute(0, 2, 3, 1)
+        for epi in (EPI_LINEAR, EPI_RELU):
+            want = ref if epi == EPI_LINEAR else ref.clamp_min(0)
+            outs = []
+            for v in (0, 1):
+                option("conv_halo64", v)
+                out = torch.empty(N, H, W, cout, device="cuda", dtype=torch.float16)
+                db.conv2d_nhwc(xs, wp, pack_conv_halo(wgt), bp, 3, 3, cout, epi, out, cout, None, None, None, None)
+                torch.cuda.synchronize()
+                assert (out.float() - want).abs().max() <= 1e-2 * max(1.0, want.abs().max().item()), (v, N, H, cins, cout)
+                outs.append(out.float())
+            option("conv_halo64", 0)
+            assert (outs[0] - outs[1]).abs().max() <= 2.0 ** -9 * max(1.0, want.abs().max().item())
+
+
 def test_conv7x7_on_four_channels_and_global_context_kernels(db):
     """the two single-purpose kernels of the update operator against torch: flow_encoder.0 (7x7 on the 4 motion
     channels, droid_net.py:89) and the ConvGRU's global-context reduction mean(sigmoid(w(net)) * net) (gru.py:23-24)"""
