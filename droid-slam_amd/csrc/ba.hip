@@ -1981,6 +1981,24 @@ static int ba_finish_impl(float* poses, float* disps, const int64_t* jj,
                     dx_out, dz_out, num_frames, (hipStream_t)stream, own_lo, own_hi);
 }
 
+// the depth blocks behind a built system (after dh_ba_build): Qinv = 1 / C and w, [K, ht*wd] f32 each, rows in the order of
+// kx [K] (the sorted source frames) -- the reference's `C` and `w` of ba_cuda (droid_kernels.cu:1407-1408); read by the parity
+// tests, and by callers that want per-pixel depth covariances (Q is the marginal's diagonal)
+extern "C" int dh_ba_depth_blocks(const void* workspace, size_t workspace_bytes, int num_frames, int n_edges, int ht, int wd,
+                                  int t0, int t1, const float** Qinv_out, const float** w_out, const int** kx_out, const int** K_out) {
+  int rc = check_args(num_frames, n_edges, ht, wd, t0, t1);
+  if (rc != DH_OK) return rc;
+  if (!workspace) return DH_ERR_ARG;
+  const BaLayout L = make_layout(num_frames, n_edges, ht * wd, t0, t1, 0);
+  if (workspace_bytes < L.total || ((uintptr_t)workspace & 255)) return DH_ERR_WORKSPACE;
+  const char* ws = (const char*)workspace;
+  if (Qinv_out) *Qinv_out = (const float*)(ws + L.Q);
+  if (w_out) *w_out = (const float*)(ws + L.W);
+  if (kx_out) *kx_out = (const int*)(ws + L.kx);
+  if (K_out) *K_out = (const int*)(ws + L.meta);          // device int: the number of depth blocks
+  return DH_OK;
+}
+
 extern "C" int dh_ba_finish(float* poses, float* disps, const int64_t* jj,
                             int num_frames, int n_edges, int ht, int wd, int t0, int t1,
                             float lm, float ep, int motion_only, float* dx_out, float* dz_out,

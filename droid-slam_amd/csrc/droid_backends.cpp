@@ -169,6 +169,17 @@ std::vector<torch::Tensor> ba_finish_owned(torch::Tensor poses, torch::Tensor di
   return ba_finish_any(poses, disps, jj, ws, n_eta_rows, t0, t1, lm, ep, motion_only, own_lo, own_hi);
 }
 
+// {Qinv [F,HW], w [F,HW] f32 (rows < K valid, ordered like kx), kx [F] int32, K [1] int32}: views into the workspace of ba_build
+std::vector<torch::Tensor> ba_depth_blocks(torch::Tensor ws, torch::Tensor disps, torch::Tensor jj, const int t0, const int t1) {
+  CHECK_INPUT(ws); CHECK_INPUT(disps); CHECK_INPUT(jj);
+  const int F = (int)disps.size(0), ht = (int)disps.size(1), wd = (int)disps.size(2), E = (int)jj.size(0);
+  const float *q = nullptr, *w = nullptr; const int *kx = nullptr, *K = nullptr;
+  check_status(dh_ba_depth_blocks(ws.data_ptr(), (size_t)ws.numel(), F, E, ht, wd, t0, t1, &q, &w, &kx, &K), "ba_depth_blocks");
+  auto f32 = disps.options().dtype(torch::kFloat32), i32 = disps.options().dtype(torch::kInt32);
+  return {torch::from_blob((void*)q, {F, (int64_t)ht * wd}, f32), torch::from_blob((void*)w, {F, (int64_t)ht * wd}, f32),
+          torch::from_blob((void*)kx, {F}, i32), torch::from_blob((void*)K, {1}, i32)};
+}
+
 // packed exchange of the co-visible 6x6 blocks (dh_ba_pack_blocks / dh_ba_unpack_blocks): `packed` f64
 // [36 * n_blocks + 6 (t1 - t0) + 2], bp / bq int32 block rows / columns; disps / jj only give the sizes
 void ba_pack_blocks(torch::Tensor ws, torch::Tensor disps, torch::Tensor jj, const int t0, const int t1, const bool motion_only,
@@ -382,14 +393,25 @@ torch::Tensor altcorr_forward_nhwc_levels(torch::Tensor fmap1, std::vector<torch
 // ---- MI355X-native correlation pyramid (own layout; droid_amd.corr.CorrBlock) ----------------------------
 // h_real / w_real > 0: the features are an h_real x w_real image, zero-padded to the canvas size of the tensors
 // (dh_corr_pyramid_build_canvas); 0 = the tensors ARE the image
-torch::Tensor corr_pyramid_build(torch::Tensor fmap1, torch::Tensor fmap2, const int h_real, const int w_real) {
+// out: optional pre-allocated pyramid storage (float16, contiguous, at least E records) -- the caller's ARENA: a 105 GB hipMalloc
+// costs seconds on a cold device, so callers that rebuild pyramids of the same graph (FactorGraph.update_lowmem) keep the storage
+torch::Tensor corr_pyramid_build(torch::Tensor fmap1, torch::Tensor fmap2, const int h_real, const int w_real,
+                                 const c10::optional<torch::Tensor>& out) {
   CHECK_INPUT(fmap1); CHECK_INPUT(fmap2);
   TORCH_CHECK(fmap1.scalar_type() == torch::kFloat16 && fmap2.scalar_type() == torch::kFloat16, "fmaps must be float16");
   TORCH_CHECK(fmap1.dim() == 4 && fmap1.sizes() == fmap2.sizes(), "corr_pyramid_build: fmaps [E,C,h,w] of equal shape");
   const int E = (int)fmap1.size(0), C = (int)fmap1.size(1), h = (int)fmap1.size(2), w = (int)fmap1.size(3);
   const size_t bytes1 = dh_corr_pyramid_bytes(1, h, w);
   TORCH_CHECK(bytes1 > 0, "corr_pyramid_build: unsupported image size (need h % 8 == 0 and w in {16,32,64})");
-  torch::Tensor pyr = torch::empty({E, (int64_t)(bytes1 / 2)}, fmap1.options());
+  torch::Tensor pyr;
+  if (out.has_value() && out->defined()) {
+    CHECK_INPUT((*out));
+    TORCH_CHECK(out->scalar_type() == torch::kFloat16 && out->dim() == 2 && out->size(0) >= E && (size_t)out->size(1) * 2 == bytes1,
+                "corr_pyramid_build: out must be float16 [>= E, record elements] for this image size");
+    pyr = out->narrow(0, 0, E);
+  } else {
+    pyr = torch::empty({E, (int64_t)(bytes1 / 2)}, fmap1.options());
+  }
   const int chunk = 256;                                  // bounds the channel-last scratch copies
   const size_t wsb = dh_corr_pyramid_workspace_bytes(std::min(E, chunk), h, w);
   torch::Tensor ws = torch::empty({(int64_t)wsb}, fmap1.options().dtype(torch::kUInt8));
@@ -686,6 +708,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   // MI355X extensions (not in the reference module)
   m.def("ba_ex", &ba_ex, "bundle adjustment with a per-pixel depth-prior weight");
   m.def("ba_build", &ba_build, "per-rank reduced camera system (split BA)");
+  m.def("ba_depth_blocks", &ba_depth_blocks, "views of Qinv = 1/C, w, kx, K in the workspace of ba_build (the keep-alive is the caller's: hold `ws`)");
   m.def("ba_finish", &ba_finish, "damp + solve + back-substitute + retract (split BA)");
   m.def("ba_build_shard", &ba_build_shard, "ba_build without a host synchronisation (edge-sharded BA)");
   m.def("ba_finish_owned", &ba_finish_owned, "ba_finish that only moves the depths of frames [own_lo, own_hi)");
@@ -697,7 +720,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("corr_volume_build", &corr_volume_build, "all-pairs volume in the reference layout (any image size)");
   m.def("corr_volume_pool", &corr_volume_pool, "2x2 average pooling of the last two dims of a reference-layout volume");
   m.def("corr_pyramid_build", &corr_pyramid_build, "all-pairs correlation pyramid, MI355X layout", py::arg("fmap1"), py::arg("fmap2"),
-        py::arg("h_real") = 0, py::arg("w_real") = 0);
+        py::arg("h_real") = 0, py::arg("w_real") = 0, py::arg("out") = py::none());
   m.def("corr_pyramid_lookup", &corr_pyramid_lookup, "fused 4-level lookup on the MI355X pyramid");
   m.def("corr_pyramid_lookup_nhwc", &corr_pyramid_lookup_nhwc, "fused 4-level lookup, channel-last output for the update operator");
   m.def("corr_pyramid_lookup_corr0", &corr_pyramid_lookup_corr0, "4-level lookup fused with the correlation encoder's first layer (1x1, 196 -> 128, ReLU)");

@@ -116,7 +116,10 @@ class CorrBlock:
     of transposed features at transposed coordinates is the transposed volume, the 7x7 window comes out with its axes swapped
     and is swapped back (or, for lookup_corr0, meets weights with the window swapped: UpdateModule.transposed_twin)."""
 
-    def __init__(self, fmap1, fmap2, num_levels=4, radius=3):
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=3, out=None):
+        """out: optional storage for the pyramid from CorrBlock.arena(...) (fp16 [>= E, record elements]); the block then is
+        a view of its first E records.  A 105 GB hipMalloc takes seconds on a cold device (bench.py `ms_pyramid_alloc`), the
+        build itself tens of milliseconds: callers that rebuild pyramids (FactorGraph.update_lowmem) keep the storage."""
         assert num_levels == 4 and radius == 3, "the fused pyramid is specialised to 4 levels / radius 3"
         batch, num, dim, ht, wd = fmap1.shape
         assert batch == 1
@@ -129,9 +132,14 @@ class CorrBlock:
             f1, f2, ht, wd = f1.transpose(-1, -2), f2.transpose(-1, -2), wd, ht
         if (self.hc, self.wc) != (ht, wd):
             pad = (0, self.wc - wd, 0, self.hc - ht)
-            self.pyramid = droid_backends.corr_pyramid_build(F.pad(f1, pad).contiguous(), F.pad(f2, pad).contiguous(), ht, wd)
+            self.pyramid = droid_backends.corr_pyramid_build(F.pad(f1, pad).contiguous(), F.pad(f2, pad).contiguous(), ht, wd, out)
         else:
-            self.pyramid = droid_backends.corr_pyramid_build(f1.contiguous(), f2.contiguous())
+            self.pyramid = droid_backends.corr_pyramid_build(f1.contiguous(), f2.contiguous(), 0, 0, out)
+
+    @staticmethod
+    def arena(num, ht, wd, device):
+        """uninitialised storage for the pyramid of `num` edges of an ht x wd image (CorrBlock(..., out=arena))"""
+        return torch.empty(num, CorrBlock.bytes_per_edge(ht, wd) // 2, dtype=torch.float16, device=device)
 
     @staticmethod
     def is_transposed(ht, wd):

@@ -196,6 +196,20 @@ class FactorGraph:
         need = E * CorrBlock.bytes_per_edge(ht, wd) + E * ht * wd * 3584
         return need < 0.6 * total
 
+    def _pyramid_arena(self, E, ht, wd):
+        """storage for update_lowmem's per-call pyramid, kept across calls (reallocated only when a call has more edges than any
+        before it; released by release_pyramid_arena()): the pyramid is rebuilt on every call because the graph changes between calls, its memory
+        need not be -- a cold 105 GB allocation takes seconds (bench.py `ms_pyramid_alloc`), the build 41 ms"""
+        a = getattr(self, "_arena", None)
+        rec = CorrBlock.bytes_per_edge(ht, wd) // 2
+        if a is None or a.shape[0] < E or a.shape[1] != rec:
+            self._arena = a = None
+            self._arena = a = CorrBlock.arena(E, ht, wd, self.device)
+        return a
+
+    def release_pyramid_arena(self):
+        self._arena = None
+
     def _ba_global(self, tb, wb, itrs, use_inactive, EP, t):
         ii, jj = self.ii, self.jj
         if use_inactive:
@@ -218,7 +232,7 @@ class FactorGraph:
                      device only: deterministic across runs; 105 + 44 GB for 4096 edges at 48x64), else "alt"; an
                      out-of-memory error during the build also falls back to "alt".
         Both paths skip the edges the reference's chunk loop never visits (source frame beyond the last chunk).
-        The pyramid is dropped when the call returns."""
+        The pyramid's CONTENT is dropped when the call returns; its storage is kept for the next call (_pyramid_arena)."""
         v = self.video
         t = v.counter.value
         num, rig, ch, ht, wd = v.fmaps.shape
@@ -234,11 +248,17 @@ class FactorGraph:
             ii_v, jj_v = (self.ii, self.jj) if sel is None else (self.ii[sel], self.jj[sel])
             c = (ii_v == jj_v).long() if rig > 1 else torch.zeros_like(ii_v)
             try:
-                block = CorrBlock(v.fmaps[ii_v, 0][None], v.fmaps[jj_v, c][None])
+                block = CorrBlock(v.fmaps[ii_v, 0][None], v.fmaps[jj_v, c][None], out=self._pyramid_arena(len(ii_v), ht, wd))
+                # the update operator's full-batch activations (~3.5 KB per edge-pixel) are allocated inside the first step:
+                # reserve them now, while nothing of this call has been written, so that an out-of-memory condition (other
+                # tenants of the device) still falls back to the alt-correlation loop with the state untouched
+                probe = torch.empty(len(ii_v) * ht * wd * 3584, dtype=torch.uint8, device=self.device)
+                del probe
             except torch.cuda.OutOfMemoryError:
                 if corr == "pyramid":
                     raise
                 block = None                                        # "auto": fall through to the alt-correlation loop
+                self._arena = None
                 torch.cuda.empty_cache()
             if block is not None:
                 for _ in range(steps):

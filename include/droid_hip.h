@@ -197,6 +197,11 @@ int dh_ba_build(const float* poses, const float* disps, const float* intrinsics,
                 int num_frames, int n_edges, int n_eta_rows, int ht, int wd,
                 int t0, int t1, int motion_only,
                 double** Hsys_out, double** bsys_out, void* workspace, size_t workspace_bytes, dh_stream_t stream);
+/* Views into a workspace after dh_ba_build (non-motion-only): Qinv = 1 / C and w of the depth blocks, [K, ht*wd] f32, rows
+ * ordered like kx [K] (sorted source frames; *K_out points at the DEVICE int K) = `C`, `w` of the reference's ba_cuda
+ * (src/droid_kernels.cu:1407-1408; the stage its accum_cuda calls feed, :957-1007). */
+int dh_ba_depth_blocks(const void* workspace, size_t workspace_bytes, int num_frames, int n_edges, int ht, int wd,
+                       int t0, int t1, const float** Qinv_out, const float** w_out, const int** kx_out, const int** K_out);
 int dh_ba_finish(float* poses, float* disps, const int64_t* jj,
                  int num_frames, int n_edges, int ht, int wd, int t0, int t1,
                  float lm, float ep, int motion_only, float* dx_out, float* dz_out,

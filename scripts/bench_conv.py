@@ -2,7 +2,8 @@
 """Micro-benchmark of the implicit-GEMM convolution shapes of the update operator (one MI355X)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "droid-slam_amd")]
+# DH_ABLATION_BUILD=1: the -DDH_ABLATION library (droid-slam_amd/ablation/), for the kernels that only exist there
+sys.path[:0] = [ROOT] + ([os.path.join(ROOT, "droid-slam_amd", "ablation")] if os.environ.get("DH_ABLATION_BUILD") else []) + [os.path.join(ROOT, "droid-slam_amd")]
 import torch
 import droid_backends as db
 from droid_amd.update import pack_conv, pack_conv_halo, pack_conv_wino, EPI_RELU, EPI_LINEAR, LAYOUT_WINO

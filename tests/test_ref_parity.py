@@ -273,6 +273,16 @@ def test_reduced_camera_system_vs_reference(db, ref, cfg):
     scale = np.maximum(blk(H), 1e-3 * np.abs(H).max())
     assert (err / scale).max() <= 2e-4
     assert np.abs(bm - b).max() <= 1e-5 * np.abs(b).max() + 1e-5 * np.abs(H).max() * 1e-3
+    # the depth blocks themselves (accum_cuda of Cii / bz + the eta / sensor-depth terms, droid_kernels.cu:957-1007,1405-1408):
+    # C and w per source frame, fp32 sums of <= deg(frame) terms on both sides
+    qinv, wq, kx, K = db.ba_depth_blocks(ws, dev(g["disps"]), dev(g["jj"]), t0, t1)
+    K = int(K.item())
+    assert K == C.shape[0] == w.shape[0]
+    want_kx = np.unique(np.concatenate([np.arange(t0, t1), g["ii"]]))
+    assert np.array_equal(kx[:K].cpu().numpy(), want_kx)
+    Cm = 1.0 / qinv[:K].cpu().numpy().astype(np.float64)
+    assert (np.abs(Cm - C) / np.abs(C)).max() <= 1e-5
+    assert np.abs(wq[:K].cpu().numpy() - w).max() <= 1e-5 * np.abs(w).max()
 
 
 # ------------------------------------------------------------------------------------------ correlation lookups
