@@ -1195,9 +1195,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(ConvParams P) {
   else conv_epilogue<EPI, 2, 4>(P, acc, (long)P.N * HW, m0, n0, wm0, wn0, lane, HW);
 }
 
-// ---- 3x3, 64-cout tile in the SECOND form (option conv_halo64): the flow encoder's 128 -> 64 layer ----------------------------------
-// That layer runs in the first-generation halo kernel (conv3x3_halo_kernel<.., 64>: eight waves of 64 px x 32 couts, weights staged
-// through registers) at 0.80-0.90 PFLOP/s where the 128-cout layers reach 1.0-1.1 on the same operands.  This is conv3x3_halo4_kernel
+#endif  // DH_ABLATION
+
+// ---- 3x3, 64-cout tile in the SECOND form (option conv_halo64, on by default since round 5): the flow encoder's 128 -> 64 layer -------
+// That layer ran in the first-generation halo kernel (conv3x3_halo_kernel<.., 64>: eight waves of 64 px x 32 couts, weights staged
+// through registers) at 0.75-0.90 PFLOP/s where the 128-cout layers reach 1.0-1.1 on the same operands; measured at 4096 edges on one
+// box (profiles/r05_b_conv_halo64_ab.txt): 2.464 ms -> 1.827 ms (0.30 -> 0.41 of the fp16 MFMA peak).  This is conv3x3_halo4_kernel
 // with half the couts: four waves, a wave owns one image row and all 64 couts (2 x 2 accumulator tiles, the production wave tile), the
 // (32-channel chunk, kernel row) weight groups arrive by LDS-DMA into two 12-KB buffers -- 50 KB of LDS, three workgroups per CU.
 // Weights: the conv3x3_halo2_kernel layout of the layer padded to 128 couts (droid_amd.update.pack_conv_halo under this option); a
@@ -1317,7 +1320,6 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo64_kernel(ConvParams P) {
 #undef GLDS16S
   staged_epilogue<EPI, 2, 64, 256>(P, acc, s_conv, m0, n0, wm0, wn0, tid, HW);
 }
-#endif  // DH_ABLATION
 
 #ifdef DH_ABLATION   // 512-pixel-tile form: measured equal in energy, slower in time (profiles/r04_d_conv_halo3_ab.json): not in release builds
 // ---- 3x3, 128-cout tile, THIRD form: 512-pixel tile (8 image rows), 128 x 64 per wave -- opt-in (option conv_halo3) -----------
@@ -2048,9 +2050,18 @@ int launch_halo4(const ConvParams& P0, hipStream_t st) {
   return DH_OK;
 }
 
+#endif  // DH_ABLATION
+
+// the rule under which droid_amd.update.pack_conv_halo lays a 64-cout 3x3 layer out as the halo2 layout of the layer padded to 128
+// couts (read by BOTH sides: a launch that cannot take conv3x3_halo64_kernel must then not hand `weights_halo` to the first halo kernel)
+inline bool halo64_layout(const ConvParams& P) {
+  return opts().conv_halo64 && opts().conv_halo2 && P.KH == 3 && P.KW == 3 && P.CoutPad == 64 && P.Ctot % H2CK == 0;
+}
+
 // conv3x3_halo64_kernel: 3x3, Cout <= 64 = CoutPad, W == 64, H % 4 == 0, 32-channel segments, fp16 output through the staged epilogue;
 // `weights_halo` must be the halo2 layout of the layer padded to 128 couts (the packer follows the same option)
 inline bool halo64_ok(const ConvParams& P) {
+  if (!halo64_layout(P)) return false;
   if (!opts().conv_halo64 || !opts().conv_halo || !P.wt_halo || P.KH != 3 || P.KW != 3 || P.W != 64 || P.H % 4 || P.CoutPad != 64) return false;
   if (P.Ctot % H2CK || P.cinit || P.out_f32 || P.gterm) return false;
   for (int i = 0; i < P.nseg; ++i) if (P.segC[i] % H2CK) return false;
@@ -2068,7 +2079,6 @@ int launch_halo64(const ConvParams& P0, hipStream_t st) {
   DH_LAUNCH_CHECK();
   return DH_OK;
 }
-#endif  // DH_ABLATION
 
 #ifdef DH_ABLATION
 template <int EPI>
@@ -2207,6 +2217,7 @@ bool glo_ok(const ConvParams& P) {
 // small-Cout convolutions (CoutPad == 32 or 64): bound by re-reading the activations in the generic loop
 bool halo_small_ok(const ConvParams& P, int bn) {
   if (P.cinit) return false;
+  if (bn == 64 && halo64_layout(P)) return false;           // weights_halo holds the padded halo2 layout (conv3x3_halo64_kernel's): generic loop
   if (!P.wt_halo || P.KH != 3 || P.KW != 3 || P.W != 64 || P.H % 4 || P.CoutPad != bn) return false;
   for (int i = 0; i < P.nseg; ++i) if (P.segC[i] % (halo_afc(bn) * halo_ck(bn))) return false;
   return true;
@@ -2465,8 +2476,8 @@ extern "C" int dh_conv2d_nhwc_f16_ex2(const void* const* inputs, const int* in_c
     }
   }
 #endif
-#ifdef DH_ABLATION
   if (halo64_ok(P)) return P.epi == EPI_RELU ? launch_halo64<EPI_RELU>(P, st) : launch_halo64<EPI_LINEAR>(P, st);
+#ifdef DH_ABLATION
   if (opts().conv_halo4 && !(P.epi == EPI_LINEAR && P.out_f32)) {                      // measurement variant: four 64 x 128 waves per workgroup
     switch (P.epi) {
       case EPI_LINEAR: if (halo2_ok<EPI_LINEAR>(P)) return launch_halo4<EPI_LINEAR>(P, st); break;

@@ -36,13 +36,13 @@ Options& opts() {
     v.conv_abl = env_int("DH_CONV_ABL", 0);
     v.conv_halo3 = env_int("DH_CONV_HALO3", 0);
     v.conv_halo4 = env_int("DH_CONV_HALO4", 0);
-    v.conv_halo64 = env_int("DH_CONV_HALO64", 0);
+    v.conv_halo64 = env_int("DH_CONV_HALO64", 1);
 #ifndef DH_ABLATION
     // release build: the prototype / timing-ablation kernels are not compiled in; a stray environment variable cannot
     // select a variant that returns wrong results (lookup_mode 2-5) or does not exist
     if (v.lookup_mode != 1 && v.lookup_mode != 6) v.lookup_mode = 0;
     if (v.chol_lookahead != 0) v.chol_lookahead = 1;
-    v.conv_dma = 0; v.dma_var = 0; v.pyr_build_chunk = 0; v.altcorr_v1 = 0; v.conv_wino = 0; v.conv_abl = 0; v.conv_halo3 = 0; v.conv_halo4 = 0; v.conv_halo64 = 0; v.lookup_fill = 0;
+    v.conv_dma = 0; v.dma_var = 0; v.pyr_build_chunk = 0; v.altcorr_v1 = 0; v.conv_wino = 0; v.conv_abl = 0; v.conv_halo3 = 0; v.conv_halo4 = 0; v.lookup_fill = 0;
 #endif
     return v;
   }();
@@ -58,7 +58,7 @@ static bool allowed(const char* name, int value) {
   if (!strcmp(name, "chol_lookahead")) return value == 0 || value == 1;                 // 2: dataflow schedule, -DDH_ABLATION builds
   if (!strcmp(name, "lookup_mode")) return value == 0 || value == 1 || value == 6;      // 1: nt tap loads, 6: synchronous twin -- same results (2-5, 7: timing ablations)
   if (!strcmp(name, "conv_dma") || !strcmp(name, "dma_var") || !strcmp(name, "pyr_build_chunk") || !strcmp(name, "altcorr_v1") ||
-      !strcmp(name, "conv_wino") || !strcmp(name, "conv_abl") || !strcmp(name, "conv_halo3") || !strcmp(name, "conv_halo4") || !strcmp(name, "conv_halo64") || !strcmp(name, "lookup_fill"))
+      !strcmp(name, "conv_wino") || !strcmp(name, "conv_abl") || !strcmp(name, "conv_halo3") || !strcmp(name, "conv_halo4") || !strcmp(name, "lookup_fill"))
     return value == 0;
   return true;
 #endif

@@ -107,6 +107,8 @@ class DistBA:
         self.world = dist.get_world_size(group) if (world is None and dist.is_initialized()) else (world or 1)
         self.group = group
         self.frame_lo, self.frame_hi = frame_lo, frame_hi
+        self._owned_given = (frame_lo, frame_hi) != (0, 1 << 30)   # the defaults mean "owns everything": only right for one rank
+        self._partition_ok = None       # (lo, hi, F) of the last validated ownership partition
         if backend is None:
             import droid_backends as backend          # HIP path; fails loudly without the extension
         self.be = backend
@@ -151,6 +153,28 @@ class DistBA:
 
     def set_owned_frames(self, lo, hi):
         self.frame_lo, self.frame_hi = int(lo), int(hi)
+        self._owned_given = True
+        self._partition_ok = None
+
+    def _validate_partition(self, lo, hi, F, device):
+        """The final depth exchange zeroes the maps a rank does not own and SUMS: right only if the ranks' [lo, hi) ranges
+        partition [0, F) exactly.  Checked once per (lo, hi, F) with one small all-reduce of per-frame ownership counts
+        (a frame owned twice would come out multiplied, an unowned one zeroed) -- every rank raises together."""
+        if self._partition_ok == (lo, hi, F):
+            return
+        if self.world > 1 and not self._owned_given:
+            raise RuntimeError("DistBA: world size %d but set_owned_frames() was never called: every rank would claim all "
+                               "depth maps and the final exchange would multiply them by the world size" % self.world)
+        if self.world > 1 or self.always_reduce:
+            own = torch.zeros(F, dtype=torch.int32, device=device)
+            own[lo:hi] = 1
+            self._allreduce(own)
+            bad = torch.nonzero(own != 1)[:, 0]
+            if bad.numel():
+                f = int(bad[0].item())
+                raise RuntimeError("DistBA: the ranks' owned frame ranges do not partition [0, %d): frame %d has %d owners "
+                                   "(%d frames affected)" % (F, f, int(own[f].item()), int(bad.numel())))
+        self._partition_ok = (lo, hi, F)
 
     def _allreduce(self, t):
         if self.world > 1 or self.always_reduce:
@@ -187,6 +211,8 @@ class DistBA:
            iterations=2, lm=1e-4, ep=0.1, motion_only=False):
         F = disps.shape[0]
         lo, hi = max(0, self.frame_lo), min(F, self.frame_hi)
+        if not motion_only:
+            self._validate_partition(lo, hi, F, disps.device)
         args = (poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1, iterations, lm, ep, motion_only, lo, hi)
         packed = self._pattern is not None and self._pattern[:2] == (int(t0), int(t1))
         # host-side and cached per edge list; a stale pattern is reported THROUGH the exchange, never by a rank-local decision

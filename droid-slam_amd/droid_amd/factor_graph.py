@@ -19,6 +19,7 @@ import torch
 import droid_backends as db
 from .corr import CorrBlock, CorrBlockRef, AltCorrBlock
 from ._cache import tensor_cache_key
+from .trace import roctx_range
 
 
 class FactorGraph:
@@ -158,28 +159,33 @@ class FactorGraph:
 
     def update(self, t0=None, t1=None, itrs=2, use_inactive=False, EP=1e-7, motion_only=False):
         ii, jj = self.ii, self.jj
-        coords1 = self.video.reproject(ii, jj)[0][0]                                          # [E,h,w,2]
+        with roctx_range("droid.update/reproject"):
+            coords1 = self.video.reproject(ii, jj)[0][0]                                      # [E,h,w,2]
         if self.corr_impl != "volume":
             raise RuntimeError("update() needs corr_impl='volume' (use update_lowmem for 'alt')")
-        if self._native_corr:
-            feats, corr0 = self._pyramid_features(self.corr, coords1)
-        else:
-            feats, corr0 = self.update_op.corr_to_nhwc(self.corr(coords1[None])[0]), None
-        dw, damping, upmask, uniq = self._operator(self._net, coords1, self.target[0].contiguous(), feats, ii, corr0)
+        with roctx_range("droid.update/corr_lookup"):
+            if self._native_corr:
+                feats, corr0 = self._pyramid_features(self.corr, coords1)
+            else:
+                feats, corr0 = self.update_op.corr_to_nhwc(self.corr(coords1[None])[0]), None
+        with roctx_range("droid.update/update_operator"):
+            dw, damping, upmask, uniq = self._operator(self._net, coords1, self.target[0].contiguous(), feats, ii, corr0)
         if t0 is None:
             t0 = max(1, ii.min().item() + 1)
-        target, weight, tb, wb = db.ba_inputs(coords1, dw)
-        self.target, self.weight = target[None], weight[None]
-        self.damping[uniq] = damping
-        if use_inactive:
-            m = (self.ii_inac >= t0 - 3) & (self.jj_inac >= t0 - 3)
-            ii = torch.cat([self.ii_inac[m], ii]); jj = torch.cat([self.jj_inac[m], jj])
-            tb = torch.cat([self.target_inac[0, m].permute(0, 3, 1, 2), tb]).contiguous()
-            wb = torch.cat([self.weight_inac[0, m].permute(0, 3, 1, 2), wb]).contiguous()
-        eta = (.2 * self.damping[torch.unique(ii)] + EP).contiguous()
-        self.video.ba(tb, wb, eta, ii, jj, t0, t1, itrs=itrs, lm=1e-4, ep=0.1, motion_only=motion_only)
+        with roctx_range("droid.update/ba"):
+            target, weight, tb, wb = db.ba_inputs(coords1, dw)
+            self.target, self.weight = target[None], weight[None]
+            self.damping[uniq] = damping
+            if use_inactive:
+                m = (self.ii_inac >= t0 - 3) & (self.jj_inac >= t0 - 3)
+                ii = torch.cat([self.ii_inac[m], ii]); jj = torch.cat([self.jj_inac[m], jj])
+                tb = torch.cat([self.target_inac[0, m].permute(0, 3, 1, 2), tb]).contiguous()
+                wb = torch.cat([self.weight_inac[0, m].permute(0, 3, 1, 2), wb]).contiguous()
+            eta = (.2 * self.damping[torch.unique(ii)] + EP).contiguous()
+            self.video.ba(tb, wb, eta, ii, jj, t0, t1, itrs=itrs, lm=1e-4, ep=0.1, motion_only=motion_only)
         if self.upsample:
-            self.video.upsample(uniq, upmask)
+            with roctx_range("droid.update/upsample"):
+                self.video.upsample(uniq, upmask)
         self.age += 1
 
     # ---- global BA (factor_graph.py:266-330) --------------------------------------------------------------------------
@@ -218,7 +224,8 @@ class FactorGraph:
             wb = torch.cat([self.weight_inac[0].permute(0, 3, 1, 2), wb]).contiguous()
         eta = (.2 * self.damping[torch.unique(ii)] + EP).contiguous()
         self.age += 1
-        self.video.ba(tb, wb, eta, ii, jj, 1, t, itrs=itrs, lm=1e-5, ep=1e-2, motion_only=False)
+        with roctx_range("droid.update_lowmem/ba"):
+            self.video.ba(tb, wb, eta, ii, jj, 1, t, itrs=itrs, lm=1e-5, ep=1e-2, motion_only=False)
         self.video.dirty[:t] = True
 
     def update_lowmem(self, t0=None, t1=None, itrs=2, use_inactive=False, EP=1e-7, steps=8, corr="auto"):
@@ -248,7 +255,8 @@ class FactorGraph:
             ii_v, jj_v = (self.ii, self.jj) if sel is None else (self.ii[sel], self.jj[sel])
             c = (ii_v == jj_v).long() if rig > 1 else torch.zeros_like(ii_v)
             try:
-                block = CorrBlock(v.fmaps[ii_v, 0][None], v.fmaps[jj_v, c][None], out=self._pyramid_arena(len(ii_v), ht, wd))
+                with roctx_range("droid.update_lowmem/pyramid_build"):
+                    block = CorrBlock(v.fmaps[ii_v, 0][None], v.fmaps[jj_v, c][None], out=self._pyramid_arena(len(ii_v), ht, wd))
                 # the update operator's full-batch activations (~3.5 KB per edge-pixel) are allocated inside the first step:
                 # reserve them now, while nothing of this call has been written, so that an out-of-memory condition (other
                 # tenants of the device) still falls back to the alt-correlation loop with the state untouched
@@ -262,13 +270,16 @@ class FactorGraph:
                 torch.cuda.empty_cache()
             if block is not None:
                 for _ in range(steps):
-                    coords_all = v.reproject(self.ii, self.jj)[0][0]
+                    with roctx_range("droid.update_lowmem/reproject"):
+                        coords_all = v.reproject(self.ii, self.jj)[0][0]
                     if sel is None:
                         coords1, net, target_prev = coords_all, self._net, self.target[0].contiguous()
                     else:
                         coords1, net, target_prev = coords_all[sel].contiguous(), self._net[sel].contiguous(), self.target[0][sel].contiguous()
-                    feats, corr0 = self._pyramid_features(block, coords1)
-                    dw, damping, upmask, uniq = self._operator(net, coords1, target_prev, feats, ii_v, corr0)
+                    with roctx_range("droid.update_lowmem/corr_lookup"):
+                        feats, corr0 = self._pyramid_features(block, coords1)
+                    with roctx_range("droid.update_lowmem/update_operator"):
+                        dw, damping, upmask, uniq = self._operator(net, coords1, target_prev, feats, ii_v, corr0)
                     target, weight, tb, wb = db.ba_inputs(coords1, dw)
                     if sel is not None:                                 # unvisited edges keep what they had
                         self._net[sel] = net

@@ -108,7 +108,7 @@ def pack_conv_halo(weight):
         return None
     cp = _round_up(cout, 32)                # CoutPad of pack_conv
     if cp == 64 and droid_backends.get_option("conv_halo64") and droid_backends.get_option("conv_halo2"):
-        cp = 128                            # conv3x3_halo64_kernel (-DDH_ABLATION builds) reads the halo2 layout of the layer padded to 128 couts
+        cp = 128                            # conv3x3_halo64_kernel reads the halo2 layout of the layer padded to 128 couts (csrc/conv.hip halo64_layout)
     w = torch.zeros(cp, ctot, 9, dtype=torch.float32, device=weight.device)
     w[:cout] = weight.float().reshape(cout, ctot, 9)
     if _dma_layout(cp, ctot):

@@ -2,7 +2,13 @@
 """Generate tests/golden/graph_c2_python.npz and graph_stereo_python.npz by running the REFERENCE's own factor_graph.py +
 depth_video.py + modules/corr.py + droid_net.py, unmodified, on CPU (build container only: needs /root/reference):
 
-    python tests/golden/make_graph_scale_golden.py [stereo] [c2] [tum] [wide] [c3]
+    python tests/golden/make_graph_scale_golden.py [stereo] [c2] [tum] [wide] [c3] [--probe]
+
+--probe (c2 / c3 only): the same scenario with the stored feature / hidden-state / context maps (fmaps, nets, inps) moved by ONE
+fp16 ulp on half of their values (seeded) -> /tmp/graph_<cfg>_probe.npz, and the movement of every quantity the composed tests
+of tests/test_scale_gpu.py assert, in the tests' own metrics, -> tests/golden/graph_scale_probe.json.  That file calibrates the
+tests' tolerances: an implementation that rounds differently somewhere (accumulation order, fp16 stores) moves the outputs by
+about what a rounding-level change of the inputs does.
 
 Same replacements as make_graph_golden.py (droid_backends -> oracle-backed shim, lietorch / torch_scatter shims, the two
 hard-coded "cuda" devices); the update operator runs under torch.autocast(fp16) like under factor_graph.py's decorators.
@@ -30,7 +36,66 @@ from droid_amd import synthetic as syn
 from droid_amd.weights import fill_deterministic
 from golden_inputs import graph_scenario, C2_SAMPLE_EDGES, stereo_scenario
 
+PROBE = "--probe" in sys.argv
 ref_dv, ref_fg, ref_net = base.ref_dv, base.ref_fg, base.ref_net
+
+
+def perturb_one_ulp(g, seed=77):
+    """fmaps / nets / inps (fp16) moved by one ulp on half of their values: the bit pattern +-1 (sign-magnitude, so +1 on the
+    pattern = one ulp away from zero, -1 = one ulp towards zero); zeros and the largest finite values are left alone"""
+    rng = np.random.default_rng(seed)
+    for k in ("fmaps", "nets", "inps"):
+        a = np.ascontiguousarray(g[k]).astype(np.float16)
+        bits = a.view(np.uint16).copy()
+        mag = bits & 0x7FFF
+        move = rng.random(bits.shape) < 0.5
+        up = rng.random(bits.shape) < 0.5
+        ok = move & (mag > 0) & (mag < 0x7BFF)
+        bits = np.where(ok & up, bits + 1, np.where(ok & ~up, bits - 1, bits)).astype(np.uint16)
+        g[k] = bits.view(np.float16).reshape(a.shape)
+    return g
+
+
+def _rot_angle(q, qr):
+    v = q[:, 3:4] * -qr[:, :3] + qr[:, 3:4] * q[:, :3] + np.cross(q[:, :3], -qr[:, :3])
+    return 2 * np.linalg.norm(v, axis=-1)
+
+
+def probe_report(cfg, G, P):
+    """movement golden -> perturbed run, per iteration, in the metrics of tests/test_scale_gpu.py's composed tests"""
+    import json
+    f64 = lambda a: np.asarray(a, dtype=np.float64)
+    rep = {}
+    for tag in ("U1", "U2"):
+        r = {}
+        p, rp = f64(P[tag + "_poses"]), f64(G[tag + "_poses"])
+        r["pose_trans_max"] = float(np.abs(p[:, :3] - rp[:, :3]).max())
+        r["pose_rot_max_rad"] = float(_rot_angle(p[:, 3:], rp[:, 3:]).max())
+        dk = tag + ("_disps" if tag + "_disps" in G else "_disps_f")
+        e = np.abs(f64(P[dk]) - f64(G[dk])) / np.maximum(1.0, np.abs(f64(G[dk])))
+        r["disps_rel_q99"], r["disps_rel_max"] = float(np.quantile(e, 0.99)), float(e.max())
+        if tag + "_disps_mean" in G:
+            r["disps_frame_mean_max"] = float(np.abs(f64(P[tag + "_disps_mean"]) - f64(G[tag + "_disps_mean"])).max())
+        r["net_s_max"] = float(np.abs(f64(P[tag + "_net_s"]) - f64(G[tag + "_net_s"])).max())
+        t = np.abs(f64(P[tag + "_target_s"]) - f64(G[tag + "_target_s"]))
+        r["target_s_q999"], r["target_s_max"] = float(np.quantile(t, 0.999)), float(t.max())
+        r["weight_s_max"] = float(np.abs(f64(P[tag + "_weight_s"]) - f64(G[tag + "_weight_s"])).max())
+        mk = tag + ("_damping" if tag + "_damping" in G else "_damping_f")
+        r["damping_rel_max"] = float(np.abs(f64(P[mk]) - f64(G[mk])).max() / np.abs(f64(G[mk])).max())
+        if tag + "_damping_mean" in G:
+            r["damping_frame_mean_rel_max"] = float(np.abs(f64(P[tag + "_damping_mean"]) - f64(G[tag + "_damping_mean"])).max() / np.abs(f64(G[tag + "_damping_mean"])).max())
+        r["flow_mean_max"] = float(np.abs(f64(P[tag + "_flow_mean"]) - f64(G[tag + "_flow_mean"])).max())
+        r["weight_mean_max"] = float(np.abs(f64(P[tag + "_weight_mean"]) - f64(G[tag + "_weight_mean"])).max())
+        r["net_absmean_max"] = float(np.abs(f64(P[tag + "_net_absmean"]) - f64(G[tag + "_net_absmean"])).max())
+        rep[tag] = r
+        print("probe %s %s: %s" % (cfg, tag, "  ".join("%s %.2e" % kv for kv in r.items())), flush=True)
+    path = os.path.join(HERE, "graph_scale_probe.json")
+    allp = json.load(open(path)) if os.path.exists(path) else {}
+    allp[cfg] = rep
+    allp["_about"] = ("movement of the composed goldens (reference factor_graph.py on CPU, tests/golden/make_graph_scale_golden.py) when "
+                      "fmaps / nets / inps move by one fp16 ulp on half of their values (--probe); metrics = those asserted by "
+                      "tests/test_scale_gpu.py::test_composed_update_at_c{2,3}_matches_reference_factor_graph")
+    json.dump(allp, open(path, "w"), indent=1, sort_keys=True)
 import modules.corr as ref_corr                    # reference (already imported by factor_graph.py)
 
 
@@ -63,6 +128,8 @@ def snap(out, tag, video, fg, N, sample=None):
 
 def scenario_c2():
     g = syn.make_graph("C2", with_features=True)
+    if PROBE:
+        g = perturb_one_ulp(g)
     N, ht, wd = g["n_frames"], g["ht"], g["wd"]
     video = ref_dv.DepthVideo(image_size=[8 * ht, 8 * wd], buffer=N + 2, stereo=False, device="cpu")
     video.poses[:N] = torch.as_tensor(g["poses"]); video.disps[:N] = torch.as_tensor(g["disps"])
@@ -83,6 +150,9 @@ def scenario_c2():
             fg.update(t0=1, t1=None, itrs=2, use_inactive=False)
             print("C2 update %d: %.1f s" % (k, time.time() - t), flush=True)
             snap(out, "U%d" % k, video, fg, N, sample)
+    if PROBE:
+        np.savez_compressed("/tmp/graph_c2_probe.npz", **out)
+        return probe_report("C2", np.load(os.path.join(HERE, "graph_c2_python.npz")), out)
     np.savez_compressed(os.path.join(HERE, "graph_c2_python.npz"), **out)
     print("graph_c2: |dpose| %.3e %.3e  |ddisp| %.3e %.3e" % (
         np.abs(out["U1_poses"] - g["poses"]).max(), np.abs(out["U2_poses"] - g["poses"]).max(),
@@ -234,6 +304,8 @@ def scenario_c3():
     |hidden state| for ALL 4096 edges."""
     from golden_inputs import C3_SAMPLE_EDGES, C3_SAMPLE_FRAMES
     g = syn.make_graph("C3", with_features=True)
+    if PROBE:
+        g = perturb_one_ulp(g)
     N, ht, wd = g["n_frames"], g["ht"], g["wd"]
     video = ref_dv.DepthVideo(image_size=[8 * ht, 8 * wd], buffer=N + 2, stereo=False, device="cpu")
     video.poses[:N] = torch.as_tensor(g["poses"]); video.disps[:N] = torch.as_tensor(g["disps"])
@@ -267,12 +339,16 @@ def scenario_c3():
                 out[tag + "_net_absmean"] = torch.stack([net[s:s + 256].float().abs().mean(dim=(1, 2, 3)) for s in range(0, net.shape[0], 256)]).reshape(-1).numpy().copy()
     finally:
         ref_fg.CorrBlock = ref_corr.CorrBlock
+    if PROBE:
+        np.savez_compressed("/tmp/graph_c3_probe.npz", **out)
+        return probe_report("C3", np.load(os.path.join(HERE, "graph_c3_python.npz")), out)
     np.savez_compressed(os.path.join(HERE, "graph_c3_python.npz"), **out)
     print("graph_c3: |dpose| %.3e %.3e" % (np.abs(out["U1_poses"] - g["poses"]).max(), np.abs(out["U2_poses"] - g["poses"]).max()))
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["stereo", "c2", "tum"]
+    which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["stereo", "c2", "tum"]
+    assert not PROBE or set(which) <= {"c2", "c3"}, "--probe exists for c2 / c3"
     if "tum" in which:
         scenario_tum_size()
     if "wide" in which:

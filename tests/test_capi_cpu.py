@@ -177,7 +177,27 @@ def test_convolution_weight_packing_layouts(built):
     # small cout tiles: 32-channel slabs, cout padded to the tile
     p = U.pack_conv_halo(torch.randn(4, 256, 3, 3).half())
     assert tuple(p.shape) == (1, 8, 9, 32, 32) and torch.count_nonzero(p[0, :, :, 4:]) == 0
-    assert tuple(U.pack_conv_halo(torch.randn(64, 128, 3, 3).half()).shape) == (1, 4, 9, 64, 32)
+    # 64-cout layers (flow_encoder.2): conv3x3_halo64_kernel (option conv_halo64, default 1) reads the halo2 layout of the layer PADDED
+    # to 128 couts -- rows 64..127 zero; with the option off, the first halo kernel's 64-cout slabs
+    saved64 = db.get_option("conv_halo64")
+    assert saved64 == 1
+    w64 = torch.randn(64, 128, 3, 3).half()
+    p = U.pack_conv_halo(w64)
+    assert tuple(p.shape) == (1, 4, 3, 3, 128, 4, 8) and torch.count_nonzero(p[:, :, :, :, 64:]) == 0
+    for _ in range(500):
+        c, dy, dx, r, sp, e = (rnd.randrange(n) for n in (4, 3, 3, 64, 4, 8))
+        assert p[0, c, dy, dx, r, sp, e] == w64[r, c * 32 + (sp ^ ((r >> 2) & 3)) * 8 + e, dy, dx]
+    p48 = U.pack_conv_halo(torch.randn(48, 128, 3, 3).half())                       # CoutPad = 64 as well
+    assert tuple(p48.shape) == (1, 4, 3, 3, 128, 4, 8) and torch.count_nonzero(p48[:, :, :, :, 48:]) == 0
+    db.set_option("conv_halo64", 0)
+    p = U.pack_conv_halo(w64)
+    assert tuple(p.shape) == (1, 4, 9, 64, 32)
+    for _ in range(200):
+        c, t, r, e = (rnd.randrange(n) for n in (4, 9, 64, 32))
+        assert p[0, c, t, r, e] == w64[r, c * 32 + e, t // 3, t % 3]
+    db.set_option("conv_halo64", 1); db.set_option("conv_halo2", 0)                 # the padded layout needs the halo2 rule too
+    assert tuple(U.pack_conv_halo(w64).shape) == (1, 4, 9, 64, 32)
+    db.set_option("conv_halo2", 1); db.set_option("conv_halo64", saved64)
     assert U.pack_conv_halo(torch.randn(128, 8, 7, 7).half()) is None              # not a 3x3 kernel
     # correlation channel map: our level-planar (yoff, xoff) order against the reference's (xoff, yoff) order
     m = U.corr_channel_map()

@@ -142,6 +142,49 @@ def test_sharded_ba_two_ranks_gloo(tmp_path, packed):
     assert np.abs(got["disps"] - d).max() < 1e-5 * max(1.0, np.abs(d).max())
 
 
+def _bad_partition_worker(rank, world, port, mode, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from droid_amd import synthetic as syn
+        from droid_amd.dist_ba import DistBA, shard_edges_by_source_frame, local_eta_rows
+        g = syn.small_graph(n_frames=7, seed=11, ht=8, wd=12, radius=3)
+        t0, t1 = 1, g["n_frames"]
+        shards, bounds = shard_edges_by_source_frame(g["ii"], world)
+        mine = shards[rank]
+        rows, _ = local_eta_rows(g["ii"], g["ii"][mine], t0, t1)
+        T = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a)).to(dt)
+        poses, disps = T(g["poses"]), T(g["disps"])
+        solver = DistBA(world, backend=OracleBackend())
+        if mode == "overlap":                                  # frame bounds[1] owned by both ranks
+            solver.set_owned_frames(bounds[rank], bounds[rank + 1] + (1 if rank == 0 else 0))
+        elif mode == "gap":                                    # frame bounds[1] owned by nobody
+            solver.set_owned_frames(bounds[rank] + (1 if rank == 1 else 0), bounds[rank + 1])
+        msg = ""
+        try:
+            solver.ba(poses, disps, T(g["intrinsics"]), T(g["disps_sens"]), T(g["targets"][mine]), T(g["weights"][mine]),
+                      T(g["eta"][rows]), T(g["ii"][mine], torch.int64), T(g["jj"][mine], torch.int64), t0, t1, 2, 1e-4, 0.1)
+        except RuntimeError as exc:
+            msg = str(exc)
+        unchanged = bool(np.array_equal(disps.numpy(), g["disps"].astype(np.float64)))
+        open("%s.%d" % (out, rank), "w").write("%d|%s" % (unchanged, msg))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["never_set", "overlap", "gap"])
+def test_ownership_ranges_that_do_not_partition_the_frames_are_refused_on_every_rank(tmp_path, mode):
+    """the final depth exchange zeroes the maps a rank does not own and SUMS: ranges that overlap, leave a gap, or were never
+    set (the constructor default = everything) would multiply / zero depth maps silently -- every rank raises before anything moves"""
+    out = str(tmp_path / "r")
+    port = 29700 + (os.getpid() % 2000) + {"never_set": 0, "overlap": 5, "gap": 9}[mode]
+    mp.spawn(_bad_partition_worker, args=(2, port, mode, out), nprocs=2, join=True)
+    for rank in (0, 1):
+        unchanged, msg = open("%s.%d" % (out, rank)).read().split("|", 1)
+        assert unchanged == "1"
+        assert ("set_owned_frames() was never called" in msg) if mode == "never_set" else ("do not partition" in msg)
+
+
 def test_partition_covers_every_edge_once_and_keeps_source_frames_together():
     from droid_amd.dist_ba import shard_edges_by_source_frame
     rng = np.random.default_rng(0)

@@ -719,12 +719,13 @@ def test_conv2d_nhwc_matches_torch_conv(db, option, halo, dma, halo2):
 
 
 def test_conv_64_cout_layer_in_the_second_kernel_form(db, option):
-    """conv3x3_halo64_kernel (-DDH_ABLATION build, option conv_halo64): the flow encoder's 128 -> 64 layer as four waves of 64 px x 64
-    couts with LDS-DMA weights, against torch's fp32 convolution and against the production kernel (different accumulation order:
-    one fp16 ulp), image borders and two segments included"""
-    if not db.get_option("ablation_build"):
-        pytest.skip("conv3x3_halo64_kernel is only part of a -DDH_ABLATION build (DROID_HIP_TEST_ABLATION=1)")
+    """conv3x3_halo64_kernel (option conv_halo64, the default since round 5): the flow encoder's 128 -> 64 layer as four waves of
+    64 px x 64 couts with LDS-DMA weights, against torch's fp32 convolution and against the first halo kernel (conv_halo64 = 0;
+    different accumulation order: one fp16 ulp), image borders and two segments included.  Then the launches that CANNOT take the
+    kernel while the weights are packed for it (fp32 output; an image that is not 64 wide): they must fall to the generic loop
+    (which reads the plain weight copy), never hand the padded layout to the first halo kernel."""
     from droid_amd.update import pack_conv, pack_conv_halo, EPI_LINEAR, EPI_RELU
+    assert db.get_option("conv_halo64") == 1
     torch.manual_seed(1)
     for (N, H, W, cins, cout) in [(2, 8, 64, (128,), 64), (3, 12, 64, (64, 64), 64), (8, 48, 64, (128,), 64), (1, 4, 64, (32, 96), 48)]:
         xs = [torch.randn(N, H, W, c, device="cuda").half() for c in cins]
@@ -738,13 +739,26 @@ def test_conv_64_cout_layer_in_the_second_kernel_form(db, option):
             outs = []
             for v in (0, 1):
                 option("conv_halo64", v)
+                wh = pack_conv_halo(wgt)
+                assert wh.numel() == (128 if v else 64) * sum(cins) * 9          # padded halo2 layout / the first halo kernel's
                 out = torch.empty(N, H, W, cout, device="cuda", dtype=torch.float16)
-                db.conv2d_nhwc(xs, wp, pack_conv_halo(wgt), bp, 3, 3, cout, epi, out, cout, None, None, None, None)
+                db.conv2d_nhwc(xs, wp, wh, bp, 3, 3, cout, epi, out, cout, None, None, None, None)
                 torch.cuda.synchronize()
                 assert (out.float() - want).abs().max() <= 1e-2 * max(1.0, want.abs().max().item()), (v, N, H, cins, cout)
                 outs.append(out.float())
-            option("conv_halo64", 0)
             assert (outs[0] - outs[1]).abs().max() <= 2.0 ** -9 * max(1.0, want.abs().max().item())
+    # ---- launches outside the kernel's domain with the padded layout in `weights_halo`
+    option("conv_halo64", 1)
+    for (N, H, W, f32_out) in [(2, 8, 64, True), (2, 8, 32, False), (1, 6, 64, False)]:
+        xs = [torch.randn(N, H, W, 128, device="cuda").half()]
+        wgt = torch.randn(64, 128, 3, 3, device="cuda") / (128 * 9) ** 0.5
+        bias = torch.randn(64, device="cuda")
+        wp, bp = pack_conv(wgt, bias)
+        ref = torch.nn.functional.conv2d(xs[0].float().permute(0, 3, 1, 2), wgt.half().float(), bias, padding=1).permute(0, 2, 3, 1)
+        out = torch.empty(N, H, W, 64, device="cuda", dtype=torch.float32 if f32_out else torch.float16)
+        db.conv2d_nhwc(xs, wp, pack_conv_halo(wgt), bp, 3, 3, 64, EPI_LINEAR, out, 64, None, None, None, None, out_raw_f32=f32_out)
+        torch.cuda.synchronize()
+        assert (out.float() - ref).abs().max() <= 1e-2 * max(1.0, ref.abs().max().item()), (N, H, W, f32_out)
 
 
 def test_conv7x7_on_four_channels_and_global_context_kernels(db):
