@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--no-lowmem", action="store_true", help="do not add the update_lowmem line (child process) to the default line")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic in this run (rocprofv3 --pmc pass in a child process)")
     ap.add_argument("--no-sensitivity", action="store_true", help="skip the untimed flow-sensitivity runs of the lookup kernel")
+    ap.add_argument("--no-projection", action="store_true", help="skip the untimed 1/2/4/8-rank projection (dist_projection: the BA timed on the "
+                    "whole graph and on a 1/8 shard to separate its redundant part)")
     ap.add_argument("--lowmem", action="store_true", help="time FactorGraph.update_lowmem steps (the global-BA iteration, "
                     "reference factor_graph.py:266-330) instead of FactorGraph.update steps")
     ap.add_argument("--lowmem-corr", default="auto", choices=["auto", "alt", "pyramid"], help="correlation features of the "
@@ -276,6 +278,54 @@ def cpu_baseline(g, n_lookup_edges=64, n_update_edges=128, repeats=3):
             "host_cores": ncores, "threads": {"ba": th_ba, "lookup": th_lk, "update": th_up},
             "ba_s": t_ba, "lookup_s": t_lk, "update_s": t_up, "ms_per_global_ba_cpu": 1e3 * t_ba,
             "value_1core": 1.0 / per_ep1}
+
+
+def project_ranks(db, g, dev, tensors, lk, up, ba):
+    """PREDICTION, not a measurement (no multi-GPU node is reachable from the build sessions; the round driver's SCALE run is the
+    measurement): the step time of the edge-sharded design at N = 1, 2, 4, 8 ranks, from quantities measured in THIS run:
+      * lookup and update operator are per-edge work -> 1/N of this run's times (the C2 line, 512 edges = the per-rank share at
+        N = 8, runs the operator at 6.35 ms against 49.0 / 8 = 6.1: +4 % small-batch penalty, applied for N > 1);
+      * the BA splits into a part that shards with the edges (build, Gram, depth back-substitution) and a REDUNDANT part every
+        rank repeats (damping, fp64 Cholesky, back solve, retraction): separated here by timing droid_backends.ba on the whole
+        graph and on one rank's shard of 1/8 of the edges (same poses, same solve);
+      * collectives per ba(): `itrs` all-reduces of the packed co-visible blocks + one of the depth maps, priced with the ring
+        formula 2 (N-1)/N x bytes / link_rate + N-proportional hop latency.  link_rate = 100 GB/s (xGMI link 153.6 GB/s peak x 0.65:
+        an ASSUMPTION until the driver's SCALE run), hop latency 6 us."""
+    from droid_amd.dist_ba import shard_edges_by_source_frame, reduced_system_pattern
+    poses0, disps0, intr, sens, tgt, wgt, eta, ii, jj, N = tensors
+    E = int(ii.numel())
+    shards, _ = shard_edges_by_source_frame(g["ii"], 8)
+    mine = torch.as_tensor(shards[0], device=dev)
+
+    def t_ba(sel):
+        a = (tgt, wgt, ii, jj) if sel is None else (tgt[sel].contiguous(), wgt[sel].contiguous(), ii[sel].contiguous(), jj[sel].contiguous())
+
+        def run():
+            p, d = poses0.clone(), disps0.clone()
+            db.ba(p, d, intr, sens, a[0], a[1], eta, a[2], a[3], 1, N, g["itrs"], g["lm"], g["ep"], False)
+        return _time_ms(run, reps=5)
+    t_full, t_shard = t_ba(None), t_ba(mine)
+    frac = len(shards[0]) / float(E)
+    shardable = max(0.0, (t_full - t_shard) / (1.0 - frac))
+    redundant = max(0.0, t_full - shardable)
+    bp, bq = reduced_system_pattern(g["ii"], g["jj"], 1, N)
+    packed_bytes = 8 * (36 * len(bp) + 6 * (N - 1) + 2)
+    disps_bytes = 4 * int(disps0.numel())
+    link, hop = 100e9, 6e-6
+    out = {"kind": "prediction from this run's single-GPU measurements (see bench.py project_ranks); NOT a measurement",
+           "inputs": {"ms_corr_lookup": lk, "ms_update_operator": up, "ms_per_global_ba": ba, "ms_ba_whole_graph_isolated": t_full,
+                      "ms_ba_one_eighth_shard_isolated": t_shard, "ms_ba_sharded_part": shardable, "ms_ba_redundant_part": redundant,
+                      "allreduce_bytes_per_gn_iteration": packed_bytes, "allreduce_bytes_disps": disps_bytes,
+                      "assumed_link_GBs": link / 1e9, "assumed_hop_latency_us": hop * 1e6, "small_batch_penalty": 1.04},
+           "ranks": {}}
+    for n in (1, 2, 4, 8):
+        ar = lambda b: 0.0 if n == 1 else 1e3 * (2.0 * (n - 1) / n * b / link + 2 * (n - 1) * hop)
+        coll = g["itrs"] * ar(packed_bytes) + ar(disps_bytes)
+        pen = 1.0 if n == 1 else 1.04
+        ms = pen * (lk + up) / n + shardable / n + redundant + coll
+        out["ranks"][str(n)] = {"ms_per_step": ms, "ms_collectives": coll, "ms_ba": shardable / n + redundant + coll,
+                                "speedup": (lk + up + shardable + redundant) / ms, "amdahl_redundant_share": redundant / ms}
+    return out
 
 
 def launch_ranks(args):
@@ -653,6 +703,13 @@ def main():
                   "note": "context term of the gate convolutions computed once (FactorGraph.update's cache); not the headline value"}
         ctx_box[0] = None
 
+    projection = None
+    if world == 1 and upd is not None and corr is not None and not args.no_projection and cfg.name in ("C3", "C5"):
+        try:
+            # (the graph's own synthetic BA inputs: ground-truth reprojection + noise as targets, weights in (0, 1))
+            projection = project_ranks(db, g, dev, (poses0, disps0, intr, sens, targets, weights, eta, ii, jj, N), lk, up, ba)
+        except Exception as exc:                          # an informational field must never cost the bench line
+            projection = {"error": repr(exc)}
     check = sens_out = None
     if world == 1 and upd is not None and corr is not None and inp_edges is None:
         if not args.no_check:
@@ -746,6 +803,8 @@ def main():
             out["check"] = check
         if dist_info is not None:
             out["dist"] = dist_info
+        if projection is not None:
+            out["dist_projection"] = projection
         if upd is not None and up > 0:
             # secondary roofline (the contract's `roofline` object stays the HBM-bound lookup named by north_star): the
             # update operator is where the step time goes; algorithmic flops of this rank's convolutions (edge-level ones

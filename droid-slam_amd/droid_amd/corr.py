@@ -6,8 +6,8 @@ Inference only (no autograd): the hot path runs under ``torch.no_grad()`` in the
 (droid_slam/droid.py:62, droid_backend.py:24).
 
 ``CorrBlock``     materialised 4-level pyramid in the MI355X layout of csrc/corr_pyramid.hip (8x8 source blocks,
-                  x-adjacent displacement pairs, one record of 25.6 MB per edge at 48x64; any image with at most 64 columns or at
-                  most 64 rows, on a canvas with h % 8 == 0, w in {16, 32, 64});
+                  x-adjacent displacement pairs, one record of 25.6 MB per edge at 48x64; ANY image size: on a canvas with h % 8 == 0,
+                  w in {16, 32, 64}, transposed when only the rows fit, in 64-column strips when neither dimension does);
                   built on the MFMA (droid_backends.corr_pyramid_build), one launch looks up all four levels
                   (corr_pyramid_lookup), optionally fused with the correlation encoder's first layer (lookup_corr0).
 ``CorrBlockRef``  the reference layout ``[E, h1, w1, h2/2^l, w2/2^l]`` for any image size; lookup =
@@ -116,6 +116,13 @@ class CorrBlock:
     of transposed features at transposed coordinates is the transposed volume, the 7x7 window comes out with its axes swapped
     and is swapped back (or, for lookup_corr0, meets weights with the window swapped: UpdateModule.transposed_twin)."""
 
+    # Images with more than 64 columns AND more than 64 rows (round 5; e.g. 72x96 from a 576x768 input): the correlation volume is
+    # linear in the target image, and a lookup reads zero outside a volume -- so the image is cut into column STRIPS of at most 64
+    # pixels, one pyramid record per (source strip, target strip) pair on h x 64 canvases, and a lookup is the SUM over the target
+    # strips of the lookups at coordinates shifted by the strip's origin (a window that straddles a strip border gets its taps from
+    # both records; strips start at multiples of 64, so no 2x2 pooling cell straddles one, and floor pooling of the last strip
+    # equals floor pooling of the image: (64 k + r) >> l = (64 k >> l) + (r >> l)).  Same kernels, nS x nT launches' worth of work.
+
     def __init__(self, fmap1, fmap2, num_levels=4, radius=3, out=None):
         """out: optional storage for the pyramid from CorrBlock.arena(...) (fp16 [>= E, record elements]); the block then is
         a view of its first E records.  A 105 GB hipMalloc takes seconds on a cold device (bench.py `ms_pyramid_alloc`), the
@@ -127,7 +134,19 @@ class CorrBlock:
         self.ht, self.wd = ht, wd
         self.hc, self.wc = self.canvas(ht, wd)
         self.transposed = self.is_transposed(ht, wd)
+        self.strips = self.strip_bounds(ht, wd)                   # [(x0, width)] of the column strips, or None
         f1, f2 = fmap1[0].half(), fmap2[0].half()
+        if self.strips is not None:
+            assert out is None, "the strip form allocates its own records"
+            nS = len(self.strips)
+            pad = lambda f, x0, ws: F.pad(f[..., x0:x0 + ws], (0, 64 - ws, 0, self.hc - ht))
+            recs = []
+            for (xs, ws) in self.strips:                          # source strip
+                a = pad(f1, xs, ws).contiguous()
+                for (xt, wt) in self.strips:                      # target strip: pooled levels cut at (ht >> l) x (wt >> l)
+                    recs.append(droid_backends.corr_pyramid_build(a, pad(f2, xt, wt).contiguous(), ht, wt))
+            self.records, self.pyramid = recs, None               # record (source strip si, target strip ti) = records[si * nS + ti], [E, elems]
+            return
         if self.transposed:
             f1, f2, ht, wd = f1.transpose(-1, -2), f2.transpose(-1, -2), wd, ht
         if (self.hc, self.wc) != (ht, wd):
@@ -146,26 +165,55 @@ class CorrBlock:
         return wd > 64 and ht <= 64
 
     @staticmethod
+    def strip_bounds(ht, wd):
+        """[(x0, width)] of the 64-column strips of an image with more than 64 columns and more than 64 rows, else None"""
+        if wd <= 64 or ht <= 64:
+            return None
+        return [(x0, min(64, wd - x0)) for x0 in range(0, wd, 64)]
+
+    @staticmethod
     def canvas(ht, wd):
-        """size of the pyramid's canvas for an ht x wd image (of the transposed image if is_transposed(ht, wd)), or None if it has
-        none (more than 64 columns AND more than 64 rows)"""
+        """size of the pyramid's canvas for an ht x wd image (of the transposed image if is_transposed(ht, wd); of ONE column strip
+        if the image has more than 64 columns and more than 64 rows: strip_bounds)"""
         if CorrBlock.is_transposed(ht, wd):
             ht, wd = wd, ht
         if wd > 64:
-            return None
+            return (ht + 7) // 8 * 8, 64
         return (ht + 7) // 8 * 8, (16 if wd <= 16 else 32 if wd <= 32 else 64)
 
     @staticmethod
     def supported(ht, wd):
-        return CorrBlock.canvas(ht, wd) is not None
+        return ht >= 1 and wd >= 1
 
     @staticmethod
     def bytes_per_edge(ht, wd):
         """size of one edge's record (csrc/corr_pyramid.hip make_dims: per level and 8x8 source block (h2 + 1 zero row) x w2
         displacement cells x 64 pixels, fp16) = dh_corr_pyramid_bytes(1, canvas of (ht, wd))"""
+        strips = CorrBlock.strip_bounds(ht, wd)
         ht, wd = CorrBlock.canvas(ht, wd)
         nblk = (ht // 8) * (wd // 8)
-        return sum(nblk * ((ht >> l) + 1) * (wd >> l) * 64 * 2 for l in range(4))
+        return sum(nblk * ((ht >> l) + 1) * (wd >> l) * 64 * 2 for l in range(4)) * (len(strips) ** 2 if strips else 1)
+
+    @staticmethod
+    def window_spread(coords):
+        """How much of the pyramid layout's coalescing a flow keeps: coords [E,h,w,2] (or [1,E,h,w,2]) -> mean over the 8x8 source
+        blocks (= waves of the lookup) of (8 + range_y) (10 + range_x) / 80, range = max - min of the integer tap origin
+        floor(coords - coords0) inside the block at level 0.  1.0 = every lane of a wave wants the same displacement cells (a
+        translation); a reprojection flow sits at 1.1-1.3; independent random coordinates at ~60.  The number of 128-byte lines
+        a wave touches -- and with it the lookup's time -- grows like this figure (scripts/lookup_traffic_model.py), while the
+        reference layout (CorrBlockRef) costs the same ~6.4x whatever the flow: FactorGraph switches layouts above SPREAD_LIMIT."""
+        c = coords.reshape(-1, *coords.shape[-3:])
+        E, h, w, _ = c.shape
+        h8, w8 = h // 8 * 8, w // 8 * 8
+        if E == 0 or h8 == 0 or w8 == 0:
+            return 1.0
+        yy, xx = torch.meshgrid(torch.arange(h8, device=c.device, dtype=c.dtype), torch.arange(w8, device=c.device, dtype=c.dtype), indexing="ij")
+        d = torch.floor(c[:, :h8, :w8] - torch.stack([xx, yy], -1)).clamp(-4.0 * w, 4.0 * w)        # displacement of the tap origin
+        d = d.reshape(E, h8 // 8, 8, w8 // 8, 8, 2)
+        rng = d.amax(dim=(2, 4)) - d.amin(dim=(2, 4))                                               # [E, h/8, w/8, 2] (x, y)
+        return float(((10.0 + rng[..., 0]) * (8.0 + rng[..., 1])).mean().item() / 80.0)
+
+    SPREAD_LIMIT = 6.0        # the reference-layout kernels take ~6.4x the pyramid lookup's time on a coherent flow (bench.py roofline_sensitivity)
 
     def _coords(self, coords):
         """[1,E,h,w,2] -> [E,hc,wc,2] contiguous (of the transposed image: pixel (x, y) looks at (y', x')); canvas pixels outside
@@ -179,8 +227,26 @@ class CorrBlock:
             c = F.pad(c, (0, 0, 0, self.wc - wd, 0, self.hc - ht), value=-1.0e4)
         return c.contiguous()
 
+    def _strip_lookup(self, coords):
+        """[1,E,h,w,2] -> [E,196,h,w] fp16: per source strip the sum over the target strips of the record's lookup at shifted coordinates"""
+        batch, num, ht, wd, _ = coords.shape
+        c = coords.reshape(batch * num, ht, wd, 2)
+        nS = len(self.strips)
+        cols = []
+        for si, (xs, ws) in enumerate(self.strips):
+            cs = F.pad(c[:, :, xs:xs + ws], (0, 0, 0, 64 - ws, 0, self.hc - ht), value=-1.0e4)            # canvas pixels look far outside
+            acc = None
+            for ti, (xt, wt) in enumerate(self.strips):
+                shift = torch.tensor([float(xt), 0.0], device=c.device)
+                o = droid_backends.corr_pyramid_lookup(self.records[si * nS + ti], (cs - shift).contiguous())[:, :, :ht, :ws]
+                acc = o.float() if acc is None else acc + o.float()
+            cols.append(acc.half())
+        return torch.cat(cols, -1)
+
     def __call__(self, coords):
         batch, num, ht, wd, _ = coords.shape
+        if self.strips is not None:
+            return self._strip_lookup(coords).reshape(batch, num, -1, ht, wd)
         out = droid_backends.corr_pyramid_lookup(self.pyramid, self._coords(coords))
         if self.transposed:           # [E, level, xoff' = yoff, yoff' = xoff, x, y] -> [E, level, xoff, yoff, y, x]
             out = out[:, :, :wd, :ht].reshape(batch * num, 4, 7, 7, wd, ht).permute(0, 1, 3, 2, 5, 4)
@@ -190,6 +256,11 @@ class CorrBlock:
     def lookup_nhwc(self, coords):
         """[1,E,h,w,2] -> [4,E,h,w,56] level-planar channel-last features for droid_amd.update.UpdateModule.forward_nhwc"""
         batch, num, ht, wd, _ = coords.shape
+        if self.strips is not None:                          # reference-layout sum -> the level-planar channel-last form
+            feats = self._strip_lookup(coords).view(num, 4, 7, 7, ht, wd)                   # [E, level, xoff, yoff, h, w]
+            out = torch.zeros(4, num, ht, wd, 56, dtype=feats.dtype, device=feats.device)
+            out[..., :49] = feats.permute(1, 0, 4, 5, 3, 2).reshape(4, num, ht, wd, 49)      # channel = yoff * 7 + xoff
+            return out
         out = droid_backends.corr_pyramid_lookup_nhwc(self.pyramid, self._coords(coords))
         if self.transposed:           # channel = yoff' * 7 + xoff' = xoff * 7 + yoff  ->  yoff * 7 + xoff
             k = torch.arange(56, device=out.device)
@@ -201,6 +272,8 @@ class CorrBlock:
         """[1,E,h,w,2] -> [E,h,w,128] f16: the lookup and the first layer of the update operator's correlation encoder
         (Conv2d(196,128,1) + ReLU, droid_net.py:96-100) in one kernel; pass it to UpdateModule.forward_nhwc(corr0=...)"""
         batch, num, ht, wd, _ = coords.shape
+        if self.strips is not None:                          # ReLU(layer) does not distribute over the strips' sum: lookup, then the layer
+            return update_op.corr0_layer(self._strip_lookup(coords))
         wpk, bias = (update_op.transposed_twin() if self.transposed else update_op).params["corr0_fused"]
         out = droid_backends.corr_pyramid_lookup_corr0(self.pyramid, self._coords(coords), wpk, bias)
         if self.transposed:
@@ -208,12 +281,20 @@ class CorrBlock:
         return out if (self.hc, self.wc) == (ht, wd) else out[:, :ht, :wd].contiguous()
 
     def cat(self, other):
+        if self.strips is not None:
+            self.records = [torch.cat([a, b], 0) for a, b in zip(self.records, other.records)]
+            return self
         self.pyramid = torch.cat([self.pyramid, other.pyramid], 0)
         return self
 
     def __getitem__(self, index):
+        if self.strips is not None:
+            self.records = [r[index] for r in self.records]
+            return self
         self.pyramid = self.pyramid[index]
         return self
 
     def bytes(self):
+        if self.strips is not None:
+            return sum(r.numel() * r.element_size() for r in self.records)
         return self.pyramid.numel() * self.pyramid.element_size()

@@ -23,7 +23,8 @@ from .trace import roctx_range
 
 
 class FactorGraph:
-    def __init__(self, video, update_op, device="cuda", corr_impl="volume", max_factors=-1, upsample=False, chunk_frames=8, native_corr=None):
+    def __init__(self, video, update_op, device="cuda", corr_impl="volume", max_factors=-1, upsample=False, chunk_frames=8, native_corr=None,
+                 coherence_fallback=True):
         self.video = video
         self.update_op = update_op
         self.device = video.device if hasattr(video, "device") else torch.device(device)
@@ -47,6 +48,12 @@ class FactorGraph:
         # the MI355X pyramid (any image up to 64 columns wide: sizes outside its layout sit on a zero-padded canvas, see
         # droid_amd.corr.CorrBlock); native_corr=False forces the reference-layout volumes (CorrBlockRef), the only form for wider images
         self._native_corr = CorrBlock.supported(ht, wd) if native_corr is None else (bool(native_corr) and CorrBlock.supported(ht, wd))
+        # The pyramid layout coalesces when the 64 pixels of an 8x8 block look at the same displacement cells (every flow a
+        # reprojection produces); for an INCOHERENT flow it is slower than the reference layout.  update() therefore measures the
+        # spread of the flow once per edge list (CorrBlock.window_spread, one read-back) and, beyond CorrBlock.SPREAD_LIMIT, rebuilds
+        # the volumes in the reference layout and stays there.  native_corr=True pins the pyramid; coherence_fallback=False skips the check.
+        self._coherence_fallback = bool(coherence_fallback) and native_corr is None
+        self._coherence_key = None
 
     # ---- reference-shaped views of the channel-last state ---------------------------------------------------------
     @property
@@ -157,6 +164,23 @@ class FactorGraph:
             self._ctx_key, self._ctx = key, (uniq, ix.contiguous(), inp_frames, ctx, ii)     # (ii kept alive: its address is in the key)
         return self._ctx[:4]
 
+    def _check_flow_coherence(self, coords1):
+        """once per edge list: if the flow's window spread says the pyramid layout would be slower than the reference layout,
+        rebuild every edge's volumes as CorrBlockRef (sticky for this graph; the pyramid is released first)"""
+        key = tensor_cache_key(self.ii, self.jj)
+        if key is not None and key == self._coherence_key:
+            return
+        self._coherence_key, self._coherence_ii = key, (self.ii, self.jj)          # (kept alive: their addresses are in the key)
+        self.last_window_spread = spread = CorrBlock.window_spread(coords1)
+        if spread <= CorrBlock.SPREAD_LIMIT:
+            return
+        ii, jj = self.ii, self.jj
+        c = (ii == jj).long()
+        self.corr = None                                                            # 105 GB at C3: release before the rebuild
+        torch.cuda.empty_cache()
+        self.corr = CorrBlockRef(self.video.fmaps[ii, 0][None], self.video.fmaps[jj, c][None])
+        self._native_corr = False
+
     def update(self, t0=None, t1=None, itrs=2, use_inactive=False, EP=1e-7, motion_only=False):
         ii, jj = self.ii, self.jj
         with roctx_range("droid.update/reproject"):
@@ -164,6 +188,8 @@ class FactorGraph:
         if self.corr_impl != "volume":
             raise RuntimeError("update() needs corr_impl='volume' (use update_lowmem for 'alt')")
         with roctx_range("droid.update/corr_lookup"):
+            if self._native_corr and self._coherence_fallback:
+                self._check_flow_coherence(coords1)
             if self._native_corr:
                 feats, corr0 = self._pyramid_features(self.corr, coords1)
             else:
@@ -256,7 +282,8 @@ class FactorGraph:
             c = (ii_v == jj_v).long() if rig > 1 else torch.zeros_like(ii_v)
             try:
                 with roctx_range("droid.update_lowmem/pyramid_build"):
-                    block = CorrBlock(v.fmaps[ii_v, 0][None], v.fmaps[jj_v, c][None], out=self._pyramid_arena(len(ii_v), ht, wd))
+                    arena = self._pyramid_arena(len(ii_v), ht, wd) if CorrBlock.strip_bounds(ht, wd) is None else None
+                    block = CorrBlock(v.fmaps[ii_v, 0][None], v.fmaps[jj_v, c][None], out=arena)
                 # the update operator's full-batch activations (~3.5 KB per edge-pixel) are allocated inside the first step:
                 # reserve them now, while nothing of this call has been written, so that an out-of-memory condition (other
                 # tenants of the device) still falls back to the alt-correlation loop with the state untouched

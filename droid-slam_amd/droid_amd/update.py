@@ -274,12 +274,14 @@ class UpdateModule:
         # call -- the step is bound by the socket's power, and a joule costs the same on any stream; off by default.
         self.streams = os.environ.get("DH_UPDATE_STREAMS", "0") == "1"
         self._side = None
+        self._derived = {}                     # slot -> (key of the source tensor, derived tensor, source kept alive): see _cached
 
     # ---- parameters ----------------------------------------------------------------------------
     def load_state_dict(self, sd, prefix=""):
         """sd: reference names ('gru.convz.weight', ...), optionally prefixed (e.g. 'update.')."""
         g = lambda n: sd[prefix + n].to(self.device)
         self._sd, self._twin = {k + s_: sd[prefix + k + s_] for k in PARAM_SHAPES for s_ in (".weight", ".bias")}, None
+        self._derived = {}                     # (context terms of the previous weights)
         P = {}
         conv = lambda name, cin_pad=None: _Conv(*pack_conv(g(name + ".weight"), g(name + ".bias"), cin_pad),
                                                 PARAM_SHAPES[name][2], PARAM_SHAPES[name][0],
@@ -362,6 +364,17 @@ class UpdateModule:
         forward_nhwc recomputes it on every call unless the caller passes it in."""
         return self.params["ctx"]([inp_frames], EPI_LINEAR, out_raw_f32=True)
 
+    def corr0_layer(self, corr):
+        """corr_encoder.0 (1x1, 196 -> 128, ReLU; droid_net.py:96-100) on correlation features [E,196,h,w] (reference layout; pixel
+        counts that are a multiple of 128 go through droid_backends.corr0_nchw, others through the channel-last form) or on the
+        level-planar channel-last [4,E,h,w,56] -> [E,h,w,128] f16"""
+        P = self.params
+        if corr.dim() == 4 and corr.shape[1] == COR_PLANES:
+            if self.wants_reference_layout_corr(corr.shape[2], corr.shape[3]):
+                return droid_backends.corr0_nchw(corr.contiguous(), P["corr0_nchw"][0], P["corr0_nchw"][1])
+            corr = self.corr_to_nhwc(corr)
+        return P["corr0"]([corr[0], corr[1], corr[2], corr[3]], EPI_RELU)
+
     @staticmethod
     def wants_reference_layout_corr(h, w):
         """True where forward_nhwc is fastest on the UNPADDED reference-layout correlation features [E,196,h,w]
@@ -408,12 +421,7 @@ class UpdateModule:
             if self._side is None:
                 self._side = (torch.cuda.Stream(device=net.device), torch.cuda.Stream(device=net.device))
             side = self._side
-        if corr0 is not None:
-            c0 = corr0
-        elif corr.dim() == 4 and corr.shape[1] == COR_PLANES:      # reference layout [E,196,h,w] (see wants_reference_layout_corr)
-            c0 = droid_backends.corr0_nchw(corr, P["corr0_nchw"][0], P["corr0_nchw"][1])
-        else:
-            c0 = P["corr0"]([corr[0], corr[1], corr[2], corr[3]], EPI_RELU)
+        c0 = corr0 if corr0 is not None else self.corr0_layer(corr)
         if inp is None and not (w == 64 and h % 4 == 0):
             inp = inp_frames[inp_index]        # image shape outside the production kernel: the reference's data flow
         with _Fork(side[0], main) as fb:       # flow encoder
@@ -461,6 +469,20 @@ class UpdateModule:
         ab.join(eta, upmask)
         return net, dw[..., :2], dw[..., 2:], eta[..., 0], upmask
 
+    def _cached(self, slot, src, fn):
+        """fn(src), kept for as long as `src` is the same tensor with the same version counter (FactorGraph._context hands the same
+        frame-level context tensor to every update iteration between two keyframe changes).  `src` is kept alive with the entry, so
+        its address cannot be handed to another tensor while the entry exists; inference-mode tensors have no version: recomputed."""
+        if src is None:
+            return None
+        key = tensor_cache_key(src)
+        hit = self._derived.get(slot)
+        if key is not None and hit is not None and hit[0] == key:
+            return hit[1]
+        val = fn(src)
+        self._derived[slot] = (key, val, src)
+        return val
+
     def _forward_canvas(self, net, inp, corr, flow, ii, inp_frames, inp_index, corr0):
         """forward_nhwc for an image that is not 64 pixels wide / a multiple of four rows high (TUM's 30x40, 16x32, ...): the
         tensors are embedded into zero-padded canvases [.., ceil4(h), 64, C], the production kernels run on the canvases with
@@ -477,8 +499,12 @@ class UpdateModule:
             corr_c, corr0_c = F.pad(corr, (0, Wc - w, 0, Hc - h)).contiguous(), None
         else:                                                                         # [4,E,h,w,56]
             corr_c, corr0_c = F.pad(corr, (0, 0, 0, Wc - w, 0, Hc - h)).contiguous(), None
-        n, delta, weight, eta, upmask = self.forward_nhwc(net_c, pad(inp), corr_c, pad(flow), ii, inp_frames=pad(inp_frames),
-                                                          inp_index=inp_index, ctx=None, corr0=corr0_c, _mask=(h, w))
+        # the frame-level context features and the gates' context term depend on the keyframes only: the padded copy and its
+        # convolution are kept across the update iterations (round 4 recomputed both on every call for every non-64-wide image)
+        inpf_c = self._cached("canvas_inp_%dx%d" % (h, w), inp_frames, pad)
+        ctx = self._cached("canvas_ctx_%dx%d" % (h, w), inpf_c, self.context_term) if (inp is None and inpf_c is not None) else None
+        n, delta, weight, eta, upmask = self.forward_nhwc(net_c, pad(inp), corr_c, pad(flow), ii, inp_frames=inpf_c,
+                                                          inp_index=inp_index, ctx=ctx, corr0=corr0_c, _mask=(h, w))
         net.copy_(n[:, :h, :w])
         self.last_dw = crop(self.last_dw)
         return net, self.last_dw[..., :2], self.last_dw[..., 2:], eta[:, :h, :w].contiguous(), crop(upmask)
@@ -512,7 +538,8 @@ class UpdateModule:
         twin = self.transposed_twin()
         t = lambda x: None if x is None else x.transpose(1, 2).contiguous()                 # [N,h,w,C] <-> [N,w,h,C]
         corr_t = None if (corr is None or corr0 is not None) else self.transpose_corr(corr)
-        n, _, _, eta, upmask = twin.forward_nhwc(t(net), t(inp), corr_t, t(flow), ii, inp_frames=t(inp_frames), inp_index=inp_index,
+        inpf_t = self._cached("transposed_inp", inp_frames, t)       # (a stable tensor: the twin's canvas copy / context term then hit too)
+        n, _, _, eta, upmask = twin.forward_nhwc(t(net), t(inp), corr_t, t(flow), ii, inp_frames=inpf_t, inp_index=inp_index,
                                                  corr0=t(corr0))
         net.copy_(n.transpose(1, 2))
         self.last_dw = t(twin.last_dw)

@@ -256,12 +256,16 @@ def test_round3_entry_points_and_host_helpers(built):
         assert CorrBlock.bytes_per_edge(h, w) == lib.dh_corr_pyramid_bytes(1, h, w)
     assert CorrBlock.supported(40, 64) and CorrBlock.canvas(40, 64) == (40, 64) and CorrBlock.canvas(48, 64) == (48, 64)
     # sizes outside the layout up to 64 columns sit on a zero-padded canvas; wider images up to 64 rows sit on it TRANSPOSED;
-    # more than 64 in both dimensions: no native pyramid
+    # more than 64 in both dimensions: 64-column strips, one record per (source strip, target strip) pair (round 5)
     assert CorrBlock.supported(30, 40) and CorrBlock.canvas(30, 40) == (32, 64) and CorrBlock.canvas(12, 16) == (16, 16)
     assert CorrBlock.supported(30, 80) and CorrBlock.is_transposed(30, 80) and CorrBlock.canvas(30, 80) == (80, 32)
     assert CorrBlock.canvas(60, 80) == (80, 64) and CorrBlock.canvas(41, 73) == (80, 64) and not CorrBlock.is_transposed(64, 64)
     assert CorrBlock.bytes_per_edge(41, 73) == lib.dh_corr_pyramid_bytes(1, 80, 64)
-    assert not CorrBlock.supported(72, 80) and CorrBlock.canvas(65, 65) is None
+    assert CorrBlock.supported(72, 80) and CorrBlock.canvas(72, 96) == (72, 64) and CorrBlock.canvas(65, 65) == (72, 64)
+    assert CorrBlock.strip_bounds(72, 96) == [(0, 64), (64, 32)] and CorrBlock.strip_bounds(65, 130) == [(0, 64), (64, 64), (128, 2)]
+    assert CorrBlock.strip_bounds(64, 96) is None and CorrBlock.strip_bounds(96, 64) is None and CorrBlock.strip_bounds(48, 64) is None
+    assert CorrBlock.bytes_per_edge(72, 96) == 4 * lib.dh_corr_pyramid_bytes(1, 72, 64)
+    assert CorrBlock.bytes_per_edge(96, 64) == lib.dh_corr_pyramid_bytes(1, 96, 64)          # (more rows than 64 alone need no strips)
     assert CorrBlock.bytes_per_edge(30, 40) == CorrBlock.bytes_per_edge(32, 64)
 
 

@@ -25,3 +25,23 @@ def test_frame_distance_matrix_matches_reference_orchestration(golden_dir):
     d = 0.5 * (ogeom.frame_distance(S["poses"], S["disps"], S["intrinsics"][0], ii, jj, S["prox_beta"]) +
                ogeom.frame_distance(S["poses"], S["disps"], S["intrinsics"][0], jj, ii, S["prox_beta"]))
     assert np.abs(d - G["B_dist"]).max() <= 1e-5 * max(1.0, np.abs(G["B_dist"]).max())
+
+
+def test_window_spread_separates_coherent_from_incoherent_flows():
+    """host logic behind FactorGraph's layout fallback (droid_amd.corr.CorrBlock.window_spread): 1.0 for a translation, a little
+    above for an affine / reprojection-like flow, far beyond CorrBlock.SPREAD_LIMIT for independent random coordinates"""
+    import torch
+    from droid_amd.corr import CorrBlock
+    h, w = 48, 64
+    yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    grid = torch.stack([xx, yy], -1)[None]
+    assert CorrBlock.window_spread(grid + torch.tensor([3.3, -2.6])) == 1.0
+    affine = grid * torch.tensor([1.05, 0.97]) + 0.03 * grid.flip(-1) + torch.tensor([-4.2, 1.7])
+    assert 1.0 < CorrBlock.window_spread(affine) < 1.6
+    gen = torch.Generator().manual_seed(0)
+    rnd = torch.stack([torch.rand(3, h, w, generator=gen) * w, torch.rand(3, h, w, generator=gen) * h], -1)
+    assert CorrBlock.window_spread(rnd) > 5 * CorrBlock.SPREAD_LIMIT
+    # depth discontinuities: half of every 8x8 block displaced by 30 pixels -> (10 + 30) / 10 = 4x the window union in x
+    step = grid.clone(); step[..., 0] += 30.0 * ((xx % 8) >= 4)
+    assert 3.9 < CorrBlock.window_spread(step) < 4.1
+    assert CorrBlock.window_spread(rnd[:0]) == 1.0

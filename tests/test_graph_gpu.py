@@ -119,6 +119,52 @@ def test_proximity_factors_and_update_lowmem_match_reference(db, golden_dir):
     assert (outs[0][0] - outs[1][0]).abs().max() < 1e-5 and (outs[0][1] - outs[1][1]).abs().max() < 1e-4
 
 
+def test_incoherent_flow_switches_the_graph_to_reference_layout_volumes(db):
+    """FactorGraph.update measures the flow's window spread once per edge list (CorrBlock.window_spread): a reprojection flow keeps
+    the pyramid; a flow without spatial coherence (random per-pixel depths under a large baseline: 100-pixel jumps between
+    neighbours) is slower in the pyramid layout than in the reference layout, so the graph rebuilds its volumes as
+    CorrBlockRef and stays there.  Results = those of a graph that was told native_corr=False from the start."""
+    from droid_amd.corr import CorrBlock, CorrBlockRef
+    from droid_amd.factor_graph import FactorGraph
+    S = graph_scenario()
+    N = S["n_frames"]
+    # coherent: the scenario's own state
+    video, upd = _setup(S)
+    fg = FactorGraph(video, upd, corr_impl="volume", max_factors=-1, upsample=False)
+    fg.add_neighborhood_factors(0, N, r=2)
+    fg.update(t0=1, t1=None, itrs=2, use_inactive=False)
+    assert isinstance(fg.corr, CorrBlock) and fg._native_corr and fg.last_window_spread < 2.0
+    # incoherent: independent depths per pixel, one-unit baselines
+    S2 = dict(S)
+    rng = np.random.default_rng(3)
+    S2["disps"] = rng.uniform(0.05, 4.0, S["disps"].shape).astype(np.float32)
+    poses = S["poses"].copy(); poses[:, 0] = np.arange(N) * 1.0
+    S2["poses"] = poses
+    outs = []
+    for kw in (dict(), dict(native_corr=False)):
+        video, upd = _setup(S2)
+        fg = FactorGraph(video, upd, corr_impl="volume", max_factors=-1, upsample=False, **kw)
+        fg.add_neighborhood_factors(0, N, r=2)
+        fg.update(t0=1, t1=None, itrs=2, use_inactive=False)
+        torch.cuda.synchronize()
+        assert isinstance(fg.corr, CorrBlockRef) and not fg._native_corr
+        if not kw:
+            assert fg.last_window_spread > CorrBlock.SPREAD_LIMIT
+            fg.update(t0=1, t1=None, itrs=2, use_inactive=False)            # stays in the reference layout, no second check
+        else:
+            fg.update(t0=1, t1=None, itrs=2, use_inactive=False)
+        torch.cuda.synchronize()
+        outs.append((video.poses[:N].clone(), video.disps[:N].clone(), fg.net.clone(), fg.target.clone()))
+    for a, b in zip(*outs):                                   # the same kernels on the same inputs (atomics in the BA: not bit-pinned)
+        assert torch.allclose(a.float(), b.float(), atol=1e-5, rtol=1e-5)
+    # pinned: native_corr=True keeps the pyramid whatever the flow
+    video, upd = _setup(S2)
+    fg = FactorGraph(video, upd, corr_impl="volume", max_factors=-1, upsample=False, native_corr=True)
+    fg.add_neighborhood_factors(0, N, r=2)
+    fg.update(t0=1, t1=None, itrs=2, use_inactive=False)
+    assert isinstance(fg.corr, CorrBlock) and fg._native_corr
+
+
 @pytest.mark.parametrize("case", [dict(t=40, t0=0, t1=0, rad=2, nms=2, thresh=16.0, max_factors=-1, stereo=False),
                                   dict(t=64, t0=10, t1=4, rad=1, nms=1, thresh=12.0, max_factors=300, stereo=True),
                                   dict(t=96, t0=91, t1=71, rad=2, nms=2, thresh=16.0, max_factors=48, stereo=False),
