@@ -40,6 +40,30 @@ if ABLATION:
     EXT = os.path.join(OUTDIR, "droid_backends.so")
 
 
+# DROID_HIP_SANITIZE=1: a THIRD, separate build under droid-slam_amd/sanitize/ whose HOST code (argument checks, workspace layouts,
+# option store, launch geometry -- everything of the C ABI that runs on the CPU) is instrumented with AddressSanitizer +
+# UndefinedBehaviorSanitizer (the host-test build).  Device code is unchanged (hipcc ignores -fsanitize for gfx950
+# without xnack+).  Run python under the matching runtime: tests/test_sanitize_cpu.py and scripts/sanitize_run.sh show how.
+SANITIZE = os.environ.get("DROID_HIP_SANITIZE", "0") == "1"
+if SANITIZE:
+    assert not ABLATION, "DROID_HIP_SANITIZE and DROID_HIP_ABLATION are separate builds"
+    HIP_FLAGS = [f for f in HIP_FLAGS if f != "-O3"] + ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",
+                                                          "-fno-sanitize-recover=undefined", "-Wno-option-ignored"]
+    OUTDIR = os.path.join(HERE, "sanitize")
+    OBJ = os.path.join(HERE, "build", "sanitize")
+    os.makedirs(OUTDIR, exist_ok=True)
+    LIB = os.path.join(OUTDIR, "libdroid_hip.so")
+    EXT = os.path.join(OUTDIR, "droid_backends.so")
+
+
+def asan_runtime():
+    """path of the AddressSanitizer runtime that matches hipcc's clang (to LD_PRELOAD into python for the sanitize build)"""
+    r = subprocess.run([os.path.join(os.path.dirname(os.path.realpath(HIPCC)), "..", "lib", "llvm", "bin", "clang"),
+                        "--print-file-name=libclang_rt.asan-x86_64.so"], stdout=subprocess.PIPE, text=True)
+    path = r.stdout.strip()
+    return path if r.returncode == 0 and os.path.isabs(path) and os.path.exists(path) else None
+
+
 # per-file flags.  corr_pyramid.hip: without the SLP vectoriser hipcc keeps the lookup's fp32 interpolation scalar and folds the fp16
 # operands / results into v_fma_mix_f32 / v_fma_mixlo_f16 instead of packing pairs into v_pk_*_f32 behind explicit conversions
 # (packed fp32 runs at half rate on this part: same flops, more instructions)
@@ -87,7 +111,7 @@ def build_lib(force=False, verbose=False):
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(lambda c: _run(c, verbose), jobs))
     if force or jobs or _newer(LIB, objs):
-        _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs, verbose)
+        _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + (["-fsanitize=address,undefined", "-shared-libsan", "-Wno-option-ignored"] if SANITIZE else []) + objs, verbose)
     return LIB
 
 
@@ -175,8 +199,9 @@ def build_ext(force=False, verbose=False):
 
 def build_all(force=False, verbose=False):
     build_lib(force, verbose)
-    audit_asm_loads(force, verbose)
-    audit_spills(force, verbose)
+    if not SANITIZE:                      # (the ISA audits judge the release flags)
+        audit_asm_loads(force, verbose)
+        audit_spills(force, verbose)
     build_ext(force, verbose)
     return LIB, EXT
 

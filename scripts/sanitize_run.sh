@@ -1,0 +1,24 @@
+#!/bin/bash
+# ASAN + UBSAN run of the host side of the C ABI.  Builds droid-slam_amd/sanitize/ if it is missing, then
+#   * CPU (anywhere):  tests/test_sanitize_cpu.py  -- argument checks, size queries, option store, weight packing
+#   * GPU box (if a device is visible): the raw-pointer ctypes launches, the BA / lookup parity cases and smoke() with the
+#     sanitized host code around the real kernels (workspace carving, launch geometry, option reads on the launch paths)
+# usage: bash scripts/sanitize_run.sh [OUTDIR]
+OUT=${1:-gpurun_out/sanitize}; mkdir -p $OUT
+cd "$(dirname "$0")/.."
+[ -f droid-slam_amd/sanitize/libdroid_hip.so ] || DROID_HIP_SANITIZE=1 python droid-slam_amd/build.py
+RT=$(python - <<'PY'
+import importlib.util, os
+s = importlib.util.spec_from_file_location("b", os.path.join("droid-slam_amd", "build.py")); m = importlib.util.module_from_spec(s); s.loader.exec_module(m)
+print(m.asan_runtime() or "")
+PY
+)
+[ -n "$RT" ] || { echo "no ASAN runtime"; exit 1; }
+python -m pytest tests/test_sanitize_cpu.py -q 2>&1 | tail -n 3
+if python -c "import torch,sys; sys.exit(0 if torch.cuda.is_available() else 1)" 2>/dev/null; then
+  export LD_PRELOAD=$RT DROID_HIP_TEST_SANITIZE=1
+  export ASAN_OPTIONS=detect_leaks=0:halt_on_error=1:protect_shadow_gap=0:exitcode=97 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1:exitcode=98
+  timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -p no:cacheprovider \
+      -k "raw_c_abi or ba_small or ba_config_c2 or pyramid_vs_oracle or lookup_fused or 64_cout" > $OUT/gpu_asan.log 2>&1
+  echo "gpu tests under asan rc=$?"; tail -n 6 $OUT/gpu_asan.log; grep -c "AddressSanitizer\|runtime error:" $OUT/gpu_asan.log
+fi

@@ -12,6 +12,11 @@ for p in (ROOT, PKG):
 if os.environ.get("DROID_HIP_TEST_ABLATION", "0") == "1":
     sys.path.insert(0, os.path.join(PKG, "ablation"))
 
+# DROID_HIP_TEST_SANITIZE=1: the ASAN + UBSAN host build (droid-slam_amd/sanitize/, DROID_HIP_SANITIZE=1 python droid-slam_amd/build.py);
+# python must run under the matching runtime (tests/test_sanitize_cpu.py starts such a process)
+if os.environ.get("DROID_HIP_TEST_SANITIZE", "0") == "1":
+    sys.path.insert(0, os.path.join(PKG, "sanitize"))
+
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 

@@ -12,8 +12,9 @@ import torch  # noqa: F401  (must precede loading libdroid_hip: shares torch's H
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "droid-slam_amd")
-LIB = os.path.join(PKG, "libdroid_hip.so")
-EXT = os.path.join(PKG, "droid_backends.so")
+LIBDIR = os.path.join(PKG, "sanitize") if os.environ.get("DROID_HIP_TEST_SANITIZE", "0") == "1" else PKG
+LIB = os.path.join(LIBDIR, "libdroid_hip.so")
+EXT = os.path.join(LIBDIR, "droid_backends.so")
 
 
 @pytest.fixture(scope="module")

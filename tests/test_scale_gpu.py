@@ -262,7 +262,8 @@ def _record_deviation(cfg, tag, m):
 # perturbation of its inputs (tests/golden/graph_scale_probe.json, written by make_graph_scale_golden.py --probe), but never
 # below FLOOR: what fp32 geometry / an fp16 store can resolve at all (the golden's geometry and BA run in fp64 on the CPU).
 COMPOSED_FACTOR = 10.0
-FLOOR = {"pose_trans_max": 2e-6, "pose_rot_max_rad": 2e-6,          # fp32 poses of magnitude ~1-8: a few ulp
+FLOOR = {"pose_trans_max": 1e-5, "pose_rot_max_rad": 1e-5,          # the product's BA is fp32 (fp64 solve), the golden's fp64: measured 2.5e-6 / 2.0e-6
+                                                                   # at C2 (profiles/r05_c_composed_deviation.json); SURVEY 8c states 1e-4
          "disps_rel_q99": 1e-4, "disps_rel_max": 1e-3,              # depths rel 1e-3
          "disps_frame_mean_max": 1e-5,
          "net_s_max": 2.0 ** -9, "weight_s_max": 2.0 ** -10,        # one fp16 ulp of values in [1, 2) / [0.5, 1)
