@@ -2,7 +2,7 @@
 """Generate tests/golden/graph_c2_python.npz and graph_stereo_python.npz by running the REFERENCE's own factor_graph.py +
 depth_video.py + modules/corr.py + droid_net.py, unmodified, on CPU (build container only: needs /root/reference):
 
-    python tests/golden/make_graph_scale_golden.py [stereo] [c2] [tum] [wide] [c3] [--probe]
+    python tests/golden/make_graph_scale_golden.py [stereo] [c2] [tum] [wide] [big] [c3] [--probe]
 
 --probe (c2 / c3 only): the same scenario with the stored feature / hidden-state / context maps (fmaps, nets, inps) moved by ONE
 fp16 ulp on half of their values (seeded) -> /tmp/graph_<cfg>_probe.npz, and the movement of every quantity the composed tests
@@ -210,6 +210,35 @@ def scenario_tum_size():
 WIDE_SAMPLE_EDGES = [0, 5, 13]
 
 
+def scenario_big():
+    """scenario G: 4 keyframes at 72 x 96 (a 576 x 768 input): more than 64 columns AND rows -> the HIP path keeps the pyramid in
+    64-column strips (CorrBlock.strips) and runs the update operator through its generic loop.  Same recipe as scenario W."""
+    _scenario_sampled(4, 72, 96, "graph_big_python.npz", "graph_big", [0, 3, 9])
+
+
+def _scenario_sampled(n_frames, ht, wd, fname, label, sample_edges):
+    S = graph_scenario(n_frames, ht, wd)
+    N = S["n_frames"]
+    video = ref_dv.DepthVideo(image_size=[8 * ht, 8 * wd], buffer=N + 2, stereo=False, device="cpu")
+    video.poses[:N] = torch.as_tensor(S["poses"]); video.disps[:N] = torch.as_tensor(S["disps"])
+    video.intrinsics[:N] = torch.as_tensor(S["intrinsics"])
+    video.fmaps[:N, 0] = torch.as_tensor(S["fmaps"]); video.nets[:N] = torch.as_tensor(S["nets"]); video.inps[:N] = torch.as_tensor(S["inps"])
+    video.counter.value = N
+    out = {}
+    with torch.no_grad():
+        fg = ref_fg.FactorGraph(video, update_operator(S["weight_seed"]), device="cpu", corr_impl="volume", max_factors=-1, upsample=True)
+        fg.add_neighborhood_factors(0, N, r=2)
+        out["ii"], out["jj"] = fg.ii.numpy().copy(), fg.jj.numpy().copy()
+        out["target0_s"] = fg.target[0][sample_edges].numpy().copy()
+        for k in (1, 2):
+            fg.update(t0=1, t1=None, itrs=2, use_inactive=False)
+            snap(out, "U%d" % k, video, fg, N, sample=sample_edges)
+            out["U%d_net_s" % k] = out["U%d_net_s" % k][:, :, ::3, ::3].copy()              # (every third pixel: 0.6 instead of 5.3 MB)
+            out["U%d_disps_up" % k] = video.disps_up[:N].numpy()[:, ::4, ::4].astype(np.float16)
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print("%s: %d edges; |dpose| %.3e %.3e" % (label, len(out["ii"]), np.abs(out["U1_poses"] - S["poses"]).max(), np.abs(out["U2_poses"] - S["poses"]).max()))
+
+
 def scenario_wide():
     """scenario W: 5 keyframes at 41 x 73 (a 16:9 video at the reference's demo resolution, demo.py:33-40: 1080p -> 328 x 584):
     more than 64 columns, so the HIP path keeps the image TRANSPOSED on its 64-column canvases (CorrBlock.transposed,
@@ -353,6 +382,8 @@ if __name__ == "__main__":
         scenario_tum_size()
     if "wide" in which:
         scenario_wide()
+    if "big" in which:
+        scenario_big()
     if "stereo" in which:
         scenario_stereo()
     if "c2" in which:

@@ -468,6 +468,53 @@ def test_composed_update_at_tum_image_size_matches_reference_factor_graph(db, go
         assert np.quantile(e, 0.99) <= 1e-2 * scale + 2.0 ** -10
 
 
+def test_composed_update_at_72x96_in_strips_matches_reference_factor_graph(db, golden_dir):
+    """72 x 96 at 1/8 resolution (a 576 x 768 input): more than 64 columns AND rows -> the pyramid is kept in 64-column strips
+    (CorrBlock.strips: four records per edge, lookups summed over the two target strips) and the update operator runs its generic
+    loop.  Two composed update iterations with upsampling against the golden of the reference's unmodified factor_graph.py
+    (tests/golden/make_graph_scale_golden.py big); tolerances of the 16:9 test."""
+    from droid_amd.corr import CorrBlock
+    from droid_amd.factor_graph import FactorGraph
+    from droid_amd.update import UpdateModule
+    from droid_amd.weights import deterministic_state_dict
+    from golden_inputs import graph_scenario
+    G = np.load(os.path.join(golden_dir, "graph_big_python.npz"))
+    S = graph_scenario(4, 72, 96)
+    N, ht, wd = S["n_frames"], S["ht"], S["wd"]
+    sample = [0, 3, 9]
+    video = _video(N, ht, wd, S["poses"], S["disps"], S["intrinsics"], S["fmaps"], S["nets"], S["inps"])
+    upd = UpdateModule("cuda").load_state_dict(deterministic_state_dict(_SD(), seed=S["weight_seed"]))
+    fg = FactorGraph(video, upd, corr_impl="volume", max_factors=-1, upsample=True)
+    fg.add_neighborhood_factors(0, N, r=2)
+    assert isinstance(fg.corr, CorrBlock) and fg.corr.strips == [(0, 64), (64, 32)] and len(fg.corr.records) == 4
+    assert np.array_equal(fg.ii.cpu().numpy(), G["ii"]) and np.array_equal(fg.jj.cpu().numpy(), G["jj"])
+    c = lambda t: t.float().cpu().numpy()
+    assert np.abs(c(fg.target[0])[sample] - G["target0_s"]).max() < 2e-4
+    for k, scale in ((1, 1.0), (2, 2.0)):
+        fg.update(t0=1, t1=None, itrs=2, use_inactive=False)
+        torch.cuda.synchronize()
+        assert isinstance(fg.corr, CorrBlock) and fg._native_corr            # (the reprojection flow keeps the pyramid layout)
+        tag = "U%d" % k
+        p, rp = c(video.poses)[:N], G[tag + "_poses"]
+        assert np.abs(p[:, :3] - rp[:, :3]).max() <= 2e-3 * scale
+        assert _rot_angle(p[:, 3:].astype(np.float64), rp[:, 3:].astype(np.float64)).max() <= 2e-3 * scale
+        d, rd = c(video.disps)[:N], G[tag + "_disps"]
+        e = np.abs(d - rd) / np.maximum(1.0, np.abs(rd))
+        assert np.quantile(e, 0.99) <= 1e-2 * scale and e.max() <= 0.1 * scale
+        assert np.abs(c(fg.net[0])[sample][:, :, ::3, ::3] - G[tag + "_net_s"].astype(np.float32)).max() <= 2.0 ** -8 * scale
+        tg, rtg = c(fg.target[0])[sample], G[tag + "_target_s"]
+        assert np.quantile(np.abs(tg - rtg), 0.999) <= 2e-2 * scale and np.abs(tg - rtg).max() <= 0.5 * scale
+        assert np.abs(c(fg.weight[0])[sample] - G[tag + "_weight_s"]).max() <= 2.0 ** -8 * scale
+        yy, xx = torch.meshgrid(torch.arange(ht, device="cuda", dtype=torch.float32), torch.arange(wd, device="cuda", dtype=torch.float32), indexing="ij")
+        grid = torch.stack([xx, yy], -1)
+        assert np.abs(c((fg.target[0] - grid).abs().mean(dim=(1, 2, 3))) - G[tag + "_flow_mean"]).max() <= 2e-3 * scale * max(1.0, G[tag + "_flow_mean"].max())
+        assert np.abs(c(fg.weight[0].mean(dim=(1, 2, 3))) - G[tag + "_weight_mean"]).max() <= 2.0 ** -9 * scale
+        du, rdu = c(video.disps_up)[:N][:, ::4, ::4], G[tag + "_disps_up"].astype(np.float32)
+        e = np.abs(du - rdu) / np.maximum(1.0, np.abs(rdu))
+        assert np.quantile(e, 0.99) <= 1e-2 * scale + 2.0 ** -10
+    _free()
+
+
 def test_composed_update_at_16_9_image_size_matches_reference_factor_graph(db, golden_dir):
     """41 x 73 at 1/8 resolution (a 1080p video through the reference's demo.py resize: 328 x 584): more than 64 columns, at most 64
     rows -> the image is kept TRANSPOSED on the 64-column canvases of the production kernels (CorrBlock.transposed: pyramid of the
