@@ -60,6 +60,10 @@ def parse():
     ap.add_argument("--no-lowmem", action="store_true", help="do not add the update_lowmem line (child process) to the default line")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic in this run (rocprofv3 --pmc pass in a child process)")
     ap.add_argument("--no-sensitivity", action="store_true", help="skip the untimed flow-sensitivity runs of the lookup kernel")
+    ap.add_argument("--emulate-world", type=int, default=0, help="single-GPU emulation of ONE rank of an N-rank run: time the step on that "
+                    "rank's edge shard (same poses, same redundant solve) WITHOUT the collectives -- the compute a rank would do; the "
+                    "default line runs this for N = 2, 4, 8 in child processes and adds the modelled collectives (dist_projection)")
+    ap.add_argument("--emulate-rank", type=int, default=0)
     ap.add_argument("--no-projection", action="store_true", help="skip the untimed 1/2/4/8-rank projection (dist_projection: the BA timed on the "
                     "whole graph and on a 1/8 shard to separate its redundant part)")
     ap.add_argument("--lowmem", action="store_true", help="time FactorGraph.update_lowmem steps (the global-BA iteration, "
@@ -328,6 +332,39 @@ def project_ranks(db, g, dev, tensors, lk, up, ba):
     return out
 
 
+def emulate_ranks(projection, config, timeout_s=150):
+    """fills projection["ranks"][N]["ms_compute_measured"] (N = 2, 4, 8): `bench.py --emulate-world N --emulate-rank 0` in a child
+    process = the step on rank 0's edge shard of an N-rank partition, same poses and the same redundant solve, no collectives;
+    `ms_per_step_measured_compute_plus_modelled_collectives` adds the projection's collective model.  Any failure leaves the
+    analytic figures alone."""
+    import subprocess
+    for n in (2, 4, 8):
+        r = projection["ranks"].get(str(n))
+        if r is None:
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", config, "--emulate-world", str(n), "--emulate-rank", "0", "--steps", "10",
+               "--warmup", "3", "--no-cpu-baseline", "--no-check", "--no-lowmem", "--no-pmc", "--no-sensitivity", "--no-projection"]
+        try:
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
+            lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+            if p.returncode != 0 or not lines:
+                r["emulation"] = "failed (rc %d): %s" % (p.returncode, p.stderr.strip()[-200:])
+                continue
+            d = json.loads(lines[-1])
+            r["ms_compute_measured"] = d["ms_per_step"]
+            r["ms_compute_measured_parts"] = {k: d.get(k) for k in ("ms_corr_lookup", "ms_update_operator", "ms_per_global_ba")}
+            r["edges_of_the_emulated_rank"] = d["emulated_rank"]["edges"]
+            r["ms_per_step_measured_compute_plus_modelled_collectives"] = d["ms_per_step"] + r["ms_collectives"]
+        except subprocess.TimeoutExpired:
+            r["emulation"] = "exceeded %d s" % timeout_s
+        except Exception as exc:
+            r["emulation"] = repr(exc)
+    one = projection["ranks"]["1"]["ms_per_step"]
+    for n, r in projection["ranks"].items():
+        if "ms_per_step_measured_compute_plus_modelled_collectives" in r:
+            r["speedup_measured_compute"] = one / r["ms_per_step_measured_compute_plus_modelled_collectives"]
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher around it: start the N ranks here (one process per GPU, RCCL) by
     re-executing this command line under torch.distributed.run, the form the round driver itself uses for N > 1."""
@@ -517,8 +554,11 @@ def main():
 
     # ---- edge sharding by source frame (contiguous frame ranges balanced by edge count) ----
     from droid_amd.dist_ba import DistBA, shard_edges_by_source_frame, local_eta_rows
-    shards, bounds = shard_edges_by_source_frame(ii_all, world)
-    mine = shards[rank]
+    emulate = args.emulate_world > 1 and world == 1
+    shard_world, shard_rank = (args.emulate_world, args.emulate_rank) if emulate else (world, rank)
+    assert 0 <= shard_rank < shard_world
+    shards, bounds = shard_edges_by_source_frame(ii_all, shard_world)
+    mine = shards[shard_rank]
     eta_rows, kx_local = local_eta_rows(ii_all, ii_all[mine], 1, N)      # depth blocks of this rank's BA
     d = lambda a, **kw: torch.as_tensor(np.ascontiguousarray(a), **kw).to(dev)
     ii, jj = d(ii_all[mine]), d(jj_all[mine])
@@ -571,7 +611,7 @@ def main():
         net = d(g["nets"])[ii].permute(0, 2, 3, 1).contiguous()        # hidden state per edge, NHWC fp16
         # context features: frame-level table of this rank's source frames (the reference gathers video.inps[ii] per edge,
         # factor_graph.py:135; every edge of a source frame carries the same 128 channels)
-        f_lo, f_hi = int(bounds[rank]), int(min(bounds[rank + 1], N))
+        f_lo, f_hi = int(bounds[shard_rank]), int(min(bounds[shard_rank + 1], N))
         inps_frames = d(g["inps"])[f_lo:f_hi].permute(0, 2, 3, 1).contiguous()       # [frames,h,w,128] f16
         inp_index = (ii - f_lo).contiguous()
         inp_edges = inps_frames[inp_index].contiguous() if args.per_edge_inp else None
@@ -690,7 +730,7 @@ def main():
     # step -- what droid_amd.factor_graph.FactorGraph.update does between keyframe insertions (its `_context` cache).  The timed
     # steps above recompute it every time, as the reference's convolutions over [net, inp, corr, flow] do.
     steady = None
-    if world == 1 and upd is not None and corr is not None and inp_edges is None and ht % 4 == 0 and wd == 64:
+    if world == 1 and not emulate and upd is not None and corr is not None and inp_edges is None and ht % 4 == 0 and wd == 64:
         ctx_box[0] = upd.context_term(inps_frames)
         for _ in range(2):
             step(False)
@@ -704,14 +744,14 @@ def main():
         ctx_box[0] = None
 
     projection = None
-    if world == 1 and upd is not None and corr is not None and not args.no_projection and cfg.name in ("C3", "C5"):
+    if world == 1 and not emulate and upd is not None and corr is not None and not args.no_projection and cfg.name in ("C3", "C5"):
         try:
             # (the graph's own synthetic BA inputs: ground-truth reprojection + noise as targets, weights in (0, 1))
             projection = project_ranks(db, g, dev, (poses0, disps0, intr, sens, targets, weights, eta, ii, jj, N), lk, up, ba)
         except Exception as exc:                          # an informational field must never cost the bench line
             projection = {"error": repr(exc)}
     check = sens_out = None
-    if world == 1 and upd is not None and corr is not None and inp_edges is None:
+    if world == 1 and not emulate and upd is not None and corr is not None and inp_edges is None:
         if not args.no_check:
             def product():
                 step(False)
@@ -822,6 +862,14 @@ def main():
                                                "unit": "TFLOP/s", "frac": tf / 2500.0, "algorithmic_flops": flops}
           except Exception as exc:                        # an informational field must never cost the bench line
             out["roofline_update_operator"] = {"error": repr(exc)}
+        if emulate:
+            out["emulated_rank"] = {"rank": shard_rank, "of": shard_world, "edges": int(E), "frames": [f_lo, f_hi] if upd is not None else None,
+                                    "note": "ONE process on ONE GPU running the step on this rank's edge shard: the rank's compute (lookup, "
+                                            "update operator, build of its edges, the redundant solve) WITHOUT the collectives; `value` "
+                                            "counts this shard's edge-pixels only; not a multi-GPU measurement"}
+            out["value"] = E * HW / (ms * 1e-3)
+            print(json.dumps(out))
+            return
         if not args.no_cpu_baseline and world == 1:        # rank 0 at N = 1 only (the other ranks would wait in teardown)
             out["cpu_baseline"] = cpu_baseline(g)
         if world == 1 and not args.no_lowmem and corr is not None and cfg.name == "C3":
@@ -844,6 +892,13 @@ def main():
                 out["roofline"]["traffic"], out["roofline"]["traffic_source"] = per_ep * E * HW, why
             elif out["roofline"]["traffic_source"]:
                 out["roofline"]["traffic_source"] += " [in-run pass: %s]" % why
+        if projection is not None and "ranks" in projection and corr is not None:
+            # the per-rank COMPUTE of the projection measured instead of scaled: child processes run one rank's shard of an
+            # N-rank partition on this GPU (bench.py --emulate-world N); the collectives stay modelled
+            corr.pyramid = None
+            import gc
+            gc.collect(); torch.cuda.empty_cache()
+            emulate_ranks(projection, cfg.name)
         print(json.dumps(out))
     if dist_on:
         dist.destroy_process_group()
