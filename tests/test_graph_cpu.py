@@ -45,3 +45,16 @@ def test_window_spread_separates_coherent_from_incoherent_flows():
     step = grid.clone(); step[..., 0] += 30.0 * ((xx % 8) >= 4)
     assert 3.9 < CorrBlock.window_spread(step) < 4.1
     assert CorrBlock.window_spread(rnd[:0]) == 1.0
+
+
+def test_committed_goldens_match_their_hash_manifest(golden_dir):
+    """tests/golden/MANIFEST.sha256 pins every committed golden vector (outputs of the reference's own code, which only the build
+    container can regenerate) to the bytes the tolerances were set against; `python tests/golden/manifest.py --write` after a
+    deliberate regeneration"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("golden_manifest", os.path.join(golden_dir, "manifest.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    cur, want = m.current(), m.read()
+    assert set(cur) == set(m.GENERATOR), sorted(set(m.GENERATOR) - set(cur))
+    assert cur == want, [n for n in cur if cur[n] != want.get(n)]
