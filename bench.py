@@ -255,8 +255,9 @@ def cpu_baseline(g, n_lookup_edges=64, n_update_edges=128, repeats=3):
     # ---- one core (the figure of round 1): BA on the 128-frame sub-graph, 16-edge lookup / update samples
     torch.set_num_threads(1)
     with threadpoolctl.threadpool_limits(limits=1):
-        sub = subgraph(128)
-        t0 = time.perf_counter(); run_ba(sub, 128, 1); t_ba1 = time.perf_counter() - t0
+        n1 = min(128, g["n_frames"])                      # (C2 has 64 keyframes)
+        sub = subgraph(n1)
+        t0 = time.perf_counter(); run_ba(sub, n1, 1); t_ba1 = time.perf_counter() - t0
         small_pyr = [v[:16] for v in pyr]; small_c = coords[:16]
         t0 = time.perf_counter(); ocorr.corr_block_lookup_torch(small_pyr, small_c, 3); t_lk1 = time.perf_counter() - t0
         u16 = tuple(a[:16] for a in uargs)

@@ -1,7 +1,7 @@
 """Profiler ranges and event timers for the hot path (the MI355X counterpart of the reference's
 droid_slam/cuda_timer.py:3-23).
 
-``roctx_range(name)``  a ROCTX range (libroctx64: roctxRangePushA / roctxRangePop) around a stage of FactorGraph.update /
+``roctx_range(name)``  a ROCTX range (librocprofiler-sdk-roctx, else libroctx64: roctxRangePushA / roctxRangePop) around a stage of FactorGraph.update /
                        update_lowmem / DistBA.ba.  `rocprofv3 --marker-trace --kernel-trace -- <cmd>` shows the kernels of a
                        step grouped under reproject / corr_lookup / update_operator / ba / upsample.  A push/pop pair costs
                        ~100 ns with no tool attached; DROID_HIP_ROCTX=0 turns the ranges into no-ops.
@@ -21,7 +21,9 @@ _enabled = os.environ.get("DROID_HIP_ROCTX", "1") != "0"
 def _roctx():
     global _lib, _enabled
     if _lib is None and _enabled:
-        for name in ("libroctx64.so", "libroctx64.so.4", "/opt/rocm/lib/libroctx64.so"):
+        # rocprofv3 (rocprofiler-sdk) records the ranges of ITS roctx library; the roctracer-era libroctx64 is the fall-back for older tools
+        for name in ("librocprofiler-sdk-roctx.so", "/opt/rocm/lib/librocprofiler-sdk-roctx.so", "libroctx64.so", "libroctx64.so.4",
+                     "/opt/rocm/lib/libroctx64.so"):
             try:
                 lib = ctypes.CDLL(name)
                 lib.roctxRangePushA.argtypes = [ctypes.c_char_p]

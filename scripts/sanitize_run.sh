@@ -18,7 +18,12 @@ python -m pytest tests/test_sanitize_cpu.py -q 2>&1 | tail -n 3
 if python -c "import torch,sys; sys.exit(0 if torch.cuda.is_available() else 1)" 2>/dev/null; then
   export LD_PRELOAD=$RT DROID_HIP_TEST_SANITIZE=1
   export ASAN_OPTIONS=detect_leaks=0:halt_on_error=1:protect_shadow_gap=0:exitcode=97 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1:exitcode=98
-  timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -p no:cacheprovider \
+  # (1) does torch + the HIP runtime come up at all under the ASAN runtime on this box?  (2) one raw C-ABI launch  (3) the parity cases
+  timeout 300 python -X faulthandler -u -c "import torch; x = torch.zeros(4, device='cuda'); torch.cuda.synchronize(); print('hip under asan ok', x.sum().item())" > $OUT/gpu_asan_probe.log 2>&1
+  echo "hip-under-asan probe rc=$?"; tail -n 5 $OUT/gpu_asan_probe.log
+  timeout 600 python -X faulthandler -u -m pytest tests/test_gpu_parity.py -m gpu -q -x -s -p no:cacheprovider -k "raw_c_abi_call" > $OUT/gpu_asan_one.log 2>&1
+  echo "one raw C-ABI test under asan rc=$?"; tail -n 8 $OUT/gpu_asan_one.log
+  timeout 900 python -X faulthandler -u -m pytest tests/test_gpu_parity.py -m gpu -q -x -p no:cacheprovider \
       -k "raw_c_abi or ba_small or ba_config_c2 or pyramid_vs_oracle or lookup_fused or 64_cout" > $OUT/gpu_asan.log 2>&1
   echo "gpu tests under asan rc=$?"; tail -n 6 $OUT/gpu_asan.log; grep -c "AddressSanitizer\|runtime error:" $OUT/gpu_asan.log
 fi
