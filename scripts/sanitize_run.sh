@@ -1,8 +1,11 @@
 #!/bin/bash
 # ASAN + UBSAN run of the host side of the C ABI.  Builds droid-slam_amd/sanitize/ if it is missing, then
 #   * CPU (anywhere):  tests/test_sanitize_cpu.py  -- argument checks, size queries, option store, weight packing
-#   * GPU box (if a device is visible): the raw-pointer ctypes launches, the BA / lookup parity cases and smoke() with the
-#     sanitized host code around the real kernels (workspace carving, launch geometry, option reads on the launch paths)
+#   * GPU box (if a device is visible): attempts the raw-pointer ctypes launches and the BA / lookup parity cases with the sanitized
+#     host code around the real kernels.  MEASURED on the pool's boxes (profiles/r05_e_sanitizer_gpu_attempt.txt): not possible with
+#     this image -- the ROCm compiler-rt ASAN runtime intercepts hsa_amd_memory_pool_allocate and aborts the first HIP allocation
+#     ("out of memory: allocator is trying to allocate 0x400000 bytes"); it needs the ASAN builds of the ROCm runtime
+#     (/opt/rocm/lib/asan, not installed).  The host-side coverage is therefore the CPU test.
 # usage: bash scripts/sanitize_run.sh [OUTDIR]
 OUT=${1:-gpurun_out/sanitize}; mkdir -p $OUT
 cd "$(dirname "$0")/.."

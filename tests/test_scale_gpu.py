@@ -262,14 +262,14 @@ def _record_deviation(cfg, tag, m):
 # perturbation of its inputs (tests/golden/graph_scale_probe.json, written by make_graph_scale_golden.py --probe), but never
 # below FLOOR: what fp32 geometry / an fp16 store can resolve at all (the golden's geometry and BA run in fp64 on the CPU).
 COMPOSED_FACTOR = 10.0
-# Measured on MI355X (profiles/r05_d_composed_deviation.json), deviation / probe movement: hidden state, targets, confidence weights,
+# Measured on MI355X (profiles/r05_e_composed_deviation.json), deviation / probe movement: hidden state, targets, confidence weights,
 # damping -- everything the fp16 network decides -- 0.8-2.2x; depths (q99) 1.4-1.8x; poses 10-19x, per-edge mean flow 5-16x, per-frame
 # mean depth 32x: those three are GEOMETRY, where the product computes in fp32 (reprojection, Jacobians, Schur complement; fp64 only
-# in the solve) and the golden in fp64 -- their floors are what that difference is (absolute: poses 2.5e-6 .. 5.8e-6, mean flow
-# 3.3e-5 .. 8.9e-5 px, frame-mean depth 3.0e-5), with a 3x margin, still 30-100x inside SURVEY 8c's stated fp32 tolerances.
+# in the solve) and the golden in fp64 -- their floors are what that difference is (absolute: poses 2.5e-6 .. 7.3e-6, mean flow
+# 3.3e-5 .. 1.1e-4 px, frame-mean depth 3.0e-5 .. 6.7e-5 over the two iterations at C2 and C3), with a 3x margin, still 30-100x inside SURVEY 8c's stated fp32 tolerances.
 FLOOR = {"pose_trans_max": 2e-5, "pose_rot_max_rad": 2e-5,          # SURVEY 8c states 1e-4
          "disps_rel_q99": 1e-4, "disps_rel_max": 1e-3,              # depths rel 1e-3
-         "disps_frame_mean_max": 1e-4,
+         "disps_frame_mean_max": 2e-4,                              # measured 3.0e-5 (C3 iteration 1), 6.7e-5 (iteration 2)
          "net_s_max": 2.0 ** -9, "weight_s_max": 2.0 ** -10,        # one fp16 ulp of values in [1, 2) / [0.5, 1)
          "target_s_q999": 2.0 ** -10, "target_s_max": 2.0 ** -8,    # delta head output in fp16
          "damping_rel_max": 2.0 ** -10, "damping_frame_mean_rel_max": 2.0 ** -11,
