@@ -61,7 +61,22 @@ struct ConvParams {
   const float* cinit; const int64_t* cinit_idx; int cinit_stride; int cinit_off;
   int xcd_tiles;          // > 0: 1-D grid, workgroup id -> (pixel tile, cout tile) through xcd_decode(); = pixel tiles per XCD
   int ny;                 // cout tiles
+#ifdef DH_ABLATION
+  unsigned long long* ts; // phase timestamps per workgroup (dh_conv_set_timestamps; scripts/conv_timeline.py), else nullptr
+#endif
 };
+
+// Phase timestamps of the 3x3 kernels (-DDH_ABLATION builds, when a buffer is set): thread 0 of every workgroup stores the
+// 100 MHz wall clock at  0 kernel entry, 1 accumulators initialised / first fetches issued, 2 first barrier passed (the first
+// MFMA can issue), 3 main loop left, 4 epilogue done;  slot 5 = HW_ID, 6 = XCC_ID (which CU ran it).
+#ifdef DH_ABLATION
+#define DH_CTS(i) do { if (P.ts && threadIdx.x == 0) P.ts[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = wall_clock64(); } while (0)
+#define DH_CTS_ID() do { if (P.ts && threadIdx.x == 0) { P.ts[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 5] = __builtin_amdgcn_s_getreg(63492); \
+                                                         P.ts[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 6] = __builtin_amdgcn_s_getreg(63508); } } while (0)
+#else
+#define DH_CTS(i) do { } while (0)
+#define DH_CTS_ID() do { } while (0)
+#endif
 
 // XCD-aware workgroup order (the dispatcher places workgroup b on XCD b % 8, each XCD has its own L2): XCD x walks the
 // contiguous run of pixel tiles [x * T, (x + 1) * T) and visits the cout tiles of a pixel tile back to back, so the halo
@@ -917,6 +932,7 @@ constexpr int H2_LDS_BYTES = H2A_BYTES + 2 * H2B_BYTES;  // 74,496 (the staged e
 template <int EPI, bool STAGED = true, bool CINIT = false, int ABL = 0>
 __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
   extern __shared__ __half s_conv[];
+  DH_CTS(0); DH_CTS_ID();
   char* const lds = reinterpret_cast<char*>(s_conv);
   const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)s_conv;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -994,6 +1010,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
   half8 abl_af[2] = {}, abl_bf[2] = {};                  // (ABL != 0 only: operands that outlive a step)
   H2_FETCH_A(0)
   H2_DMA_B(0)
+  DH_CTS(1);
   for (int c = 0; c < nchunks; ++c) {
     // every wave has finished the previous chunk's reads of the halo tile
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1013,6 +1030,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
       // memory operations complete in order): they get two steps to land instead of one.
       if (dy == 1 && c + 1 < nchunks && !(ABL & 4)) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (step == 0) DH_CTS(2);
       if (step + 1 < nsteps && (!(ABL & 2) || step < 1)) H2_DMA_B(step + 1)           // into the buffer last read in step - 1
       if (dy == 0 && c + 1 < nchunks && !(ABL & 4)) H2_FETCH_A(c + 1)
       const char* const Bcur = lds + H2A_BYTES + (step & 1) * H2B_BYTES;
@@ -1060,6 +1078,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
 #undef H2_FETCH_A
 #undef H2_DMA_B
 #undef GLDS16S
+  DH_CTS(3);
   if constexpr ((ABL & 8) != 0) {                        // no epilogue: one never-taken store keeps the accumulators live
     float sum = 0.f;
 #pragma unroll
@@ -1074,6 +1093,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
   if constexpr (EPI == EPI_HEADS0) staged_heads0_epilogue(P, acc, s_conv, m0, n0, wm0, wn0, tid);
   else if constexpr (STAGED) staged_epilogue<EPI, 2, 128>(P, acc, s_conv, m0, n0, wm0, wn0, tid, HW);
   else conv_epilogue<EPI, 2, 2>(P, acc, (long)P.N * HW, m0, n0, wm0, wn0, lane, HW);
+  DH_CTS(4);
 }
 
 #ifdef DH_ABLATION   // four-wave form of the second kernel (measurement variant, option conv_halo4)
@@ -1341,6 +1361,7 @@ constexpr int H3_LDS_BYTES = H3A_BYTES + 2 * H2B_BYTES;  // 91,392 (the staged e
 template <int EPI, bool STAGED = true, bool CINIT = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(ConvParams P) {
   extern __shared__ __half s_conv[];
+  DH_CTS(0); DH_CTS_ID();
   char* const lds = reinterpret_cast<char*>(s_conv);
   const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)s_conv;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1414,6 +1435,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(ConvParams P) {
 
   H3_FETCH_A(0)
   H3_DMA_B(0)
+  DH_CTS(1);
   for (int c = 0; c < nchunks; ++c) {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave has finished the previous chunk's reads of the halo tile
     int ahy_o = ahy, ax_o = ax;
@@ -1430,6 +1452,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(ConvParams P) {
       // as in the second form; the next chunk's 5 halo loads (issued after the DMA pieces one step ago) may stay in flight at dy == 1
       if (dy == 1 && c + 1 < nchunks) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (step == 0) DH_CTS(2);
       if (step + 1 < nsteps) H3_DMA_B(step + 1)
       if (dy == 0 && c + 1 < nchunks) H3_FETCH_A(c + 1)
       const char* const Bcur = lds + H3A_BYTES + (step & 1) * H2B_BYTES;
@@ -1462,6 +1485,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(ConvParams P) {
 #undef H3_FETCH_A
 #undef H3_DMA_B
 #undef GLDS16S
+  DH_CTS(3);
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     if constexpr (EPI == EPI_HEADS0) staged_heads0_epilogue(P, acc[h], s_conv, m0 + h * 256, n0, wm0, wn0, tid);
@@ -1469,6 +1493,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(ConvParams P) {
     else conv_epilogue<EPI, 2, 2>(P, acc[h], (long)P.N * HW, m0 + h * 256, n0, wm0, wn0, lane, HW);
     if (h == 0) __syncthreads();                          // the staging tile is reused by the second half
   }
+  DH_CTS(4);
 }
 
 #endif  // DH_ABLATION
@@ -2400,6 +2425,20 @@ __global__ __launch_bounds__(512, 2) void corr0_nchw_kernel(const __half* __rest
 
 }  // namespace
 
+// -DDH_ABLATION builds: per-workgroup phase timestamps of the 3x3 kernels into `buf` (8 x uint64 per workgroup, `capacity`
+// workgroups; nullptr switches them off again).  Launches with more workgroups than `capacity` run without timestamps.
+namespace { unsigned long long* g_conv_ts = nullptr; long g_conv_ts_cap = 0; }
+extern "C" int dh_conv_set_timestamps(void* buf, long capacity) {
+#ifdef DH_ABLATION
+  if (capacity < 0 || (buf && ((uintptr_t)buf & 7))) return DH_ERR_ARG;
+  g_conv_ts = (unsigned long long*)buf; g_conv_ts_cap = buf ? capacity : 0;
+  return DH_OK;
+#else
+  (void)buf; (void)capacity;
+  return DH_ERR_UNSUPPORTED;                                 // measurement hook of the -DDH_ABLATION build
+#endif
+}
+
 extern "C" int dh_conv2d_nhwc_f16_ex(const void* const* inputs, const int* in_channels, const int* in_strides, int n_inputs,
                                      const void* weights, const void* weights_halo, const float* bias,
                                      int N, int H, int W, int KH, int KW, int Cout, int CoutPad, int Kpad, int epilogue,
@@ -2448,6 +2487,9 @@ extern "C" int dh_conv2d_nhwc_f16_ex2(const void* const* inputs, const int* in_c
   P.wt = (const __half*)weights; P.wt_halo = (const __half*)weights_halo; P.bias = bias;
   P.N = N; P.H = H; P.W = W; P.KH = KH; P.KW = KW; P.Cout = Cout; P.CoutPad = CoutPad; P.Kpad = Kpad; P.epi = epilogue;
   P.out = out; P.out_f32 = out_is_f32; P.out_stride = out_stride;
+#ifdef DH_ABLATION
+  P.ts = ((long)N * H * W / 256) * ((CoutPad + 127) / 128) <= g_conv_ts_cap ? g_conv_ts : nullptr;
+#endif
   P.gterm = gterm; P.aux0 = (const __half*)aux0; P.aux0_stride = aux0_stride;
   P.aux1 = (const __half*)aux1; P.aux1_stride = aux1_stride; P.red = red;
   hipStream_t st = (hipStream_t)stream;

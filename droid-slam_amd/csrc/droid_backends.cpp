@@ -732,6 +732,15 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         py::arg("epilogue"), py::arg("out"), py::arg("out_stride"), py::arg("gterm"), py::arg("aux0"), py::arg("aux1"), py::arg("red"),
         py::arg("cinit") = py::none(), py::arg("cinit_idx") = py::none(), py::arg("cinit_off") = 0, py::arg("out_raw_f32") = false,
         py::arg("weights_layout") = 0);
+  m.def("conv_set_timestamps", [](c10::optional<torch::Tensor> buf) {
+    if (buf.has_value() && buf->defined()) {
+      CHECK_INPUT((*buf));
+      TORCH_CHECK(buf->scalar_type() == torch::kInt64 && buf->dim() == 2 && buf->size(1) == 8, "conv_set_timestamps: int64 [workgroups, 8]");
+      check_status(dh_conv_set_timestamps(buf->data_ptr(), (long)buf->size(0)), "conv_set_timestamps");
+    } else {
+      check_status(dh_conv_set_timestamps(nullptr, 0), "conv_set_timestamps");
+    }
+  }, "-DDH_ABLATION builds: phase timestamps of the 3x3 convolution kernels into an int64 [workgroups, 8] tensor (None = off)");
   m.def("canvas_mask_", &canvas_mask_, "zero the canvas pixels outside the h x w image (fp16 NHWC, in place)");
   m.def("motion_features", &motion_features, "cat(coords1 - coords0, target - coords1).clamp(-64, 64) as fp16 NHWC");
   m.def("ba_inputs", &ba_inputs, "target = coords1 + delta, weight; also in ba's [E,2,h,w] layout");

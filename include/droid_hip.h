@@ -343,6 +343,11 @@ int dh_conv2d_nhwc_f16_ex2(const void* const* inputs, const int* in_channels, co
                           float* red, const float* cinit, const int64_t* cinit_idx, int cinit_stride, int cinit_off,
                           dh_stream_t stream);
 
+/* Measurement hook (-DDH_ABLATION builds; DH_ERR_UNSUPPORTED in the shipped library): per-workgroup phase timestamps of the 3x3
+ * convolution kernels -- 8 x uint64 per workgroup: 100 MHz wall clock at kernel entry / first fetches issued / first barrier passed /
+ * main loop left / epilogue done, then HW_ID and XCC_ID (which CU).  scripts/conv_timeline.py turns them into per-CU timelines. */
+int dh_conv_set_timestamps(void* buf, long capacity_workgroups);
+
 /* corr_encoder.0 (reference droid_net.py:83-86: 1x1 convolution 196 -> 128 + relu) on the REFERENCE-layout correlation
  * features: x [E,196,HW] f16 (what dh_corr_pyramid_lookup / corr_index_forward produce, channel = level*49 + xoff*7 + yoff),
  * wp [128,208] f16 = weight[cout][cin] zero-padded to 208 input channels, bias [128] f32 -> out [E,HW,128] f16 channel-last.

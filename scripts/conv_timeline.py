@@ -1,0 +1,114 @@
+#!/usr/bin/env python
+"""Per-CU phase timeline of the gate convolution ("record the per-phase timeline that shows where the overlap
+fails").  -DDH_ABLATION build only: every workgroup of conv3x3_halo2_kernel (256-pixel tile, TWO workgroups per CU: the product)
+and conv3x3_halo3_kernel (512-pixel tile, ONE workgroup per CU: 13 % fewer joules, no faster) stores the 100 MHz wall clock at
+kernel entry / first fetches issued / first barrier passed / main loop left / epilogue done plus the CU it ran on
+(dh_conv_set_timestamps).  Per CU the intervals [first barrier, main loop left] are the time its matrix pipe has work; everything
+else -- the accumulator start values from the context term, the first halo + weight group in flight, the GRU epilogue and its
+staged store -- is exposed unless another workgroup of the same CU is in ITS main loop.
+
+    python scripts/conv_timeline.py [--edges 1024] [--out gpurun_out/conv_timeline.json]
+"""
+import argparse, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "droid-slam_amd", "ablation"), os.path.join(ROOT, "droid-slam_amd")]
+import numpy as np
+import torch
+import droid_backends as db
+assert db.get_option("ablation_build") == 1, "needs the -DDH_ABLATION build (DROID_HIP_ABLATION=1 python droid-slam_amd/build.py)"
+from droid_amd.update import UpdateModule, EPI_RELU, EPI_GRU_ZR
+from droid_amd.weights import deterministic_state_dict
+from oracle import update as oupd          # (shape template of the state dict only)
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--edges", type=int, default=1024)
+ap.add_argument("--out", default=None)
+a = ap.parse_args()
+E, K, h, w = a.edges, max(1, a.edges // 8), 48, 64
+
+
+class _SD:
+    def state_dict(self):
+        return oupd.empty_state_dict()
+
+
+torch.manual_seed(0)
+upd = UpdateModule("cuda").load_state_dict(deterministic_state_dict(_SD(), seed=7))
+P = upd.params
+net = torch.tanh(torch.randn(E, h, w, 128, device="cuda")).half()
+c = torch.relu(torch.randn(E, h, w, 128, device="cuda")).half()
+f = torch.relu(torch.randn(E, h, w, 64, device="cuda")).half()
+inp_frames = torch.relu(torch.randn(K, h, w, 128, device="cuda")).half()
+idx = (torch.arange(E, device="cuda") // 8).clamp(max=K - 1)
+ctx = upd.context_term(inp_frames)
+gzr = torch.randn(E, 256, device="cuda") * 0.1
+zr = torch.empty(E, h, w, 256, device="cuda", dtype=torch.float16)
+launches = {"relu (bare convolution, plain staged epilogue)": lambda: P["zr_e"]([net, c, f], EPI_RELU, out=zr),
+            "gru+cinit (the product's z|r launch)": lambda: P["zr_e"]([net, c, f], EPI_GRU_ZR, out=zr, gterm=gzr, aux0=net, cinit=ctx, cinit_idx=idx, cinit_off=0)}
+nwg = (E * h * w // 256) * 2
+buf = torch.zeros(nwg, 8, dtype=torch.int64, device="cuda")
+
+
+def analyse(t, n):
+    """t [n, 8] int64 (10 ns ticks) -> statistics over the steady part of the launch"""
+    t = t[:n].astype(np.int64)
+    cu = (t[:, 5] >> 8 & 0xFF) | ((t[:, 6] & 0xF) << 8)                     # (se, sh, cu) of HW_ID + XCC_ID
+    t0 = t[:, 0].min()
+    ph = (t[:, :5] - t0) * 0.01                                             # microseconds
+    span = ph[:, 4].max()
+    out = {"workgroups": int(n), "compute_units_seen": int(len(np.unique(cu))), "launch_us": float(span),
+           "prologue_us_mean": float((ph[:, 2] - ph[:, 0]).mean()), "prologue_us_p90": float(np.quantile(ph[:, 2] - ph[:, 0], 0.9)),
+           "of_which_until_fetches_issued_us": float((ph[:, 1] - ph[:, 0]).mean()),
+           "main_loop_us_mean": float((ph[:, 3] - ph[:, 2]).mean()),
+           "epilogue_us_mean": float((ph[:, 4] - ph[:, 3]).mean()), "epilogue_us_p90": float(np.quantile(ph[:, 4] - ph[:, 3], 0.9))}
+    # per CU: fraction of its busy span during which at least one resident workgroup is inside its main loop, and the mean number
+    # of workgroups resident / in their main loop
+    cover, resident, inloop = [], [], []
+    for u in np.unique(cu):
+        m = cu == u
+        if m.sum() < 4:
+            continue
+        s0, s1 = ph[m, 0].min(), ph[m, 4].max()
+        ev = sorted([(x, 1) for x in ph[m, 2]] + [(x, -1) for x in ph[m, 3]])
+        depth, last, on = 0, s0, 0.0
+        for x, d in ev:
+            if depth > 0:
+                on += x - last
+            depth += d; last = x
+        cover.append(on / (s1 - s0))
+        resident.append((ph[m, 4] - ph[m, 0]).sum() / (s1 - s0)); inloop.append((ph[m, 3] - ph[m, 2]).sum() / (s1 - s0))
+    out.update({"cu_main_loop_coverage_mean": float(np.mean(cover)), "cu_main_loop_coverage_min": float(np.min(cover)),
+                "workgroups_resident_per_cu_mean": float(np.mean(resident)), "workgroups_in_main_loop_per_cu_mean": float(np.mean(inloop))})
+    return out
+
+
+res = {"edges": E, "what": __doc__.split("\n\n")[0], "cases": []}
+for halo3 in (0, 1):
+    db.set_option("conv_halo3", halo3)
+    upd = UpdateModule("cuda").load_state_dict(deterministic_state_dict(_SD(), seed=7)); P = upd.params       # (weights packed under the option)
+    for name, fn in {"relu (bare convolution, plain staged epilogue)": lambda: P["zr_e"]([net, c, f], EPI_RELU, out=zr),
+                     "gru+cinit (the product's z|r launch)": lambda: P["zr_e"]([net, c, f], EPI_GRU_ZR, out=zr, gterm=gzr, aux0=net, cinit=ctx, cinit_idx=idx, cinit_off=0)}.items():
+        db.conv_set_timestamps(None)
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        ms_plain = e0.elapsed_time(e1)
+        buf.zero_(); db.conv_set_timestamps(buf)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        ms_ts = e0.elapsed_time(e1)
+        db.conv_set_timestamps(None)
+        n = nwg if not halo3 else nwg // 2
+        r = analyse(buf.cpu().numpy(), n)
+        r.update({"kernel": "conv3x3_halo3_kernel (512-px tile, one workgroup per CU)" if halo3 else "conv3x3_halo2_kernel (256-px tile, two workgroups per CU)",
+                  "launch": name, "ms_without_timestamps": ms_plain, "ms_with_timestamps": ms_ts})
+        res["cases"].append(r)
+        print("%-58s %-46s %.3f ms (%.3f with timestamps): prologue %.1f us (p90 %.1f), main loop %.1f us, epilogue %.1f us (p90 %.1f); per CU: "
+              "%.2f workgroups resident, %.2f in their main loop, main-loop coverage %.3f (min %.3f)" % (
+                  r["kernel"], name, ms_plain, ms_ts, r["prologue_us_mean"], r["prologue_us_p90"], r["main_loop_us_mean"], r["epilogue_us_mean"],
+                  r["epilogue_us_p90"], r["workgroups_resident_per_cu_mean"], r["workgroups_in_main_loop_per_cu_mean"],
+                  r["cu_main_loop_coverage_mean"], r["cu_main_loop_coverage_min"]), flush=True)
+db.set_option("conv_halo3", 0)
+if a.out:
+    json.dump(res, open(a.out, "w"), indent=1)
