@@ -58,6 +58,10 @@ struct ConvParams {
   // accumulator start values: acc(image n, pixel r, cout) = cinit[(cinit_idx[n] * H*W + r) * cinit_stride + cinit_off + cout]
   // -- the contribution of input channels that are shared by all images of a group (the ConvGRU's per-source-frame
   // context features), computed once per group by another convolution and kept in fp32
+  // cinit_stride < 0 (round 5): the ACCUMULATOR-TILE layout -- cinit holds, per (frame pixel tile of 256, cout tile of 128), the
+  // 64 x 64 wave tiles of conv3x3_halo2_kernel as the registers hold them: [pixel tile][cout tile of -cinit_stride / 128][wave 8]
+  // [a*2+b][q>>2][lane 64][q&3] fp32, written by the same kernel with out_f32 == 3 (store_acc_tile) and read back as sixteen
+  // 16-byte loads per lane (1 KB contiguous per wave-load) instead of 64 dword loads
   const float* cinit; const int64_t* cinit_idx; int cinit_stride; int cinit_off;
   int xcd_tiles;          // > 0: 1-D grid, workgroup id -> (pixel tile, cout tile) through xcd_decode(); = pixel tiles per XCD
   int ny;                 // cout tiles
@@ -121,6 +125,43 @@ __device__ __forceinline__ void init_acc_tile(const ConvParams& P, f32x16 (&acc)
 #pragma unroll
       for (int q = 0; q < 16; ++q)            // 32 lanes read one 128-byte run of a pixel's couts
         acc[a][b][q] = co_ok ? base[(long)(a * 32 + (q & 3) + 8 * (q >> 2)) * P.cinit_stride + b * 32] : 0.f;
+  }
+}
+
+// the accumulator-tile layout (ConvParams::cinit_stride < 0): register dump / restore of the 2 x 2 tiles of a 64 x 64 wave tile
+using f32x4v = __attribute__((ext_vector_type(4))) float;
+__device__ __forceinline__ long acc_tile_base(long pixel_tile, int n_cout_tiles, int cout_tile, int wave) {
+  return (((pixel_tile * n_cout_tiles + cout_tile) * 8 + wave) * 4) * 4 * 64;          // in 16-byte units
+}
+__device__ __forceinline__ void init_acc_tile_tiled(const ConvParams& P, f32x16 (&acc)[2][2], long m0, int n0, int wave, int lane, int HW) {
+  const int img0 = (int)(m0 / HW);
+  const long pt = (long)P.cinit_idx[img0] * (HW / BM) + (m0 - (long)img0 * HW) / BM;
+  const f32x4v* base = reinterpret_cast<const f32x4v*>(P.cinit) + acc_tile_base(pt, -P.cinit_stride / 128, (P.cinit_off + n0) / 128, wave) + lane;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4v v = base[((a * 2 + b) * 4 + j) * 64];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[a][b][4 * j + i] = v[i];
+      }
+}
+__device__ __forceinline__ void store_acc_tile(const ConvParams& P, const f32x16 (&acc)[2][2], long m0, int n0, int wn0, int wave, int lane) {
+  f32x4v* base = reinterpret_cast<f32x4v*>(P.out) + acc_tile_base(m0 / BM, P.CoutPad / 128, n0 / 128, wave) + lane;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const float bias = P.bias[n0 + wn0 + b * 32 + (lane & 31)];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4v v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = acc[a][b][4 * j + i] + bias;
+        base[((a * 2 + b) * 4 + j) * 64] = v;
+      }
   }
 }
 
@@ -929,7 +970,8 @@ constexpr int H2_LDS_BYTES = H2A_BYTES + 2 * H2B_BYTES;  // 74,496 (the staged e
 // ABL (only instantiated != 0 in -DDH_ABLATION builds, option "conv_abl", WRONG results by construction): timing / power
 // attribution of the main loop.  bit 0: fragment reads only in the first step (operands stay in registers); bit 1: no weight
 // DMA after the first two groups; bit 2: no halo fetch after the first chunk; bit 3: no epilogue; bit 4: no MFMAs.
-template <int EPI, bool STAGED = true, bool CINIT = false, int ABL = 0>
+template <int EPI, bool STAGED = true, int CINIT = 0, int ABL = 0>      // CINIT: 0 zero, 1 pixel-major start values, 2 start values in the accumulator-tile
+                                                                         // layout, 3 (STAGED = false) zero start, OUTPUT in that layout (out_f32 == 3)
 __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
   extern __shared__ __half s_conv[];
   DH_CTS(0); DH_CTS_ID();
@@ -970,7 +1012,8 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
   }
 
   f32x16 acc[2][2];
-  if constexpr (CINIT) init_acc_tile<2, 2>(P, acc, m0, n0, wm0, wn0, lane, HW);
+  if constexpr (CINIT == 2) init_acc_tile_tiled(P, acc, m0, n0, wave, lane, HW);
+  else if constexpr (CINIT == 1) init_acc_tile<2, 2>(P, acc, m0, n0, wm0, wn0, lane, HW);
   else zero_acc<2, 2>(acc);
 
   u32x4 ra[A_PIECES];
@@ -1092,6 +1135,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
   }
   if constexpr (EPI == EPI_HEADS0) staged_heads0_epilogue(P, acc, s_conv, m0, n0, wm0, wn0, tid);
   else if constexpr (STAGED) staged_epilogue<EPI, 2, 128>(P, acc, s_conv, m0, n0, wm0, wn0, tid, HW);
+  else if constexpr (CINIT == 3) store_acc_tile(P, acc, m0, n0, wn0, wave, lane);      // the context term for the CINIT == 2 launches
   else conv_epilogue<EPI, 2, 2>(P, acc, (long)P.N * HW, m0, n0, wm0, wn0, lane, HW);
   DH_CTS(4);
 }
@@ -2018,6 +2062,12 @@ int launch_halo2(const ConvParams& P0, hipStream_t st) {
   P.ny = (int)grid.y;
   if (opts().conv_xcd && grid.x % 8 == 0) { P.xcd_tiles = (int)(grid.x / 8); grid = dim3(grid.x * grid.y, 1); }
   if constexpr (EPI == EPI_LINEAR) {
+    if (P.out_f32 == 3) {                                 // fp32 output in the accumulator-tile layout: 16-byte stores, 1 KB per wave-store
+      DH_LDS_OPTIN((&conv3x3_halo2_kernel<EPI, false, 3>), 80 * 1024);
+      hipLaunchKernelGGL((conv3x3_halo2_kernel<EPI, false, 3>), grid, dim3(512), H2_LDS_BYTES, st, P);
+      DH_LAUNCH_CHECK();
+      return DH_OK;
+    }
     if (P.out_f32) {                                      // fp32 output: 32 lanes already store one full 128-byte run per pixel
       DH_LDS_OPTIN((&conv3x3_halo2_kernel<EPI, false>), 80 * 1024);
       hipLaunchKernelGGL((conv3x3_halo2_kernel<EPI, false>), grid, dim3(512), H2_LDS_BYTES, st, P);
@@ -2026,9 +2076,15 @@ int launch_halo2(const ConvParams& P0, hipStream_t st) {
     }
   }
   if constexpr (EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q) {
+    if (P.cinit && P.cinit_stride < 0) {                  // start values in the accumulator-tile layout
+      DH_LDS_OPTIN((&conv3x3_halo2_kernel<EPI, true, 2>), 80 * 1024);
+      hipLaunchKernelGGL((conv3x3_halo2_kernel<EPI, true, 2>), grid, dim3(512), H2_LDS_BYTES, st, P);
+      DH_LAUNCH_CHECK();
+      return DH_OK;
+    }
     if (P.cinit) {
-      DH_LDS_OPTIN((&conv3x3_halo2_kernel<EPI, true, true>), 80 * 1024);
-      hipLaunchKernelGGL((conv3x3_halo2_kernel<EPI, true, true>), grid, dim3(512), H2_LDS_BYTES, st, P);
+      DH_LDS_OPTIN((&conv3x3_halo2_kernel<EPI, true, 1>), 80 * 1024);
+      hipLaunchKernelGGL((conv3x3_halo2_kernel<EPI, true, 1>), grid, dim3(512), H2_LDS_BYTES, st, P);
       DH_LAUNCH_CHECK();
       return DH_OK;
     }
@@ -2480,8 +2536,11 @@ extern "C" int dh_conv2d_nhwc_f16_ex2(const void* const* inputs, const int* in_c
   if (epilogue == EPI_GRU_Q && (!aux0 || !aux1)) return DH_ERR_ARG;
   if (epilogue == EPI_HEADS0 && (!red || !aux1)) return DH_ERR_ARG;
   if (epilogue != EPI_GLO && epilogue != EPI_HEADS0 && !out) return DH_ERR_ARG;
-  if (out_is_f32 < 0 || out_is_f32 > 2) return DH_ERR_ARG;
-  if (cinit && (!cinit_idx || cinit_stride < cinit_off + Cout || cinit_off < 0)) return DH_ERR_ARG;
+  if (out_is_f32 < 0 || out_is_f32 > 3) return DH_ERR_ARG;
+  if (cinit && cinit_stride >= 0 && (!cinit_idx || cinit_stride < cinit_off + Cout || cinit_off < 0)) return DH_ERR_ARG;
+  if (cinit && cinit_stride < 0 && (!cinit_idx || (-cinit_stride) % 128 || cinit_off < 0 || cinit_off % 128 || Cout % 128 || cinit_off + Cout > -cinit_stride))
+    return DH_ERR_ARG;                                       // accumulator-tile layout: whole 128-cout tiles
+  if (out_is_f32 == 3 && (Cout % 128 || CoutPad != Cout || epilogue != EPI_LINEAR)) return DH_ERR_ARG;
   if (N == 0) return DH_OK;
   P.cinit = cinit; P.cinit_idx = cinit_idx; P.cinit_stride = cinit_stride; P.cinit_off = cinit_off;
   P.wt = (const __half*)weights; P.wt_halo = (const __half*)weights_halo; P.bias = bias;
@@ -2493,6 +2552,16 @@ extern "C" int dh_conv2d_nhwc_f16_ex2(const void* const* inputs, const int* in_c
   P.gterm = gterm; P.aux0 = (const __half*)aux0; P.aux0_stride = aux0_stride;
   P.aux1 = (const __half*)aux1; P.aux1_stride = aux1_stride; P.red = red;
   hipStream_t st = (hipStream_t)stream;
+  if ((P.cinit && P.cinit_stride < 0) || P.out_f32 == 3) {    // accumulator-tile layout: conv3x3_halo2_kernel only (writer and reader share its tiling)
+    if (weights_layout != DH_CONV_LAYOUT_AUTO) return DH_ERR_UNSUPPORTED;
+    switch (P.epi) {
+      case EPI_LINEAR: if (P.out_f32 == 3 && !P.cinit && halo2_ok<EPI_LINEAR>(P)) return launch_halo2<EPI_LINEAR>(P, st); break;
+      case EPI_GRU_ZR: if (P.out_f32 != 3 && halo2_ok<EPI_GRU_ZR>(P)) return launch_halo2<EPI_GRU_ZR>(P, st); break;
+      case EPI_GRU_Q: if (P.out_f32 != 3 && halo2_ok<EPI_GRU_Q>(P)) return launch_halo2<EPI_GRU_Q>(P, st); break;
+      default: break;
+    }
+    return DH_ERR_UNSUPPORTED;
+  }
   if (weights_layout == DH_CONV_LAYOUT_WINO) {              // prototype: F(2,3) along x; weights_halo = droid_amd.update.pack_conv_wino
 #ifdef DH_ABLATION
     switch (P.epi) {

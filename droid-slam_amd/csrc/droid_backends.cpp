@@ -508,7 +508,7 @@ void conv2d_nhwc(std::vector<torch::Tensor> inputs, torch::Tensor weight, c10::o
                  int64_t Cout, int64_t epilogue, c10::optional<torch::Tensor> out, int64_t out_stride,
                  c10::optional<torch::Tensor> gterm, c10::optional<torch::Tensor> aux0, c10::optional<torch::Tensor> aux1,
                  c10::optional<torch::Tensor> red, c10::optional<torch::Tensor> cinit, c10::optional<torch::Tensor> cinit_idx,
-                 int64_t cinit_off, bool out_raw_f32, int64_t weights_layout) {
+                 int64_t cinit_off, bool out_raw_f32, int64_t weights_layout, bool out_tiled, bool cinit_tiled) {
   TORCH_CHECK(!inputs.empty() && inputs.size() <= 4, "conv2d_nhwc: 1..4 inputs");
   const void* ptrs[4]; int chans[4], strides[4];
   const int64_t N = inputs[0].size(0), H = inputs[0].size(1), W = inputs[0].size(2);
@@ -535,13 +535,21 @@ void conv2d_nhwc(std::vector<torch::Tensor> inputs, torch::Tensor weight, c10::o
     TORCH_CHECK(cinit_idx.has_value(), "conv2d_nhwc: cinit needs cinit_idx");
     const torch::Tensor& it = *cinit_idx;
     CHECK_INPUT(ct); CHECK_F32(ct); CHECK_INPUT(it); CHECK_I64(it);
-    TORCH_CHECK(ct.dim() == 4 && ct.size(1) == H && ct.size(2) == W && it.numel() == N, "conv2d_nhwc: cinit [K,H,W,C] f32, cinit_idx [N] i64");
-    ci = ct.data_ptr<float>(); cidx = it.data_ptr<int64_t>(); cstride = (int)ct.size(3);
+    if (cinit_tiled) {      // accumulator-tile layout (include/droid_hip.h): [K, H*W/256 pixel tiles, C/128 cout tiles, 32768 floats per tile]
+      TORCH_CHECK(ct.dim() == 4 && ct.size(1) * 256 == H * W && ct.size(3) == 32768 && it.numel() == N,
+                  "conv2d_nhwc: tiled cinit [K, H*W/256, C/128, 32768] f32, cinit_idx [N] i64");
+      cstride = -(int)ct.size(2) * 128;
+    } else {
+      TORCH_CHECK(ct.dim() == 4 && ct.size(1) == H && ct.size(2) == W && it.numel() == N, "conv2d_nhwc: cinit [K,H,W,C] f32, cinit_idx [N] i64");
+      cstride = (int)ct.size(3);
+    }
+    ci = ct.data_ptr<float>(); cidx = it.data_ptr<int64_t>();
   }
   TORCH_CHECK(!out_raw_f32 || out_f32, "conv2d_nhwc: out_raw_f32 needs a float32 output");
+  TORCH_CHECK(!out_tiled || (out_f32 && out_raw_f32), "conv2d_nhwc: out_tiled needs a raw float32 output");
   check_status(dh_conv2d_nhwc_f16_ex2(ptrs, chans, strides, (int)inputs.size(), weight.data_ptr(), opt_ptr(weight_halo), (int)weights_layout, bias.data_ptr<float>(),
                                      (int)N, (int)H, (int)W, (int)KH, (int)KW, (int)Cout, (int)weight.size(0), (int)weight.size(1),
-                                     (int)epilogue, opt_ptr(out), out_f32 ? (out_raw_f32 ? 2 : 1) : 0, (int)out_stride,
+                                     (int)epilogue, opt_ptr(out), out_f32 ? (out_tiled ? 3 : out_raw_f32 ? 2 : 1) : 0, (int)out_stride,
                                      gterm.has_value() ? gterm->data_ptr<float>() : nullptr,
                                      opt_ptr(aux0), last(aux0), opt_ptr(aux1), last(aux1),
                                      red.has_value() ? red->data_ptr<float>() : nullptr, ci, cidx, cstride, (int)cinit_off,
@@ -731,7 +739,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         py::arg("inputs"), py::arg("weight"), py::arg("weight_halo"), py::arg("bias"), py::arg("KH"), py::arg("KW"), py::arg("Cout"),
         py::arg("epilogue"), py::arg("out"), py::arg("out_stride"), py::arg("gterm"), py::arg("aux0"), py::arg("aux1"), py::arg("red"),
         py::arg("cinit") = py::none(), py::arg("cinit_idx") = py::none(), py::arg("cinit_off") = 0, py::arg("out_raw_f32") = false,
-        py::arg("weights_layout") = 0);
+        py::arg("weights_layout") = 0, py::arg("out_tiled") = false, py::arg("cinit_tiled") = false);
   m.def("conv_set_timestamps", [](c10::optional<torch::Tensor> buf) {
     if (buf.has_value() && buf->defined()) {
       CHECK_INPUT((*buf));

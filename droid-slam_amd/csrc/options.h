@@ -24,6 +24,7 @@ struct Options {
   int altcorr_v1;       // DH_ALTCORR_V1 (0): first form of the MFMA alt-correlation kernel (register staging) for A/B runs
   int conv_wino;        // DH_CONV_WINO (0): read by the host packer only (droid_amd.update): gate convolutions through the Winograd F(2,3) prototype
   int conv_halo3;       // DH_CONV_HALO3 (0): 3x3 / 128-cout convolutions through the 512-pixel-tile form (conv3x3_halo3_kernel: 128 x 64 per wave, one workgroup per CU) instead of conv3x3_halo2_kernel; same weight layout, same results up to the accumulation order of nothing (identical k order)
+  int cinit_tiled;      // DH_CINIT_TILED (1): host side (UpdateModule): the gates' per-frame context term in the accumulator-tile layout (16-byte start-value loads); 0 = pixel-major
   int conv_halo64;      // DH_CONV_HALO64 (1): 3x3 layers with 64 couts through conv3x3_halo64_kernel (0 = first halo kernel); read by the weight packer too
   int conv_halo4;       // DH_CONV_HALO4 (0): -DDH_ABLATION builds only: the second kernel with four 64 x 128 waves per workgroup
   int conv_abl;         // DH_CONV_ABL (0): -DDH_ABLATION builds only: timing-ablation mask of conv3x3_halo2_kernel (wrong results)

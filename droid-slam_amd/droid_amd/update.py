@@ -214,15 +214,22 @@ class _Conv:
             self._epoch = epoch
 
     def __call__(self, inputs, epi, out=None, out_stride=None, gterm=None, aux0=None, aux1=None, red=None,
-                 cinit=None, cinit_idx=None, cinit_off=0, out_raw_f32=False):
+                 cinit=None, cinit_idx=None, cinit_off=0, out_raw_f32=False, out_tiled=False):
+        """out_tiled (with out_raw_f32): the fp32 output in the accumulator-tile layout of csrc/conv.hip (ConvParams::cinit_stride < 0),
+        returned as [N, h*w/256 pixel tiles, cout/128 cout tiles, 32768 floats per tile] (frame-major: slices of whole frames stay
+        valid); a `cinit` tensor of that shape is read back in that layout"""
         self._check_layout()
         x0 = inputs[0]
+        if out is None and out_tiled:
+            assert out_raw_f32 and (x0.shape[1] * x0.shape[2]) % 256 == 0 and self.cout % 128 == 0
+            out = torch.empty(x0.shape[0], x0.shape[1] * x0.shape[2] // 256, self.cout // 128, 32768, dtype=torch.float32, device=x0.device)
         if out is None and epi not in (EPI_GLO, EPI_HEADS0):
             out = torch.empty(x0.shape[0], x0.shape[1], x0.shape[2], self.cout,
                               dtype=torch.float32 if out_raw_f32 else torch.float16, device=x0.device)
-        stride = 0 if out is None else (out.shape[-1] if out_stride is None else out_stride)
+        stride = 0 if out is None else (self.cout if out_tiled else out.shape[-1] if out_stride is None else out_stride)
+        cinit_tiled = cinit is not None and cinit.dim() == 4 and cinit.shape[-1] == 32768 and cinit.shape[1] * 256 == x0.shape[1] * x0.shape[2]
         droid_backends.conv2d_nhwc(list(inputs), self.w, self.wh, self.b, self.k, self.k, self.cout, epi, out, stride,
-                                   gterm, aux0, aux1, red, cinit, cinit_idx, cinit_off, out_raw_f32, self.layout)
+                                   gterm, aux0, aux1, red, cinit, cinit_idx, cinit_off, out_raw_f32, self.layout, out_tiled, cinit_tiled)
         return out
 
 
@@ -358,11 +365,20 @@ class UpdateModule:
         return x.to(torch.float16).contiguous()
 
     # ---- the operator ----------------------------------------------------------------------------
-    def context_term(self, inp_frames):
+    def context_term(self, inp_frames, tiled=None):
         """inp_frames [K,h,w,128] f16 -> [K,h,w,384] f32: the context features' share of the z | r | q pre-activations
         (no bias).  Depends only on the frames' context features, i.e. it can be kept for as long as the keyframes live;
-        forward_nhwc recomputes it on every call unless the caller passes it in."""
-        return self.params["ctx"]([inp_frames], EPI_LINEAR, out_raw_f32=True)
+        forward_nhwc recomputes it on every call unless the caller passes it in.
+        Round 5: by default (option cinit_tiled) the 1536 bytes per pixel are stored in the ACCUMULATOR-TILE layout of the gate
+        kernel (the registers of its 64 x 64 wave tiles, dumped by the producing launch and restored by the gate launches with
+        16-byte loads: profiles/r05_f_conv_phase_timeline.txt shows the pixel-major form holding a workgroup 18 us before its first
+        MFMA).  Same values; the tensor then has the shape [K, h*w/256, 3, 32768] and is only meaningful as `cinit=` of the gate convolutions."""
+        P = self.params
+        if tiled is None:
+            tiled = (droid_backends.get_option("cinit_tiled") == 1 and droid_backends.get_option("conv_halo") == 1
+                     and droid_backends.get_option("conv_halo2") == 1 and P["zr_e"].layout == LAYOUT_AUTO and P["ctx"].wh is not None
+                     and inp_frames.shape[2] == 64 and inp_frames.shape[1] % 4 == 0)
+        return P["ctx"]([inp_frames], EPI_LINEAR, out_raw_f32=True, out_tiled=bool(tiled))
 
     def corr0_layer(self, corr):
         """corr_encoder.0 (1x1, 196 -> 128, ReLU; droid_net.py:96-100) on correlation features [E,196,h,w] (reference layout; pixel

@@ -321,7 +321,12 @@ int dh_heads_gather(const float* partials, const float* bias4, float* dw, int N,
  * (out_is_f32 = 2), and the per-edge gate convolutions run over 320 instead of 448 input channels starting from it --
  * the same sum, associated differently.  Supported where the gate convolutions take their production kernel (3x3, W == 64,
  * H % 4 == 0, every in_channels[i] % 32 == 0, epilogue 3 or 4); DH_ERR_UNSUPPORTED otherwise (the caller then gathers the
- * context features per edge and uses dh_conv2d_nhwc_f16 on all 448 channels). */
+ * context features per edge and uses dh_conv2d_nhwc_f16 on all 448 channels).
+ * Round 5, the ACCUMULATOR-TILE layout of that per-frame tensor: out_is_f32 == 3 (writer; epilogue 0, Cout % 128 == 0) stores the
+ * 64 x 64 wave tiles of the kernel as its registers hold them -- [pixel tile of 256][cout tile of 128][wave 8][a*2+b][q>>2]
+ * [lane 64][q&3] fp32, the same N*H*W*Cout floats -- and cinit_stride = -(Cout of that tensor) (reader; cinit_off % 128 == 0)
+ * restores them with sixteen 16-byte loads per lane (1 KB contiguous per wave-load) instead of 64 dword loads: the same values,
+ * i.e. bit-identical results; both only in the production 3x3 kernel, DH_ERR_UNSUPPORTED elsewhere. */
 int dh_conv2d_nhwc_f16_ex(const void* const* inputs, const int* in_channels, const int* in_strides, int n_inputs,
                           const void* weights, const void* weights_halo, const float* bias,
                           int N, int H, int W, int KH, int KW, int Cout, int CoutPad, int Kpad, int epilogue,

@@ -34,7 +34,8 @@ c = torch.relu(torch.randn(E, h, w, 128, device="cuda")).half()
 f = torch.relu(torch.randn(E, h, w, 64, device="cuda")).half()
 inp_frames = torch.relu(torch.randn(K, h, w, 128, device="cuda")).half()
 idx = (torch.arange(E, device="cuda") // 8).clamp(max=K - 1)
-ctx = upd.context_term(inp_frames)
+ctx = upd.context_term(inp_frames, tiled=False)          # pixel-major start values (rounds 2-4)
+ctx_t = upd.context_term(inp_frames, tiled=True)         # accumulator-tile layout (round 5 default)
 gzr = torch.randn(E, 256, device="cuda") * 0.1
 gq = torch.randn(E, 128, device="cuda") * 0.1
 zr = torch.empty(E, h, w, 256, device="cuda", dtype=torch.float16)
@@ -55,10 +56,14 @@ for rep in range(2):
         ("z|r relu", lambda: P["zr_e"]([net, c, f], EPI_RELU, out=zr), 256),
         ("z|r gru", lambda: P["zr_e"]([net, c, f], EPI_GRU_ZR, out=zr, gterm=gzr, aux0=net), 256),
         ("z|r gru+cinit", lambda: P["zr_e"]([net, c, f], EPI_GRU_ZR, out=zr, gterm=gzr, aux0=net, cinit=ctx, cinit_idx=idx, cinit_off=0), 256),
+        ("z|r gru+cinit-t", lambda: P["zr_e"]([net, c, f], EPI_GRU_ZR, out=zr, gterm=gzr, aux0=net, cinit=ctx_t, cinit_idx=idx, cinit_off=0), 256),
         ("q relu", lambda: P["q_e"]([zr[..., 128:], c, f], EPI_RELU, out=out), 128),
         ("q gru", lambda: P["q_e"]([zr[..., 128:], c, f], EPI_GRU_Q, out=out, gterm=gq, aux0=net, aux1=zr), 128),
         ("q gru+cinit", lambda: P["q_e"]([zr[..., 128:], c, f], EPI_GRU_Q, out=out, gterm=gq, aux0=net, aux1=zr, cinit=ctx, cinit_idx=idx, cinit_off=256), 128),
+        ("q gru+cinit-t", lambda: P["q_e"]([zr[..., 128:], c, f], EPI_GRU_Q, out=out, gterm=gq, aux0=net, aux1=zr, cinit=ctx_t, cinit_idx=idx, cinit_off=256), 128),
+        ("ctx conv", lambda: upd.context_term(inp_frames, tiled=False), 0),
+        ("ctx conv tiled", lambda: upd.context_term(inp_frames, tiled=True), 0),
     ]
     for name, fn, cout in rows:
         ms = timed(fn)
-        print("%-14s %7.3f ms  %.3f PFLOP/s" % (name, ms, fl(cout) / ms / 1e12), flush=True)
+        print("%-16s %7.3f ms  %.3f PFLOP/s" % (name, ms, (fl(cout) if cout else 2.0 * K * h * w * 128 * 9 * 384) / ms / 1e12), flush=True)

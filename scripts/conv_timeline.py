@@ -40,11 +40,10 @@ c = torch.relu(torch.randn(E, h, w, 128, device="cuda")).half()
 f = torch.relu(torch.randn(E, h, w, 64, device="cuda")).half()
 inp_frames = torch.relu(torch.randn(K, h, w, 128, device="cuda")).half()
 idx = (torch.arange(E, device="cuda") // 8).clamp(max=K - 1)
-ctx = upd.context_term(inp_frames)
+ctx_pm = upd.context_term(inp_frames, tiled=False)          # pixel-major [K,h,w,384] (rounds 2-4)
+ctx_tl = upd.context_term(inp_frames, tiled=True)           # accumulator-tile layout (round 5 default)
 gzr = torch.randn(E, 256, device="cuda") * 0.1
 zr = torch.empty(E, h, w, 256, device="cuda", dtype=torch.float16)
-launches = {"relu (bare convolution, plain staged epilogue)": lambda: P["zr_e"]([net, c, f], EPI_RELU, out=zr),
-            "gru+cinit (the product's z|r launch)": lambda: P["zr_e"]([net, c, f], EPI_GRU_ZR, out=zr, gterm=gzr, aux0=net, cinit=ctx, cinit_idx=idx, cinit_off=0)}
 nwg = (E * h * w // 256) * 2
 buf = torch.zeros(nwg, 8, dtype=torch.int64, device="cuda")
 
@@ -86,8 +85,12 @@ res = {"edges": E, "what": __doc__.split("\n\n")[0], "cases": []}
 for halo3 in (0, 1):
     db.set_option("conv_halo3", halo3)
     upd = UpdateModule("cuda").load_state_dict(deterministic_state_dict(_SD(), seed=7)); P = upd.params       # (weights packed under the option)
-    for name, fn in {"relu (bare convolution, plain staged epilogue)": lambda: P["zr_e"]([net, c, f], EPI_RELU, out=zr),
-                     "gru+cinit (the product's z|r launch)": lambda: P["zr_e"]([net, c, f], EPI_GRU_ZR, out=zr, gterm=gzr, aux0=net, cinit=ctx, cinit_idx=idx, cinit_off=0)}.items():
+    cases = {"relu (bare convolution, plain staged epilogue)": lambda: P["zr_e"]([net, c, f], EPI_RELU, out=zr),
+             "gru (GRU epilogue, accumulators from zero)": lambda: P["zr_e"]([net, c, f], EPI_GRU_ZR, out=zr, gterm=gzr, aux0=net),
+             "gru+cinit, pixel-major context term (rounds 2-4)": lambda: P["zr_e"]([net, c, f], EPI_GRU_ZR, out=zr, gterm=gzr, aux0=net, cinit=ctx_pm, cinit_idx=idx, cinit_off=0)}
+    if not halo3:             # (the 512-pixel form reads pixel-major start values only)
+        cases["gru+cinit, accumulator-tile context term (the product's z|r launch)"] = lambda: P["zr_e"]([net, c, f], EPI_GRU_ZR, out=zr, gterm=gzr, aux0=net, cinit=ctx_tl, cinit_idx=idx, cinit_off=0)
+    for name, fn in cases.items():
         db.conv_set_timestamps(None)
         for _ in range(3):
             fn()
@@ -104,7 +107,7 @@ for halo3 in (0, 1):
         r.update({"kernel": "conv3x3_halo3_kernel (512-px tile, one workgroup per CU)" if halo3 else "conv3x3_halo2_kernel (256-px tile, two workgroups per CU)",
                   "launch": name, "ms_without_timestamps": ms_plain, "ms_with_timestamps": ms_ts})
         res["cases"].append(r)
-        print("%-58s %-46s %.3f ms (%.3f with timestamps): prologue %.1f us (p90 %.1f), main loop %.1f us, epilogue %.1f us (p90 %.1f); per CU: "
+        print("%-58s %-70s %.3f ms (%.3f with timestamps): prologue %.1f us (p90 %.1f), main loop %.1f us, epilogue %.1f us (p90 %.1f); per CU: "
               "%.2f workgroups resident, %.2f in their main loop, main-loop coverage %.3f (min %.3f)" % (
                   r["kernel"], name, ms_plain, ms_ts, r["prologue_us_mean"], r["prologue_us_p90"], r["main_loop_us_mean"], r["epilogue_us_mean"],
                   r["epilogue_us_p90"], r["workgroups_resident_per_cu_mean"], r["workgroups_in_main_loop_per_cu_mean"],

@@ -66,6 +66,12 @@ def test_argument_errors_are_reported_before_any_launch(built):
     assert lib.dh_segment_mean_f16(None, None, None, None, 3, ctypes.c_long(12), None) == 1                       # row % 8
     assert lib.dh_conv2d_nhwc_f16(None, None, None, 1, None, None, None, 1, 8, 8, 3, 3, 4, 32, 64, 0,
                                   None, 0, 4, None, None, 0, None, 0, None, None) == 1
+    # round 5: the accumulator-tile layout (out_is_f32 == 3 / cinit_stride < 0) takes whole 128-cout tiles and the plain epilogue only
+    assert lib.dh_conv2d_nhwc_f16(None, None, None, 1, None, None, None, 1, 8, 64, 3, 3, 64, 64, 1152, 0,
+                                  None, 3, 64, None, None, 0, None, 0, None, None) == 1
+    assert lib.dh_conv2d_nhwc_f16(None, None, None, 1, None, None, None, 1, 8, 64, 3, 3, 128, 128, 1152, 1,
+                                  None, 3, 128, None, None, 0, None, 0, None, None) == 1
+    assert lib.dh_conv_set_timestamps(None, 0) == 4                      # measurement hook of the -DDH_ABLATION build only
     rows, cols = ctypes.c_int(), ctypes.c_int()
     assert lib.dh_ba_system_shape(1, 512, ctypes.byref(rows), ctypes.byref(cols)) == 0
     assert cols.value == 3072 and rows.value == 3072 + 64

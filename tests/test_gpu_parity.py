@@ -761,6 +761,62 @@ def test_conv_64_cout_layer_in_the_second_kernel_form(db, option):
         assert (out.float() - ref).abs().max() <= 1e-2 * max(1.0, ref.abs().max().item()), (N, H, W, f32_out)
 
 
+def test_context_term_in_the_accumulator_tile_layout_is_the_same_numbers(db, option):
+    """round 5: the gates' per-frame context term is stored as the register tiles of conv3x3_halo2_kernel (option cinit_tiled, the
+    default) -- [frame][pixel tile of 256][cout tile of 128][wave][a*2+b][q>>2][lane][q&3] -- and restored by the gate launches with
+    16-byte loads.  (a) un-tiled on the host it EQUALS the pixel-major tensor element for element; (b) the update operator returns
+    bit-identical results with either form (same fp32 start values, same MFMA order); (c) a slice of whole frames stays valid."""
+    from droid_amd.update import UpdateModule
+    from droid_amd.weights import deterministic_state_dict
+    from oracle import update as oupd
+
+    class _SD:
+        def state_dict(self):
+            return oupd.empty_state_dict()
+    torch.manual_seed(5)
+    upd = UpdateModule("cuda").load_state_dict(deterministic_state_dict(_SD(), seed=3))
+    K, E, h, w = 3, 7, 12, 64
+    inp_frames = torch.relu(torch.randn(K, h, w, 128, device="cuda")).half()
+    assert db.get_option("cinit_tiled") == 1
+    t = upd.context_term(inp_frames)
+    p = upd.context_term(inp_frames, tiled=False)
+    assert tuple(t.shape) == (K, h * w // 256, 3, 32768) and tuple(p.shape) == (K, h, w, 384)
+    # (a) host-side un-tiling by the layout rule of include/droid_hip.h
+    tt = t.view(K, h * w // 256, 3, 8, 2, 2, 4, 64, 4).cpu()            # [k, pt, ct, wave, a, b, j, lane, i]
+    wave, a, b, j, lane, i = torch.meshgrid(*[torch.arange(n) for n in (8, 2, 2, 4, 64, 4)], indexing="ij")
+    q = 4 * j + i
+    pix = (wave & 3) * 64 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5)          # pixel inside the 256-pixel tile
+    co = (wave >> 2) * 64 + b * 32 + (lane & 31)                                       # cout inside the 128-cout tile
+    pp = p.view(K, h * w // 256, 256, 3, 128).cpu()
+    assert torch.equal(tt, pp[:, :, pix, :, co].permute(6, 7, 8, 0, 1, 2, 3, 4, 5))
+    # (b) the operator with either form
+    ii = torch.tensor([0, 0, 0, 1, 1, 2, 2], device="cuda")
+    net0 = torch.tanh(torch.randn(E, h, w, 128, device="cuda")).half()
+    corr = torch.randn(E, 196, h, w, device="cuda").half()
+    flow = torch.zeros(E, h, w, 8, device="cuda", dtype=torch.float16); flow[..., :4] = torch.randn(E, h, w, 4, device="cuda").half()
+    outs = []
+    for ctx in (t, p, None):
+        n = net0.clone()
+        r = upd.forward_nhwc(n, None, corr, flow, ii, inp_frames=inp_frames, inp_index=ii, ctx=ctx)
+        torch.cuda.synchronize()
+        outs.append([x.clone() for x in r])
+    option("cinit_tiled", 0)
+    n = net0.clone()
+    r = upd.forward_nhwc(n, None, corr, flow, ii, inp_frames=inp_frames, inp_index=ii)
+    torch.cuda.synchronize()
+    outs.append([x.clone() for x in r])
+    for other in outs[1:]:
+        for x, y in zip(outs[0], other):
+            assert torch.equal(x, y)
+    # (c) frames 1..2 only, edges re-indexed
+    option("cinit_tiled", 1)
+    sel = ii >= 1
+    n = net0[sel].clone()
+    r = upd.forward_nhwc(n, None, corr[sel].contiguous(), flow[sel].contiguous(), ii[sel].contiguous(), inp_frames=inp_frames[1:], inp_index=(ii[sel] - 1).contiguous(), ctx=t[1:])
+    torch.cuda.synchronize()
+    assert torch.equal(r[0], outs[0][0][sel]) and torch.equal(r[1], outs[0][1][sel]) and torch.equal(r[2], outs[0][2][sel])
+
+
 def test_conv7x7_on_four_channels_and_global_context_kernels(db):
     """the two single-purpose kernels of the update operator against torch: flow_encoder.0 (7x7 on the 4 motion
     channels, droid_net.py:89) and the ConvGRU's global-context reduction mean(sigmoid(w(net)) * net) (gru.py:23-24)"""
