@@ -16,7 +16,7 @@ import numpy as np
 import torch
 import droid_backends as db
 assert db.get_option("ablation_build") == 1, "needs the -DDH_ABLATION build (DROID_HIP_ABLATION=1 python droid-slam_amd/build.py)"
-from droid_amd.update import UpdateModule, EPI_RELU, EPI_GRU_ZR
+from droid_amd.update import UpdateModule, EPI_RELU, EPI_GRU_ZR, EPI_HEADS0
 from droid_amd.weights import deterministic_state_dict
 from oracle import update as oupd          # (shape template of the state dict only)
 
@@ -90,6 +90,13 @@ for halo3 in (0, 1):
              "gru+cinit, pixel-major context term (rounds 2-4)": lambda: P["zr_e"]([net, c, f], EPI_GRU_ZR, out=zr, gterm=gzr, aux0=net, cinit=ctx_pm, cinit_idx=idx, cinit_off=0)}
     if not halo3:             # (the 512-pixel form reads pixel-major start values only)
         cases["gru+cinit, accumulator-tile context term (the product's z|r launch)"] = lambda: P["zr_e"]([net, c, f], EPI_GRU_ZR, out=zr, gterm=gzr, aux0=net, cinit=ctx_tl, cinit_idx=idx, cinit_off=0)
+    if not halo3:             # the other 3x3 launches of the operator that run in this kernel
+        part = torch.empty(2, E * h // 4, 6, 64, 4, dtype=torch.float32, device="cuda")
+        w2p = P["heads2_fused"][0]
+        x128 = torch.empty(E, h, w, 128, device="cuda", dtype=torch.float16)
+        cases["128 -> 128 relu (corr_encoder.2 / agg.conv1)"] = lambda: P["agg1"]([net], EPI_RELU, out=x128)
+        cases["heads: 128 -> 256 + the fused second layer (EPI_HEADS0)"] = lambda: P["heads0"]([net], EPI_HEADS0, aux1=w2p, red=part)
+        cases["context term 128 -> 384, accumulator-tile output (512 frames at E = 4096)"] = lambda: upd.context_term(inp_frames, tiled=True)
     for name, fn in cases.items():
         db.conv_set_timestamps(None)
         for _ in range(3):
@@ -102,8 +109,9 @@ for halo3 in (0, 1):
         e0.record(); fn(); e1.record(); torch.cuda.synchronize()
         ms_ts = e0.elapsed_time(e1)
         db.conv_set_timestamps(None)
-        n = nwg if not halo3 else nwg // 2
-        r = analyse(buf.cpu().numpy(), n)
+        tb = buf.cpu().numpy()
+        n = int((tb[:, 4] != 0).sum())                       # workgroups that reported (they fill the buffer from index 0)
+        r = analyse(tb, n)
         r.update({"kernel": "conv3x3_halo3_kernel (512-px tile, one workgroup per CU)" if halo3 else "conv3x3_halo2_kernel (256-px tile, two workgroups per CU)",
                   "launch": name, "ms_without_timestamps": ms_plain, "ms_with_timestamps": ms_ts})
         res["cases"].append(r)

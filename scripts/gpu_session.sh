@@ -10,6 +10,9 @@ TAG=${1:-s}; shift
 PHASES=${@:-tests bench prof}
 export TMPDIR=/tmp
 OUT=gpurun_out/$TAG; mkdir -p $OUT
+# a box whose device does not come up is given back at once (session r5h sat 300 s on one: no output, the box returned as wedged)
+timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); torch.cuda.synchronize(); print('device ok:', torch.cuda.get_device_name(0), float(x.sum()))" \
+  || { echo "device probe failed or timed out: giving the box back"; exit 3; }
 for ph in $PHASES; do
   case $ph in
     tests)
