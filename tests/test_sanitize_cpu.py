@@ -28,6 +28,9 @@ def test_c_abi_host_paths_under_asan_and_ubsan():
     lib = os.path.join(PKG, "sanitize", "libdroid_hip.so")
     if not os.path.exists(lib):
         pytest.skip("sanitize build absent (DROID_HIP_SANITIZE=1 python droid-slam_amd/build.py)")
+    srcs = [os.path.join(PKG, "csrc", f) for f in os.listdir(os.path.join(PKG, "csrc"))] + [os.path.join(ROOT, "include", "droid_hip.h")]
+    if os.path.getmtime(lib) < max(os.path.getmtime(f) for f in srcs):
+        pytest.skip("sanitize build is older than the sources (DROID_HIP_SANITIZE=1 python droid-slam_amd/build.py)")
     rt = _asan_runtime()
     if rt is None:
         pytest.skip("no AddressSanitizer runtime next to hipcc's clang")
