@@ -16,7 +16,7 @@ import numpy as np
 import torch
 import droid_backends as db
 assert db.get_option("ablation_build") == 1, "needs the -DDH_ABLATION build (DROID_HIP_ABLATION=1 python droid-slam_amd/build.py)"
-from droid_amd.update import UpdateModule, EPI_RELU, EPI_GRU_ZR, EPI_HEADS0
+from droid_amd.update import UpdateModule, EPI_RELU, EPI_GRU_ZR, EPI_GRU_Q, EPI_HEADS0
 from droid_amd.weights import deterministic_state_dict
 from oracle import update as oupd          # (shape template of the state dict only)
 
@@ -90,6 +90,13 @@ for halo3 in (0, 1):
              "gru+cinit, pixel-major context term (rounds 2-4)": lambda: P["zr_e"]([net, c, f], EPI_GRU_ZR, out=zr, gterm=gzr, aux0=net, cinit=ctx_pm, cinit_idx=idx, cinit_off=0)}
     if not halo3:             # (the 512-pixel form reads pixel-major start values only)
         cases["gru+cinit, accumulator-tile context term (the product's z|r launch)"] = lambda: P["zr_e"]([net, c, f], EPI_GRU_ZR, out=zr, gterm=gzr, aux0=net, cinit=ctx_tl, cinit_idx=idx, cinit_off=0)
+    if not halo3:             # the q gate (one cout tile per pixel tile; its epilogue reads z and the old state)
+        gq = torch.randn(E, 128, device="cuda") * 0.1
+        zr_in = torch.rand(E, h, w, 256, device="cuda").half()
+        outq = torch.empty(E, h, w, 128, device="cuda", dtype=torch.float16)
+        cases["q: relu (bare convolution 320 -> 128)"] = lambda: P["q_e"]([zr_in[..., 128:], c, f], EPI_RELU, out=outq)
+        cases["q: gru (tanh + state update, accumulators from zero)"] = lambda: P["q_e"]([zr_in[..., 128:], c, f], EPI_GRU_Q, out=outq, gterm=gq, aux0=net, aux1=zr_in)
+        cases["q: gru+cinit, accumulator-tile context term (the product's q launch)"] = lambda: P["q_e"]([zr_in[..., 128:], c, f], EPI_GRU_Q, out=outq, gterm=gq, aux0=net, aux1=zr_in, cinit=ctx_tl, cinit_idx=idx, cinit_off=256)
     if not halo3:             # the other 3x3 launches of the operator that run in this kernel
         part = torch.empty(2, E * h // 4, 6, 64, 4, dtype=torch.float32, device="cuda")
         w2p = P["heads2_fused"][0]
