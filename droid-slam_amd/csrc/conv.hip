@@ -67,6 +67,7 @@ struct ConvParams {
   int ny;                 // cout tiles
 #ifdef DH_ABLATION
   unsigned long long* ts; // phase timestamps per workgroup (dh_conv_set_timestamps; scripts/conv_timeline.py), else nullptr
+  unsigned long long* ts_step; unsigned ts_step_wg0;     // per-step stamps of 256 workgroups from ts_step_wg0 on (64 slots each), else nullptr
 #endif
 };
 
@@ -77,9 +78,13 @@ struct ConvParams {
 #define DH_CTS(i) do { if (P.ts && threadIdx.x == 0) P.ts[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = wall_clock64(); } while (0)
 #define DH_CTS_ID() do { if (P.ts && threadIdx.x == 0) { P.ts[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 5] = __builtin_amdgcn_s_getreg(63492); \
                                                          P.ts[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 6] = __builtin_amdgcn_s_getreg(63508); } } while (0)
+// per-STEP stamps of the main loop for the workgroups [P.ts_step_wg0, P.ts_step_wg0 + 256): 64 slots each behind the per-workgroup block
+#define DH_CTS_STEP(step_) do { if (P.ts_step && threadIdx.x == 0) { const unsigned w_ = blockIdx.y * gridDim.x + blockIdx.x - P.ts_step_wg0; \
+                                 if (w_ < 256u && (step_) < 64) P.ts_step[(size_t)w_ * 64 + (step_)] = wall_clock64(); } } while (0)
 #else
 #define DH_CTS(i) do { } while (0)
 #define DH_CTS_ID() do { } while (0)
+#define DH_CTS_STEP(step_) do { } while (0)
 #endif
 
 // XCD-aware workgroup order (the dispatcher places workgroup b on XCD b % 8, each XCD has its own L2): XCD x walks the
@@ -1093,6 +1098,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
       if (dy == 1 && c + 1 < nchunks && !(ABL & 4)) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       if (step == 0) DH_CTS(2);
+      DH_CTS_STEP(step);
       if (step + 1 < nsteps && (!(ABL & 2) || step < 1)) H2_DMA_B(step + 1)           // into the buffer last read in step - 1
       if (dy == 0 && c + 1 < nchunks && !(ABL & 4)) H2_FETCH_A(c + 1)
       const char* const Bcur = lds + H2A_BYTES + (step & 1) * H2B_BYTES;
@@ -2566,7 +2572,13 @@ extern "C" int dh_conv2d_nhwc_f16_ex2(const void* const* inputs, const int* in_c
   P.N = N; P.H = H; P.W = W; P.KH = KH; P.KW = KW; P.Cout = Cout; P.CoutPad = CoutPad; P.Kpad = Kpad; P.epi = epilogue;
   P.out = out; P.out_f32 = out_is_f32; P.out_stride = out_stride;
 #ifdef DH_ABLATION
-  P.ts = ((long)N * H * W / 256) * ((CoutPad + 127) / 128) <= g_conv_ts_cap ? g_conv_ts : nullptr;
+  {
+    const long nwg = ((long)N * H * W / 256) * ((CoutPad + 127) / 128);
+    P.ts = nwg <= g_conv_ts_cap ? g_conv_ts : nullptr;
+    // per-step stamps of 256 workgroups from the middle of the launch, in the 2048 rows behind the per-workgroup block
+    P.ts_step = (P.ts && nwg + 2048 <= g_conv_ts_cap) ? g_conv_ts + nwg * 8 : nullptr;
+    P.ts_step_wg0 = (unsigned)(nwg / 2);
+  }
 #endif
   P.gterm = gterm; P.aux0 = (const __half*)aux0; P.aux0_stride = aux0_stride;
   P.aux1 = (const __half*)aux1; P.aux1_stride = aux1_stride; P.red = red;

@@ -45,7 +45,7 @@ ctx_tl = upd.context_term(inp_frames, tiled=True)           # accumulator-tile l
 gzr = torch.randn(E, 256, device="cuda") * 0.1
 zr = torch.empty(E, h, w, 256, device="cuda", dtype=torch.float16)
 nwg = (E * h * w // 256) * 2
-buf = torch.zeros(nwg, 8, dtype=torch.int64, device="cuda")
+buf = torch.zeros(nwg + 2048, 8, dtype=torch.int64, device="cuda")          # + 256 workgroups x 64 per-step stamps
 
 
 def analyse(t, n):
@@ -117,8 +117,16 @@ for halo3 in (0, 1):
         ms_ts = e0.elapsed_time(e1)
         db.conv_set_timestamps(None)
         tb = buf.cpu().numpy()
-        n = int((tb[:, 4] != 0).sum())                       # workgroups that reported (they fill the buffer from index 0)
+        n = int((tb[:nwg, 4] != 0).sum())                    # workgroups that reported (they fill the buffer from index 0)
         r = analyse(tb, n)
+        if not halo3:                                        # per-step stamps of 256 workgroups from the middle of the launch
+            st = tb[n:n + 2048].reshape(256, 64).astype(np.int64)
+            ns = int((st[0] != 0).sum())
+            if ns > 2:
+                d = np.diff(st[:, :ns], axis=1) * 0.01       # [256, ns - 1] microseconds per step
+                r["steps"] = ns
+                r["step_us_median_by_index"] = [float(x) for x in np.median(d, axis=0)]
+                r["step_us_mean"] = float(d.mean()); r["step_us_p90"] = float(np.quantile(d, 0.9)); r["step_us_min"] = float(d.min())
         r.update({"kernel": "conv3x3_halo3_kernel (512-px tile, one workgroup per CU)" if halo3 else "conv3x3_halo2_kernel (256-px tile, two workgroups per CU)",
                   "launch": name, "ms_without_timestamps": ms_plain, "ms_with_timestamps": ms_ts})
         res["cases"].append(r)
@@ -127,6 +135,9 @@ for halo3 in (0, 1):
                   r["kernel"], name, ms_plain, ms_ts, r["prologue_us_mean"], r["prologue_us_p90"], r["main_loop_us_mean"], r["epilogue_us_mean"],
                   r["epilogue_us_p90"], r["workgroups_resident_per_cu_mean"], r["workgroups_in_main_loop_per_cu_mean"],
                   r["cu_main_loop_coverage_mean"], r["cu_main_loop_coverage_min"]), flush=True)
+        if "steps" in r:
+            print("      per step (us, median over 256 workgroups, step 0 -> 1 first): %s | mean %.2f p90 %.2f min %.2f" % (
+                " ".join("%.1f" % x for x in r["step_us_median_by_index"]), r["step_us_mean"], r["step_us_p90"], r["step_us_min"]), flush=True)
 db.set_option("conv_halo3", 0)
 if a.out:
     json.dump(res, open(a.out, "w"), indent=1)
