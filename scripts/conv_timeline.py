@@ -104,6 +104,8 @@ for halo3 in (0, 1):
         cases["128 -> 128 relu (corr_encoder.2 / agg.conv1)"] = lambda: P["agg1"]([net], EPI_RELU, out=x128)
         cases["heads: 128 -> 256 + the fused second layer (EPI_HEADS0)"] = lambda: P["heads0"]([net], EPI_HEADS0, aux1=w2p, red=part)
         cases["context term 128 -> 384, accumulator-tile output (512 frames at E = 4096)"] = lambda: upd.context_term(inp_frames, tiled=True)
+    tiles = E * h * w // 256
+    nwg_of = lambda name: (tiles if name.startswith(("q:", "128 -> 128")) else (K * h * w // 256) * 3 if name.startswith("context term") else 2 * tiles) // (2 if halo3 else 1)
     for name, fn in cases.items():
         db.conv_set_timestamps(None)
         for _ in range(3):
@@ -117,7 +119,8 @@ for halo3 in (0, 1):
         ms_ts = e0.elapsed_time(e1)
         db.conv_set_timestamps(None)
         tb = buf.cpu().numpy()
-        n = int((tb[:nwg, 4] != 0).sum())                    # workgroups that reported (they fill the buffer from index 0)
+        n = nwg_of(name)                                     # workgroups of this launch (rows 0 .. n-1; the per-step stamps follow)
+        assert (tb[:n, 4] != 0).all() and (n >= nwg or (tb[n + 2048:, 4] == 0).all()), name
         r = analyse(tb, n)
         if not halo3:                                        # per-step stamps of 256 workgroups from the middle of the launch
             st = tb[n:n + 2048].reshape(256, 64).astype(np.int64)
