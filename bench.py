@@ -580,8 +580,7 @@ def main():
     if args.no_lookup:
         corr = None
     else:
-        CorrBlock(fmaps[ii[:8], 0][None], fmaps[jj[:8], c[:8]][None])          # code objects, LDS opt-in, allocator
-        f1, f2 = fmaps[ii, 0][None], fmaps[jj, c][None]
+        CorrBlock.from_frames(fmaps, ii[:8], jj[:8])                             # code objects, LDS opt-in, allocator
         torch.cuda.synchronize()
         # the pyramid's STORAGE first, timed on its own with the host clock: hipMalloc of 105 GB at C3 maps the pages and is
         # synchronous -- seconds on a cold device (the first process of a fresh box), not part of the build
@@ -590,12 +589,14 @@ def main():
         torch.cuda.synchronize()
         ms_alloc = 1e3 * (time.perf_counter() - t_a)
         e0, e1, e2 = _ev(), _ev(), _ev()
-        e0.record(); corr = CorrBlock(f1, f2, out=arena); e1.record()           # first build into fresh pages
-        corr = CorrBlock(f1, f2, out=arena); e2.record()                        # the same build again (what update_lowmem pays per call)
+        # the product's build (FactorGraph.add_factors / update_lowmem): features transposed + pooled once per frame, the build
+        # kernel indexed by the edges' frames -- all of this rank's edges
+        e0.record(); corr = CorrBlock.from_frames(fmaps, ii, jj, out=arena); e1.record()        # first build into fresh pages
+        corr = CorrBlock.from_frames(fmaps, ii, jj, out=arena); e2.record()                     # the same build again (what update_lowmem pays per call)
         torch.cuda.synchronize()
-        ms_build = e0.elapsed_time(e1)                        # all of this rank's edges: transposes, pooling, row-ring build kernel
+        ms_build = e0.elapsed_time(e1)
         ms_rebuild = e1.elapsed_time(e2)
-        del f1, f2, arena
+        del arena
     torch.cuda.synchronize()
     torch.cuda.empty_cache()                              # (the per-edge feature gathers and the build workspace)
     # ---- ConvGRU update operator: random-init weights of the reference architecture (no droid.pth here) ----

@@ -354,10 +354,13 @@ __device__ __forceinline__ void ring_level(const half8 (&afrag)[4], const __half
   for (int o = tid; o < w2 * 8; o += NT) z[o] = uint4{0u, 0u, 0u, 0u};
 }
 
+// idx1 / idx2 (round 5, optional): edge e reads the prepared rows of FRAME idx1[e] / idx2[e] (dh_corr_pyramid_prepare_frames +
+// dh_corr_pyramid_build_indexed: features transposed and pooled once per frame instead of once per edge); nullptr = row e
 template <int W, int NT = 256>
 __global__ __launch_bounds__(NT) void pyr_build_ring_kernel(const __half* __restrict__ f1T, const __half* __restrict__ f2T,
                                                              __half* __restrict__ pyr, PyrDims D, long f1_stride_e,
-                                                             long f2_stride_e) {
+                                                             long f2_stride_e, const int64_t* __restrict__ idx1 = nullptr,
+                                                             const int64_t* __restrict__ idx2 = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_ring_raw[];
   unsigned char* const ring = s_ring_raw;                          // [R][w2 * 32 dwords]
   unsigned char* const sB = s_ring_raw + (size_t)W * 1024;         // [target][256 B], 16-byte quads XOR-ed with row & 15
@@ -369,11 +372,11 @@ __global__ __launch_bounds__(NT) void pyr_build_ring_kernel(const __half* __rest
   half8 afrag[4];
   {
     const int p = wave * 16 + (lane & 15);
-    const __half* row = f1T + (long)e * f1_stride_e + ((long)(by * 8 + (p >> 3)) * W + bx * 8 + (p & 7)) * CH;
+    const __half* row = f1T + (idx1 ? (long)idx1[e] : (long)e) * f1_stride_e + ((long)(by * 8 + (p >> 3)) * W + bx * 8 + (p & 7)) * CH;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) afrag[ks] = *reinterpret_cast<const half8*>(row + ks * 32 + (lane >> 4) * 8);
   }
-  const __half* bbase = f2T + (long)e * f2_stride_e;
+  const __half* bbase = f2T + (idx2 ? (long)idx2[e] : (long)e) * f2_stride_e;
   __half* obase = pyr + (long)e * D.edge_elems;
   const int h = D.h;
 #define RING_LEVEL(l_)                                                                                               \
@@ -1037,6 +1040,66 @@ extern "C" int dh_corr_pyramid_build(const void* fmap1, const void* fmap2, void*
 // caller passes canvas-sized features, zero outside the image.  Level l of the image's pyramid has (h_real >> l) x (w_real >> l)
 // cells (avg_pool2d floors, corr.py:36); the canvas levels carry zeros beyond them, which is what a lookup outside a
 // reference-layout volume reads (correlation_kernels.cu:48 within_bounds).
+namespace {
+// the row-ring build kernel on prepared (channel-last, pooled) features; idx1 / idx2 = nullptr: row e of f1T / f2T
+int launch_ring(const __half* f1T, const __half* f2T, __half* pyramid, const PyrDims& D, long s1, long s2, int E, int w,
+                const int64_t* idx1, const int64_t* idx2, hipStream_t st) {
+  const size_t lds = (size_t)w * 1024 + (size_t)(w > 16 ? w : 16) * 256;       // row ring + one staged target row
+  const dim3 grid(D.nblk, E);
+  if (w == 64 && opts().pyr_build_waves == 8) {
+    DH_LDS_OPTIN((&pyr_build_ring_kernel<64, 512>), 80 * 1024);
+    hipLaunchKernelGGL((pyr_build_ring_kernel<64, 512>), grid, dim3(512), lds, st, f1T, f2T, pyramid, D, s1, s2, idx1, idx2);
+  } else if (w == 64) {
+    DH_LDS_OPTIN((&pyr_build_ring_kernel<64>), 80 * 1024);
+    hipLaunchKernelGGL(pyr_build_ring_kernel<64>, grid, dim3(256), lds, st, f1T, f2T, pyramid, D, s1, s2, idx1, idx2);
+  } else if (w == 32) {
+    hipLaunchKernelGGL(pyr_build_ring_kernel<32>, grid, dim3(256), lds, st, f1T, f2T, pyramid, D, s1, s2, idx1, idx2);
+  } else {
+    hipLaunchKernelGGL(pyr_build_ring_kernel<16>, grid, dim3(256), lds, st, f1T, f2T, pyramid, D, s1, s2, idx1, idx2);
+  }
+  return DH_OK;
+}
+}  // namespace
+
+// Frame-level preparation (round 5): fmaps [F,C,h,w] f16 (canvas-sized, zero outside the h_real x w_real image) -> prepared
+// [F][T = sum_l h2_l w2_l][C] rows: level 0 = the channel-last transpose, levels 1..3 = 2x2 mean pooling with avg_pool2d's floor
+// (what dh_corr_pyramid_build_canvas does per EDGE: a frame appears in ~8 edges as source and ~8 as target).
+extern "C" size_t dh_corr_pyramid_prepared_bytes(int F, int h, int w) {
+  if (F < 0 || !dims_ok(h, w)) return 0;
+  return (size_t)F * (size_t)make_dims(h, w).tgt_off[NLEV] * CH * sizeof(__half);
+}
+extern "C" int dh_corr_pyramid_prepare_frames(const void* fmaps, void* prepared, int F, int C, int h, int w, int h_real, int w_real,
+                                              dh_stream_t stream) {
+  if (h_real <= 0 || w_real <= 0 || h_real > h || w_real > w) return DH_ERR_ARG;
+  if (F < 0 || C != CH || !dims_ok(h, w)) return C != CH && F >= 0 && dims_ok(h, w) ? DH_ERR_UNSUPPORTED : DH_ERR_ARG;
+  if (F == 0) return DH_OK;
+  if (!fmaps || !prepared) return DH_ERR_ARG;
+  const PyrDims D = make_dims(h, w);
+  hipStream_t st = (hipStream_t)stream;
+  const int HW = h * w;
+  const long s2 = (long)D.tgt_off[NLEV] * CH;
+  hipLaunchKernelGGL(pyr_transpose_kernel, dim3((HW + 63) / 64, F), dim3(256), 0, st, (const __half*)fmaps, (__half*)prepared, HW, s2, 0);
+  for (int l = 1; l < NLEV; ++l)
+    hipLaunchKernelGGL(pyr_pool_kernel, dim3(D.h2[l] * D.w2[l], F), dim3(CH), 0, st, (__half*)prepared, s2, D.tgt_off[l - 1],
+                       D.tgt_off[l], D.h2[l - 1], D.w2[l - 1], h_real >> l, w_real >> l);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+// pyramid of E edges from prepared frames: edge e = (source frame idx1[e], target frame idx2[e]) of `prepared` (F frames; the
+// source side reads its level-0 rows).  Bit-identical to dh_corr_pyramid_build_canvas on the gathered per-edge features.
+extern "C" int dh_corr_pyramid_build_indexed(const void* prepared, const int64_t* idx1, const int64_t* idx2, void* pyramid,
+                                             int F, int E, int h, int w, dh_stream_t stream) {
+  if (F < 0 || E < 0 || !dims_ok(h, w)) return DH_ERR_ARG;
+  if (E == 0) return DH_OK;
+  if (!prepared || !idx1 || !idx2 || !pyramid || F == 0) return DH_ERR_ARG;
+  const PyrDims D = make_dims(h, w);
+  const long s2 = (long)D.tgt_off[NLEV] * CH;
+  const int rc = launch_ring((const __half*)prepared, (const __half*)prepared, (__half*)pyramid, D, s2, s2, E, w, idx1, idx2, (hipStream_t)stream);
+  if (rc != DH_OK) return rc;
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
 extern "C" int dh_corr_pyramid_build_canvas(const void* fmap1, const void* fmap2, void* pyramid, void* workspace,
                                             size_t workspace_bytes, int E, int C, int h, int w, int h_real, int w_real, dh_stream_t stream) {
   if (h_real <= 0 || w_real <= 0 || h_real > h || w_real > w) return DH_ERR_ARG;
@@ -1062,23 +1125,8 @@ extern "C" int dh_corr_pyramid_build_canvas(const void* fmap1, const void* fmap2
   } else
 #endif
   {
-    const size_t lds = (size_t)w * 1024 + (size_t)(w > 16 ? w : 16) * 256;       // row ring + one staged target row
-    const dim3 grid(D.nblk, E);
-    if (w == 64 && opts().pyr_build_waves == 8) {
-      DH_LDS_OPTIN((&pyr_build_ring_kernel<64, 512>), 80 * 1024);
-      hipLaunchKernelGGL((pyr_build_ring_kernel<64, 512>), grid, dim3(512), lds, st, (const __half*)f1T, (const __half*)f2T,
-                         (__half*)pyramid, D, s1, s2);
-    } else if (w == 64) {
-      DH_LDS_OPTIN((&pyr_build_ring_kernel<64>), 80 * 1024);
-      hipLaunchKernelGGL(pyr_build_ring_kernel<64>, grid, dim3(256), lds, st, (const __half*)f1T, (const __half*)f2T,
-                         (__half*)pyramid, D, s1, s2);
-    } else if (w == 32) {
-      hipLaunchKernelGGL(pyr_build_ring_kernel<32>, grid, dim3(256), lds, st, (const __half*)f1T, (const __half*)f2T,
-                         (__half*)pyramid, D, s1, s2);
-    } else {
-      hipLaunchKernelGGL(pyr_build_ring_kernel<16>, grid, dim3(256), lds, st, (const __half*)f1T, (const __half*)f2T,
-                         (__half*)pyramid, D, s1, s2);
-    }
+    const int rc = launch_ring((const __half*)f1T, (const __half*)f2T, (__half*)pyramid, D, s1, s2, E, w, nullptr, nullptr, st);
+    if (rc != DH_OK) return rc;
   }
   DH_LAUNCH_CHECK();
   return DH_OK;

@@ -424,6 +424,48 @@ torch::Tensor corr_pyramid_build(torch::Tensor fmap1, torch::Tensor fmap2, const
   return pyr;
 }
 
+// frame-level build: prepared = corr_pyramid_prepare_frames(fmaps [F,C,h,w] f16 (canvas-sized), h_real, w_real) -> [F, T, C] f16;
+// corr_pyramid_build_indexed(prepared, idx1 [E] i64, idx2 [E] i64, h, w, out=None) -> pyramid [E, record elements]
+torch::Tensor corr_pyramid_prepare_frames(torch::Tensor fmaps, const int h_real, const int w_real) {
+  CHECK_INPUT(fmaps);
+  TORCH_CHECK(fmaps.scalar_type() == torch::kFloat16 && fmaps.dim() == 4, "corr_pyramid_prepare_frames: fmaps [F,C,h,w] float16");
+  const int F = (int)fmaps.size(0), C = (int)fmaps.size(1), h = (int)fmaps.size(2), w = (int)fmaps.size(3);
+  const size_t bytes = dh_corr_pyramid_prepared_bytes(F, h, w);
+  TORCH_CHECK(F == 0 || bytes > 0, "corr_pyramid_prepare_frames: unsupported image size (need h % 8 == 0 and w in {16,32,64})");
+  torch::Tensor prep = torch::empty({F, F > 0 ? (int64_t)(bytes / 2 / F / C) : 0, C}, fmaps.options());
+  check_status(dh_corr_pyramid_prepare_frames(fmaps.data_ptr(), prep.data_ptr(), F, C, h, w, h_real > 0 ? h_real : h, w_real > 0 ? w_real : w,
+                                              cur_stream()), "corr_pyramid_prepare_frames");
+  return prep;
+}
+
+torch::Tensor corr_pyramid_build_indexed(torch::Tensor prepared, torch::Tensor idx1, torch::Tensor idx2, const int h, const int w,
+                                         const c10::optional<torch::Tensor>& out) {
+  CHECK_INPUT(prepared); CHECK_INPUT(idx1); CHECK_INPUT(idx2); CHECK_I64(idx1); CHECK_I64(idx2);
+  TORCH_CHECK(prepared.scalar_type() == torch::kFloat16 && prepared.dim() == 3 && prepared.size(2) == 128, "corr_pyramid_build_indexed: prepared [F,T,128] float16");
+  const int F = (int)prepared.size(0), E = (int)idx1.size(0);
+  TORCH_CHECK(idx2.size(0) == E, "corr_pyramid_build_indexed: idx1 / idx2 of equal length");
+  const size_t bytes1 = dh_corr_pyramid_bytes(1, h, w);
+  TORCH_CHECK(bytes1 > 0 && (size_t)prepared.size(1) * 128 * 2 * (size_t)std::max(F, 1) == dh_corr_pyramid_prepared_bytes(std::max(F, 1), h, w),
+              "corr_pyramid_build_indexed: prepared does not belong to this image size");
+  if (E > 0) {                                            // one read-back for the four bounds (an index outside the tensor would be a wild read)
+    torch::Tensor b = torch::stack({idx1.min(), idx1.max(), idx2.min(), idx2.max()}).cpu();
+    const int64_t* bp = b.data_ptr<int64_t>();
+    TORCH_CHECK(bp[0] >= 0 && bp[1] < F && bp[2] >= 0 && bp[3] < F, "corr_pyramid_build_indexed: frame index out of range");
+  }
+  torch::Tensor pyr;
+  if (out.has_value() && out->defined()) {
+    CHECK_INPUT((*out));
+    TORCH_CHECK(out->scalar_type() == torch::kFloat16 && out->dim() == 2 && out->size(0) >= E && (size_t)out->size(1) * 2 == bytes1,
+                "corr_pyramid_build_indexed: out must be float16 [>= E, record elements] for this image size");
+    pyr = out->narrow(0, 0, E);
+  } else {
+    pyr = torch::empty({E, (int64_t)(bytes1 / 2)}, prepared.options());
+  }
+  check_status(dh_corr_pyramid_build_indexed(prepared.data_ptr(), idx1.data_ptr<int64_t>(), idx2.data_ptr<int64_t>(), pyr.data_ptr(), F, E, h, w,
+                                             cur_stream()), "corr_pyramid_build_indexed");
+  return pyr;
+}
+
 torch::Tensor corr_pyramid_lookup(torch::Tensor pyramid, torch::Tensor coords) {
   CHECK_INPUT(pyramid); CHECK_INPUT(coords); CHECK_F32(coords);
   TORCH_CHECK(pyramid.scalar_type() == torch::kFloat16, "pyramid must be float16");
@@ -729,6 +771,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("corr_volume_pool", &corr_volume_pool, "2x2 average pooling of the last two dims of a reference-layout volume");
   m.def("corr_pyramid_build", &corr_pyramid_build, "all-pairs correlation pyramid, MI355X layout", py::arg("fmap1"), py::arg("fmap2"),
         py::arg("h_real") = 0, py::arg("w_real") = 0, py::arg("out") = py::none());
+  m.def("corr_pyramid_prepare_frames", &corr_pyramid_prepare_frames, "channel-last transpose + pooled levels once per frame", py::arg("fmaps"),
+        py::arg("h_real") = 0, py::arg("w_real") = 0);
+  m.def("corr_pyramid_build_indexed", &corr_pyramid_build_indexed, "pyramid of edges (idx1[e], idx2[e]) from prepared frames", py::arg("prepared"),
+        py::arg("idx1"), py::arg("idx2"), py::arg("h"), py::arg("w"), py::arg("out") = py::none());
   m.def("corr_pyramid_lookup", &corr_pyramid_lookup, "fused 4-level lookup on the MI355X pyramid");
   m.def("corr_pyramid_lookup_nhwc", &corr_pyramid_lookup_nhwc, "fused 4-level lookup, channel-last output for the update operator");
   m.def("corr_pyramid_lookup_corr0", &corr_pyramid_lookup_corr0, "4-level lookup fused with the correlation encoder's first layer (1x1, 196 -> 128, ReLU)");

@@ -155,6 +155,33 @@ class CorrBlock:
         else:
             self.pyramid = droid_backends.corr_pyramid_build(f1.contiguous(), f2.contiguous(), 0, 0, out)
 
+    @classmethod
+    def from_frames(cls, fmaps, ii, jj, out=None):
+        """The block the reference builds as CorrBlock(fmaps[ii, 0][None], fmaps[jj, c][None]) (factor_graph.py:128-133; c = 1 on the
+        stereo self-edges), from the frame buffer itself: fmaps [N, rig, C, h, w] (video.fmaps), ii / jj [E] int64.  The channel-last
+        transpose and the pooled levels are computed once per FRAME that occurs in the edge list (droid_backends.corr_pyramid_prepare_frames)
+        instead of once per edge, and the build kernel reads them through the edge's frame indices (corr_pyramid_build_indexed): no
+        per-edge feature gathers (2 x 3.2 GB at C3), the same records bit for bit.  Image sizes that are kept transposed or in strips
+        take the per-edge constructor."""
+        N, rig, C, ht, wd = fmaps.shape
+        ii = ii.to(fmaps.device, torch.long).reshape(-1); jj = jj.to(fmaps.device, torch.long).reshape(-1)
+        c = (ii == jj).long() if rig > 1 else torch.zeros_like(ii)
+        if cls.is_transposed(ht, wd) or cls.strip_bounds(ht, wd) is not None or ii.numel() == 0:
+            return cls(fmaps[ii, 0][None], fmaps[jj, c][None], out=out)
+        self = cls.__new__(cls)
+        self.num_levels, self.radius = 4, 3
+        self.ht, self.wd = ht, wd
+        self.hc, self.wc = cls.canvas(ht, wd)
+        self.transposed, self.strips = False, None
+        E = ii.numel()
+        frames, inv = torch.unique(torch.cat([ii * rig, jj * rig + c]), return_inverse=True)      # only the frames the edges touch
+        f = fmaps.reshape(N * rig, C, ht, wd)[frames].half()
+        if (self.hc, self.wc) != (ht, wd):
+            f = F.pad(f, (0, self.wc - wd, 0, self.hc - ht))
+        prep = droid_backends.corr_pyramid_prepare_frames(f.contiguous(), ht, wd)
+        self.pyramid = droid_backends.corr_pyramid_build_indexed(prep, inv[:E].contiguous(), inv[E:].contiguous(), self.hc, self.wc, out)
+        return self
+
     @staticmethod
     def arena(num, ht, wd, device):
         """uninitialised storage for the pyramid of `num` edges of an ht x wd image (CorrBlock(..., out=arena))"""

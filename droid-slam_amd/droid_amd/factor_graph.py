@@ -93,9 +93,11 @@ class FactorGraph:
             self.rm_factors(ix >= self.max_factors - ii.shape[0], store=True)
         net = self.video.nets[ii].permute(0, 2, 3, 1).contiguous()
         if self.corr_impl == "volume":
-            c = (ii == jj).long()
-            f1 = self.video.fmaps[ii, 0][None]; f2 = self.video.fmaps[jj, c][None]
-            corr = CorrBlock(f1, f2) if self._native_corr else CorrBlockRef(f1, f2)
+            if self._native_corr:                                     # features prepared once per frame, indexed by the edges
+                corr = CorrBlock.from_frames(self.video.fmaps, ii, jj)
+            else:
+                c = (ii == jj).long()
+                corr = CorrBlockRef(self.video.fmaps[ii, 0][None], self.video.fmaps[jj, c][None])
             self.corr = corr if self.corr is None else self.corr.cat(corr)
         target, _ = self.video.reproject(ii, jj)
         self.ii = torch.cat([self.ii, ii]); self.jj = torch.cat([self.jj, jj]); self.age = torch.cat([self.age, torch.zeros_like(ii)])
@@ -283,7 +285,7 @@ class FactorGraph:
             try:
                 with roctx_range("droid.update_lowmem/pyramid_build"):
                     arena = self._pyramid_arena(len(ii_v), ht, wd) if CorrBlock.strip_bounds(ht, wd) is None else None
-                    block = CorrBlock(v.fmaps[ii_v, 0][None], v.fmaps[jj_v, c][None], out=arena)
+                    block = CorrBlock.from_frames(v.fmaps, ii_v, jj_v, out=arena)
                 # the update operator's full-batch activations (~3.5 KB per edge-pixel) are allocated inside the first step:
                 # reserve them now, while nothing of this call has been written, so that an out-of-memory condition (other
                 # tenants of the device) still falls back to the alt-correlation loop with the state untouched

@@ -134,6 +134,16 @@ int dh_corr_pyramid_build(const void* fmap1, const void* fmap2, void* pyramid, v
  * (coords of canvas pixels outside the image are don't-cares, their outputs are to be dropped). */
 int dh_corr_pyramid_build_canvas(const void* fmap1, const void* fmap2, void* pyramid, void* workspace,
                                  size_t workspace_bytes, int E, int C, int h, int w, int h_real, int w_real, dh_stream_t stream);
+/* Frame-level form of the build (round 5): the channel-last transpose and the three pooled levels of a feature map are computed
+ * once per FRAME -- fmaps [F,C,h,w] f16 -> prepared [F][sum_l (h>>l)(w>>l)][C] f16, dh_corr_pyramid_prepared_bytes(F, h, w) bytes --
+ * and the pyramid of edge e is built from the prepared rows of frames idx1[e] (source) and idx2[e] (target; for the reference's
+ * stereo pairs the second camera's maps are frames of the same tensor: factor_graph.py:128-133 fmaps[jj, c]).  Same records, bit
+ * for bit, as dh_corr_pyramid_build_canvas on the gathered per-edge features; no per-edge feature copies, no workspace. */
+size_t dh_corr_pyramid_prepared_bytes(int F, int h, int w);
+int dh_corr_pyramid_prepare_frames(const void* fmaps, void* prepared, int F, int C, int h, int w, int h_real, int w_real,
+                                   dh_stream_t stream);
+int dh_corr_pyramid_build_indexed(const void* prepared, const int64_t* idx1, const int64_t* idx2, void* pyramid,
+                                  int F, int E, int h, int w, dh_stream_t stream);
 int dh_corr_pyramid_lookup(const void* pyramid, const float* coords, void* out,
                            int E, int h, int w, dh_stream_t stream);
 /* same lookup written channel-last for the update operator of this library (dh_conv2d_nhwc_f16):

@@ -72,6 +72,15 @@ def test_argument_errors_are_reported_before_any_launch(built):
     assert lib.dh_conv2d_nhwc_f16(None, None, None, 1, None, None, None, 1, 8, 64, 3, 3, 128, 128, 1152, 1,
                                   None, 3, 128, None, None, 0, None, 0, None, None) == 1
     assert lib.dh_conv_set_timestamps(None, 0) == 4                      # measurement hook of the -DDH_ABLATION build only
+    # frame-level pyramid build (round 5)
+    lib.dh_corr_pyramid_prepared_bytes.restype = ctypes.c_size_t
+    assert lib.dh_corr_pyramid_prepared_bytes(3, 48, 64) == 3 * (3072 + 768 + 192 + 48) * 128 * 2 and lib.dh_corr_pyramid_prepared_bytes(3, 48, 40) == 0
+    assert lib.dh_corr_pyramid_prepare_frames(None, None, 2, 128, 48, 64, 48, 64, None) == 1          # null pointers
+    assert lib.dh_corr_pyramid_prepare_frames(None, None, 0, 128, 48, 64, 48, 64, None) == 0          # no frames
+    assert lib.dh_corr_pyramid_prepare_frames(None, None, 2, 64, 48, 64, 48, 64, None) == 4           # C != 128
+    assert lib.dh_corr_pyramid_prepare_frames(None, None, 2, 128, 48, 64, 50, 64, None) == 1          # image larger than its canvas
+    assert lib.dh_corr_pyramid_build_indexed(None, None, None, None, 2, 0, 48, 64, None) == 0         # no edges
+    assert lib.dh_corr_pyramid_build_indexed(None, None, None, None, 2, 3, 48, 64, None) == 1
     rows, cols = ctypes.c_int(), ctypes.c_int()
     assert lib.dh_ba_system_shape(1, 512, ctypes.byref(rows), ctypes.byref(cols)) == 0
     assert cols.value == 3072 and rows.value == 3072 + 64

@@ -578,6 +578,41 @@ def test_native_pyramid_build_kernels_are_bit_identical(db, option):
         assert torch.equal(b, c)
 
 
+@pytest.mark.parametrize("shape,rig", [((48, 64), 1), ((16, 32), 2), ((30, 40), 1), ((24, 16), 2), ((41, 73), 1), ((72, 96), 1)])
+def test_pyramid_from_frames_is_bit_identical_to_the_per_edge_build(db, shape, rig):
+    """round 5: CorrBlock.from_frames(video.fmaps, ii, jj) -- features transposed and pooled once per frame
+    (dh_corr_pyramid_prepare_frames), the build kernel indexed by the edges' frames (dh_corr_pyramid_build_indexed) -- against
+    CorrBlock(fmaps[ii, 0], fmaps[jj, c]) (factor_graph.py:128-133): the same records bit for bit, mono and stereo (c = 1 on the
+    self-edges), on canvases, into an arena; transposed / strip image sizes fall back to the per-edge constructor."""
+    from droid_amd.corr import CorrBlock
+    h, w = shape
+    torch.manual_seed(h * 7 + w + rig)
+    N = 6
+    fmaps = torch.randn(N, rig, 128, h, w, device="cuda").half()
+    ii = torch.tensor([0, 1, 1, 2, 3, 3, 4, 5, 5, 2], device="cuda")
+    jj = torch.tensor([1, 0, 2, 1, 3 if rig > 1 else 4, 5, 3, 4, 5 if rig > 1 else 0, 4], device="cuda")
+    c = (ii == jj).long() if rig > 1 else torch.zeros_like(ii)
+    want = CorrBlock(fmaps[ii, 0][None], fmaps[jj, c][None])
+    got = CorrBlock.from_frames(fmaps, ii, jj)
+    torch.cuda.synchronize()
+    assert (got.transposed, got.strips, got.hc, got.wc) == (want.transposed, want.strips, want.hc, want.wc)
+    if want.strips is not None:
+        assert all(torch.equal(a, b) for a, b in zip(got.records, want.records))
+    else:
+        assert got.pyramid.shape == want.pyramid.shape and torch.equal(got.pyramid, want.pyramid)
+        if not want.transposed:
+            arena = CorrBlock.arena(len(ii) + 3, h, w, "cuda")
+            again = CorrBlock.from_frames(fmaps, ii, jj, out=arena)
+            torch.cuda.synchronize()
+            assert again.pyramid.data_ptr() == arena.data_ptr() and torch.equal(again.pyramid, want.pyramid)
+    yy, xx = torch.meshgrid(torch.arange(h, device="cuda", dtype=torch.float32), torch.arange(w, device="cuda", dtype=torch.float32), indexing="ij")
+    coords = (torch.stack([xx, yy], -1)[None, None] + torch.tensor([1.3, -2.1], device="cuda")).expand(1, len(ii), h, w, 2).contiguous()
+    assert torch.equal(got(coords), want(coords))
+    with pytest.raises(RuntimeError):                         # a frame index outside the prepared tensor is refused, not read
+        prep = db.corr_pyramid_prepare_frames(torch.zeros(2, 128, 16, 16, device="cuda", dtype=torch.float16))
+        db.corr_pyramid_build_indexed(prep, torch.tensor([0, 2], device="cuda"), torch.tensor([1, 1], device="cuda"), 16, 16)
+
+
 def test_native_pyramid_cat_and_index(db):
     from droid_amd.corr import CorrBlock
     torch.manual_seed(4)
