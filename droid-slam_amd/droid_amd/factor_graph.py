@@ -14,6 +14,9 @@ add_neighborhood_factors, add_proximity_factors`).  MI355X-first underneath:
     the greedy NMS walk are kernels (droid_backends.proximity_nms), one 4-byte read-back tells how many edges were chosen.
 The reference copies the matrix to the CPU and loops over it in Python (factor_graph.py:363-409).
 """
+import os
+import time
+
 import torch
 
 import droid_backends as db
@@ -282,6 +285,9 @@ class FactorGraph:
             sel = None if all_visited else torch.nonzero(self.ii < limit)[:, 0]
             ii_v, jj_v = (self.ii, self.jj) if sel is None else (self.ii[sel], self.jj[sel])
             c = (ii_v == jj_v).long() if rig > 1 else torch.zeros_like(ii_v)
+            trace = os.environ.get("DH_LOWMEM_TRACE", "0") == "1"      # wall-clock phases of a call (diagnostics; synchronises)
+            if trace:
+                torch.cuda.synchronize(); _t0 = time.perf_counter()
             try:
                 with roctx_range("droid.update_lowmem/pyramid_build"):
                     arena = self._pyramid_arena(len(ii_v), ht, wd) if CorrBlock.strip_bounds(ht, wd) is None else None
@@ -297,8 +303,13 @@ class FactorGraph:
                 block = None                                        # "auto": fall through to the alt-correlation loop
                 self._arena = None
                 torch.cuda.empty_cache()
+            if trace:
+                torch.cuda.synchronize(); _t1 = time.perf_counter()
+                print("update_lowmem trace: pyramid build + reservation %.1f ms (block %s)" % (1e3 * (_t1 - _t0), "ok" if block is not None else "FELL BACK"), flush=True)
             if block is not None:
                 for _ in range(steps):
+                    if trace:
+                        torch.cuda.synchronize(); _t2 = time.perf_counter()
                     with roctx_range("droid.update_lowmem/reproject"):
                         coords_all = v.reproject(self.ii, self.jj)[0][0]
                     if sel is None:
@@ -321,6 +332,8 @@ class FactorGraph:
                     if self.upsample:
                         v.upsample(uniq, upmask)
                     self._ba_global(tb, wb, itrs, use_inactive, EP, t)
+                    if trace:
+                        torch.cuda.synchronize(); print("update_lowmem trace: step %.1f ms" % (1e3 * (time.perf_counter() - _t2)), flush=True)
                 return
         corr_op = AltCorrBlock(v.fmaps.view(1, num * rig, ch, ht, wd))
         for _ in range(steps):
