@@ -292,11 +292,15 @@ class FactorGraph:
                 with roctx_range("droid.update_lowmem/pyramid_build"):
                     arena = self._pyramid_arena(len(ii_v), ht, wd) if CorrBlock.strip_bounds(ht, wd) is None else None
                     block = CorrBlock.from_frames(v.fmaps, ii_v, jj_v, out=arena)
-                # the update operator's full-batch activations (~3.5 KB per edge-pixel) are allocated inside the first step:
-                # reserve them now, while nothing of this call has been written, so that an out-of-memory condition (other
-                # tenants of the device) still falls back to the alt-correlation loop with the state untouched
-                probe = torch.empty(len(ii_v) * ht * wd * 3584, dtype=torch.uint8, device=self.device)
-                del probe
+                # the update operator's full-batch activations (~3.5 KB per edge-pixel) are allocated inside the first step: check
+                # now, while nothing of this call has been written, that they fit -- what the driver reports free plus what torch's
+                # allocator holds unused -- so that a device shared with other tenants still falls back to the alt-correlation loop
+                # with the state untouched.  (No trial allocation: a 45 GB probe block fragments the allocator's segments and cost
+                # the NEXT call a fresh 1.2 s hipMalloc -- measured, round 5.)
+                need = len(ii_v) * ht * wd * 3584
+                free_b = torch.cuda.mem_get_info(self.device)[0] + torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)
+                if free_b < need:
+                    raise torch.cuda.OutOfMemoryError("update_lowmem: %.1f GB of operator activations do not fit next to the pyramid (%.1f GB free)" % (need / 1e9, free_b / 1e9))
             except torch.cuda.OutOfMemoryError:
                 if corr == "pyramid":
                     raise
