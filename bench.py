@@ -823,8 +823,12 @@ def main():
                 "pyramid_GB": (corr.bytes() / 1e9 if corr is not None else 0.0)},
             "ms_per_global_ba": ba, "ms_corr_lookup": lk, "ms_update_operator": up,
             # setup, outside the timed steps: once per edge lifetime (factor_graph.py:128-133).  alloc = the storage (hipMalloc,
-            # host clock), build = the first build into it, rebuild = the same build again into the same storage (HIP events)
-            "ms_pyramid_alloc": ms_alloc, "ms_pyramid_build": ms_build, "ms_pyramid_rebuild": ms_rebuild,
+            # host clock); the two builds: HIP events
+            # ms_pyramid_build = the build into storage that has been written before (what every build after a process's first one
+            # costs: box-independent); ms_pyramid_first_build = the first one, which also touches 105 GB of fresh pages (61-77 ms on a
+            # fresh box); ms_pyramid_rebuild = alias of ms_pyramid_build (the key of the profiles/r05_* files, where ms_pyramid_build
+            # still was the first build)
+            "ms_pyramid_alloc": ms_alloc, "ms_pyramid_first_build": ms_build, "ms_pyramid_build": ms_rebuild, "ms_pyramid_rebuild": ms_rebuild,
             "roofline": {"kernel": "pyr_lookup_corr0_kernel<64> (1 launch = 4-level pyramid lookup of all edges + the 196 -> 128 layer that "
                          "consumes it; 744 B/ep = 2*(240 taps + 128 outputs) + 8)" if fused_lookup else
                          "pyr_lookup_kernel<64, %s> (1 launch = 4-level pyramid lookup of all edges)" % (
