@@ -58,3 +58,39 @@ def test_lookup_of_transposed_features_is_the_transposed_lookup():
     out_t = ocorr.corr_block_lookup(ocorr.corr_pyramid(f1t, f2t, 4), coords_t, 3)                # [E,196,w,h]
     back = out_t.reshape(E, 4, 7, 7, w, h).transpose(0, 1, 3, 2, 5, 4).reshape(E, 196, h, w)     # CorrBlock.__call__, transposed
     assert np.abs(back - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
+def test_lookup_is_the_sum_of_the_lookups_on_target_strips():
+    """the algebra behind CorrBlock.strips (images with more than 64 columns and rows), on the oracle: the correlation volume is
+    linear in the target features and a lookup reads zero outside its volume (correlation_kernels.cu:48 within_bounds), so the
+    4-level lookup of a source strip equals the SUM over disjoint target strips of the lookups in the strips' own pyramids at
+    coordinates shifted by the strip origin -- windows that straddle a strip border included, and floor pooling included as long as
+    the strips start at multiples of 2^3 (here: strips of 8 and 16 columns on a 12 x 27 image; the product uses 64)."""
+    rng = np.random.default_rng(5)
+    E, C, h, w = 2, 16, 12, 27
+    f1 = rng.standard_normal((E, C, h, w)).astype(np.float32); f2 = rng.standard_normal((E, C, h, w)).astype(np.float32)
+    yy, xx = np.meshgrid(np.arange(h, dtype=np.float32), np.arange(w, dtype=np.float32), indexing="ij")
+    coords = (np.stack([xx, yy], -1)[None] + rng.uniform(-4, 4, (E, 1, 1, 2)).astype(np.float32) + 0.13 * yy[None, :, :, None]).astype(np.float32)
+    ref = ocorr.corr_block_lookup(ocorr.corr_pyramid(f1, f2, 4), coords, 3)                       # [E,196,h,w]
+
+    def pyramid(a, b):                                             # a [E,C,h,wa], b [E,C,h,wb] -> 4 levels of [E,h,wa,h2,wb2]
+        va = a.reshape(E, C, -1).astype(np.float64) / 4.0; vb = b.reshape(E, C, -1).astype(np.float64) / 4.0
+        vol = np.einsum("ecp,ecq->epq", va, vb).reshape(E, a.shape[2], a.shape[3], b.shape[2], b.shape[3])
+        out = []
+        for _ in range(4):
+            out.append(vol); vol = ocorr.avg_pool2(vol)
+        return out
+
+    for bounds in ([(0, 8), (8, 8), (16, 11)], [(0, 16), (16, 11)]):                               # target (and source) strips (x0, width)
+        cols = []
+        for (xs, ws) in bounds:
+            acc = 0.0
+            for (xt, wt) in bounds:
+                pyr = pyramid(f1[..., xs:xs + ws], f2[..., xt:xt + wt])
+                c = coords[:, :, xs:xs + ws].copy(); c[..., 0] -= xt
+                cc = np.ascontiguousarray(np.moveaxis(c, -1, 1)).astype(np.float32)
+                acc = acc + np.concatenate([ocorr.corr_index_forward(v, (cc / np.float32(2 ** l)).astype(np.float32), 3).reshape(E, -1, h, ws)
+                                            for l, v in enumerate(pyr)], axis=1)
+            cols.append(acc)
+        got = np.concatenate(cols, -1)
+        assert got.shape == ref.shape and np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max(), bounds
