@@ -328,9 +328,11 @@ __global__ __launch_bounds__(256) void ba_build_kernel(
       if (!ok[q]) continue;
       const int p = px[q];
       const float ds = disps_sens[(long)f * HW + p];
-      const bool m = ds > 0.f;
-      // depth prior: the reference's constant alpha = 0.05 (:1405), or per pixel (dh_ba_ex: confidence of the sensor depth)
+      // depth prior: the reference's constant alpha = 0.05 (:1405), or per pixel (dh_ba_ex: confidence of the sensor depth).
+      // Zero (or negative) confidence = no prior at that pixel: it is damped by eta like a pixel without sensor depth
+      // (alpha = 0 with all weights zero would make C = 0)
       const float al = alpha ? alpha[(long)f * HW + p] : ALPHA_PRIOR;
+      const bool m = ds > 0.f && al > 0.f;
       const float C = Cs[q] + (m ? al : (eta_ok ? eta[(long)k * HW + p] : 1.f));
       const float w = Ws[q] - (m ? al * (h[q] - ds) : 0.f);
       Q[(long)k * HW + p] = 1.f / C;
@@ -1862,7 +1864,7 @@ extern "C" int dh_ba_system_shape(int t0, int t1, int* rows, int* cols) {
 }
 
 static int ba_build_impl(int strict, const float* poses, const float* disps, const float* intrinsics, const float* disps_sens,
-                         const float* targets, const float* weights, const float* eta,
+                         const float* alpha, const float* targets, const float* weights, const float* eta,
                            const int64_t* ii, const int64_t* jj,
                            int num_frames, int n_edges, int n_eta_rows, int ht, int wd,
                            int t0, int t1, int motion_only,
@@ -1879,7 +1881,7 @@ static int ba_build_impl(int strict, const float* poses, const float* disps, con
   hipStream_t st = (hipStream_t)stream;
   rc = run_prep(L, ws, ii, jj, n_edges, num_frames, t0, t1, motion_only ? -1 : n_eta_rows, st);
   if (rc != DH_OK) return rc;
-  rc = run_build(L, ws, poses, disps, intrinsics, disps_sens, targets, weights, eta, n_eta_rows, nullptr, ii, jj,
+  rc = run_build(L, ws, poses, disps, intrinsics, disps_sens, targets, weights, eta, n_eta_rows, alpha, ii, jj,
                  num_frames, n_edges, ht * wd, wd, t0, motion_only, st);
   if (Hsys_out) *Hsys_out = (double*)(ws + L.H);
   if (bsys_out) *bsys_out = (double*)(ws + L.H) + (size_t)L.npad * L.ld;
@@ -1894,7 +1896,7 @@ extern "C" int dh_ba_build(const float* poses, const float* disps, const float* 
                            int t0, int t1, int motion_only,
                            double** Hsys_out, double** bsys_out, void* workspace, size_t workspace_bytes,
                            dh_stream_t stream) {
-  return ba_build_impl(1, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, num_frames, n_edges, n_eta_rows,
+  return ba_build_impl(1, poses, disps, intrinsics, disps_sens, nullptr, targets, weights, eta, ii, jj, num_frames, n_edges, n_eta_rows,
                        ht, wd, t0, t1, motion_only, Hsys_out, bsys_out, workspace, workspace_bytes, stream);
 }
 
@@ -1907,7 +1909,21 @@ extern "C" int dh_ba_build_shard(const float* poses, const float* disps, const f
                                  int t0, int t1, int motion_only,
                                  double** Hsys_out, double** bsys_out, void* workspace, size_t workspace_bytes,
                                  dh_stream_t stream) {
-  return ba_build_impl(0, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, num_frames, n_edges, n_eta_rows,
+  return ba_build_impl(0, poses, disps, intrinsics, disps_sens, nullptr, targets, weights, eta, ii, jj, num_frames, n_edges, n_eta_rows,
+                       ht, wd, t0, t1, motion_only, Hsys_out, bsys_out, workspace, workspace_bytes, stream);
+}
+
+// dh_ba_build_shard with the per-pixel weight of the sensor-depth prior of dh_ba_ex (BASELINE configs[4] is defined on the sharded
+// path): alpha [num_frames,ht,wd] f32 or NULL (= the reference's constant 0.05).  A depth block is assembled from the edges of its
+// source frame, which all live on the frame's owner: the prior enters the system once, on that rank, like in dh_ba_ex.
+extern "C" int dh_ba_build_shard_ex(const float* poses, const float* disps, const float* intrinsics, const float* disps_sens,
+                                    const float* alpha, const float* targets, const float* weights, const float* eta,
+                                    const int64_t* ii, const int64_t* jj,
+                                    int num_frames, int n_edges, int n_eta_rows, int ht, int wd,
+                                    int t0, int t1, int motion_only,
+                                    double** Hsys_out, double** bsys_out, void* workspace, size_t workspace_bytes,
+                                    dh_stream_t stream) {
+  return ba_build_impl(0, poses, disps, intrinsics, disps_sens, alpha, targets, weights, eta, ii, jj, num_frames, n_edges, n_eta_rows,
                        ht, wd, t0, t1, motion_only, Hsys_out, bsys_out, workspace, workspace_bytes, stream);
 }
 

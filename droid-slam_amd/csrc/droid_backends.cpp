@@ -99,7 +99,8 @@ std::vector<torch::Tensor> ba_ex(torch::Tensor poses, torch::Tensor disps, torch
 // returns {workspace (opaque, keeps everything alive), system [(npad+48), npad] f64 view into it}: rows
 // 0..npad-1 = reduced camera matrix (6P x 6P in the top-left corner), row npad = right-hand side.
 static std::vector<torch::Tensor> ba_build_any(bool shard, torch::Tensor poses, torch::Tensor disps, torch::Tensor intrinsics,
-                                               torch::Tensor disps_sens, torch::Tensor targets, torch::Tensor weights,
+                                               torch::Tensor disps_sens, c10::optional<torch::Tensor> alpha,
+                                               torch::Tensor targets, torch::Tensor weights,
                                                torch::Tensor eta, torch::Tensor ii, torch::Tensor jj, const int t0, const int t1,
                                                const bool motion_only) {
   CHECK_INPUT(targets); CHECK_INPUT(weights); CHECK_INPUT(poses); CHECK_INPUT(disps);
@@ -113,12 +114,26 @@ static std::vector<torch::Tensor> ba_build_any(bool shard, torch::Tensor poses, 
   TORCH_CHECK(wsb > 0, "ba_build: invalid arguments");
   torch::Tensor ws = torch::empty({(int64_t)wsb}, poses.options().dtype(torch::kUInt8));
   double* H = nullptr; double* b = nullptr;
-  check_status((shard ? dh_ba_build_shard : dh_ba_build)(
-                   poses.data_ptr<float>(), disps.data_ptr<float>(), intrinsics.data_ptr<float>(),
-                   disps_sens.data_ptr<float>(), targets.data_ptr<float>(), weights.data_ptr<float>(),
-                   eta.data_ptr<float>(), ii.data_ptr<int64_t>(), jj.data_ptr<int64_t>(), F, E, K, ht, wd,
-                   t0, t1, motion_only ? 1 : 0, &H, &b, ws.data_ptr(), wsb, cur_stream()),
-               "ba_build");
+  const float* al = nullptr;
+  if (alpha.has_value()) {
+    const torch::Tensor& a = *alpha;
+    CHECK_INPUT(a); CHECK_F32(a);
+    TORCH_CHECK(shard, "ba_build: the per-pixel prior weight exists on ba_ex and ba_build_shard_ex");
+    TORCH_CHECK(a.numel() == disps.numel(), "ba_build_shard_ex: alpha must have the shape of disps");
+    al = a.data_ptr<float>();
+  }
+  if (shard)
+    check_status(dh_ba_build_shard_ex(poses.data_ptr<float>(), disps.data_ptr<float>(), intrinsics.data_ptr<float>(),
+                                      disps_sens.data_ptr<float>(), al, targets.data_ptr<float>(), weights.data_ptr<float>(),
+                                      eta.data_ptr<float>(), ii.data_ptr<int64_t>(), jj.data_ptr<int64_t>(), F, E, K, ht, wd,
+                                      t0, t1, motion_only ? 1 : 0, &H, &b, ws.data_ptr(), wsb, cur_stream()),
+                 "ba_build_shard");
+  else
+    check_status(dh_ba_build(poses.data_ptr<float>(), disps.data_ptr<float>(), intrinsics.data_ptr<float>(),
+                             disps_sens.data_ptr<float>(), targets.data_ptr<float>(), weights.data_ptr<float>(),
+                             eta.data_ptr<float>(), ii.data_ptr<int64_t>(), jj.data_ptr<int64_t>(), F, E, K, ht, wd,
+                             t0, t1, motion_only ? 1 : 0, &H, &b, ws.data_ptr(), wsb, cur_stream()),
+                 "ba_build");
   int rows = 0, cols = 0;
   check_status(dh_ba_system_shape(t0, t1, &rows, &cols), "ba_system_shape");
   torch::Tensor sys = torch::from_blob(H, {rows, cols}, poses.options().dtype(torch::kFloat64));
@@ -129,7 +144,7 @@ std::vector<torch::Tensor> ba_build(torch::Tensor poses, torch::Tensor disps, to
                                     torch::Tensor disps_sens, torch::Tensor targets, torch::Tensor weights,
                                     torch::Tensor eta, torch::Tensor ii, torch::Tensor jj, const int t0, const int t1,
                                     const bool motion_only) {
-  return ba_build_any(false, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1, motion_only);
+  return ba_build_any(false, poses, disps, intrinsics, disps_sens, c10::nullopt, targets, weights, eta, ii, jj, t0, t1, motion_only);
 }
 
 // the edge-sharded solver's build (dh_ba_build_shard): no host synchronisation, the argument flag travels with the exchange
@@ -137,7 +152,15 @@ std::vector<torch::Tensor> ba_build_shard(torch::Tensor poses, torch::Tensor dis
                                           torch::Tensor disps_sens, torch::Tensor targets, torch::Tensor weights,
                                           torch::Tensor eta, torch::Tensor ii, torch::Tensor jj, const int t0, const int t1,
                                           const bool motion_only) {
-  return ba_build_any(true, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1, motion_only);
+  return ba_build_any(true, poses, disps, intrinsics, disps_sens, c10::nullopt, targets, weights, eta, ii, jj, t0, t1, motion_only);
+}
+
+// ba_build_shard with ba_ex's per-pixel depth-prior weight alpha [buf,ht,wd] (dh_ba_build_shard_ex; BASELINE configs[4] on the sharded path)
+std::vector<torch::Tensor> ba_build_shard_ex(torch::Tensor poses, torch::Tensor disps, torch::Tensor intrinsics,
+                                             torch::Tensor disps_sens, torch::Tensor alpha, torch::Tensor targets, torch::Tensor weights,
+                                             torch::Tensor eta, torch::Tensor ii, torch::Tensor jj, const int t0, const int t1,
+                                             const bool motion_only) {
+  return ba_build_any(true, poses, disps, intrinsics, disps_sens, alpha, targets, weights, eta, ii, jj, t0, t1, motion_only);
 }
 
 static std::vector<torch::Tensor> ba_finish_any(torch::Tensor poses, torch::Tensor disps, torch::Tensor jj, torch::Tensor ws,
@@ -761,6 +784,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("ba_depth_blocks", &ba_depth_blocks, "views of Qinv = 1/C, w, kx, K in the workspace of ba_build (the keep-alive is the caller's: hold `ws`)");
   m.def("ba_finish", &ba_finish, "damp + solve + back-substitute + retract (split BA)");
   m.def("ba_build_shard", &ba_build_shard, "ba_build without a host synchronisation (edge-sharded BA)");
+  m.def("ba_build_shard_ex", &ba_build_shard_ex, "ba_build_shard with a per-pixel depth-prior weight");
   m.def("ba_finish_owned", &ba_finish_owned, "ba_finish that only moves the depths of frames [own_lo, own_hi)");
   m.def("ba_pack_blocks", &ba_pack_blocks, "co-visible 6x6 blocks + rhs + flags -> one contiguous f64 buffer");
   m.def("ba_unpack_blocks", &ba_unpack_blocks, "all-reduced buffer -> system + flags");

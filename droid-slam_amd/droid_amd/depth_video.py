@@ -57,6 +57,10 @@ class DepthVideo:
         self.nets = torch.zeros(buffer, 128, ht // 8, wd // 8, dtype=torch.half, device=self.device)
         self.inps = torch.zeros(buffer, 128, ht // 8, wd // 8, dtype=torch.half, device=self.device)
         self.poses[:, 6] = 1.0                                   # identity (depth_video.py:41)
+        # per-pixel confidence of the sensor depth = the weight of the depth prior in the BA (BASELINE.json configs[4]).  None: the
+        # reference's constant 0.05 (src/droid_kernels.cu:1405-1408) through droid_backends.ba; set_depth_confidence() allocates
+        # [buffer, ht/8, wd/8] f32 (0.05 where never set) and ba() then goes through droid_backends.ba_ex
+        self.disps_conf = None
 
     def get_lock(self):
         return self.counter.get_lock()
@@ -132,13 +136,29 @@ class DepthVideo:
             d = db.frame_distance(self.poses, self.disps, intr, ii, jj, beta)
         return d.reshape(N, N) if return_matrix else d
 
+    DEPTH_PRIOR_WEIGHT = 0.05                                     # src/droid_kernels.cu:1405
+
+    def set_depth_confidence(self, index, conf):
+        """per-pixel weight of the sensor-depth prior of frame(s) `index`: conf [.., ht/8, wd/8] (or full resolution, sampled at
+        [3::8, 3::8] like the depth itself, depth_video.py:93-94), >= 0; applies where disps_sens > 0"""
+        if self.disps_conf is None:
+            self.disps_conf = torch.full_like(self.disps_sens, self.DEPTH_PRIOR_WEIGHT)
+        conf = torch.as_tensor(conf, dtype=torch.float, device=self.device)
+        if conf.shape[-2:] == (self.ht, self.wd) and (self.ht, self.wd) != tuple(self.disps_conf.shape[-2:]):
+            conf = conf[..., 3::8, 3::8]
+        self.disps_conf[index] = conf
+
     def ba(self, target, weight, eta, ii, jj, t0=1, t1=None, itrs=2, lm=1e-4, ep=0.1, motion_only=False):
         """dense bundle adjustment, in place on poses / disps (depth_video.py:213-225)"""
         with self.get_lock():
             if t1 is None:
                 t1 = max(ii.max().item(), jj.max().item()) + 1
-            db.ba(self.poses, self.disps, self.intrinsics[0].contiguous(), self.disps_sens, target, weight, eta, ii, jj,
-                  t0, t1, itrs, lm, ep, motion_only)
+            if self.disps_conf is None:
+                db.ba(self.poses, self.disps, self.intrinsics[0].contiguous(), self.disps_sens, target, weight, eta, ii, jj,
+                      t0, t1, itrs, lm, ep, motion_only)
+            else:
+                db.ba_ex(self.poses, self.disps, self.intrinsics[0].contiguous(), self.disps_sens, self.disps_conf, target, weight, eta,
+                         ii, jj, t0, t1, itrs, lm, ep, motion_only)
             self.disps.clamp_(min=0.001)
 
     def upsample(self, ix, mask):

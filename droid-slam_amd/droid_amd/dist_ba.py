@@ -109,6 +109,7 @@ class DistBA:
         self.frame_lo, self.frame_hi = frame_lo, frame_hi
         self._owned_given = (frame_lo, frame_hi) != (0, 1 << 30)   # the defaults mean "owns everything": only right for one rank
         self._partition_ok = None       # (lo, hi, F) of the last validated ownership partition
+        self._ranges = None             # every rank's (lo, hi), gathered by set_owned_frames
         if backend is None:
             import droid_backends as backend          # HIP path; fails loudly without the extension
         self.be = backend
@@ -152,28 +153,38 @@ class DistBA:
         return self._blocks[1:]
 
     def set_owned_frames(self, lo, hi):
+        """COLLECTIVE: every rank of the group calls it, together (like a constructor of the process group's state).  The
+        ranks' [lo, hi) ranges are gathered here, once, and every rank keeps the same table; ba() then checks ON THE HOST, with no
+        further collective, that the table partitions the frames -- so whether a rank validates can never differ between ranks
+        (a rank-local cache miss that issued an all-reduce the others skipped would have hung or corrupted the exchange)."""
         self.frame_lo, self.frame_hi = int(lo), int(hi)
         self._owned_given = True
         self._partition_ok = None
+        self._ranges = None
+        if self.world > 1 or self.always_reduce:
+            dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
+            mine = torch.tensor([self.frame_lo, self.frame_hi], dtype=torch.int64, device=dev)
+            table = [torch.empty_like(mine) for _ in range(dist.get_world_size(self.group))]
+            dist.all_gather(table, mine, group=self.group)
+            self._ranges = sorted((int(t[0]), int(t[1])) for t in torch.stack(table).cpu())
 
     def _validate_partition(self, lo, hi, F, device):
         """The final depth exchange zeroes the maps a rank does not own and SUMS: right only if the ranks' [lo, hi) ranges
-        partition [0, F) exactly.  Checked once per (lo, hi, F) with one small all-reduce of per-frame ownership counts
-        (a frame owned twice would come out multiplied, an unowned one zeroed) -- every rank raises together."""
+        partition [0, F) exactly (a frame owned twice would come out multiplied, an unowned one zeroed).  Decided from the table
+        set_owned_frames gathered: the same answer on every rank, no communication -- every rank raises together."""
         if self._partition_ok == (lo, hi, F):
             return
         if self.world > 1 and not self._owned_given:
             raise RuntimeError("DistBA: world size %d but set_owned_frames() was never called: every rank would claim all "
                                "depth maps and the final exchange would multiply them by the world size" % self.world)
-        if self.world > 1 or self.always_reduce:
-            own = torch.zeros(F, dtype=torch.int32, device=device)
-            own[lo:hi] = 1
-            self._allreduce(own)
-            bad = torch.nonzero(own != 1)[:, 0]
-            if bad.numel():
-                f = int(bad[0].item())
+        if self._ranges is not None:
+            own = np.zeros(F, dtype=np.int64)
+            for a, b in self._ranges:
+                own[max(0, min(a, F)):max(0, min(b, F))] += 1
+            bad = np.nonzero(own != 1)[0]
+            if bad.size:
                 raise RuntimeError("DistBA: the ranks' owned frame ranges do not partition [0, %d): frame %d has %d owners "
-                                   "(%d frames affected)" % (F, f, int(own[f].item()), int(bad.numel())))
+                                   "(%d frames affected)" % (F, int(bad[0]), int(own[bad[0]]), int(bad.size)))
         self._partition_ok = (lo, hi, F)
 
     def _allreduce(self, t):
@@ -181,13 +192,16 @@ class DistBA:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     def _iterate(self, packed, stale, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1,
-                 iterations, lm, ep, motion_only, lo, hi):
+                 iterations, lm, ep, motion_only, lo, hi, alpha=None):
         """-> (dx, dz, status): status = device tensor [2] (f64), summed over ranks: [argument flags, stale patterns]"""
         be = self.be
         dx = dz = None
         status = None
         for _ in range(iterations):
-            ws, system = be.ba_build_shard(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1, motion_only)
+            if alpha is None:
+                ws, system = be.ba_build_shard(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1, motion_only)
+            else:                                           # per-pixel weight of the sensor-depth prior (BASELINE configs[4])
+                ws, system = be.ba_build_shard_ex(poses, disps, intrinsics, disps_sens, alpha, targets, weights, eta, ii, jj, t0, t1, motion_only)
             if packed:
                 bp, bq, buf = self._block_buffers(disps.device)
                 be.ba_pack_blocks(ws, disps, jj, t0, t1, motion_only, bp, bq, stale, buf)
@@ -208,7 +222,10 @@ class DistBA:
         return dx, dz, status
 
     def ba(self, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1,
-           iterations=2, lm=1e-4, ep=0.1, motion_only=False):
+           iterations=2, lm=1e-4, ep=0.1, motion_only=False, alpha=None):
+        """alpha: optional [F,ht,wd] f32, the per-pixel weight of the sensor-depth prior (droid_backends.ba_ex; None = the
+        reference's constant 0.05, src/droid_kernels.cu:1405-1408).  Replicated like disps_sens; a frame's prior enters the
+        system on the rank that holds the frame's edges."""
         F = disps.shape[0]
         lo, hi = max(0, self.frame_lo), min(F, self.frame_hi)
         if not motion_only:
@@ -217,12 +234,12 @@ class DistBA:
         packed = self._pattern is not None and self._pattern[:2] == (int(t0), int(t1))
         # host-side and cached per edge list; a stale pattern is reported THROUGH the exchange, never by a rank-local decision
         stale = 0 if (not packed or self._local_blocks_covered(ii, jj, t0, t1)) else 1
-        dx, dz, status = self._iterate(packed, stale, *args)
+        dx, dz, status = self._iterate(packed, stale, *args, alpha=alpha)
         flags = status.cpu().tolist() if status is not None else [0.0, 0.0]     # the call's one synchronisation
         if packed and flags[1] != 0:
             # some rank's blocks are not in the pattern: no rank has applied an update; all repeat with the dense exchange
             packed = False
-            dx, dz, status = self._iterate(False, 0, *args)
+            dx, dz, status = self._iterate(False, 0, *args, alpha=alpha)
             flags = status.cpu().tolist() if status is not None else [0.0, 0.0]
         self.last_exchange_packed = packed
         if not motion_only and (self.world > 1 or self.always_reduce):

@@ -57,6 +57,46 @@ class FactorGraph:
         # the volumes in the reference layout and stays there.  native_corr=True pins the pyramid; coherence_fallback=False skips the check.
         self._coherence_fallback = bool(coherence_fallback) and native_corr is None
         self._coherence_key = None
+        # the gates' per-frame context term is kept between keyframe insertions (_context); False recomputes it in every update
+        # iteration, like the reference's convolutions over [net, inp, corr, flow] do (bench.py times that form)
+        self.cache_context = True
+        self.phase_events = None        # a list: update() appends (name, start, end) torch.cuda.Event triples (bench.py)
+        self._stats_key = None
+
+    # ---- which edges' state this object holds ---------------------------------------------------------------------
+    # `ii, jj, age, ii_inac, jj_inac` are the graph's edge lists.  The per-edge state (hidden state, targets, weights, volumes)
+    # belongs to the edges `_local_edges()` returns: all of them here, this rank's shard in droid_amd.dist_graph.DistFactorGraph.
+    def _local_edges(self):
+        return self.ii, self.jj
+
+    def _local_inactive(self):
+        return self.ii_inac, self.jj_inac
+
+    def _edge_stats(self):
+        """(min source frame, max frame + 1) of the edge list, read back ONCE per edge list (the reference does `.item()` /
+        python `range(tensor)` on them in every update, factor_graph.py:228,284)"""
+        key = tensor_cache_key(self.ii, self.jj)
+        if key is None or key != self._stats_key:
+            r = torch.stack([self.ii.min(), self.ii.max(), self.jj.max()]).tolist()
+            self._stats_key, self._stats = key, (int(r[0]), int(r[1]), int(r[2]), self.ii, self.jj)
+        return self._stats[:3]
+
+    def _replicated(self, t):
+        return t                                    # (one process: droid_amd.dist_graph broadcasts rank 0's copy)
+
+    def _unique_cached(self, ii):
+        """torch.unique(ii) (a read-back: the output size is data dependent), once per edge-list tensor"""
+        key = tensor_cache_key(ii)
+        if key is None or getattr(self, "_uniq_key", None) != key:
+            self._uniq_key, self._uniq = key, (torch.unique(ii), ii)
+        return self._uniq[0]
+
+    def _solve(self, tb, wb, ii, jj, t0, t1, itrs, lm, ep, motion_only, EP, uniq=None):
+        """eta of the depth blocks (factor_graph.py:251) + the dense BA over the edges (ii, jj) with targets / weights (tb, wb)"""
+        if uniq is None:
+            uniq = self._unique_cached(ii)
+        eta = (.2 * self.damping[uniq] + EP).contiguous()
+        self.video.ba(tb, wb, eta, ii, jj, t0, t1, itrs=itrs, lm=lm, ep=ep, motion_only=motion_only)
 
     # ---- reference-shaped views of the channel-last state ---------------------------------------------------------
     @property
@@ -94,6 +134,12 @@ class FactorGraph:
         if self.max_factors > 0 and self.ii.shape[0] + ii.shape[0] > self.max_factors and self.corr is not None and remove:
             ix = torch.argsort(self.age, stable=True)                 # factor_graph.py:121-122 (mask indexed by edge position)
             self.rm_factors(ix >= self.max_factors - ii.shape[0], store=True)
+        self._append_factors(ii, jj)
+        self.ii = torch.cat([self.ii, ii]); self.jj = torch.cat([self.jj, jj]); self.age = torch.cat([self.age, torch.zeros_like(ii)])
+
+    def _append_factors(self, ii, jj):
+        """per-edge state of new edges: hidden state from the source frame's context network output, correlation volumes, the
+        first target = the reprojection (factor_graph.py:124-145)"""
         net = self.video.nets[ii].permute(0, 2, 3, 1).contiguous()
         if self.corr_impl == "volume":
             if self._native_corr:                                     # features prepared once per frame, indexed by the edges
@@ -103,7 +149,6 @@ class FactorGraph:
                 corr = CorrBlockRef(self.video.fmaps[ii, 0][None], self.video.fmaps[jj, c][None])
             self.corr = corr if self.corr is None else self.corr.cat(corr)
         target, _ = self.video.reproject(ii, jj)
-        self.ii = torch.cat([self.ii, ii]); self.jj = torch.cat([self.jj, jj]); self.age = torch.cat([self.age, torch.zeros_like(ii)])
         self._net = net if self._net is None else torch.cat([self._net, net], 0)
         self.target = torch.cat([self.target, target], 1)
         self.weight = torch.cat([self.weight, torch.zeros_like(target)], 1)
@@ -111,9 +156,14 @@ class FactorGraph:
     def rm_factors(self, mask, store=False):
         if store:
             self.ii_inac = torch.cat([self.ii_inac, self.ii[mask]]); self.jj_inac = torch.cat([self.jj_inac, self.jj[mask]])
+        self._drop_state(mask, store)
+        self.ii = self.ii[~mask]; self.jj = self.jj[~mask]; self.age = self.age[~mask]
+
+    def _drop_state(self, mask, store):
+        """per-edge state of removed edges (mask over the edges whose state this object holds)"""
+        if store:
             self.target_inac = torch.cat([self.target_inac, self.target[:, mask]], 1)
             self.weight_inac = torch.cat([self.weight_inac, self.weight[:, mask]], 1)
-        self.ii = self.ii[~mask]; self.jj = self.jj[~mask]; self.age = self.age[~mask]
         if self.corr_impl == "volume" and self.corr is not None:
             self.corr = self.corr[~mask]
         if self._net is not None:
@@ -161,7 +211,7 @@ class FactorGraph:
         added or removed, not between the update iterations in between: kept until either changes (tensor version counters)."""
         inps = self.video.inps
         key = tensor_cache_key(ii, inps)
-        if key is None or getattr(self, "_ctx_key", None) != key:
+        if key is None or not self.cache_context or getattr(self, "_ctx_key", None) != key:
             uniq, ix = torch.unique(ii, return_inverse=True)
             inp_frames = inps[uniq].permute(0, 2, 3, 1).contiguous()
             h, w = inp_frames.shape[1:3]
@@ -172,26 +222,51 @@ class FactorGraph:
     def _check_flow_coherence(self, coords1):
         """once per edge list: if the flow's window spread says the pyramid layout would be slower than the reference layout,
         rebuild every edge's volumes as CorrBlockRef (sticky for this graph; the pyramid is released first)"""
-        key = tensor_cache_key(self.ii, self.jj)
+        ii, jj = self._local_edges()
+        key = tensor_cache_key(ii, jj)
         if key is not None and key == self._coherence_key:
             return
-        self._coherence_key, self._coherence_ii = key, (self.ii, self.jj)          # (kept alive: their addresses are in the key)
+        self._coherence_key, self._coherence_ii = key, (ii, jj)                    # (kept alive: their addresses are in the key)
         self.last_window_spread = spread = CorrBlock.window_spread(coords1)
         if spread <= CorrBlock.SPREAD_LIMIT:
             return
-        ii, jj = self.ii, self.jj
         c = (ii == jj).long()
         self.corr = None                                                            # 105 GB at C3: release before the rebuild
         torch.cuda.empty_cache()
         self.corr = CorrBlockRef(self.video.fmaps[ii, 0][None], self.video.fmaps[jj, c][None])
         self._native_corr = False
 
-    def update(self, t0=None, t1=None, itrs=2, use_inactive=False, EP=1e-7, motion_only=False):
-        ii, jj = self.ii, self.jj
+    def _ba_t1(self, t0, use_inactive):
+        """the BA window's end when the caller gives none: one past the largest frame index of the BA's edges
+        (depth_video.py:218-219), from the cached edge statistics instead of two read-backs per call"""
+        _, imax, jmax = self._edge_stats()
+        t1 = max(imax, jmax) + 1
+        if use_inactive and len(self.ii_inac) > 0:
+            key = (tensor_cache_key(self.ii_inac, self.jj_inac), t0)
+            if key[0] is None or getattr(self, "_inac_t1_key", None) != key:
+                m = (self.ii_inac >= t0 - 3) & (self.jj_inac >= t0 - 3)
+                top = torch.where(m, torch.maximum(self.ii_inac, self.jj_inac), torch.full_like(self.ii_inac, -1)).max()
+                self._inac_t1_key, self._inac_t1 = key, (int(top.item()) + 1, self.ii_inac, self.jj_inac)
+            t1 = max(t1, self._inac_t1[0])
+        return t1
+
+    def update(self, t0=None, t1=None, itrs=2, use_inactive=False, EP=1e-7, motion_only=False, lm=1e-4, ep=0.1):
+        """one update iteration (factor_graph.py:214-263).  `lm`, `ep`: the BA's damping (the reference's update() fixes 1e-4 / 0.1,
+        its update_lowmem 1e-5 / 1e-2; bench.py runs the global-BA parameters through this full-batch form)."""
+        ii, jj = self._local_edges()
+        ev = self.phase_events
+
+        def mark():
+            if ev is None:
+                return None
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            return e
         with roctx_range("droid.update/reproject"):
             coords1 = self.video.reproject(ii, jj)[0][0]                                      # [E,h,w,2]
         if self.corr_impl != "volume":
             raise RuntimeError("update() needs corr_impl='volume' (use update_lowmem for 'alt')")
+        e0 = mark()
         with roctx_range("droid.update/corr_lookup"):
             if self._native_corr and self._coherence_fallback:
                 self._check_flow_coherence(coords1)
@@ -199,25 +274,37 @@ class FactorGraph:
                 feats, corr0 = self._pyramid_features(self.corr, coords1)
             else:
                 feats, corr0 = self.update_op.corr_to_nhwc(self.corr(coords1[None])[0]), None
+        e1 = mark()
         with roctx_range("droid.update/update_operator"):
             dw, damping, upmask, uniq = self._operator(self._net, coords1, self.target[0].contiguous(), feats, ii, corr0)
         if t0 is None:
-            t0 = max(1, ii.min().item() + 1)
+            t0 = max(1, self._edge_stats()[0] + 1)
+        if t1 is None:
+            t1 = self._ba_t1(t0, use_inactive)
         with roctx_range("droid.update/ba"):
             target, weight, tb, wb = db.ba_inputs(coords1, dw)
             self.target, self.weight = target[None], weight[None]
             self.damping[uniq] = damping
+            uniq_ba = uniq
             if use_inactive:
-                m = (self.ii_inac >= t0 - 3) & (self.jj_inac >= t0 - 3)
-                ii = torch.cat([self.ii_inac[m], ii]); jj = torch.cat([self.jj_inac[m], jj])
+                ii_in, jj_in = self._local_inactive()
+                m = (ii_in >= t0 - 3) & (jj_in >= t0 - 3)
+                ii = torch.cat([ii_in[m], ii]); jj = torch.cat([jj_in[m], jj])
                 tb = torch.cat([self.target_inac[0, m].permute(0, 3, 1, 2), tb]).contiguous()
                 wb = torch.cat([self.weight_inac[0, m].permute(0, 3, 1, 2), wb]).contiguous()
-            eta = (.2 * self.damping[torch.unique(ii)] + EP).contiguous()
-            self.video.ba(tb, wb, eta, ii, jj, t0, t1, itrs=itrs, lm=1e-4, ep=0.1, motion_only=motion_only)
+                uniq_ba = None
+            e2 = mark()
+            self._solve(tb, wb, ii, jj, t0, t1, itrs, lm, ep, motion_only, EP, uniq=uniq_ba)
+        e3 = mark()
+        if ev is not None:
+            ev.append((e0, e1, e2, e3))
         if self.upsample:
             with roctx_range("droid.update/upsample"):
-                self.video.upsample(uniq, upmask)
+                self._upsample(uniq, upmask)
         self.age += 1
+
+    def _upsample(self, frames, upmask):
+        self.video.upsample(frames, upmask)
 
     # ---- global BA (factor_graph.py:266-330) --------------------------------------------------------------------------
     def _pyramid_fits(self, E, ht, wd):
@@ -232,6 +319,12 @@ class FactorGraph:
         total = torch.cuda.get_device_properties(self.device).total_memory
         need = E * CorrBlock.bytes_per_edge(ht, wd) + E * ht * wd * 3584
         return need < 0.6 * total
+
+    def _check_activations_fit(self, E, ht, wd):
+        need = E * ht * wd * 3584
+        free_b = torch.cuda.mem_get_info(self.device)[0] + torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)
+        if free_b < need:
+            raise torch.cuda.OutOfMemoryError("update_lowmem: %.1f GB of operator activations do not fit next to the pyramid (%.1f GB free)" % (need / 1e9, free_b / 1e9))
 
     def _pyramid_arena(self, E, ht, wd):
         """storage for update_lowmem's per-call pyramid, kept across calls (reallocated only when a call has more edges than any
@@ -248,15 +341,15 @@ class FactorGraph:
         self._arena = None
 
     def _ba_global(self, tb, wb, itrs, use_inactive, EP, t):
-        ii, jj = self.ii, self.jj
+        ii, jj = self._local_edges()
         if use_inactive:
-            ii = torch.cat([self.ii_inac, ii]); jj = torch.cat([self.jj_inac, jj])
+            ii_in, jj_in = self._local_inactive()
+            ii = torch.cat([ii_in, ii]); jj = torch.cat([jj_in, jj])
             tb = torch.cat([self.target_inac[0].permute(0, 3, 1, 2), tb]).contiguous()
             wb = torch.cat([self.weight_inac[0].permute(0, 3, 1, 2), wb]).contiguous()
-        eta = (.2 * self.damping[torch.unique(ii)] + EP).contiguous()
         self.age += 1
         with roctx_range("droid.update_lowmem/ba"):
-            self.video.ba(tb, wb, eta, ii, jj, 1, t, itrs=itrs, lm=1e-5, ep=1e-2, motion_only=False)
+            self._solve(tb, wb, ii, jj, 1, t, itrs, 1e-5, 1e-2, False, EP)
         self.video.dirty[:t] = True
 
     def update_lowmem(self, t0=None, t1=None, itrs=2, use_inactive=False, EP=1e-7, steps=8, corr="auto"):
@@ -275,19 +368,21 @@ class FactorGraph:
         t = v.counter.value
         num, rig, ch, ht, wd = v.fmaps.shape
         s = self.chunk_frames
+        lii, ljj = self._local_edges()
         # the reference's chunk loop (factor_graph.py:284-287) runs over source frames [ii.min(), jj.max()] in steps of s: edges
         # whose source frame lies beyond the last chunk are never visited and keep their previous hidden state / target /
         # weight.  Both correlation paths reproduce that, so they are equivalent up to fp16 rounding of the features.
-        lo, hi = int(self.ii.min().item()), int(self.jj.max().item()) + 1
+        imin, imax, jmax = self._edge_stats()
+        lo, hi = imin, jmax + 1
         limit = lo + (hi - lo + s - 1) // s * s
-        all_visited = int(self.ii.max().item()) < limit
-        if corr == "pyramid" or (corr == "auto" and self._pyramid_fits(len(self.ii), ht, wd)):
-            sel = None if all_visited else torch.nonzero(self.ii < limit)[:, 0]
-            ii_v, jj_v = (self.ii, self.jj) if sel is None else (self.ii[sel], self.jj[sel])
-            c = (ii_v == jj_v).long() if rig > 1 else torch.zeros_like(ii_v)
+        all_visited = imax < limit
+        if len(lii) > 0 and (corr == "pyramid" or (corr == "auto" and self._pyramid_fits(len(lii), ht, wd))):
+            sel = None if all_visited else torch.nonzero(lii < limit)[:, 0]
+            ii_v, jj_v = (lii, ljj) if sel is None else (lii[sel], ljj[sel])
             trace = os.environ.get("DH_LOWMEM_TRACE", "0") == "1"      # wall-clock phases of a call (diagnostics; synchronises)
             if trace:
                 torch.cuda.synchronize(); _t0 = time.perf_counter()
+            arena = None
             try:
                 with roctx_range("droid.update_lowmem/pyramid_build"):
                     arena = self._pyramid_arena(len(ii_v), ht, wd) if CorrBlock.strip_bounds(ht, wd) is None else None
@@ -297,16 +392,17 @@ class FactorGraph:
                 # allocator holds unused -- so that a device shared with other tenants still falls back to the alt-correlation loop
                 # with the state untouched.  (No trial allocation: a 45 GB probe block fragments the allocator's segments and cost
                 # the NEXT call a fresh 1.2 s hipMalloc -- measured, round 5.)
-                need = len(ii_v) * ht * wd * 3584
-                free_b = torch.cuda.mem_get_info(self.device)[0] + torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)
-                if free_b < need:
-                    raise torch.cuda.OutOfMemoryError("update_lowmem: %.1f GB of operator activations do not fit next to the pyramid (%.1f GB free)" % (need / 1e9, free_b / 1e9))
+                self._check_activations_fit(len(ii_v), ht, wd)
             except torch.cuda.OutOfMemoryError:
                 if corr == "pyramid":
                     raise
-                block = None                                        # "auto": fall through to the alt-correlation loop
+                # "auto": fall through to the alt-correlation loop -- with the pyramid's storage really released (the local
+                # `arena` is the last reference to ~105 GB at C3: without dropping it empty_cache() frees nothing)
+                block = None
+                arena = None
                 self._arena = None
                 torch.cuda.empty_cache()
+            del arena
             if trace:
                 torch.cuda.synchronize(); _t1 = time.perf_counter()
                 print("update_lowmem trace: pyramid build + reservation %.1f ms (block %s)" % (1e3 * (_t1 - _t0), "ok" if block is not None else "FELL BACK"), flush=True)
@@ -315,7 +411,7 @@ class FactorGraph:
                     if trace:
                         torch.cuda.synchronize(); _t2 = time.perf_counter()
                     with roctx_range("droid.update_lowmem/reproject"):
-                        coords_all = v.reproject(self.ii, self.jj)[0][0]
+                        coords_all = v.reproject(lii, ljj)[0][0]
                     if sel is None:
                         coords1, net, target_prev = coords_all, self._net, self.target[0].contiguous()
                     else:
@@ -334,14 +430,14 @@ class FactorGraph:
                     self.target, self.weight = target[None], weight[None]
                     self.damping[uniq] = damping
                     if self.upsample:
-                        v.upsample(uniq, upmask)
+                        self._upsample(uniq, upmask)
                     self._ba_global(tb, wb, itrs, use_inactive, EP, t)
                     if trace:
                         torch.cuda.synchronize(); print("update_lowmem trace: step %.1f ms" % (1e3 * (time.perf_counter() - _t2)), flush=True)
                 return
         corr_op = AltCorrBlock(v.fmaps.view(1, num * rig, ch, ht, wd))
         for _ in range(steps):
-            coords1 = v.reproject(self.ii, self.jj)[0][0]
+            coords1 = v.reproject(lii, ljj)[0][0]
             target_prev = self.target[0].contiguous()
             if not all_visited:
                 # edges beyond the last chunk are not visited and keep their previous target / weight (see above)
@@ -349,20 +445,20 @@ class FactorGraph:
                 tb = target.permute(0, 3, 1, 2).contiguous(); wb = weight.permute(0, 3, 1, 2).contiguous()
             else:                                                       # every edge is written below
                 target = torch.empty_like(target_prev); weight = torch.empty_like(target_prev)
-                tb = torch.empty(len(self.ii), 2, ht, wd, device=self.device); wb = torch.empty_like(tb)
+                tb = torch.empty(len(lii), 2, ht, wd, device=self.device); wb = torch.empty_like(tb)
             for i in range(lo, hi, s):
-                vmask = (self.ii >= i) & (self.ii < i + s)
+                vmask = (lii >= i) & (lii < i + s)
                 e = torch.nonzero(vmask)[:, 0]
                 if e.numel() == 0:
                     continue
-                iis, jjs = self.ii[e], self.jj[e]
+                iis, jjs = lii[e], ljj[e]
                 c1 = coords1[e].contiguous()
                 corr1 = corr_op(c1[None], rig * iis, rig * jjs + (iis == jjs).long())         # [1,M,196,h,w]
                 feats = corr1[0] if self.update_op.wants_reference_layout_corr(ht, wd) else self.update_op.corr_to_nhwc(corr1[0])
                 net = self._net[e].contiguous()
                 dw, damping, upmask, uniq = self._operator(net, c1, target_prev[e].contiguous(), feats, iis)
                 if self.upsample:
-                    v.upsample(uniq, upmask)
+                    self._upsample(uniq, upmask)
                 self._net[e] = net
                 tg, wg, tbe, wbe = db.ba_inputs(c1, dw)
                 target[e] = tg; weight[e] = wg; tb[e] = tbe; wb[e] = wbe
@@ -382,7 +478,7 @@ class FactorGraph:
         t = v.counter.value
         ix = torch.arange(t0, t, device=self.device); jx = torch.arange(t1, t, device=self.device)
         ii, jj = torch.meshgrid(ix, jx, indexing="ij")
-        d = v.distance(ii.reshape(-1), jj.reshape(-1), beta=beta).contiguous()
+        d = self._replicated(v.distance(ii.reshape(-1), jj.reshape(-1), beta=beta).contiguous())
         # edges that are always added (known without looking at the distances): stereo self edges + temporal neighbours
         es = []
         for i in range(t0, t):

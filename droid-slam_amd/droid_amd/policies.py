@@ -105,7 +105,11 @@ class DroidFrontend:
 class DroidBackend:
     """global bundle adjustment over all keyframes (droid_backend.py:9-43)"""
 
-    def __init__(self, update_op, video, args, chunk_frames=8):
+    def __init__(self, update_op, video, args, chunk_frames=8, graph_cls=FactorGraph, graph_kwargs=None):
+        """graph_cls / graph_kwargs: droid_amd.dist_graph.DistFactorGraph (+ group=...) runs the same global BA partitioned by
+        edge batches over the ranks of a process group (BASELINE configs[3] / [4]); every rank calls the backend together."""
+        self.graph_cls, self.graph_kwargs = graph_cls, dict(graph_kwargs or {})
+        self._arena = None                 # the pyramid's storage, kept from one global BA to the next (a cold 105 GB hipMalloc takes seconds)
         self.video = video
         self.update_op = update_op
         self.upsample = getattr(args, "upsample", False)
@@ -122,12 +126,22 @@ class DroidBackend:
         t = v.counter.value
         if normalize and not v.stereo and not torch.any(v.disps_sens):
             v.normalize()
-        graph = FactorGraph(v, self.update_op, corr_impl="alt", max_factors=16 * t, upsample=self.upsample, chunk_frames=self.chunk_frames)
+        graph = self.graph_cls(v, self.update_op, corr_impl="alt", max_factors=16 * t, upsample=self.upsample, chunk_frames=self.chunk_frames,
+                               **self.graph_kwargs)
         graph.add_proximity_factors(rad=self.backend_radius, nms=self.backend_nms, thresh=self.backend_thresh, beta=self.beta)
-        graph.update_lowmem(steps=steps, corr=self.lowmem_corr)
+        graph._arena = self._arena
+        try:
+            graph.update_lowmem(steps=steps, corr=self.lowmem_corr)
+        finally:
+            self._arena = getattr(graph, "_arena", None)      # None after an out-of-memory fallback: the storage was released
+            graph.release_pyramid_arena()                     # the returned graph does not pin ~100 GB
         graph.clear_edges()
         v.dirty[:t] = True
         return graph
+
+    def release(self):
+        """give the pyramid storage back to the allocator (e.g. before the frontend needs the memory)"""
+        self._arena = None
 
 
 class MotionFilter:

@@ -148,6 +148,17 @@ def _smooth_field(rng, n, ht, wd, lo, hi):
     return top * (1 - fy)[None, :, None] + bot * fy[None, :, None]
 
 
+def depth_confidence(n_frames, ht=HT, wd=WD, seed=1234):
+    """Seeded NON-constant per-pixel weight of the sensor-depth prior (BASELINE.json configs[4]: "per-pixel depth-confidence
+    weights"): a smooth field per frame in [0.005, 0.25] -- the reference's constant is 0.05 (src/droid_kernels.cu:1405) -- with
+    5 % of the pixels at zero confidence (the prior switched off there).  Its own random stream: the graphs of make_graph() and
+    every golden made from them are unchanged."""
+    rng = np.random.default_rng(seed + 7919)
+    conf = _smooth_field(rng, n_frames, ht, wd, 0.005, 0.25)
+    conf *= (rng.uniform(size=conf.shape) > 0.05)
+    return conf.astype(np.float32)
+
+
 def make_graph(cfg, seed=1234, ht=HT, wd=WD, with_features=False, feature_dim=128):
     """Build one synthetic BA problem.  Returns a dict of numpy arrays (float32 / int64)."""
     if isinstance(cfg, str):
@@ -196,6 +207,8 @@ def make_graph(cfg, seed=1234, ht=HT, wd=WD, with_features=False, feature_dim=12
         weights=weights.reshape(E, 2, ht, wd).astype(np.float32),
         eta=eta.astype(np.float32),
     )
+    if cfg.sensor_depth:
+        out["disps_conf"] = depth_confidence(N, ht, wd, seed)
     if with_features:
         rig = 2 if cfg.stereo else 1
         out["fmaps"] = rng.standard_normal((N, rig, feature_dim, ht, wd), dtype=np.float32).astype(np.float16)

@@ -188,7 +188,8 @@ int dh_ba(float* poses, float* disps, const float* intrinsics, const float* disp
  *   and retracts.  dh_ba() == dh_ba_build + dh_ba_finish per iteration. */
 /* dh_ba with a PER-PIXEL weight of the sensor-depth prior (BASELINE.json configs[4], "per-pixel depth-confidence weights";
  * SURVEY.md Q10b): alpha [num_frames,ht,wd] f32 replaces the reference's constant 0.05 (src/droid_kernels.cu:1405-1408) where
- * disps_sens > 0:  C = sum Cii + alpha,  w = sum bz - alpha * (disps - disps_sens).  alpha == NULL or alpha == 0.05
+ * disps_sens > 0 and alpha > 0 (zero confidence = no prior at that pixel, damped by eta like a pixel without sensor depth):
+ * C = sum Cii + alpha,  w = sum bz - alpha * (disps - disps_sens).  alpha == NULL or alpha == 0.05
  * everywhere is exactly dh_ba.  The positional signature of the reference's `ba` is fixed (src/droid.cpp:93-108), hence a
  * new entry point (droid_backends.ba_ex). */
 int dh_ba_ex(float* poses, float* disps, const float* intrinsics, const float* disps_sens, const float* alpha,
@@ -238,6 +239,15 @@ int dh_ba_build_shard(const float* poses, const float* disps, const float* intri
                       int num_frames, int n_edges, int n_eta_rows, int ht, int wd,
                       int t0, int t1, int motion_only,
                       double** Hsys_out, double** bsys_out, void* workspace, size_t workspace_bytes, dh_stream_t stream);
+/* dh_ba_build_shard with dh_ba_ex's per-pixel weight of the sensor-depth prior (alpha [num_frames,ht,wd] f32, NULL = the
+ * reference's constant 0.05, src/droid_kernels.cu:1405-1408): BASELINE.json configs[4] (stereo + per-pixel depth-confidence
+ * weights) is defined on the edge-sharded path.  The prior of a frame enters on the rank that holds the frame's edges. */
+int dh_ba_build_shard_ex(const float* poses, const float* disps, const float* intrinsics, const float* disps_sens,
+                         const float* alpha, const float* targets, const float* weights, const float* eta,
+                         const int64_t* ii, const int64_t* jj,
+                         int num_frames, int n_edges, int n_eta_rows, int ht, int wd,
+                         int t0, int t1, int motion_only,
+                         double** Hsys_out, double** bsys_out, void* workspace, size_t workspace_bytes, dh_stream_t stream);
 size_t dh_ba_packed_len(int n_blocks, int t0, int t1);
 int dh_ba_pack_blocks(const void* workspace, size_t workspace_bytes, int num_frames, int n_edges, int ht, int wd,
                       int t0, int t1, int motion_only, const int32_t* bp, const int32_t* bq, int n_blocks,

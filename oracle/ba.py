@@ -190,15 +190,16 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj,
             x, ok = solve_damped(A.reshape(6 * P, 6 * P), bA.reshape(-1), lm, ep)
             dx = x.reshape(P, 6).astype(np.float32).astype(dtype)
             _retract_poses(poses, dx, t0, t1, dtype)
-            info = dict(ok=ok)
+            info = dict(ok=ok, H=A.reshape(6 * P, 6 * P), b=bA.reshape(-1)) if return_system else dict(ok=ok)
             continue
 
         # depth block with the sensor prior (:1405-1409)
         dsens = disps_sens.reshape(disps_sens.shape[0], HW).astype(dtype)[kx]
         dcur = disps.reshape(disps.shape[0], HW).astype(dtype)[kx]
-        m = (dsens > 0).astype(dtype)
-        # the reference's constant 0.05 (:1405); alpha_map [buf,ht,wd] = the per-pixel extension (dh_ba_ex)
+        # the reference's constant 0.05 (:1405); alpha_map [buf,ht,wd] = the per-pixel extension (dh_ba_ex): zero
+        # confidence switches the prior off at that pixel (eta damps it, like a pixel without sensor depth)
         alpha = dtype(ALPHA_DEPTH_PRIOR) if alpha_map is None else alpha_map.reshape(alpha_map.shape[0], HW).astype(dtype)[kx]
+        m = ((dsens > 0) & (alpha > 0)).astype(dtype)
         C = _segsum(Cii, ii, kx) + m * alpha + (1 - m) * eta.reshape(-1, HW).astype(dtype)
         w = _segsum(bz, ii, kx) - m * alpha * (dcur - dsens)
         Q = dtype(1) / C
