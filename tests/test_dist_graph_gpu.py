@@ -4,10 +4,10 @@ everything but the transport -- ownership by source frame, each rank's pyramid /
 update operator, the rows of eta of its BA call, DistBA's packed exchange, owner-only depth updates, the per-pixel depth-confidence
 map in the sharded build (BASELINE configs[4]) -- is what runs on a multi-GPU node.
 
-Composed result of the sharded class == the single-process FactorGraph on the same inputs, within 10 x the movement the
-reference's own run shows under a one-fp16-ulp perturbation of its inputs (tests/golden/graph_scale_probe.json, the calibration of
-tests/test_scale_gpu.py): the ranks run the update operator on other batch compositions (<= 1 fp16 ulp per layer) and the BA sums
-in another order."""
+Composed result of the sharded class == the single-process FactorGraph on the same inputs, within 5 x what the single-process
+class itself moves by (a) when its edge list is reversed (the same problem at other batch positions of the update operator and in
+another summation order of the BA -- exactly what sharding changes) and (b) when its stored feature maps move by one fp16 ulp (the
+probe that calibrates tests/test_scale_gpu.py).  Measured: poses 5e-8 .. 1e-7, depths (q99) 1e-5 -- the level of (a)."""
 import json
 import os
 import sys
@@ -41,7 +41,23 @@ def _graph(name):
     return g
 
 
-def _setup(g, graph_cls, corr_impl, with_conf, **kw):
+def _perturb_one_ulp(g, seed=77):
+    """fmaps / nets / inps (fp16) moved by ONE ulp on half of their values (the probe of tests/golden/make_graph_scale_golden.py)"""
+    g = dict(g)
+    rng = np.random.default_rng(seed)
+    for k in ("fmaps", "nets", "inps"):
+        a = np.ascontiguousarray(g[k]).astype(np.float16)
+        bits = a.view(np.uint16).copy()
+        mag = bits & 0x7FFF
+        move = rng.random(bits.shape) < 0.5
+        up = rng.random(bits.shape) < 0.5
+        ok = move & (mag > 0) & (mag < 0x7BFF)
+        bits = np.where(ok & up, bits + 1, np.where(ok & ~up, bits - 1, bits)).astype(np.uint16)
+        g[k] = bits.view(np.float16).reshape(a.shape)
+    return g
+
+
+def _setup(g, graph_cls, corr_impl, with_conf, order=None, add=True, **kw):
     from droid_amd.depth_video import DepthVideo
     from droid_amd.update import UpdateModule, empty_state_dict
     from droid_amd.weights import deterministic_state_dict
@@ -61,7 +77,9 @@ def _setup(g, graph_cls, corr_impl, with_conf, **kw):
         v.set_depth_confidence(slice(0, N), d(g["conf"]))
     upd = UpdateModule("cuda").load_state_dict(deterministic_state_dict(_SD(), seed=1234))
     graph = graph_cls(v, upd, corr_impl=corr_impl, max_factors=-1, upsample=True, **kw)
-    graph.add_factors(d(g["ii"]), d(g["jj"]))
+    ii, jj = (g["ii"], g["jj"]) if order is None else (g["ii"][order], g["jj"][order])
+    if add:
+        graph.add_factors(d(ii), d(jj))
     return v, graph
 
 
@@ -74,16 +92,49 @@ def _run(graph, mode):
     torch.cuda.synchronize()
 
 
-def _worker(rank, world, port, out, name, mode, with_conf):
+def _take_turns(graph, lock):
+    """TEST RIG, only because the two ranks share ONE GPU here (a product rank has a GPU to itself): the ranks' rank-local phases
+    (pyramid build, lookup, update operator) take turns on the device; the BA phases, where the ranks exchange, run together.
+    Why: on this platform two PROCESSES running this library's >64 KB-LDS kernels (pyramid build, fused lookup, convolutions) next to
+    each other's small kernels make the latter return wrong values in lanes 48..63 of a wave -- measured with a reproject kernel that
+    is 60 compiler-generated instructions, no LDS, no scratch, unchanged inputs: 0 of 263 000 results wrong alone, 0 of 99 000 next
+    to torch's matmul / convolution kernels, 69 557 of 102 080 next to another process's update iterations
+    (profiles/r06_two_processes_one_gpu.txt, scripts/debug/victim_aggressor.py).  One process per GPU never sees it."""
+    def together(fn):
+        def wrapped(*a, **kw):
+            torch.cuda.synchronize()
+            lock.release()                                # my local phase is over: the other rank may run its own
+            dist.barrier()                                # ... and has finished it: from here on only the exchange's kernels are in flight
+            try:
+                r = fn(*a, **kw)
+                torch.cuda.synchronize()
+                dist.barrier()
+                return r
+            finally:
+                lock.acquire()
+        return wrapped
+    graph._solve = together(graph._solve)                               # the BA: DistBA's build / exchange / finish
+    graph._exchange_upsampled = together(graph._exchange_upsampled)     # the one other collective of update / update_lowmem
+
+
+def _worker(rank, world, port, out, name, mode, with_conf, lock):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from droid_amd.dist_graph import DistFactorGraph
         g = _graph(name)
-        v, graph = _setup(g, DistFactorGraph, "alt" if mode == "lowmem" else "volume", with_conf)
+        from droid_amd.dist_ba import shard_edges_by_source_frame
+        _, bounds = shard_edges_by_source_frame(g["ii"], world)          # (given up front: the ownership table is gathered in the constructor)
+        v, graph = _setup(g, DistFactorGraph, "alt" if mode == "lowmem" else "volume", with_conf, add=False, frame_bounds=bounds)
+        torch.cuda.synchronize()
+        dist.barrier()
+        lock.acquire()
+        graph.add_factors(torch.as_tensor(g["ii"]).cuda(), torch.as_tensor(g["jj"]).cuda())
+        _take_turns(graph, lock)
         own = graph._owned(graph.ii)
         assert 0 < int(own.sum()) < len(graph.ii) and len(graph._lii) == int(own.sum())
         _run(graph, mode)
+        lock.release()
         N = g["n_frames"]
         chk = torch.cat([v.poses[:N].flatten(), v.disps[:N].flatten(), v.disps_up[:N].flatten()]).cpu()
         ref = chk.clone(); dist.broadcast(ref, 0)
@@ -105,28 +156,39 @@ def _rot_angle(q, qr):
 @pytest.mark.parametrize("name,mode,with_conf", [("C2", "lowmem", False), ("C2", "update", False), ("C2", "lowmem", True), ("S64", "lowmem", True)])
 def test_two_rank_sharded_graph_equals_single_process_graph(tmp_path, golden_dir, name, mode, with_conf):
     from droid_amd.factor_graph import FactorGraph
-    from test_scale_gpu import COMPOSED_FACTOR, FLOOR
+    from test_scale_gpu import FLOOR
     assert torch.cuda.is_available()
     out = str(tmp_path / "rank%d.npz")
     port = 29100 + (os.getpid() % 1500) + 7 * int(with_conf) + 13 * int(mode == "update") + 29 * int(name != "C2")
-    mp.spawn(_worker, args=(2, port, out, name, mode, with_conf), nprocs=2, join=True)
+    lock = mp.get_context("spawn").Lock()
+    mp.spawn(_worker, args=(2, port, out, name, mode, with_conf, lock), nprocs=2, join=True)
     g = _graph(name)
     N = g["n_frames"]
     v, graph = _setup(g, FactorGraph, "alt" if mode == "lowmem" else "volume", with_conf)
     _run(graph, mode)
     r = [np.load(out % k) for k in (0, 1)]
-    probe = json.load(open(os.path.join(golden_dir, "graph_scale_probe.json")))["C2"]["U2"]
-    tol = lambda k: max(COMPOSED_FACTOR * probe[k], FLOOR[k])
     f64 = lambda t: np.asarray(t.float().cpu().numpy(), dtype=np.float64)
-    m = {}
-    p, rp = f64(v.poses[:N]), r[0]["poses"].astype(np.float64)
-    m["pose_trans_max"] = float(np.abs(p[:, :3] - rp[:, :3]).max())
-    m["pose_rot_max_rad"] = float(_rot_angle(rp[:, 3:], p[:, 3:]).max())
-    d = f64(v.disps[:N])
-    e = np.abs(r[0]["disps"] - d) / np.maximum(1.0, np.abs(d))
-    m["disps_rel_q99"], m["disps_rel_max"] = float(np.quantile(e, 0.99)), float(e.max())
-    # per-edge state and per-frame damping, put back together from the two ranks
     E = len(g["ii"])
+
+    def deviation(poses, disps, disps_up, net, tgt, wgt, damping):
+        """the composed tests' metrics (tests/test_scale_gpu.py) of a run against the single-process run"""
+        m = {}
+        p = f64(v.poses[:N])
+        m["pose_trans_max"] = float(np.abs(p[:, :3] - poses[:, :3]).max())
+        m["pose_rot_max_rad"] = float(_rot_angle(poses[:, 3:].astype(np.float64), p[:, 3:]).max())
+        d = f64(v.disps[:N])
+        e = np.abs(disps - d) / np.maximum(1.0, np.abs(d))
+        m["disps_rel_q99"], m["disps_rel_max"] = float(np.quantile(e, 0.99)), float(e.max())
+        m["net_s_max"] = float(np.abs(net - f64(graph._net[:, ::4, ::4])).max())
+        t = np.abs(tgt - f64(graph.target[0]))
+        m["target_s_q999"], m["target_s_max"] = float(np.quantile(t, 0.999)), float(t.max())
+        m["weight_s_max"] = float(np.abs(wgt - f64(graph.weight[0])).max())
+        dm = f64(graph.damping[:N])
+        m["damping_rel_max"] = float(np.abs(damping - dm).max() / np.abs(dm).max())
+        up = f64(v.disps_up[:N, ::8, ::8])
+        m["disps_up_rel_max"] = float((np.abs(disps_up - up) / np.maximum(1.0, np.abs(up))).max())
+        return m
+    # per-edge state and per-frame damping, put back together from the two ranks
     net = np.zeros((E,) + r[0]["net"].shape[1:]); tgt = np.zeros((E,) + r[0]["target"].shape[1:]); wgt = np.zeros_like(tgt)
     seen = np.zeros(E, dtype=int)
     damping = np.zeros_like(r[0]["damping"])
@@ -135,30 +197,46 @@ def test_two_rank_sharded_graph_equals_single_process_graph(tmp_path, golden_dir
         net[ix] = r[k]["net"]; tgt[ix] = r[k]["target"]; wgt[ix] = r[k]["weight"]; seen[ix] += 1
         damping[int(r[k]["lo"]):int(r[k]["hi"])] = r[k]["damping"][int(r[k]["lo"]):int(r[k]["hi"])]
     assert np.all(seen == 1)
-    m["net_s_max"] = float(np.abs(net - f64(graph._net[:, ::4, ::4])).max())
-    t = np.abs(tgt - f64(graph.target[0]))
-    m["target_s_q999"], m["target_s_max"] = float(np.quantile(t, 0.999)), float(t.max())
-    m["weight_s_max"] = float(np.abs(wgt - f64(graph.weight[0])).max())
-    dm = f64(graph.damping[:N])
-    m["damping_rel_max"] = float(np.abs(damping - dm).max() / np.abs(dm).max())
-    up = f64(v.disps_up[:N, ::8, ::8])
-    eu = np.abs(r[0]["disps_up"] - up) / np.maximum(1.0, np.abs(up))
+    m = deviation(r[0]["poses"], r[0]["disps"], r[0]["disps_up"], net, tgt, wgt, damping)
+    # The yardstick: the SAME single-process class on the same graph with its edge list reversed -- mathematically the same
+    # problem, other batch positions in the update operator and another summation order in the BA, which is all the sharding
+    # changes too.  The sharded run may differ from the single-process run by COMPOSED_FACTOR x what that does (the `max`
+    # metrics sit on single ill-conditioned pixels near an epipole), or by the composed tests' fp32 floors.
+    order = np.arange(E)[::-1].copy()
+    vp, gp = _setup(g, FactorGraph, "alt" if mode == "lowmem" else "volume", with_conf, order=order)
+    _run(gp, mode)
+    inv = np.empty(E, dtype=np.int64); inv[order] = np.arange(E)
+    perm = deviation(f64(vp.poses[:N]), f64(vp.disps[:N]), f64(vp.disps_up[:N, ::8, ::8]), f64(gp._net[:, ::4, ::4])[inv],
+                     f64(gp.target[0])[inv], f64(gp.weight[0])[inv], f64(gp.damping[:N]))
+    del vp, gp
+    # ... and the conditioning of the composed problem itself: the single-process run again with its stored feature / hidden-state /
+    # context maps moved by one fp16 ulp (the probe that calibrates tests/test_scale_gpu.py, here on the product and at the
+    # global BA's weaker damping lm = 1e-5 / ep = 1e-2)
+    vq, gq = _setup(_perturb_one_ulp(g), FactorGraph, "alt" if mode == "lowmem" else "volume", with_conf)
+    _run(gq, mode)
+    probe = deviation(f64(vq.poses[:N]), f64(vq.disps[:N]), f64(vq.disps_up[:N, ::8, ::8]), f64(gq._net[:, ::4, ::4]),
+                      f64(gq.target[0]), f64(gq.weight[0]), f64(gq.damping[:N]))
+    del vq, gq
+    # product against product: no fp64 golden in between, so none of the composed tests' fp32-geometry floors -- 5 x the larger of the
+    # two yardsticks (measured, profiles/r06_dist_graph_deviation.json: the sharded run sits at 0.3 - 1.2 x the reversed-list run in
+    # every metric; poses 5e-8 .. 1e-7 against a probe of 3e-7)
+    tol = lambda k: max(5.0 * max(perm[k], probe[k]), 1e-7)
     bad = {k: (val, tol(k)) for k, val in m.items() if not val <= tol(k)}
+    p, d = f64(v.poses[:N]), f64(v.disps[:N])
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         path = os.path.join(ROOT, "gpurun_out", "dist_graph_deviation.json")
         rec = json.load(open(path)) if os.path.exists(path) else {}
-        rec["%s/%s/%s" % (name, mode, "conf" if with_conf else "const")] = dict(m, disps_up_rel_max=float(eu.max()))
+        rec["%s/%s/%s" % (name, mode, "conf" if with_conf else "const")] = {"sharded_vs_single": m, "reversed_edge_list_vs_single": perm, "one_ulp_probe_vs_single": probe}
         json.dump(rec, open(path, "w"), indent=1, sort_keys=True)
     except OSError:
         pass
-    assert not bad, "sharded vs single process beyond %gx the one-ulp probe movement (value, tolerance): %s" % (COMPOSED_FACTOR, bad)
-    assert float(eu.max()) <= tol("disps_rel_max")
+    assert not bad, "sharded vs single process beyond 5x what reversing the edge list / a one-ulp input probe does (value, tolerance): %s" % bad
     assert np.abs(p - g["poses"][:N]).max() > 1e-3                  # the iterations moved the state
     if with_conf:
         # the confidence map matters: the constant-prior run lands somewhere else
         v2, graph2 = _setup(g, FactorGraph, "alt" if mode == "lowmem" else "volume", False)
         _run(graph2, mode)
-        assert np.abs(f64(v2.disps[:N]) - d).max() > 100 * tol("disps_rel_max")
+        assert np.abs(f64(v2.disps[:N]) - d).max() > 100 * FLOOR["disps_rel_max"]
     n = 6 * (N - 1)
     assert int(r[0]["exchange_bytes"]) < ((n + 63) // 64 * 64 + 64) * ((n + 63) // 64 * 64) * 8 // 2
