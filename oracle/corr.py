@@ -176,6 +176,48 @@ def altcorr_forward(fmap1, fmap2, coords, ii, jj, radius):
     return out
 
 
+def altcorr_forward_fast(fmap1, fmap2, coords, ii, jj, radius, edge_chunk=8):
+    """altcorr_forward for LARGE edge counts (the C5-size golden of tests/golden/make_graph_scale_golden.py: 8192 edges x 4 levels x 2
+    steps): the same integer-tap dot products (altcorr_kernel.cu:24-75), taken out of the edge's all-pairs product (f1/4)^T (f2/4)
+    (one GEMM per edge) instead of 64 gathers of the 128-channel target map; same bounds rule (a tap outside the target image is 0),
+    same bilinear blend (:160-169), same [x-off, y-off] output (:171).  torch CPU, fp64 accumulation of fp32 products' sums differs
+    from altcorr_forward by rounding only: pinned to it by tests/test_oracle_golden.py::test_fast_altcorr_equals_altcorr."""
+    import torch
+    B, M = coords.shape[:2]
+    H, W = coords.shape[3:]
+    H2, W2 = fmap2.shape[3:]
+    R = radius
+    D = 2 * R + 2
+    # (torch tensors are taken as they are and converted per edge chunk: the C5 feature buffer is 3.2 GB in fp32)
+    f1 = fmap1 if isinstance(fmap1, torch.Tensor) else torch.as_tensor(np.asarray(fmap1))
+    f2 = fmap2 if isinstance(fmap2, torch.Tensor) else torch.as_tensor(np.asarray(fmap2))
+    coords = coords.numpy() if isinstance(coords, torch.Tensor) else coords
+    C = f1.shape[2]
+    out = np.zeros((B, M, D - 1, D - 1, H, W), dtype=np.float64)
+    off = torch.arange(D) - R
+    for b in range(B):
+        for s in range(0, M, edge_chunk):
+            e = slice(s, min(M, s + edge_chunk))
+            n = e.stop - e.start
+            a = f1[b, torch.as_tensor(np.asarray(ii[e], dtype=np.int64))].float().reshape(n, C, H * W) / 4.0          # [n,C,HW]
+            t = f2[b, torch.as_tensor(np.asarray(jj[e], dtype=np.int64))].float().reshape(n, C, H2 * W2) / 4.0
+            vol = torch.bmm(a.transpose(1, 2).double(), t.double())                                     # [n,HW,H2W2] fp64
+            x = torch.as_tensor(np.asarray(coords[b, e, 0], dtype=np.float32)).reshape(n, H * W)
+            y = torch.as_tensor(np.asarray(coords[b, e, 1], dtype=np.float32)).reshape(n, H * W)
+            fx, fy = torch.floor(x), torch.floor(y)
+            dx, dy = (x - fx).double(), (y - fy).double()
+            i1 = fy.long()[:, :, None, None] + off[None, None, :, None]                                 # [n,HW,D(y tap),1]
+            j1 = fx.long()[:, :, None, None] + off[None, None, None, :]                                 # [n,HW,1,D(x tap)]
+            ok = (i1 >= 0) & (i1 < H2) & (j1 >= 0) & (j1 < W2)
+            idx = (i1.clamp(0, H2 - 1) * W2 + j1.clamp(0, W2 - 1)).reshape(n, H * W, D * D)
+            taps = torch.gather(vol, 2, idx).reshape(n, H * W, D, D) * ok
+            dx_, dy_ = dx[:, :, None, None], dy[:, :, None, None]
+            o = ((1 - dx_) * (1 - dy_) * taps[:, :, :D - 1, :D - 1] + dx_ * (1 - dy_) * taps[:, :, :D - 1, 1:]
+                 + (1 - dx_) * dy_ * taps[:, :, 1:, :D - 1] + dx_ * dy_ * taps[:, :, 1:, 1:])            # [n,HW,y-off,x-off]
+            out[b, e] = o.permute(0, 3, 2, 1).reshape(n, D - 1, D - 1, H, W).numpy()                   # -> [x-off, y-off, H, W]
+    return out
+
+
 def altcorr_backward(fmap1, fmap2, coords, corr_grad, ii, jj, radius):
     """Gradients of the alt lookup w.r.t. both feature maps (altcorr_kernel.cu:78-129, 175-225).
 

@@ -14,10 +14,17 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
+# Switches of the LARGE goldens (tests/golden/make_graph_scale_golden.py c5), off by default:
+ALPHA_MAP = None        # [buf,ht,wd] per-pixel weight of the sensor-depth prior (BASELINE configs[4]; the reference's ba has the constant 0.05)
+FAST_ALTCORR = False    # oracle.corr.altcorr_forward_fast instead of the per-tap gathers (pinned to them by tests/test_oracle_golden.py)
+BA_THREADS = 1
+
+
 def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1, iterations, lm, ep, motion_only):
     p = poses.numpy(); d = disps.numpy()                      # views: updated in place like the CUDA extension does
     dx, dz = _oba.ba(p, d, _np(intrinsics), _np(disps_sens), _np(targets), _np(weights), _np(eta), _np(ii), _np(jj),
-                     int(t0), int(t1), int(iterations), float(lm), float(ep), bool(motion_only), dtype=np.float64)
+                     int(t0), int(t1), int(iterations), float(lm), float(ep), bool(motion_only), dtype=np.float64,
+                     alpha_map=ALPHA_MAP, threads=BA_THREADS)
     return [torch.as_tensor(dx, dtype=torch.float32), torch.as_tensor(dz if dz is not None else np.zeros(0), dtype=torch.float32)]
 
 
@@ -29,7 +36,10 @@ def corr_index_forward(volume, coords, radius):
 
 
 def altcorr_forward(fmap1, fmap2, coords, ii, jj, radius):
-    out = _ocorr.altcorr_forward(_np(fmap1.float()), _np(fmap2.float()), _np(coords.float()), _np(ii), _np(jj), int(radius))
+    if FAST_ALTCORR:
+        out = _ocorr.altcorr_forward_fast(fmap1, fmap2, coords.float(), _np(ii), _np(jj), int(radius))
+    else:
+        out = _ocorr.altcorr_forward(_np(fmap1.float()), _np(fmap2.float()), _np(coords.float()), _np(ii), _np(jj), int(radius))
     return [torch.as_tensor(out).to(fmap1.dtype)]
 
 

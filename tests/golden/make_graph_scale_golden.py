@@ -2,9 +2,9 @@
 """Generate tests/golden/graph_c2_python.npz and graph_stereo_python.npz by running the REFERENCE's own factor_graph.py +
 depth_video.py + modules/corr.py + droid_net.py, unmodified, on CPU (build container only: needs /root/reference):
 
-    python tests/golden/make_graph_scale_golden.py [stereo] [c2] [tum] [wide] [big] [c3] [--probe]
+    python tests/golden/make_graph_scale_golden.py [stereo] [c2] [tum] [wide] [big] [c3] [c5] [--probe]
 
---probe (c2 / c3 only): the same scenario with the stored feature / hidden-state / context maps (fmaps, nets, inps) moved by ONE
+--probe: the same scenario with the stored feature / hidden-state / context maps (fmaps, nets, inps) moved by ONE
 fp16 ulp on half of their values (seeded) -> /tmp/graph_<cfg>_probe.npz, and the movement of every quantity the composed tests
 of tests/test_scale_gpu.py assert, in the tests' own metrics, -> tests/golden/graph_scale_probe.json.  That file calibrates the
 tests' tolerances: an implementation that rounds differently somewhere (accumulation order, fp16 stores) moves the outputs by
@@ -96,6 +96,44 @@ def probe_report(cfg, G, P):
                       "fmaps / nets / inps move by one fp16 ulp on half of their values (--probe); metrics = those asserted by "
                       "tests/test_scale_gpu.py::test_composed_update_at_c{2,3}_matches_reference_factor_graph")
     json.dump(allp, open(path, "w"), indent=1, sort_keys=True)
+def small_metrics(A, B, tag):
+    """deviation of run A from run B of one of the small scenarios (stereo / tum / wide / big), in the metrics the composed tests of
+    tests/test_scale_gpu.py assert (`_composed_small_metrics` there computes the same from the product's tensors)"""
+    f64 = lambda a: np.asarray(a, dtype=np.float64)
+    r = {}
+    p, rp = f64(A[tag + "_poses"]), f64(B[tag + "_poses"])
+    r["pose_trans_max"] = float(np.abs(p[:, :3] - rp[:, :3]).max())
+    r["pose_rot_max_rad"] = float(_rot_angle(p[:, 3:], rp[:, 3:]).max())
+    e = np.abs(f64(A[tag + "_disps"]) - f64(B[tag + "_disps"])) / np.maximum(1.0, np.abs(f64(B[tag + "_disps"])))
+    r["disps_rel_q99"], r["disps_rel_max"] = float(np.quantile(e, 0.99)), float(e.max())
+    sfx = "" if tag + "_net" in B else "_s"
+    r["net_s_max"] = float(np.abs(f64(A[tag + "_net" + sfx]) - f64(B[tag + "_net" + sfx])).max())
+    t = np.abs(f64(A[tag + "_target" + sfx]) - f64(B[tag + "_target" + sfx]))
+    r["target_s_q999"], r["target_s_max"] = float(np.quantile(t, 0.999)), float(t.max())
+    r["weight_s_max"] = float(np.abs(f64(A[tag + "_weight" + sfx]) - f64(B[tag + "_weight" + sfx])).max())
+    r["damping_rel_max"] = float(np.abs(f64(A[tag + "_damping"]) - f64(B[tag + "_damping"])).max() / np.abs(f64(B[tag + "_damping"])).max())
+    if tag + "_flow_mean" in B:
+        r["flow_mean_max"] = float(np.abs(f64(A[tag + "_flow_mean"]) - f64(B[tag + "_flow_mean"])).max())
+        r["weight_mean_max"] = float(np.abs(f64(A[tag + "_weight_mean"]) - f64(B[tag + "_weight_mean"])).max())
+    e = np.abs(f64(A[tag + "_disps_up"]) - f64(B[tag + "_disps_up"])) / np.maximum(1.0, np.abs(f64(B[tag + "_disps_up"])))
+    r["disps_up_rel_q99"], r["disps_up_rel_max"] = float(np.quantile(e, 0.99)), float(e.max())
+    return r
+
+
+def probe_report_small(name, fname, P):
+    """--probe for a small scenario: movement golden -> run with one-ulp-perturbed features, into graph_scale_probe.json[name]"""
+    import json
+    G = np.load(os.path.join(HERE, fname))
+    rep = {}
+    for tag in ("U1", "U2"):
+        rep[tag] = small_metrics(P, G, tag)
+        print("probe %s %s: %s" % (name, tag, "  ".join("%s %.2e" % kv for kv in rep[tag].items())), flush=True)
+    path = os.path.join(HERE, "graph_scale_probe.json")
+    allp = json.load(open(path)) if os.path.exists(path) else {}
+    allp[name] = rep
+    json.dump(allp, open(path, "w"), indent=1, sort_keys=True)
+
+
 import modules.corr as ref_corr                    # reference (already imported by factor_graph.py)
 
 
@@ -161,6 +199,8 @@ def scenario_c2():
 
 def scenario_stereo():
     S = stereo_scenario()
+    if PROBE:
+        S = perturb_one_ulp(S)
     N, ht, wd = S["n_frames"], S["ht"], S["wd"]
     video = ref_dv.DepthVideo(image_size=[8 * ht, 8 * wd], buffer=N + 2, stereo=True, device="cpu")
     video.poses[:N] = torch.as_tensor(S["poses"]); video.disps[:N] = torch.as_tensor(S["disps"])
@@ -177,6 +217,8 @@ def scenario_stereo():
             fg.update(t0=1, t1=None, itrs=2, use_inactive=False)
             snap(out, "U%d" % k, video, fg, N)
             out["U%d_disps_up" % k] = video.disps_up[:N].numpy().astype(np.float16)
+    if PROBE:
+        return probe_report_small("stereo", "graph_stereo_python.npz", out)
     np.savez_compressed(os.path.join(HERE, "graph_stereo_python.npz"), **out)
     print("graph_stereo: %d edges (%d stereo); |dpose| %.3e %.3e" % (
         len(out["ii"]), int((out["ii"] == out["jj"]).sum()), np.abs(out["U1_poses"] - S["poses"]).max(), np.abs(out["U2_poses"] - S["poses"]).max()))
@@ -187,6 +229,8 @@ def scenario_tum_size():
     the production convolution tiling (w == 64) applies -> reference-layout volumes with FLOOR pooling (30x40, 15x20, 7x10,
     3x5), the generic convolution loop, per-edge context features.  Two update iterations with upsampling."""
     S = graph_scenario(6, 30, 40)
+    if PROBE:
+        S = perturb_one_ulp(S)
     N, ht, wd = S["n_frames"], S["ht"], S["wd"]
     video = ref_dv.DepthVideo(image_size=[8 * ht, 8 * wd], buffer=N + 2, stereo=False, device="cpu")
     video.poses[:N] = torch.as_tensor(S["poses"]); video.disps[:N] = torch.as_tensor(S["disps"])
@@ -203,6 +247,8 @@ def scenario_tum_size():
             fg.update(t0=1, t1=None, itrs=2, use_inactive=False)
             snap(out, "U%d" % k, video, fg, N)
             out["U%d_disps_up" % k] = video.disps_up[:N].numpy().astype(np.float16)
+    if PROBE:
+        return probe_report_small("tum", "graph_tum_size_python.npz", out)
     np.savez_compressed(os.path.join(HERE, "graph_tum_size_python.npz"), **out)
     print("graph_tum_size: %d edges; |dpose| %.3e %.3e" % (len(out["ii"]), np.abs(out["U1_poses"] - S["poses"]).max(), np.abs(out["U2_poses"] - S["poses"]).max()))
 
@@ -218,6 +264,8 @@ def scenario_big():
 
 def _scenario_sampled(n_frames, ht, wd, fname, label, sample_edges):
     S = graph_scenario(n_frames, ht, wd)
+    if PROBE:
+        S = perturb_one_ulp(S)
     N = S["n_frames"]
     video = ref_dv.DepthVideo(image_size=[8 * ht, 8 * wd], buffer=N + 2, stereo=False, device="cpu")
     video.poses[:N] = torch.as_tensor(S["poses"]); video.disps[:N] = torch.as_tensor(S["disps"])
@@ -235,6 +283,8 @@ def _scenario_sampled(n_frames, ht, wd, fname, label, sample_edges):
             snap(out, "U%d" % k, video, fg, N, sample=sample_edges)
             out["U%d_net_s" % k] = out["U%d_net_s" % k][:, :, ::3, ::3].copy()              # (every third pixel: 0.6 instead of 5.3 MB)
             out["U%d_disps_up" % k] = video.disps_up[:N].numpy()[:, ::4, ::4].astype(np.float16)
+    if PROBE:
+        return probe_report_small(label.replace("graph_", ""), fname, out)
     np.savez_compressed(os.path.join(HERE, fname), **out)
     print("%s: %d edges; |dpose| %.3e %.3e" % (label, len(out["ii"]), np.abs(out["U1_poses"] - S["poses"]).max(), np.abs(out["U2_poses"] - S["poses"]).max()))
 
@@ -245,6 +295,8 @@ def scenario_wide():
     UpdateModule.transposed_twin).  Two update iterations with upsampling; hidden state / target / weight of three edges and
     per-edge means of all edges."""
     S = graph_scenario(5, 41, 73)
+    if PROBE:
+        S = perturb_one_ulp(S)
     N, ht, wd = S["n_frames"], S["ht"], S["wd"]
     video = ref_dv.DepthVideo(image_size=[8 * ht, 8 * wd], buffer=N + 2, stereo=False, device="cpu")
     video.poses[:N] = torch.as_tensor(S["poses"]); video.disps[:N] = torch.as_tensor(S["disps"])
@@ -261,6 +313,8 @@ def scenario_wide():
             fg.update(t0=1, t1=None, itrs=2, use_inactive=False)
             snap(out, "U%d" % k, video, fg, N, sample=WIDE_SAMPLE_EDGES)
             out["U%d_disps_up" % k] = video.disps_up[:N].numpy().astype(np.float16)
+    if PROBE:
+        return probe_report_small("wide", "graph_wide_python.npz", out)
     np.savez_compressed(os.path.join(HERE, "graph_wide_python.npz"), **out)
     print("graph_wide: %d edges; |dpose| %.3e %.3e" % (len(out["ii"]), np.abs(out["U1_poses"] - S["poses"]).max(), np.abs(out["U2_poses"] - S["poses"]).max()))
 
@@ -375,9 +429,67 @@ def scenario_c3():
     print("graph_c3: |dpose| %.3e %.3e" % (np.abs(out["U1_poses"] - g["poses"]).max(), np.abs(out["U2_poses"] - g["poses"]).max()))
 
 
+# --------------------------------------------------------------------------------------------- C5 (BASELINE configs[4])
+def scenario_c5():
+    """BASELINE configs[4] at FULL size: 1024 keyframes / 8192 edges / 48x64, STEREO + sensor depth + per-pixel depth-confidence weights
+    (droid_amd.synthetic.make_graph("C5", with_features=True): `disps_conf`, seeded, non-constant), through the reference's GLOBAL-BA
+    iteration -- FactorGraph.update_lowmem (factor_graph.py:266-330: alt-correlation in chunks of 8 source frames, the update operator
+    under fp16 autocast per chunk, ONE ba over all edges with lm = 1e-5, ep = 1e-2), which is what configs[3] / [4] shard over 8 GPUs.
+    Two steps (update_lowmem(steps=1) twice, a snapshot after each).  Two stand-ins of the oracle-backed droid_backends shim are
+    switched on for this size (tests/golden/_shims_graph): the GEMM form of the alt-correlation (oracle.corr.altcorr_forward_fast,
+    pinned to the per-tap form by a CPU test) and the per-pixel weight of the depth prior in `ba` (oracle.ba alpha_map; the
+    reference's kernel has the constant 0.05, src/droid_kernels.cu:1405 -- with a constant map the two coincide).
+    Kept per step: poses and per-frame means of depth / damping of every frame, depth and damping maps of C5_SAMPLE_FRAMES,
+    target / weight / 4x4-subsampled hidden state of C5_SAMPLE_EDGES, per-edge means of |target - coords0|, weight, |hidden state|
+    of ALL 8192 edges."""
+    from golden_inputs import C5_SAMPLE_EDGES, C5_SAMPLE_FRAMES
+    g = syn.make_graph("C5", with_features=True)
+    if PROBE:
+        g = perturb_one_ulp(g)
+    N, ht, wd = g["n_frames"], g["ht"], g["wd"]
+    video = ref_dv.DepthVideo(image_size=[8 * ht, 8 * wd], buffer=N + 2, stereo=True, device="cpu")
+    video.poses[:N] = torch.as_tensor(g["poses"]); video.disps[:N] = torch.as_tensor(g["disps"])
+    video.intrinsics[:N] = torch.as_tensor(g["intrinsics"]); video.disps_sens[:N] = torch.as_tensor(g["disps_sens"])
+    video.fmaps[:N] = torch.as_tensor(g["fmaps"]); video.nets[:N] = torch.as_tensor(g["nets"]); video.inps[:N] = torch.as_tensor(g["inps"])
+    video.counter.value = N
+    alpha = np.full((N + 2, ht, wd), 0.05, dtype=np.float32); alpha[:N] = g["disps_conf"]
+    base.droid_backends.ALPHA_MAP, base.droid_backends.FAST_ALTCORR, base.droid_backends.BA_THREADS = alpha, True, 8
+    out = {}
+    try:
+        with torch.no_grad():
+            fg = ref_fg.FactorGraph(video, update_operator(1234), device="cpu", corr_impl="alt", max_factors=-1, upsample=False)
+            fg.add_factors(torch.as_tensor(g["ii"]), torch.as_tensor(g["jj"]))
+            assert len(fg.ii) == len(g["ii"]) == 8192
+            out["ii"], out["jj"] = fg.ii.numpy().copy(), fg.jj.numpy().copy()
+            sample = torch.as_tensor(C5_SAMPLE_EDGES); fr = np.asarray(C5_SAMPLE_FRAMES)
+            for k in (1, 2):
+                t = time.time()
+                fg.update_lowmem(steps=1)
+                print("C5 update_lowmem step %d: %.1f s" % (k, time.time() - t), flush=True)
+                tag = "U%d" % k
+                out[tag + "_poses"] = video.poses[:N].numpy().copy()
+                d = video.disps[:N].numpy()
+                out[tag + "_disps_f"] = d[fr].copy(); out[tag + "_disps_mean"] = d.reshape(N, -1).mean(1).copy()
+                out[tag + "_damping_f"] = fg.damping[:N].numpy()[fr].copy()
+                out[tag + "_damping_mean"] = fg.damping[:N].numpy().reshape(N, -1).mean(1).copy()
+                tgt, wgt, net = fg.target[0], fg.weight[0], fg.net[0]
+                out[tag + "_target_s"] = tgt[sample].numpy().copy(); out[tag + "_weight_s"] = wgt[sample].numpy().astype(np.float16)
+                out[tag + "_net_s"] = net[sample][:, :, ::4, ::4].float().numpy().astype(np.float16)
+                out[tag + "_flow_mean"] = (tgt - fg.coords0).abs().mean(dim=(1, 2, 3)).numpy().copy()
+                out[tag + "_weight_mean"] = wgt.mean(dim=(1, 2, 3)).numpy().copy()
+                out[tag + "_net_absmean"] = torch.stack([net[s:s + 256].float().abs().mean(dim=(1, 2, 3)) for s in range(0, net.shape[0], 256)]).reshape(-1).numpy().copy()
+                np.savez_compressed("/tmp/graph_c5_%s_partial.npz" % ("probe" if PROBE else "golden"), **out)
+    finally:
+        base.droid_backends.ALPHA_MAP, base.droid_backends.FAST_ALTCORR, base.droid_backends.BA_THREADS = None, False, 1
+    if PROBE:
+        np.savez_compressed("/tmp/graph_c5_probe.npz", **out)
+        return probe_report("C5", np.load(os.path.join(HERE, "graph_c5_python.npz")), out)
+    np.savez_compressed(os.path.join(HERE, "graph_c5_python.npz"), **out)
+    print("graph_c5: |dpose| %.3e %.3e" % (np.abs(out["U1_poses"] - g["poses"]).max(), np.abs(out["U2_poses"] - g["poses"]).max()))
+
+
 if __name__ == "__main__":
     which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["stereo", "c2", "tum"]
-    assert not PROBE or set(which) <= {"c2", "c3"}, "--probe exists for c2 / c3"
     if "tum" in which:
         scenario_tum_size()
     if "wide" in which:
@@ -390,3 +502,5 @@ if __name__ == "__main__":
         scenario_c2()
     if "c3" in which:                          # not in the default list: ~62 GB host RAM, tens of minutes
         scenario_c3()
+    if "c5" in which:                          # not in the default list: ~25 GB host RAM, about an hour on 8 cores
+        scenario_c5()

@@ -60,6 +60,9 @@ C2_SAMPLE_EDGES = [0, 1, 2, 3, 254, 255, 256, 257, 508, 509, 510, 511]
 # 65th edge (hits temporal and loop-closure edges, all strips of the lookup, all frame groups of the update operator)
 C3_SAMPLE_EDGES = list(range(0, 4096, 65))[:63] + [4095]
 C3_SAMPLE_FRAMES = list(range(0, 512, 8))
+# C5 (1024 keyframes / 8192 edges, stereo): 64 edges spread over the list (the first 1024 are the stereo self-edges) + 64 frames
+C5_SAMPLE_EDGES = list(range(0, 8192, 130))[:63] + [8191]
+C5_SAMPLE_FRAMES = list(range(0, 1024, 16))
 
 
 def stereo_scenario(n_frames=6):

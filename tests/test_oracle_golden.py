@@ -210,3 +210,20 @@ def test_encoder_oracle_equals_reference_module(golden_dir):
             y = oenc.basic_encoder(sd, x, inst, autocast=True)
         ref = G[tag].astype(np.float32)
         assert np.abs(y.float().numpy() - ref).max() <= 2.0 ** -10 * np.abs(ref).max(), tag
+
+
+def test_fast_altcorr_equals_altcorr():
+    """oracle.corr.altcorr_forward_fast (GEMM + integer-tap gather; used only to make the C5-size golden in reasonable time) against
+    altcorr_forward (the restatement pinned to the reference's kernel by ref_cuda.npz): coordinates leaving the image on every side,
+    a pooled target level, stereo-style equal indices"""
+    from oracle import corr as ocorr
+    rng = np.random.default_rng(3)
+    N, C, H, W = 3, 16, 8, 12
+    f1 = rng.standard_normal((1, N, C, H, W)).astype(np.float32)
+    for H2, W2 in ((H, W), (H // 2, W // 2)):
+        f2 = rng.standard_normal((1, N, C, H2, W2)).astype(np.float32)
+        ii = np.array([0, 1, 2, 1]); jj = np.array([1, 1, 0, 2])
+        coords = np.stack([rng.uniform(-4, W2 + 4, (1, 4, H, W)), rng.uniform(-4, H2 + 4, (1, 4, H, W))], 2).astype(np.float32)
+        a = ocorr.altcorr_forward(f1, f2, coords, ii, jj, 3)
+        b = ocorr.altcorr_forward_fast(f1, f2, coords, ii, jj, 3, edge_chunk=3)
+        assert a.shape == b.shape and np.abs(a - b).max() <= 1e-5 * max(1.0, np.abs(a).max())
