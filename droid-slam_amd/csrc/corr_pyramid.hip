@@ -237,6 +237,51 @@ __global__ __launch_bounds__(256) void pyr_build_kernel(const __half* __restrict
 }
 #endif  // DH_ABLATION
 
+// ---- measurement switches of the ring build (round 6; profiles/r06_pyr_build_ab.txt) ------------------------------------------------
+// The ring loop prefetches a target row three steps ahead (global loads) and writes one finished displacement row per step (global
+// stores); as C++ the loop gets `s_waitcnt vmcnt(0)` at its head (LLVM stops counting across the back edge), i.e. every third step a
+// wave waits for all its outstanding stores.  DH_PYR_ASM issues the loads (bit 0) / stores (bit 1) as inline asm, invisible to that
+// pass, with the one wait a step needs counted by hand (vmcnt returns in order; 2 x NQ loads are issued behind the row a step waits
+// for, stores ignored = conservative; rows are then fetched at EVERY step and drained once per level).  MEASURED NEUTRAL (2.43 vs
+// 2.48 ms per 256 edges) -- the stall is not what bounds the kernel -- and an asm load keeps landing in registers the compiler has
+// reused if a wave never waits again, so the shipped build uses plain C++ (0).  DH_PYR_ABL removes one stage at a time (wrong results,
+// timing only): the stages' times ADD UP (stores 0.67 + row fetches 0.54 + B reads / MFMA 0.48 + scatter 0.19 + row staging 0.09 ms
+// of 2.57; bare loop 0.68): a step is a serial chain, and two thirds of it is the CU's vector-memory path (192 lines per block-step).
+#ifndef DH_PYR_ASM
+#define DH_PYR_ASM 0        // measurement switch (scripts/bench_pyr_build.py, profiles/r06_pyr_build_ab.txt): bit 0 = loads as asm, bit 1 = stores as asm; 0 = plain C++ (shipped)
+#endif
+#ifndef DH_PYR_ABL
+#define DH_PYR_ABL 0        // timing ablations of the ring build (WRONG results; never in a shipped build): 1 = no record stores, 2 = no scatter into the ring,
+#endif                      // 4 = no B-fragment reads / MFMAs, 8 = no global loads of the target rows, 16 = no LDS writes of them
+__device__ __forceinline__ void gload16_async(u32x4& dst, const __half* p) {
+#if DH_PYR_ABL & 8
+  dst = u32x4{(uint32_t)(uintptr_t)p, 1u, 2u, 3u};
+#elif DH_PYR_ASM & 1
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(p) : "memory");
+#else
+  dst = *reinterpret_cast<const u32x4*>(p);
+#endif
+}
+__device__ __forceinline__ void gstore16_async(__half* p, const u32x4& v) {
+#if DH_PYR_ABL & 1
+  if (v[0] == 0x7fc07fc1u) *reinterpret_cast<u32x4*>(p) = v;      // (never true: keeps the read-out alive, drops the store)
+#elif DH_PYR_ASM & 2
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#else
+  *reinterpret_cast<u32x4*>(p) = v;
+#endif
+}
+template <int N>
+__device__ __forceinline__ void wait_vm_for(u32x4& a) {
+#if DH_PYR_ASM & 1
+#ifdef DH_PYR_WAIT
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(DH_PYR_WAIT) : "memory");
+#else
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N) : "memory");
+#endif
+#endif
+}
+
 // ---- build, second form: row ring ------------------------------------------------------------------------------------
 // The chunk kernel above hands HBM 32-byte pieces (a 128-byte line per piece on the store path) and every wave reloads
 // its target rows in half-line fragments: measured 5.3 ms per 256 edges, bound by the vector-memory path, not by the
@@ -289,15 +334,21 @@ __device__ __forceinline__ void ring_level(const half8 (&afrag)[4], const __half
     b_dst[q] = row * 256 + ((quad ^ (row & 15)) << 4);
   }
 #define RING_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+  // (DH_PYR_ASM & 1, the hand-counted waits: a row is fetched for EVERY k, also the three beyond the level's last step -- the row of
+  // the last step again: every step then has exactly 2 x NQ loads issued behind the row it waits for)
 #define RING_FETCH_B(k_, s_)                                                                                         \
-  if ((k_) < nsteps) {                                                                                               \
-    const __half* trow = trow0 + (long)((ybase + (k_)) % h2) * w2 * CH;                                              \
-    if (stages) { _Pragma("unroll") for (int q = 0; q < NQ; ++q) breg[s_][q] = *reinterpret_cast<const u32x4*>(trow + b_src[q]); } \
+  if ((DH_PYR_ASM & 1) || (k_) < nsteps) {                                                                           \
+    const __half* trow = trow0 + (long)((ybase + min((k_), nsteps - 1)) % h2) * w2 * CH;                             \
+    if (stages) { _Pragma("unroll") for (int q = 0; q < NQ; ++q) gload16_async(breg[s_][q], trow + b_src[q]); }         \
   }
 #define RING_STEP(k_, s_)                                                                                            \
   if ((k_) < nsteps) {                                                                                               \
     const int k = (k_);                                                                                              \
-    if (stages) { _Pragma("unroll") for (int q = 0; q < NQ; ++q) *reinterpret_cast<u32x4*>(sB + b_dst[q]) = breg[s_][q]; } \
+    if (DH_PYR_ABL & 16) { _Pragma("unroll") for (int q = 0; q < NQ; ++q) asm volatile("" ::"v"(breg[s_][q])); }     \
+    if (stages && !(DH_PYR_ABL & 16)) {                                                                              \
+      _Pragma("unroll") for (int q = 0; q < NQ; ++q) wait_vm_for<2 * NQ>(breg[s_][q]);   /* the row fetched three steps ago */ \
+      _Pragma("unroll") for (int q = 0; q < NQ; ++q) *reinterpret_cast<u32x4*>(sB + b_dst[q]) = breg[s_][q];           \
+    }                                                                                                                \
     RING_BARRIER();                         /* target row staged; last step's completed row has been read out */    \
     RING_FETCH_B(k + 3, s_)                                                                                          \
     const int v = k - d;                    /* displacement row this lane's pixels contribute to */                  \
@@ -305,7 +356,7 @@ __device__ __forceinline__ void ring_level(const half8 (&afrag)[4], const __half
     unsigned char* const rslot = ring + (v & (R - 1)) * rowbytes;                                                    \
     f32x4 acc[NTW];                                                                                                  \
     _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};                          \
-    if (has_tiles) {                                                                                                 \
+    if (has_tiles && !(DH_PYR_ABL & 4)) {                                                                            \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {        /* the tiles' accumulation chains interleaved */       \
       half8 b[NTW];                                                                                                  \
       _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt)                                                             \
@@ -314,7 +365,8 @@ __device__ __forceinline__ void ring_level(const half8 (&afrag)[4], const __half
         acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag[ks], b[nt], acc[nt], 0, 0, 0);                        \
     }                                                                                                                \
     }                                                                                                                \
-    if (vok && has_tiles) {                                                                                          \
+    if (DH_PYR_ABL & 2) { _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt) asm volatile("" ::"v"(acc[nt])); }      \
+    if (vok && has_tiles && !(DH_PYR_ABL & 2)) {                                                                     \
       _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt)                                                             \
         _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                                \
           if (NTL > 1 || soff[nt][r] >= 0)                                                                           \
@@ -335,7 +387,7 @@ __device__ __forceinline__ void ring_level(const half8 (&afrag)[4], const __half
         o[1] = sw == 0 ? c.y : sw == 1 ? c.x : sw == 2 ? c.w : c.z;                                                  \
         o[2] = sw == 0 ? c.z : sw == 1 ? c.w : sw == 2 ? c.x : c.y;                                                  \
         o[3] = sw == 0 ? c.w : sw == 1 ? c.z : sw == 2 ? c.y : c.x;                                                  \
-        *reinterpret_cast<u32x4*>(dst + (long)n4 * 8) = o;                                                           \
+        gstore16_async(dst + (long)n4 * 8, o);                                                                       \
       }                                                                                                              \
     }                                                                                                                \
   }
@@ -347,6 +399,9 @@ __device__ __forceinline__ void ring_level(const half8 (&afrag)[4], const __half
   }
 #undef RING_STEP
 #undef RING_FETCH_B
+  // the three rows fetched past the level's end were never waited for: their data must have landed before the registers are anything
+  // else (a wave that stages nothing at the next level would never wait again) -- one full drain per level
+  if (DH_PYR_ASM & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   RING_BARRIER();                           // the ring is reused by the next level
 #undef RING_BARRIER
   // the all-zero row v = h2 of this level
@@ -354,10 +409,117 @@ __device__ __forceinline__ void ring_level(const half8 (&afrag)[4], const __half
   for (int o = tid; o < w2 * 8; o += NT) z[o] = uint4{0u, 0u, 0u, 0u};
 }
 
+// ---- level 0 of a 64-column image, TILE-MAJOR wave roles (round 6) ----------------------------------------------------------
+// ring_level gives a wave 16 source pixels (one row pair) and ALL (NT = 256) or half (NT = 512) of the target tiles of the staged row:
+// every target tile's B fragments are read from LDS by four waves, 64 KB of the 96 KB of LDS traffic of a level-0 step
+// (profiles/r05 layout notes).  Here a wave owns ONE 16-target tile and holds the A fragments of RB = 1024 / NT row pairs
+// (NT = 512: two waves per tile, 32 source pixels each, 32 A registers; NT = 256: one wave per tile with all 64 source pixels, 64 A
+// registers): a tile's B fragments are read by 2 (1) waves -- 32 (16) KB per step instead of 64.  Same MFMA instruction, same k
+// order, same fp32 -> fp16 rounding: the records are bit-identical to ring_level's (tests: test_native_pyramid_build_kernels_are_bit_identical).
+// Ring, staging, read-out: as in ring_level.
+template <int NT>
+__device__ __forceinline__ void ring_level0_tm(const __half* __restrict__ f1rows, const __half* __restrict__ trow0, __half* __restrict__ lbase,
+                                               unsigned char* __restrict__ ring, unsigned char* __restrict__ sB,
+                                               int h2, int by, int bx, int tid) {
+  constexpr int W = 64, w2 = 64, NTL = 4, R = 8;
+  constexpr int RB = 1024 / NT;                         // row pairs (16 source pixels each) per wave: 4 row pairs over NT / 256 waves per tile
+  const int lane = tid & 63, wave = tid >> 6;
+  const int tile = NT == 512 ? wave >> 1 : wave, rb0 = NT == 512 ? (wave & 1) * 2 : 0;
+  const int j = lane & 15, xq = ((lane >> 4) & 1) * 4;
+  const int ybase = by * 8;
+  constexpr int rowbytes = w2 * 128;
+  const int nsteps = h2 + R - 1;
+  // A fragments of the wave's RB row pairs: lane holds A[i = lane & 15][k = (lane >> 4) * 8 .. + 8] of pixel p = rb * 16 + i
+  half8 afrag[RB][4];
+#pragma unroll
+  for (int b = 0; b < RB; ++b) {
+    const int p = (rb0 + b) * 16 + (lane & 15);
+    const __half* row = f1rows + ((long)(by * 8 + (p >> 3)) * W + bx * 8 + (p & 7)) * CH;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) afrag[b][ks] = *reinterpret_cast<const half8*>(row + ks * 32 + (lane >> 4) * 8);
+  }
+  // ring-row byte offset of (row pair 0, register r) of this lane; row pair rb: ^ (rb << 6) (p = rb * 16 + ..: bits 4, 5 of p, no carry)
+  int soff0[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int x2 = tile * 16 + j, x1l = bx * 8 + xq + r;
+    const int u = wrap(x2 - x1l, w2), up = u >> 1, p = (lane >> 5) * 8 + xq + r;
+    const int f = (up & 3) | ((up & 4) << 2);
+    soff0[r] = ((up * 64 + (p ^ f)) << 2) + ((u & 1) << 1);
+  }
+  constexpr int NQ = (NTL * 256 + NT - 1) / NT;
+  u32x4 breg[3][NQ];
+  // staging piece q of this thread: target row (tid >> 4) + q * (NT / 16), quad tid & 15 -- NT / 16 is a multiple of 16, so the source and
+  // LDS offsets of piece q are those of piece 0 plus a constant (no per-piece address registers: the kernel sits at its register limit)
+  const int b_src0 = (tid >> 4) * CH + (tid & 15) * 8;
+  const int b_dst0 = (tid >> 4) * 256 + (((tid & 15) ^ ((tid >> 4) & 15)) << 4);
+  constexpr int B_SRC_Q = (NT >> 4) * CH, B_DST_Q = (NT >> 4) * 256;
+#define RING_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define RING_FETCH_B(k_, s_)                                                                                         \
+  if ((DH_PYR_ASM & 1) || (k_) < nsteps) {                                                                           \
+    const __half* trow = trow0 + (long)((ybase + min((k_), nsteps - 1)) % h2) * w2 * CH;                             \
+    _Pragma("unroll") for (int q = 0; q < NQ; ++q) gload16_async(breg[s_][q], trow + b_src0 + q * B_SRC_Q);          \
+  }
+#define RING_STEP(k_, s_)                                                                                            \
+  if ((k_) < nsteps) {                                                                                               \
+    const int k = (k_);                                                                                              \
+    _Pragma("unroll") for (int q = 0; q < NQ; ++q) wait_vm_for<2 * NQ>(breg[s_][q]);                                 \
+    _Pragma("unroll") for (int q = 0; q < NQ; ++q) *reinterpret_cast<u32x4*>(sB + b_dst0 + q * B_DST_Q) = breg[s_][q];           \
+    RING_BARRIER();                                                                                                  \
+    RING_FETCH_B(k + 3, s_)                                                                                          \
+    f32x4 acc[RB];                                                                                                   \
+    _Pragma("unroll") for (int b = 0; b < RB; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};                               \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                               \
+      const half8 bf = *reinterpret_cast<const half8*>(sB + (tile * 16 + j) * 256 + (((ks * 4 + (lane >> 4)) ^ j) << 4)); \
+      _Pragma("unroll") for (int b = 0; b < RB; ++b)                                                                 \
+        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag[b][ks], bf, acc[b], 0, 0, 0);                          \
+    }                                                                                                                \
+    _Pragma("unroll") for (int b = 0; b < RB; ++b) {                                                                 \
+      const int v = k - (2 * (rb0 + b) + (lane >> 5));      /* displacement row of this lane's pixels of row pair b */ \
+      if (v >= 0 && v < h2) {                                                                                        \
+        unsigned char* const rslot = ring + (v & (R - 1)) * rowbytes;                                                \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                                \
+          *reinterpret_cast<__half*>(rslot + (soff0[r] ^ ((rb0 + b) << 6))) = __float2half(acc[b][r] * 0.0625f);    \
+      }                                                                                                              \
+    }                                                                                                                \
+    RING_BARRIER();                                                                                                  \
+    const int vdone = k - (R - 1);                                                                                   \
+    if (vdone >= 0 && vdone < h2) {                                                                                  \
+      const unsigned char* src = ring + (vdone & (R - 1)) * rowbytes;                                                \
+      __half* dst = lbase + (long)vdone * (rowbytes >> 1);                                                           \
+      for (int n4 = tid; n4 < w2 * 8; n4 += NT) {                                                                    \
+        const int up = n4 >> 4, p0 = (n4 & 15) << 2;                                                                 \
+        const int f = (up & 3) | ((up & 4) << 2);                                                                    \
+        const uint4 c = *reinterpret_cast<const uint4*>(src + ((up * 64 + (p0 ^ (f & 16))) << 2));                   \
+        const int sw = f & 3;                                                                                        \
+        u32x4 o;                                                                                                     \
+        o[0] = sw == 0 ? c.x : sw == 1 ? c.y : sw == 2 ? c.z : c.w;                                                  \
+        o[1] = sw == 0 ? c.y : sw == 1 ? c.x : sw == 2 ? c.w : c.z;                                                  \
+        o[2] = sw == 0 ? c.z : sw == 1 ? c.w : sw == 2 ? c.x : c.y;                                                  \
+        o[3] = sw == 0 ? c.w : sw == 1 ? c.z : sw == 2 ? c.y : c.x;                                                  \
+        gstore16_async(dst + (long)n4 * 8, o);                                                                       \
+      }                                                                                                              \
+    }                                                                                                                \
+  }
+  RING_FETCH_B(0, 0) RING_FETCH_B(1, 1) RING_FETCH_B(2, 2)
+  for (int k3 = 0; k3 < nsteps; k3 += 3) {
+    RING_STEP(k3, 0)
+    RING_STEP(k3 + 1, 1)
+    RING_STEP(k3 + 2, 2)
+  }
+#undef RING_STEP
+#undef RING_FETCH_B
+  if (DH_PYR_ASM & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the rows fetched past the level's end: see ring_level)
+  RING_BARRIER();
+#undef RING_BARRIER
+  uint4* z = reinterpret_cast<uint4*>(lbase + (long)h2 * w2 * 64);
+  for (int o = tid; o < w2 * 8; o += NT) z[o] = uint4{0u, 0u, 0u, 0u};
+}
+
 // idx1 / idx2 (round 5, optional): edge e reads the prepared rows of FRAME idx1[e] / idx2[e] (dh_corr_pyramid_prepare_frames +
 // dh_corr_pyramid_build_indexed: features transposed and pooled once per frame instead of once per edge); nullptr = row e
-template <int W, int NT = 256>
-__global__ __launch_bounds__(NT) void pyr_build_ring_kernel(const __half* __restrict__ f1T, const __half* __restrict__ f2T,
+template <int W, int NT = 256, bool TM = false>
+__global__ __launch_bounds__(NT, TM ? (NT == 512 ? 4 : 2) : 1) void pyr_build_ring_kernel(const __half* __restrict__ f1T, const __half* __restrict__ f2T,
                                                              __half* __restrict__ pyr, PyrDims D, long f1_stride_e,
                                                              long f2_stride_e, const int64_t* __restrict__ idx1 = nullptr,
                                                              const int64_t* __restrict__ idx2 = nullptr) {
@@ -369,6 +531,12 @@ __global__ __launch_bounds__(NT) void pyr_build_ring_kernel(const __half* __rest
   constexpr int nbx = W / 8;
   const int by = sb / nbx, bx = sb - by * nbx;
   // A fragments of this wave's 16 source pixels (rows yy = 2*wave, 2*wave+1): lane holds A[i = lane&15][k = (lane>>4)*8..+8]
+  const __half* bbase = f2T + (idx2 ? (long)idx2[e] : (long)e) * f2_stride_e;
+  __half* obase = pyr + (long)e * D.edge_elems;
+  const int h = D.h;
+  if constexpr (TM && W == 64)          // (before the row-pair fragments below are loaded: its own A fragments take 32 / 64 registers)
+    ring_level0_tm<NT>(f1T + (idx1 ? (long)idx1[e] : (long)e) * f1_stride_e, bbase + (long)D.tgt_off[0] * CH,
+                       obase + D.lev_off[0] + (long)sb * D.blk_elems[0], ring, sB, h, by, bx, tid);
   half8 afrag[4];
   {
     const int p = wave * 16 + (lane & 15);
@@ -376,9 +544,6 @@ __global__ __launch_bounds__(NT) void pyr_build_ring_kernel(const __half* __rest
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) afrag[ks] = *reinterpret_cast<const half8*>(row + ks * 32 + (lane >> 4) * 8);
   }
-  const __half* bbase = f2T + (idx2 ? (long)idx2[e] : (long)e) * f2_stride_e;
-  __half* obase = pyr + (long)e * D.edge_elems;
-  const int h = D.h;
 #define RING_LEVEL(l_)                                                                                               \
   {                                                                                                                  \
     constexpr int w2 = W >> (l_);                                                                                    \
@@ -386,7 +551,10 @@ __global__ __launch_bounds__(NT) void pyr_build_ring_kernel(const __half* __rest
     ring_level<NTL, NT>(afrag, bbase + (long)D.tgt_off[l_] * CH, obase + D.lev_off[l_] + (long)sb * D.blk_elems[l_],     \
                     ring, sB, l_, h >> (l_), w2, by, bx, tid);                                                       \
   }
-  RING_LEVEL(0) RING_LEVEL(1) RING_LEVEL(2) RING_LEVEL(3)
+  if constexpr (!(TM && W == 64)) {
+    RING_LEVEL(0)
+  }
+  RING_LEVEL(1) RING_LEVEL(2) RING_LEVEL(3)
 #undef RING_LEVEL
 }
 
@@ -1046,7 +1214,13 @@ int launch_ring(const __half* f1T, const __half* f2T, __half* pyramid, const Pyr
                 const int64_t* idx1, const int64_t* idx2, hipStream_t st) {
   const size_t lds = (size_t)w * 1024 + (size_t)(w > 16 ? w : 16) * 256;       // row ring + one staged target row
   const dim3 grid(D.nblk, E);
-  if (w == 64 && opts().pyr_build_waves == 8) {
+  if (w == 64 && opts().pyr_build_tm && opts().pyr_build_waves == 8) {
+    DH_LDS_OPTIN((&pyr_build_ring_kernel<64, 512, true>), 80 * 1024);
+    hipLaunchKernelGGL((pyr_build_ring_kernel<64, 512, true>), grid, dim3(512), lds, st, f1T, f2T, pyramid, D, s1, s2, idx1, idx2);
+  } else if (w == 64 && opts().pyr_build_tm) {
+    DH_LDS_OPTIN((&pyr_build_ring_kernel<64, 256, true>), 80 * 1024);
+    hipLaunchKernelGGL((pyr_build_ring_kernel<64, 256, true>), grid, dim3(256), lds, st, f1T, f2T, pyramid, D, s1, s2, idx1, idx2);
+  } else if (w == 64 && opts().pyr_build_waves == 8) {
     DH_LDS_OPTIN((&pyr_build_ring_kernel<64, 512>), 80 * 1024);
     hipLaunchKernelGGL((pyr_build_ring_kernel<64, 512>), grid, dim3(512), lds, st, f1T, f2T, pyramid, D, s1, s2, idx1, idx2);
   } else if (w == 64) {

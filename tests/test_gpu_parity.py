@@ -576,6 +576,13 @@ def test_native_pyramid_build_kernels_are_bit_identical(db, option):
         c = db.corr_pyramid_build(f1, f2)
         option("pyr_build_waves", 8)
         assert torch.equal(b, c)
+        # round 6: level 0 with tile-major wave roles (the default, `b`) against the row-pair-major roles of rounds 2-5, 8 and 4 waves
+        option("pyr_build_tm", 0)
+        d8 = db.corr_pyramid_build(f1, f2)
+        option("pyr_build_waves", 4)
+        d4 = db.corr_pyramid_build(f1, f2)
+        option("pyr_build_waves", 8); option("pyr_build_tm", 1)
+        assert torch.equal(b, d8) and torch.equal(b, d4)
 
 
 @pytest.mark.parametrize("shape,rig", [((48, 64), 1), ((16, 32), 2), ((30, 40), 1), ((24, 16), 2), ((41, 73), 1), ((72, 96), 1)])
