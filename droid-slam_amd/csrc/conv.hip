@@ -63,6 +63,9 @@ struct ConvParams {
   // [a*2+b][q>>2][lane 64][q&3] fp32, written by the same kernel with out_f32 == 3 (store_acc_tile) and read back as sixteen
   // 16-byte loads per lane (1 KB contiguous per wave-load) instead of 64 dword loads
   const float* cinit; const int64_t* cinit_idx; int cinit_stride; int cinit_off;
+  // stride-2 "same" convolution (the encoders' down-sampling layers, extractor.py:140,151,24): H, W above are the OUTPUT size, the input
+  // is Hin x Win = 2H x 2W and output pixel (y, x) reads input (2y + dy - pad, 2x + dx - pad); conv_igemm_kernel only; 1 / H / W otherwise
+  int stride, Hin, Win;
   int xcd_tiles;          // > 0: 1-D grid, workgroup id -> (pixel tile, cout tile) through xcd_decode(); = pixel tiles per XCD
   int ny;                 // cout tiles
 #ifdef DH_ABLATION
@@ -546,7 +549,7 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_kernel(ConvParams P) {
     const bool ok = pix < M;
     const long pc = ok ? pix : 0;
     const int n = (int)(pc / HW), r = (int)(pc - (long)n * HW);
-    a_row0[i] = n * P.H; a_y[i] = ok ? r / P.W : -(1 << 20); a_x[i] = r - (r / P.W) * P.W;
+    a_row0[i] = n * P.Hin; a_y[i] = ok ? (r / P.W) * P.stride : -(1 << 20); a_x[i] = (r - (r / P.W) * P.W) * P.stride;
   }
   const int kc = tid & 7;                  // 8-half piece inside the chunk (same for all of a thread's pieces)
   // running decomposition of k = chunk*64 + kc*8 into (tap -> dy, dx) and channel c
@@ -567,8 +570,8 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_kernel(ConvParams P) {
 #pragma unroll
     for (int i = 0; i < A_PIECES; ++i) {
       const int yy = a_y[i] + cur_dy - padh, xx = a_x[i] + cur_dx - padw;
-      const bool ok = kvalid && (unsigned)yy < (unsigned)P.H && (unsigned)xx < (unsigned)P.W;
-      const __half* src = base + ((long)(a_row0[i] + (ok ? yy : 0)) * P.W + (ok ? xx : 0)) * segc + cs;
+      const bool ok = kvalid && (unsigned)yy < (unsigned)P.Hin && (unsigned)xx < (unsigned)P.Win;
+      const __half* src = base + ((long)(a_row0[i] + (ok ? yy : 0)) * P.Win + (ok ? xx : 0)) * segc + cs;
       ra[i] = ok ? *reinterpret_cast<const uint4*>(src) : uint4{0u, 0u, 0u, 0u};
     }
 #pragma unroll
@@ -2570,6 +2573,7 @@ extern "C" int dh_conv2d_nhwc_f16_ex2(const void* const* inputs, const int* in_c
   P.cinit = cinit; P.cinit_idx = cinit_idx; P.cinit_stride = cinit_stride; P.cinit_off = cinit_off;
   P.wt = (const __half*)weights; P.wt_halo = (const __half*)weights_halo; P.bias = bias;
   P.N = N; P.H = H; P.W = W; P.KH = KH; P.KW = KW; P.Cout = Cout; P.CoutPad = CoutPad; P.Kpad = Kpad; P.epi = epilogue;
+  P.stride = 1; P.Hin = H; P.Win = W;
   P.out = out; P.out_f32 = out_is_f32; P.out_stride = out_stride;
 #ifdef DH_ABLATION
   {
@@ -2715,6 +2719,31 @@ extern "C" int dh_conv2d_nhwc_f16(const void* const* inputs, const int* in_chann
   return dh_conv2d_nhwc_f16_ex(inputs, in_channels, in_strides, n_inputs, weights, weights_halo, bias, N, H, W, KH, KW, Cout,
                                CoutPad, Kpad, epilogue, out, out_is_f32, out_stride, gterm, aux0, aux0_stride, aux1, aux1_stride,
                                red, nullptr, nullptr, 0, 0, stream);
+}
+
+// Stride-2 "same" convolution of ONE dense NHWC input (k = 1, 3, 7; pad = k / 2): out[n, y, x] = sum_taps w . in[n, 2y + dy - pad, 2x + dx - pad]
+// -- exactly the even positions of the stride-1 result, computed at a quarter of its work and without the strided copy
+// (extractor.py:140 conv1, :24 / :151 the residual blocks' first convolution and 1x1 down-sampling).  Hin, Win even; linear / relu.
+extern "C" int dh_conv2d_s2_nhwc_f16(const void* input, int C, int in_stride, const void* weights, const float* bias,
+                                     int N, int Hin, int Win, int KH, int KW, int Cout, int CoutPad, int Kpad, int epilogue,
+                                     void* out, int out_stride, dh_stream_t stream) {
+  if (!input || !weights || !bias || !out) return DH_ERR_ARG;
+  if (N < 0 || Hin <= 0 || Win <= 0 || (Hin & 1) || (Win & 1) || KH <= 0 || KW <= 0 || !(KH & 1) || !(KW & 1)) return DH_ERR_ARG;
+  if (C <= 0 || C % 8 || in_stride < C || in_stride % 8 || ((uintptr_t)input) % 16) return DH_ERR_ARG;
+  if (Cout <= 0 || CoutPad < Cout || CoutPad % 32 || Kpad <= 0 || Kpad % BK || Kpad < KH * KW * C || out_stride < Cout) return DH_ERR_ARG;
+  if (epilogue != EPI_LINEAR && epilogue != EPI_RELU) return DH_ERR_UNSUPPORTED;
+  if (N == 0) return DH_OK;
+  ConvParams P{};
+  for (int i = 0; i < MAXSEG; ++i) { P.in[i] = (const __half*)input; P.segC[i] = i == 0 ? C : 1 << 30; P.segS[i] = in_stride; }
+  P.nseg = 1; P.Ctot = C; P.Kreal = KH * KW * C;
+  P.wt = (const __half*)weights; P.wt_halo = nullptr; P.bias = bias;
+  P.N = N; P.H = Hin / 2; P.W = Win / 2; P.KH = KH; P.KW = KW; P.Cout = Cout; P.CoutPad = CoutPad; P.Kpad = Kpad; P.epi = epilogue;
+  P.stride = 2; P.Hin = Hin; P.Win = Win;
+  P.out = out; P.out_f32 = 0; P.out_stride = out_stride;
+  hipStream_t st = (hipStream_t)stream;
+  if (CoutPad >= 128) return launch<64, 64, 128>(P, st);
+  if (CoutPad >= 64) return launch<64, 32, 64>(P, st);
+  return launch<32, 32, 32>(P, st);
 }
 
 extern "C" int dh_corr0_nchw_f16(const void* x, const void* wp, const float* bias, void* out, int E, int HW, dh_stream_t stream) {

@@ -568,6 +568,20 @@ torch::Tensor segment_mean(torch::Tensor x, torch::Tensor order, torch::Tensor s
 }
 
 // ---- implicit-GEMM convolution with fused epilogues (droid_amd.update.UpdateModule) ----------------------
+// stride-2 "same" convolution of one dense NHWC input (dh_conv2d_s2_nhwc_f16: the encoders' down-sampling layers) -> [N,H/2,W/2,Cout] f16
+torch::Tensor conv2d_s2_nhwc(torch::Tensor input, torch::Tensor weight, torch::Tensor bias, int64_t KH, int64_t KW, int64_t Cout, int64_t epilogue) {
+  CHECK_INPUT(input); CHECK_INPUT(weight); CHECK_INPUT(bias); CHECK_F32(bias);
+  TORCH_CHECK(input.scalar_type() == torch::kFloat16 && input.dim() == 4, "conv2d_s2_nhwc: input [N,H,W,C] float16, dense");
+  TORCH_CHECK(weight.scalar_type() == torch::kFloat16 && weight.dim() == 2, "conv2d_s2_nhwc: packed weight [CoutPad,Kpad] float16");
+  const int N = (int)input.size(0), H = (int)input.size(1), W = (int)input.size(2), C = (int)input.size(3);
+  TORCH_CHECK(H % 2 == 0 && W % 2 == 0, "conv2d_s2_nhwc: even image size");
+  torch::Tensor out = torch::empty({N, H / 2, W / 2, Cout}, input.options());
+  check_status(dh_conv2d_s2_nhwc_f16(input.data_ptr(), C, C, weight.data_ptr(), bias.data_ptr<float>(), N, H, W, (int)KH, (int)KW, (int)Cout,
+                                     (int)weight.size(0), (int)weight.size(1), (int)epilogue, out.data_ptr(), (int)Cout, cur_stream()),
+               "conv2d_s2_nhwc");
+  return out;
+}
+
 void conv2d_nhwc(std::vector<torch::Tensor> inputs, torch::Tensor weight, c10::optional<torch::Tensor> weight_halo,
                  torch::Tensor bias, int64_t KH, int64_t KW,
                  int64_t Cout, int64_t epilogue, c10::optional<torch::Tensor> out, int64_t out_stride,
@@ -805,6 +819,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("corr0_nchw", &corr0_nchw, "corr_encoder.0 (1x1, 196 -> 128, relu) on the reference-layout lookup output [E,196,h,w] -> [E,h,w,128]");
   m.def("glo_gemv", &glo_gemv, "global-context GEMV of the ConvGRU gates: fp16(bias + fp16(red * scale) wt)");
   m.def("segment_mean", &segment_mean, "mean over row segments (GraphAgg scatter_mean)");
+  m.def("conv2d_s2_nhwc", &conv2d_s2_nhwc, "stride-2 same convolution (encoders' down-sampling layers)");
   m.def("conv2d_nhwc", &conv2d_nhwc, "implicit-GEMM NHWC convolution on the fp16 MFMA with fused epilogues",
         py::arg("inputs"), py::arg("weight"), py::arg("weight_halo"), py::arg("bias"), py::arg("KH"), py::arg("KW"), py::arg("Cout"),
         py::arg("epilogue"), py::arg("out"), py::arg("out_stride"), py::arg("gterm"), py::arg("aux0"), py::arg("aux1"), py::arg("red"),

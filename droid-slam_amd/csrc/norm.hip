@@ -15,10 +15,10 @@ __global__ __launch_bounds__(256) void instance_norm_stats_kernel(const __half* 
                                                                   int pix_per_block) {
   const int n = blockIdx.y, c8 = C / 8;
   const int g = threadIdx.x % c8, lane = threadIdx.x / c8, nl = 256 / c8;
-  if (lane >= nl) return;
+  const bool active = lane < nl;                            // (C / 8 does not divide 256: the last threads only take part in the barrier)
   const int p0 = blockIdx.x * pix_per_block, p1 = min(HW, p0 + pix_per_block);
   float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int p = p0 + lane; p < p1; p += nl) {
+  for (int p = p0 + lane; active && p < p1; p += nl) {
     const uint4 v = *reinterpret_cast<const uint4*>(x + ((long)n * HW + p) * C + g * 8);
     const __half2* h2 = reinterpret_cast<const __half2*>(&v);
 #pragma unroll
@@ -27,10 +27,18 @@ __global__ __launch_bounds__(256) void instance_norm_stats_kernel(const __half* 
       s[2 * k] += f.x; s[2 * k + 1] += f.y; q[2 * k] += f.x * f.x; q[2 * k + 1] += f.y * f.y;
     }
   }
+  // Workgroup reduction first, ONE atomic per (workgroup, channel, moment).  (Rounds 3-5 let every thread add its 16 partial sums to
+  // the 2 C global accumulators of the image directly: 196 608 float atomics on 64 addresses for a 192 x 256 x 32 layer, 0.46 ms per
+  // call, fifteen calls per frame = 6.9 of the feature encoder's 7.8 ms -- profiles/r06_encoder_kernel_stats.md.)
+  __shared__ float red[16][257];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    atomicAdd(&stats[((long)n * C + g * 8 + k) * 2 + 0], s[k]);
-    atomicAdd(&stats[((long)n * C + g * 8 + k) * 2 + 1], q[k]);
+  for (int k = 0; k < 8; ++k) { red[k][threadIdx.x] = s[k]; red[8 + k][threadIdx.x] = q[k]; }
+  __syncthreads();
+  for (int t = threadIdx.x; t < c8 * 16; t += 256) {
+    const int gg = t % c8, k = (t / c8) & 7, moment = t / (c8 * 8);
+    float a = 0.f;
+    for (int l = 0; l < nl; ++l) a += red[moment * 8 + k][l * c8 + gg];
+    atomicAdd(&stats[((long)n * C + gg * 8 + k) * 2 + moment], a);
   }
 }
 

@@ -4,8 +4,9 @@ cnet = BasicEncoder(256, 'none')) and of DroidNet.extract_features' image normal
 
 They produce what the hot path consumes -- fmaps / nets / inps [buf,*,128,h/8,w/8] fp16 -- once per incoming frame
 (~11 GFLOP each at 384x512).  Every convolution runs in the implicit-GEMM MFMA kernel of this library
-(droid_backends.conv2d_nhwc, channel-last fp16, fp32 accumulation); a stride-2 "same" convolution is the stride-1 result at
-the even positions (out[i] = y[2i] exactly), a stride-2 1x1 convolution subsamples its input first; instance normalisation,
+(droid_backends.conv2d_nhwc, channel-last fp16, fp32 accumulation); the stride-2 layers (stem, the first convolution and the 1x1
+shortcut of layer2 / layer3) through its stride-2 form (droid_backends.conv2d_s2_nhwc: output pixel (y, x) reads input (2y + dy - pad,
+2x + dx - pad) -- the even positions of the stride-1 result, which is what rounds 3-5 computed in full and sliced); instance normalisation,
 residual additions and activations are droid_backends.norm_act.  Accepts the reference's parameter names
 (`conv1.weight`, `layer2.0.downsample.0.weight`, ...), so a droid.pth checkpoint loads as is.
 """
@@ -59,10 +60,14 @@ class BasicEncoder:
 
     # conv -> [instance norm] -> relu ; the convolution's own epilogue does the relu when there is no normalisation
     def _cnr(self, name, x, stride=1, relu=True):
-        fuse = relu and not self.norm and stride == 1
-        y = self.params[name]([x], EPI_RELU if fuse else EPI_LINEAR)
+        fuse = relu and not self.norm
+        p = self.params[name]
         if stride == 2:
-            y = y[:, ::2, ::2].contiguous()
+            # native stride 2 (droid_backends.conv2d_s2_nhwc): the even positions of the stride-1 result at a quarter of its work, no
+            # strided copy of the output (round 5 computed the stride-1 result -- 4.9 GFLOP for the 0.46 GFLOP stem -- and sliced it)
+            y = db.conv2d_s2_nhwc(x.contiguous(), p.w, p.b, p.k, p.k, p.cout, EPI_RELU if fuse else EPI_LINEAR)
+        else:
+            y = p([x], EPI_RELU if fuse else EPI_LINEAR)
         if self.norm or (relu and not fuse):
             y = db.norm_act(y, None, self.norm, relu)
         return y
@@ -71,7 +76,7 @@ class BasicEncoder:
         y = self._cnr(prefix + "conv1", x, stride)
         y = self._cnr(prefix + "conv2", y, 1)
         if stride != 1:
-            x = self._cnr(prefix + "downsample.0", x[:, ::2, ::2].contiguous(), 1, relu=False)
+            x = self._cnr(prefix + "downsample.0", x, 2, relu=False)             # 1x1 / 2: reads the even pixels itself
         return db.norm_act(x, y, False, True)                                   # relu(x + y)
 
     def forward(self, x):

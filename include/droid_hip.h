@@ -329,6 +329,14 @@ int dh_conv2d_nhwc_f16(const void* const* inputs, const int* in_channels, const 
                        void* out, int out_is_f32, int out_stride,
                        const float* gterm, const void* aux0, int aux0_stride, const void* aux1, int aux1_stride,
                        float* red, dh_stream_t stream);
+
+/* Stride-2 "same" convolution of one dense NHWC fp16 input (k = 1, 3 or 7, pad = k / 2; Hin, Win even): the down-sampling layers of
+ * the feature / context encoders (reference droid_slam/modules/extractor.py:140 conv1 7x7 / 2, :24 the residual blocks' first 3x3 / 2,
+ * :151 their 1x1 / 2 shortcut).  out [N, Hin/2, Win/2, out_stride] f16 = the even positions of the stride-1 result, at a quarter of
+ * its work; weights / bias / CoutPad / Kpad as dh_conv2d_nhwc_f16; epilogue 0 (linear) or 1 (relu). */
+int dh_conv2d_s2_nhwc_f16(const void* input, int C, int in_stride, const void* weights, const float* bias,
+                          int N, int Hin, int Win, int KH, int KW, int Cout, int CoutPad, int Kpad, int epilogue,
+                          void* out, int out_stride, dh_stream_t stream);
 /* dw [N,H,W,4] f32 = (delta_x, delta_y, sigmoid w_x, sigmoid w_y) from the partial sums of epilogue 8: bias4 + over the cout
  * tiles the pixel's own four-row tile's row + the row the tile above / below contributes (same image)
  * (= the heads' second 3x3 convolution, reference droid_slam/droid_net.py:95-106).  W == 64, H % 4 == 0, else DH_ERR_UNSUPPORTED. */

@@ -255,6 +255,28 @@ def test_reconstruction_dump_and_point_cloud(db, tmp_path):
     assert mask.float().mean() > 0.05 and torch.isfinite(pts).all()      # a consistent scene: part of it passes the multi-view check
 
 
+@pytest.mark.parametrize("k,cin,cout,hw", [(7, 8, 32, (48, 64)), (3, 32, 64, (24, 40)), (3, 64, 128, (16, 16)), (1, 32, 64, (24, 40)), (1, 64, 128, (6, 10))])
+def test_stride2_convolution_is_the_stride1_result_at_the_even_positions(db, k, cin, cout, hw):
+    """droid_backends.conv2d_s2_nhwc (dh_conv2d_s2_nhwc_f16: the encoders' stem, the first convolution and the 1x1 shortcut of their
+    down-sampling blocks, extractor.py:140,24,151) against the stride-1 convolution sliced [::2, ::2] -- what rounds 3-5 computed: same
+    taps, same k order per output pixel -> EQUAL bit for bit, linear and relu, several images, image borders"""
+    from droid_amd.update import pack_conv, EPI_LINEAR, EPI_RELU
+    torch.manual_seed(k * 100 + cin)
+    H, W = hw
+    x = torch.randn(3, H, W, cin, device="cuda").half()
+    w = (torch.randn(cout, cin, k, k, device="cuda") / (cin * k * k) ** 0.5)
+    b = torch.randn(cout, device="cuda")
+    wp, bp = pack_conv(w, b, None)
+    for epi in (EPI_LINEAR, EPI_RELU):
+        full = torch.empty(3, H, W, cout, dtype=torch.float16, device="cuda")
+        db.conv2d_nhwc([x], wp, None, bp, k, k, cout, epi, full, cout, None, None, None, None, None, None, 0, False, 0, False, False)
+        got = db.conv2d_s2_nhwc(x, wp, bp, k, k, cout, epi)
+        torch.cuda.synchronize()
+        assert got.shape == (3, H // 2, W // 2, cout) and torch.equal(got, full[:, ::2, ::2])
+    with pytest.raises(RuntimeError):
+        db.conv2d_s2_nhwc(x[:, :H - 1].contiguous(), wp, bp, k, k, cout, EPI_LINEAR)            # odd image height
+
+
 def test_encoders_match_reference_module_under_autocast(db, golden_dir):
     """droid_amd.encoder.BasicEncoder (MFMA convolutions + instance norm / residual kernels) vs vectors written by the
     reference's own BasicEncoder under fp16 autocast (tests/golden/encoder_python.npz); both store fp16 layer outputs"""

@@ -442,6 +442,73 @@ def test_composed_update_at_c3_matches_reference_factor_graph(db, golden_dir, c3
     _free()
 
 
+def test_composed_update_lowmem_at_c5_matches_reference_factor_graph(db, golden_dir):
+    """BASELINE configs[4] at FULL size -- 1024 keyframes / 8192 edges / 48x64, STEREO + sensor depth + the seeded NON-constant per-pixel
+    depth-confidence map (droid_amd.synthetic.depth_confidence -> DepthVideo.set_depth_confidence -> droid_backends.ba_ex) -- through
+    the global-BA iteration FactorGraph.update_lowmem (the function configs[3] / [4] shard over 8 GPUs), two steps, against the golden
+    written by the reference's unmodified factor_graph.py:266-330 on CPU (tests/golden/make_graph_scale_golden.py c5: alt-correlation
+    in chunks of 8 source frames, fp16-autocast update operator, ONE fp64 BA over all edges per step with lm = 1e-5 / ep = 1e-2).
+    The 210 GB pyramid does not fit next to the activations on one GPU, so the product takes the same formulation (MFMA
+    alt-correlation in chunks of `chunk_frames` = 8 source frames).  Tolerances: 10 x the one-ulp probe of the reference's own run."""
+    from droid_amd.depth_video import DepthVideo
+    from droid_amd.factor_graph import FactorGraph
+    from droid_amd.update import UpdateModule
+    from droid_amd.weights import deterministic_state_dict
+    from golden_inputs import C5_SAMPLE_EDGES, C5_SAMPLE_FRAMES
+    path = os.path.join(golden_dir, "graph_c5_python.npz")
+    assert os.path.exists(path), "tests/golden/graph_c5_python.npz missing (python tests/golden/make_graph_scale_golden.py c5)"
+    G = np.load(path)
+    g = syn.make_graph("C5", with_features=True)
+    N, ht, wd = g["n_frames"], g["ht"], g["wd"]
+    video = DepthVideo(image_size=[8 * ht, 8 * wd], buffer=N + 2, stereo=True, device="cuda:0")
+    video.poses[:N] = dev(g["poses"]); video.disps[:N] = dev(g["disps"]); video.intrinsics[:N] = dev(g["intrinsics"])
+    video.disps_sens[:N] = dev(g["disps_sens"])
+    video.fmaps[:N] = dev(g["fmaps"]); video.nets[:N] = dev(g["nets"]); video.inps[:N] = dev(g["inps"])
+    video.set_depth_confidence(slice(0, N), dev(g["disps_conf"]))
+    video.counter.value = N
+    upd = UpdateModule("cuda").load_state_dict(deterministic_state_dict(_SD(), seed=1234))
+    fg = FactorGraph(video, upd, corr_impl="alt", max_factors=-1, upsample=False, chunk_frames=8)
+    fg.add_factors(torch.as_tensor(g["ii"]), torch.as_tensor(g["jj"]))
+    assert np.array_equal(fg.ii.cpu().numpy(), G["ii"]) and np.array_equal(fg.jj.cpu().numpy(), G["jj"]) and len(fg.ii) == 8192
+    assert int((fg.ii == fg.jj).sum()) == 1024                         # the stereo self-edges
+    assert not fg._pyramid_fits(len(fg.ii), ht, wd)                     # -> the alt-correlation path, the reference's formulation
+    sample = torch.as_tensor(C5_SAMPLE_EDGES).cuda(); fr = np.asarray(C5_SAMPLE_FRAMES)
+    yy, xx = np.meshgrid(np.arange(ht, dtype=np.float32), np.arange(wd, dtype=np.float32), indexing="ij")
+    coords0 = torch.as_tensor(np.stack([xx, yy], -1)).cuda()
+    c = lambda t: t.float().cpu().numpy()
+    probe, bad = _probe(golden_dir), {}
+    f64 = lambda a: np.asarray(a, dtype=np.float64)
+    for k in (1, 2):
+        fg.update_lowmem(steps=1)
+        torch.cuda.synchronize()
+        tag = "U%d" % k
+        m = {}
+        p, rp = f64(c(video.poses)[:N]), f64(G[tag + "_poses"])
+        m["pose_trans_max"] = float(np.abs(p[:, :3] - rp[:, :3]).max())
+        m["pose_rot_max_rad"] = float(_rot_angle(p[:, 3:], rp[:, 3:]).max())
+        d = f64(c(video.disps)[:N])
+        e = np.abs(d[fr] - f64(G[tag + "_disps_f"])) / np.maximum(1.0, np.abs(f64(G[tag + "_disps_f"])))
+        m["disps_rel_q99"], m["disps_rel_max"] = float(np.quantile(e, 0.99)), float(e.max())
+        m["disps_frame_mean_max"] = float(np.abs(d.reshape(N, -1).mean(1) - f64(G[tag + "_disps_mean"])).max())
+        dm = f64(c(fg.damping)[:N])
+        m["damping_rel_max"] = float(np.abs(dm[fr] - f64(G[tag + "_damping_f"])).max() / np.abs(f64(G[tag + "_damping_f"])).max())
+        m["damping_frame_mean_rel_max"] = float(np.abs(dm.reshape(N, -1).mean(1) - f64(G[tag + "_damping_mean"])).max() / np.abs(f64(G[tag + "_damping_mean"])).max())
+        m["net_s_max"] = float(np.abs(f64(c(fg.net[0][sample][:, :, ::4, ::4])) - f64(G[tag + "_net_s"])).max())
+        t = np.abs(f64(c(fg.target[0][sample])) - f64(G[tag + "_target_s"]))
+        m["target_s_q999"], m["target_s_max"] = float(np.quantile(t, 0.999)), float(t.max())
+        m["weight_s_max"] = float(np.abs(f64(c(fg.weight[0][sample])) - f64(G[tag + "_weight_s"])).max())
+        m["flow_mean_max"] = float(np.abs(f64(c((fg.target[0] - coords0).abs().mean(dim=(1, 2, 3)))) - f64(G[tag + "_flow_mean"])).max())
+        m["weight_mean_max"] = float(np.abs(f64(c(fg.weight[0].mean(dim=(1, 2, 3)))) - f64(G[tag + "_weight_mean"])).max())
+        nm = torch.cat([fg.net[0][s:s + 256].float().abs().mean(dim=(1, 2, 3)) for s in range(0, 8192, 256)])
+        m["net_absmean_max"] = float(np.abs(f64(c(nm)) - f64(G[tag + "_net_absmean"])).max())
+        _check_composed("C5", tag, m, probe, bad)
+    assert not bad, "beyond %gx the one-ulp probe movement / the fp32-geometry floor (value, tolerance): %s" % (COMPOSED_FACTOR, bad)
+    # the confidence map is part of what was compared: with the reference's constant 0.05 the depths land somewhere else
+    assert np.abs(f64(g["disps_conf"]) - 0.05).max() > 0.1
+    del fg, video, upd
+    _free()
+
+
 def test_composed_stereo_update_matches_reference_factor_graph(db, golden_dir):
     """DepthVideo(stereo=True): pyramid from fmaps[jj, c] (c = 1 on stereo self-edges, factor_graph.py:128-133), stereo edges
     in the BA (droid_kernels.cu:228-238), two composed update iterations with upsampling vs the reference golden"""
