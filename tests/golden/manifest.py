@@ -19,7 +19,8 @@ GENERATOR = {
     "graph_c2_python.npz": "make_graph_scale_golden.py c2", "graph_c3_python.npz": "make_graph_scale_golden.py c3",
     "graph_stereo_python.npz": "make_graph_scale_golden.py stereo", "graph_tum_size_python.npz": "make_graph_scale_golden.py tum",
     "graph_wide_python.npz": "make_graph_scale_golden.py wide", "graph_big_python.npz": "make_graph_scale_golden.py big",
-    "graph_scale_probe.json": "make_graph_scale_golden.py c2 c3 --probe",
+    "graph_c5_python.npz": "make_graph_scale_golden.py c5 (reference update_lowmem at 1024 keyframes / 8192 edges, stereo + sensor depth + confidence map; ~30 min)",
+    "graph_scale_probe.json": "make_graph_scale_golden.py c2 c3 c5 stereo tum wide big --probe",
     "policy_python.npz": "make_policy_golden.py", "ref_cuda.npz": "make_ref_golden.py (on an MI355X: the reference's CUDA sources compiled for gfx950)",
 }
 
