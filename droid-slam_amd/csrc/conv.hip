@@ -94,14 +94,18 @@ struct ConvParams {
 // contiguous run of pixel tiles [x * T, (x + 1) * T) and visits the cout tiles of a pixel tile back to back, so the halo
 // rows shared by vertically adjacent tiles, the second cout tile's re-read of the same activations and the accumulator
 // start values of a source frame's edges are L2 hits instead of trips to the other side of the fabric.
-__device__ __forceinline__ void xcd_decode(const ConvParams& P, long& m0, int& n0, int bn, int bm = BM) {
+// Round 6: the number of pixel tiles need not be a multiple of 8 (a rank's shard of an 8-rank run holds 515 or 1025 edges: 6180 /
+// 12300 tiles, which fell back to the plain order and lost 13 % on the gates): T = ceil(tiles / 8), the last XCD's run is shorter and
+// the workgroups beyond it return at once (-> false).
+__device__ __forceinline__ bool xcd_decode(const ConvParams& P, long& m0, int& n0, int bn, int bm = BM) {
   if (P.xcd_tiles > 0) {
     const unsigned id = blockIdx.x, xcd = id & 7, slot = id >> 3;
     const unsigned y = slot % (unsigned)P.ny, t = slot / (unsigned)P.ny;
     m0 = ((long)xcd * P.xcd_tiles + t) * bm; n0 = (int)y * bn;
-  } else {
-    m0 = (long)blockIdx.x * bm; n0 = blockIdx.y * bn;
+    return m0 < (long)P.N * P.H * P.W;
   }
+  m0 = (long)blockIdx.x * bm; n0 = blockIdx.y * bn;
+  return true;
 }
 
 // v_rcp_f32 (1 ulp) instead of the IEEE division sequence (ten instructions per gate value): every result is rounded to fp16
@@ -1008,7 +1012,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wrow = wave & 3, wn0 = (wave >> 2) * 64, wm0 = wrow * 64;
   long m0; int n0;
-  xcd_decode(P, m0, n0, 128);
+  if (!xcd_decode(P, m0, n0, 128)) return;
   const int HW = P.H * P.W;
   const int img = (int)(m0 / HW), y0 = (int)((m0 - (long)img * HW) / 64);
   const int nchunks = P.Ctot / H2CK, nsteps = nchunks * 3;
@@ -1182,7 +1186,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(ConvParams P) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wrow = wave, wn0 = 0, wm0 = wrow * 64;
   long m0; int n0;
-  xcd_decode(P, m0, n0, 128);
+  if (!xcd_decode(P, m0, n0, 128)) return;
   const int HW = P.H * P.W;
   const int img = (int)(m0 / HW), y0 = (int)((m0 - (long)img * HW) / 64);
   const int nchunks = P.Ctot / H2CK, nsteps = nchunks * 3;
@@ -1308,7 +1312,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo64_kernel(ConvParams P) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wrow = wave, wn0 = 0, wm0 = wrow * 64;
   long m0; int n0;
-  xcd_decode(P, m0, n0, 64);
+  if (!xcd_decode(P, m0, n0, 64)) return;
   const int HW = P.H * P.W;
   const int img = (int)(m0 / HW), y0 = (int)((m0 - (long)img * HW) / 64);
   const int nchunks = P.Ctot / H2CK, nsteps = nchunks * 3;
@@ -1440,7 +1444,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(ConvParams P) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wrow = wave & 3, wn0 = (wave >> 2) * 64, wm0 = wrow * 64;
   long m0; int n0;
-  xcd_decode(P, m0, n0, 128, 512);
+  if (!xcd_decode(P, m0, n0, 128, 512)) return;
   const int HW = P.H * P.W;
   const int img = (int)(m0 / HW), y0 = (int)((m0 - (long)img * HW) / 64);
   const int nchunks = P.Ctot / H2CK, nsteps = nchunks * 3;
@@ -1607,7 +1611,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(ConvParams P) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wrow = wave & 3, wn0 = (wave >> 2) * 64;
   long m0; int n0;
-  xcd_decode(P, m0, n0, 128);
+  if (!xcd_decode(P, m0, n0, 128)) return;
   const int HW = P.H * P.W;
   const int img = (int)(m0 / HW), y0 = (int)((m0 - (long)img * HW) / 64);
   const int nchunks = P.Ctot / H2CK, nsteps = nchunks * 3;
@@ -2088,7 +2092,7 @@ int launch_halo2(const ConvParams& P0, hipStream_t st) {
   const long M = (long)P.N * P.H * P.W;
   dim3 grid((unsigned)(M / BM), (unsigned)(P.CoutPad / 128));
   P.ny = (int)grid.y;
-  if (opts().conv_xcd && grid.x % 8 == 0) { P.xcd_tiles = (int)(grid.x / 8); grid = dim3(grid.x * grid.y, 1); }
+  if (opts().conv_xcd) { P.xcd_tiles = (int)((grid.x + 7) / 8); grid = dim3((unsigned)P.xcd_tiles * 8 * grid.y, 1); }
   if constexpr (EPI == EPI_LINEAR) {
     if (P.out_f32 == 3) {                                 // fp32 output in the accumulator-tile layout: 16-byte stores, 1 KB per wave-store
       DH_LDS_OPTIN((&conv3x3_halo2_kernel<EPI, false, 3>), 80 * 1024);
@@ -2144,7 +2148,7 @@ int launch_halo4(const ConvParams& P0, hipStream_t st) {
   const long M = (long)P.N * P.H * P.W;
   dim3 grid((unsigned)(M / BM), (unsigned)(P.CoutPad / 128));
   P.ny = (int)grid.y;
-  if (opts().conv_xcd && grid.x % 8 == 0) { P.xcd_tiles = (int)(grid.x / 8); grid = dim3(grid.x * grid.y, 1); }
+  if (opts().conv_xcd) { P.xcd_tiles = (int)((grid.x + 7) / 8); grid = dim3((unsigned)P.xcd_tiles * 8 * grid.y, 1); }
   if constexpr (EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q) {
     if (P.cinit) {
       DH_LDS_OPTIN((&conv3x3_halo4_kernel<EPI, true, true>), 80 * 1024);
@@ -2183,7 +2187,7 @@ int launch_halo64(const ConvParams& P0, hipStream_t st) {
   const long M = (long)P.N * P.H * P.W;
   dim3 grid((unsigned)(M / BM), 1);
   P.ny = 1;
-  if (opts().conv_xcd && grid.x % 8 == 0) P.xcd_tiles = (int)(grid.x / 8);
+  if (opts().conv_xcd) { P.xcd_tiles = (int)((grid.x + 7) / 8); grid = dim3((unsigned)P.xcd_tiles * 8, 1); }
   hipLaunchKernelGGL((conv3x3_halo64_kernel<EPI>), grid, dim3(256), H64_LDS_BYTES, st, P);
   DH_LAUNCH_CHECK();
   return DH_OK;
@@ -2196,7 +2200,7 @@ int launch_halo3(const ConvParams& P0, hipStream_t st) {
   const long M = (long)P.N * P.H * P.W;
   dim3 grid((unsigned)(M / 512), (unsigned)(P.CoutPad / 128));
   P.ny = (int)grid.y;
-  if (opts().conv_xcd && grid.x % 8 == 0) { P.xcd_tiles = (int)(grid.x / 8); grid = dim3(grid.x * grid.y, 1); }
+  if (opts().conv_xcd) { P.xcd_tiles = (int)((grid.x + 7) / 8); grid = dim3((unsigned)P.xcd_tiles * 8 * grid.y, 1); }
   if constexpr (EPI == EPI_LINEAR) {
     if (P.out_f32) {
       DH_LDS_OPTIN((&conv3x3_halo3_kernel<EPI, false>), 96 * 1024);
@@ -2237,7 +2241,7 @@ int launch_wino(const ConvParams& P0, hipStream_t st) {
   const long M = (long)P.N * P.H * P.W;
   dim3 grid((unsigned)(M / BM), (unsigned)(P.CoutPad / 128));
   P.ny = (int)grid.y;
-  if (opts().conv_xcd && grid.x % 8 == 0) { P.xcd_tiles = (int)(grid.x / 8); grid = dim3(grid.x * grid.y, 1); }
+  if (opts().conv_xcd) { P.xcd_tiles = (int)((grid.x + 7) / 8); grid = dim3((unsigned)P.xcd_tiles * 8 * grid.y, 1); }
   if constexpr (EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q) {
     if (P.cinit) {
       DH_LDS_OPTIN((&conv3x3_wino_kernel<EPI, true>), WINO_LDS_BYTES);
