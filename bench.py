@@ -73,6 +73,8 @@ def parse():
     ap.add_argument("--chunk-frames", type=int, default=64, help="source frames per chunk of the alt-correlation path")
     ap.add_argument("--hand-rolled-dist", action="store_true", help="N > 1 through this script's own composition of the sharded step (rounds 2-5) "
                     "instead of the product class droid_amd.dist_graph.DistFactorGraph (A/B)")
+    ap.add_argument("--no-glo-chain", action="store_true", help="A/B: the global-context reduction as its own pass over the hidden state at the start of "
+                    "every step (rounds 1-5) instead of inside the previous step's q-gate launch")
     ap.add_argument("--no-product-class", action="store_true", help="skip the untimed `factor_graph_update` key (FactorGraph.update at the same size)")
     return ap.parse_args()
 
@@ -675,6 +677,11 @@ def main():
     uniq_ii = torch.unique(ii)
 
     lk_ms, up_ms, ba_ms = [], [], []
+    # the ConvGRU's global-context sums of the hidden state a step writes, computed inside its q-gate launch and consumed by the next step
+    # on the same tensor -- what FactorGraph._operator does between update iterations (droid_amd/factor_graph.py); --no-glo-chain: every
+    # step starts with the stand-alone reduction over the hidden state, as in rounds 1-5
+    glo_chain = not args.no_glo_chain
+    glo_box = [None]
     ctx_box = [None]       # set only for the extra `steady_state_cached_context` loop after the timed region (see below)
 
     # the update operator takes the unpadded reference-layout features where its first layer has the kernel for them
@@ -700,10 +707,11 @@ def main():
             flow = db.motion_features(coords1, target_prev)                   # factor_graph.py:221-222
             if len(chunk_slices) == 1:
                 if inp_edges is not None:
-                    _, _, _, damping, upmask = upd.forward_nhwc(net, inp_edges, feats, flow, ii, corr0=corr0)
+                    _, _, _, damping, upmask = upd.forward_nhwc(net, inp_edges, feats, flow, ii, corr0=corr0, glo_red=glo_box[0], glo_next=glo_chain)
                 else:
                     _, _, _, damping, upmask = upd.forward_nhwc(net, None, feats, flow, ii, inp_frames=inps_frames, inp_index=inp_index, corr0=corr0,
-                                                                ctx=ctx_box[0])
+                                                                ctx=ctx_box[0], glo_red=glo_box[0], glo_next=glo_chain)
+                glo_box[0] = upd.last_glo                                    # (None where the q gate's launch cannot reduce the new state)
                 dw = upd.last_dw
                 damping_buf[uniq_ii] = damping                               # factor_graph.py:238
             else:
@@ -797,6 +805,7 @@ def main():
                                                      torch.full((N, ht, wd), 1e-6, device=dev), kx_t, uniq_ii, intr, sens, conf), product)
             except torch.cuda.OutOfMemoryError as exc:        # C5 on one GPU: no room for the reference-layout copies
                 check = {"ok": None, "skipped": "out of memory for the reference-layout run: %s" % str(exc)[:80]}
+            glo_box[0] = None                                 # (check_step restored the hidden state in place: the kept sums belong to another state)
             torch.cuda.empty_cache()
         if not args.no_sensitivity:
             coords_bench, _ = db.reproject(poses0, disps0, intr, ii, jj)
@@ -1180,7 +1189,7 @@ def main_lowmem(args, dev, world, rank):
 
     def call():
         video.poses[:N] = poses0; video.disps[:N] = disps0
-        fg._net.copy_(net0); fg.target = target0.clone(); fg.weight = weight0.clone(); fg.damping.fill_(1e-6)
+        fg._net.copy_(net0); fg._glo = None; fg.target = target0.clone(); fg.weight = weight0.clone(); fg.damping.fill_(1e-6)
         fg.update_lowmem(steps=steps_per_call, corr=mode)
 
     call(); torch.cuda.synchronize()                         # code objects, LDS opt-ins, allocator pool

@@ -66,6 +66,10 @@ struct ConvParams {
   // stride-2 "same" convolution (the encoders' down-sampling layers, extractor.py:140,151,24): H, W above are the OUTPUT size, the input
   // is Hin x Win = 2H x 2W and output pixel (y, x) reads input (2y + dy - pad, 2x + dx - pad); conv_igemm_kernel only; 1 / H / W otherwise
   int stride, Hin, Win;
+  // Round 6, EPI_GRU_Q only (glo_red != nullptr): the NEXT iteration's global-context reduction fused behind the state update --
+  // glo_red[image][c] += sum over the tile's pixels of sigmoid(glo_wt . net' + glo_bias)[c] * net'[c] on the new hidden state that is
+  // still in LDS (what glo_reduce_kernel computes from HBM at the start of the next iteration: 3.2 GB of reads at 4096 edges)
+  const __half* glo_wt; const float* glo_bias; float* glo_red;
   int xcd_tiles;          // > 0: 1-D grid, workgroup id -> (pixel tile, cout tile) through xcd_decode(); = pixel tiles per XCD
   int ny;                 // cout tiles
 #ifdef DH_ABLATION
@@ -269,8 +273,8 @@ inline bool staged_epilogue_ok(const ConvParams& P) {
 
 // second phase of the staged epilogues: the workgroup walks the fp16 tile [256 px][BNT couts] in 16-byte pieces (8 couts of
 // one pixel), applies the gate algebra with 16-byte operand loads and stores a pixel's couts as one run
-template <int EPI, int BNT, int NT = 512>
-__device__ __forceinline__ void staged_tile_store(const ConvParams& P, const __half* __restrict__ sT, long m0, int n0, int tid) {
+template <int EPI, int BNT, int NT = 512, bool KEEP = false>      // KEEP: the finished pieces are also written back into the LDS tile
+__device__ __forceinline__ void staged_tile_store(const ConvParams& P, __half* __restrict__ sT, long m0, int n0, int tid) {
   constexpr int ELD = BNT + 8;
   constexpr int PPR = BNT / 8;
   constexpr int NIT = 256 * PPR / NT;
@@ -326,11 +330,12 @@ __device__ __forceinline__ void staged_tile_store(const ConvParams& P, const __h
       v = uint4{o.x, o.y, o.z, o.w};
     }
     *reinterpret_cast<uint4*>(reinterpret_cast<__half*>(P.out) + pix * P.out_stride + co) = v;
+    if constexpr (KEEP) *reinterpret_cast<uint4*>(sT + row * ELD + c8) = v;      // (a thread overwrites only the piece it has just read)
   }
 }
 
 // TN = 32-cout accumulator tiles per wave, BNT = couts of the workgroup tile (128 or 64)
-template <int EPI, int TN, int BNT, int NT = 512>
+template <int EPI, int TN, int BNT, int NT = 512, bool KEEP = false>
 __device__ __forceinline__ void staged_epilogue(const ConvParams& P, f32x16 (&acc)[2][TN], __half* __restrict__ sT, long m0, int n0,
                                                 int wm0, int wn0, int tid, int HW) {
   constexpr int ELD = BNT + 8;            // LDS row stride of the staged tile (halves)
@@ -358,7 +363,7 @@ __device__ __forceinline__ void staged_epilogue(const ConvParams& P, f32x16 (&ac
       }
   }
   __syncthreads();
-  staged_tile_store<EPI, BNT, NT>(P, sT, m0, n0, tid);
+  staged_tile_store<EPI, BNT, NT, KEEP>(P, sT, m0, n0, tid);
 }
 
 // EPI_HEADS0: first layer of the delta | weight heads (3x3, 128 -> 256, relu) FUSED with the second layer's channel
@@ -993,6 +998,86 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(ConvParams P) {
 // skeleton with its smaller steps 0.4 ms more; inside the full iteration 80.9 against 84.4 ms per step.  Those numbers are
 // from the version whose loop still spilled (hoisted tap addresses, see the `opaque` notes below); spill-free it runs
 // 448->256 in 5.95 ms (1.09 PFLOP/s) and the full iteration in 70.1 ms.
+// ---- the ConvGRU's global-context reduction on a tile in LDS (used by glo_reduce_kernel below and by the q gate, EPI_GRU_Q + glo_red) ----
+constexpr int GLD = 128 + 8;                          // LDS row stride (halves)
+
+// the reduction proper on a tile [256 px][128 ch] fp16 that sits in LDS (row stride GLD) -- shared by glo_reduce_kernel (tile staged from
+// HBM) and the q gate's fused form (round 6: the tile is the hidden state the gate has just written; ConvParams::glo_red).  Eight waves,
+// wave tile 64 px x 64 couts; the weights [128][Kpad] come from L2 straight into B fragments (two halves of K); ends with ONE atomic
+// per (workgroup, cout) into red_row[128].  Every thread of the workgroup has to have passed its last write of the tile's rows it owns;
+// the function synchronises before the first fragment read.
+__device__ __forceinline__ void glo_tile_reduce(const __half* __restrict__ wt, int Kpad, const float* __restrict__ bias_, float* __restrict__ red_row,
+                                                __half* __restrict__ s_conv, int tid, half8 (&bf)[2][4]) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wrow = wave & 3, wn0 = (wave >> 2) * 64, wm0 = wrow * 64;
+  const int p = lane & 31, kh = lane >> 5;
+  auto load_b = [&](int half) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        bf[b][ks] = *reinterpret_cast<const half8*>(wt + (long)(wn0 + b * 32 + p) * Kpad + (half * 4 + ks) * 16 + kh * 8);
+  };
+  f32x16 acc[2][2];
+  zero_acc<2, 2>(acc);
+  __syncthreads();
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      half8 af[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+        af[a] = *reinterpret_cast<const half8*>(s_conv + (wm0 + a * 32 + p) * GLD + (half * 4 + ks) * 16 + kh * 8);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b][ks], acc[a][b], 0, 0, 0);
+    }
+    if (half == 0) load_b(1);
+  }
+  // gate * feature, summed over the wave's 64 pixels per cout (same roundings as conv_epilogue's EPI_GLO)
+  float sum[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int co = wn0 + b * 32 + p;
+    const float bias = bias_[co];
+    float t = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int q = 0; q < 16; q += 2) {
+        if ((q & 7) == 0) __builtin_amdgcn_sched_barrier(0);      // (keeps the 32 LDS reads from being hoisted in one block: spills)
+        // two rows at a time: the gate values rounded to fp16 as a pair, the products as ONE packed fp16 multiply (the
+        // exact product of two fp16 numbers has 22 significant bits, so rounding it from fp32 or inside v_pk_mul_f16 is the
+        // same single rounding), their fp32 sum as one v_dot2 against (1, 1)
+        const int row = wm0 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh;
+        const half2v g = {(_Float16)sigmoidf_(acc[a][b][q] + bias), (_Float16)sigmoidf_(acc[a][b][q + 1] + bias)};
+        const half2v n = {__builtin_bit_cast(_Float16, s_conv[row * GLD + co]), __builtin_bit_cast(_Float16, s_conv[(row + 1) * GLD + co])};
+        t = __builtin_amdgcn_fdot2(g * n, half2v{(_Float16)1.f, (_Float16)1.f}, t, false);
+      }
+    sum[b] = t + __shfl_xor(t, 32, 64);
+  }
+  __syncthreads();                                    // the tile is dead: its head becomes [8 waves][64] partial sums
+  float* sR = reinterpret_cast<float*>(s_conv);
+  if (lane < 32) { sR[wave * 64 + p] = sum[0]; sR[wave * 64 + 32 + p] = sum[1]; }
+  __syncthreads();
+  if (tid < 128) {
+    const int hb = tid >> 6, c = tid & 63;            // cout half -> waves 4*hb .. 4*hb+3
+    const float t = (sR[(hb * 4 + 0) * 64 + c] + sR[(hb * 4 + 1) * 64 + c]) + (sR[(hb * 4 + 2) * 64 + c] + sR[(hb * 4 + 3) * 64 + c]);
+    atomicAdd(&red_row[tid], t);
+  }
+}
+// first half of K of the wave's B fragments (issued before the tile is complete, so that they arrive under the staging)
+__device__ __forceinline__ void glo_load_b0(const __half* __restrict__ wt, int Kpad, int tid, half8 (&bf)[2][4]) {
+  const int lane = tid & 63, wn0 = (tid >> 8) * 64, p = lane & 31, kh = lane >> 5;
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      bf[b][ks] = *reinterpret_cast<const half8*>(wt + (long)(wn0 + b * 32 + p) * Kpad + ks * 16 + kh * 8);
+}
+
 constexpr int H2CK = 32;
 constexpr int H2A_BYTES = HPIX * H2CK * 2;               // 25,344: halo [396 px][32 ch]
 constexpr int H2B_BYTES = 3 * 128 * H2CK * 2;            // 24,576: one (chunk, dy) weight group
@@ -1001,8 +1086,9 @@ constexpr int H2_LDS_BYTES = H2A_BYTES + 2 * H2B_BYTES;  // 74,496 (the staged e
 // ABL (only instantiated != 0 in -DDH_ABLATION builds, option "conv_abl", WRONG results by construction): timing / power
 // attribution of the main loop.  bit 0: fragment reads only in the first step (operands stay in registers); bit 1: no weight
 // DMA after the first two groups; bit 2: no halo fetch after the first chunk; bit 3: no epilogue; bit 4: no MFMAs.
-template <int EPI, bool STAGED = true, int CINIT = 0, int ABL = 0>      // CINIT: 0 zero, 1 pixel-major start values, 2 start values in the accumulator-tile
+template <int EPI, bool STAGED = true, int CINIT = 0, int ABL = 0, bool GLO = false>      // CINIT: 0 zero, 1 pixel-major start values, 2 start values in the accumulator-tile
                                                                          // layout, 3 (STAGED = false) zero start, OUTPUT in that layout (out_f32 == 3)
+                                                                         // GLO (EPI_GRU_Q): the next iteration's global-context reduction behind the state update
 __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
   extern __shared__ __half s_conv[];
   DH_CTS(0); DH_CTS_ID();
@@ -1166,6 +1252,15 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
     return;
   }
   if constexpr (EPI == EPI_HEADS0) staged_heads0_epilogue(P, acc, s_conv, m0, n0, wm0, wn0, tid);
+  else if constexpr (GLO) {
+    // the staged tile [256 px][128 couts] ends up holding the NEW hidden state (every thread writes its finished pieces back), and the
+    // tail of glo_reduce_kernel runs on it in place: one 128 x 128 GEMM per tile (1 / 22.5 of the gate's own MFMA work), 64 sigmoids per
+    // lane on the vector pipe under the other resident workgroup's matrix work, one atomic per (workgroup, channel)
+    staged_epilogue<EPI, 2, 128, 512, true>(P, acc, s_conv, m0, n0, wm0, wn0, tid, HW);
+    half8 bf[2][4];                    // (requested only now: 32 more registers during the state update would spill)
+    glo_load_b0(P.glo_wt, 128, tid, bf);
+    glo_tile_reduce(P.glo_wt, 128, P.glo_bias, P.glo_red + (long)img * 128, s_conv, tid, bf);
+  }
   else if constexpr (STAGED) staged_epilogue<EPI, 2, 128>(P, acc, s_conv, m0, n0, wm0, wn0, tid, HW);
   else if constexpr (CINIT == 3) store_acc_tile(P, acc, m0, n0, wn0, wave, lane);      // the context term for the CINIT == 2 launches
   else conv_epilogue<EPI, 2, 2>(P, acc, (long)P.N * HW, m0, n0, wm0, wn0, lane, HW);
@@ -1303,9 +1398,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo4_kernel(ConvParams P) {
 // (chunk, dy) group there is 3 x 128 rows of 64 bytes, of which this kernel fetches rows 0 .. 63 of every dx.
 constexpr int H64B_BYTES = 3 * 64 * H2CK * 2;                 // 12,288: one (chunk, dy) weight group, 64 couts
 constexpr int H64_LDS_BYTES = H2A_BYTES + 2 * H64B_BYTES;     // 49,920 (the staged epilogue tile needs 36,864)
-template <int EPI>
+// Round 6 (option conv_gate64, off by default): the SAME kernel on 64-cout tiles of a layer with CoutPad % 128 == 0 -- the ConvGRU gates
+// (K = 320, 256 / 128 couts: four / two cout tiles per pixel tile, visited back to back on one XCD so that the halo re-reads are L2 hits)
+// with the GRU epilogues and the accumulator-tile start values (CINIT == 2), THREE workgroups per CU instead of conv3x3_halo2_kernel's
+// two: tile n0 fetches rows (n0 & 64) .. + 63 of every dx of cout tile n0 >> 7 of the halo2 weight layout, and its wave `wrow` holds
+// exactly the registers of conv3x3_halo2_kernel's wave wrow + 4 * ((n0 >> 6) & 1) -- same MFMAs in the same k order: bit-identical.
+template <int EPI, int CINIT = 0>
 __global__ __launch_bounds__(256, 3) void conv3x3_halo64_kernel(ConvParams P) {
   extern __shared__ __half s_conv[];
+  DH_CTS(0); DH_CTS_ID();
   char* const lds = reinterpret_cast<char*>(s_conv);
   const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)s_conv;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1324,7 +1425,8 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo64_kernel(ConvParams P) {
     *reinterpret_cast<uint4*>(lds + hp * 64 + aq * 16) = uint4{0u, 0u, 0u, 0u};
   }
   const int b_voff = lane * 16;
-  const char* const bsrc = reinterpret_cast<const char*>(P.wt_halo);           // one 128-cout tile in the halo2 layout
+  // 128-cout tile n0 >> 7 of the halo2 layout, rows (n0 & 64) .. + 63 of every dx (64 rows of 64 bytes = 4096)
+  const char* const bsrc = reinterpret_cast<const char*>(P.wt_halo) + (long)(n0 >> 7) * nsteps * H2B_BYTES + ((n0 >> 6) & 1) * 4096;
   const int pl = wrow * HCOLS + (lane & 31), kh = lane >> 5;
   int b_row[2], b_x[2];
 #pragma unroll
@@ -1333,7 +1435,8 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo64_kernel(ConvParams P) {
     b_row[b] = r * 64; b_x[b] = ((r >> 2) & 3) ^ kh;
   }
   f32x16 acc[2][2];
-  zero_acc<2, 2>(acc);
+  if constexpr (CINIT == 2) init_acc_tile_tiled(P, acc, m0, n0, wave + 4 * ((n0 >> 6) & 1), lane, HW);
+  else zero_acc<2, 2>(acc);
   u32x4 ra[A_PIECES];
 #define H64_FETCH_A(chunk_)                                                                                          \
   {                                                                                                                  \
@@ -1370,6 +1473,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo64_kernel(ConvParams P) {
   }
   H64_FETCH_A(0)
   H64_DMA_B(0)
+  DH_CTS(1);
   for (int c = 0; c < nchunks; ++c) {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     int ax_o = ax;
@@ -1386,6 +1490,8 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo64_kernel(ConvParams P) {
       // (vmcnt: the group of this step was requested one step ago; at dy == 1 the six halo loads of the next chunk are younger)
       if (dy == 1 && c + 1 < nchunks) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (step == 0) DH_CTS(2);
+      DH_CTS_STEP(step);
       if (step + 1 < nsteps) H64_DMA_B(step + 1)
       if (dy == 0 && c + 1 < nchunks) H64_FETCH_A(c + 1)
       const char* const Bcur = lds + H2A_BYTES + (step & 1) * H64B_BYTES;
@@ -1414,7 +1520,9 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo64_kernel(ConvParams P) {
 #undef H64_FETCH_A
 #undef H64_DMA_B
 #undef GLDS16S
+  DH_CTS(3);
   staged_epilogue<EPI, 2, 64, 256>(P, acc, s_conv, m0, n0, wm0, wn0, tid, HW);
+  DH_CTS(4);
 }
 
 #ifdef DH_ABLATION   // 512-pixel-tile form: measured equal in energy, slower in time (profiles/r04_d_conv_halo3_ab.json): not in release builds
@@ -1917,11 +2025,9 @@ __global__ __launch_bounds__(512, 1) void conv1x1_c128_kernel(ConvParams P) {
 // (Round 3 tried persistent workgroups -- one per CU, the next tile's loads issued under the current tile's MFMAs and gate
 // algebra, weights resident in 64 registers: 1.66 instead of 1.45 ms.  Two workgroups per CU overlapping each other's phases
 // beat one workgroup overlapping its own loads; kept as it was.)
-constexpr int GLD = 128 + 8;                          // LDS row stride (halves)
 __global__ __launch_bounds__(512, 4) void glo_reduce_kernel(ConvParams P) {
   extern __shared__ __half s_conv[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wrow = wave & 3, wn0 = (wave >> 2) * 64, wm0 = wrow * 64;
+  const int tid = threadIdx.x;
   const long m0 = (long)blockIdx.x * BM;
   const int HW = P.H * P.W;
   const int img = (int)(m0 / HW);
@@ -1931,70 +2037,14 @@ __global__ __launch_bounds__(512, 4) void glo_reduce_kernel(ConvParams P) {
     const int id = tid + 512 * i;
     ra[i] = *reinterpret_cast<const uint4*>(P.in[0] + (m0 + (id >> 4)) * P.segS[0] + (id & 15) * 8);
   }
-  const int p = lane & 31, kh = lane >> 5;
   half8 bf[2][4];
-  auto load_b = [&](int half) {
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-        bf[b][ks] = *reinterpret_cast<const half8*>(P.wt + (long)(wn0 + b * 32 + p) * P.Kpad + (half * 4 + ks) * 16 + kh * 8);
-  };
-  load_b(0);
+  glo_load_b0(P.wt, P.Kpad, tid, bf);
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int id = tid + 512 * i;
     *reinterpret_cast<uint4*>(s_conv + (id >> 4) * GLD + (id & 15) * 8) = ra[i];
   }
-  f32x16 acc[2][2];
-  zero_acc<2, 2>(acc);
-  __syncthreads();
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      half8 af[2];
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-        af[a] = *reinterpret_cast<const half8*>(s_conv + (wm0 + a * 32 + p) * GLD + (half * 4 + ks) * 16 + kh * 8);
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b][ks], acc[a][b], 0, 0, 0);
-    }
-    if (half == 0) load_b(1);
-  }
-  // gate * feature, summed over the wave's 64 pixels per cout (same roundings as conv_epilogue's EPI_GLO)
-  float sum[2];
-#pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const int co = wn0 + b * 32 + p;
-    const float bias = P.bias[co];
-    float t = 0.f;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int q = 0; q < 16; q += 2) {
-        if ((q & 7) == 0) __builtin_amdgcn_sched_barrier(0);      // (keeps the 32 LDS reads from being hoisted in one block: spills)
-        // two rows at a time: the gate values rounded to fp16 as a pair, the products as ONE packed fp16 multiply (the
-        // exact product of two fp16 numbers has 22 significant bits, so rounding it from fp32 or inside v_pk_mul_f16 is the
-        // same single rounding), their fp32 sum as one v_dot2 against (1, 1)
-        const int row = wm0 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh;
-        const half2v g = {(_Float16)sigmoidf_(acc[a][b][q] + bias), (_Float16)sigmoidf_(acc[a][b][q + 1] + bias)};
-        const half2v n = {__builtin_bit_cast(_Float16, s_conv[row * GLD + co]), __builtin_bit_cast(_Float16, s_conv[(row + 1) * GLD + co])};
-        t = __builtin_amdgcn_fdot2(g * n, half2v{(_Float16)1.f, (_Float16)1.f}, t, false);
-      }
-    sum[b] = t + __shfl_xor(t, 32, 64);
-  }
-  __syncthreads();                                    // the tile is dead: its head becomes [8 waves][64] partial sums
-  float* sR = reinterpret_cast<float*>(s_conv);
-  if (lane < 32) { sR[wave * 64 + p] = sum[0]; sR[wave * 64 + 32 + p] = sum[1]; }
-  __syncthreads();
-  if (tid < 128) {
-    const int hb = tid >> 6, c = tid & 63;            // cout half -> waves 4*hb .. 4*hb+3
-    const float t = (sR[(hb * 4 + 0) * 64 + c] + sR[(hb * 4 + 1) * 64 + c]) + (sR[(hb * 4 + 2) * 64 + c] + sR[(hb * 4 + 3) * 64 + c]);
-    atomicAdd(&P.red[(long)img * P.Cout + tid], t);
-  }
+  glo_tile_reduce(P.wt, P.Kpad, P.bias, P.red + (long)img * P.Cout, s_conv, tid, bf);
 }
 
 // mean over the rows of each segment (GraphAgg's scatter_mean over the edges of a source frame, reference
@@ -2107,6 +2157,21 @@ int launch_halo2(const ConvParams& P0, hipStream_t st) {
       return DH_OK;
     }
   }
+  if constexpr (EPI == EPI_GRU_Q) {
+    if (P.glo_red) {                                      // + the next iteration's global-context reduction (ConvParams::glo_red)
+#define H2_GLO(ci_)                                                                                                  \
+      {                                                                                                              \
+        DH_LDS_OPTIN((&conv3x3_halo2_kernel<EPI, true, ci_, 0, true>), 80 * 1024);                                   \
+        hipLaunchKernelGGL((conv3x3_halo2_kernel<EPI, true, ci_, 0, true>), grid, dim3(512), H2_LDS_BYTES, st, P);   \
+        DH_LAUNCH_CHECK();                                                                                           \
+        return DH_OK;                                                                                                \
+      }
+      if (P.cinit && P.cinit_stride < 0) H2_GLO(2)
+      if (P.cinit) H2_GLO(1)
+      H2_GLO(0)
+#undef H2_GLO
+    }
+  }
   if constexpr (EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q) {
     if (P.cinit && P.cinit_stride < 0) {                  // start values in the accumulator-tile layout
       DH_LDS_OPTIN((&conv3x3_halo2_kernel<EPI, true, 2>), 80 * 1024);
@@ -2188,6 +2253,32 @@ int launch_halo64(const ConvParams& P0, hipStream_t st) {
   dim3 grid((unsigned)(M / BM), 1);
   P.ny = 1;
   if (opts().conv_xcd) { P.xcd_tiles = (int)((grid.x + 7) / 8); grid = dim3((unsigned)P.xcd_tiles * 8, 1); }
+  hipLaunchKernelGGL((conv3x3_halo64_kernel<EPI>), grid, dim3(256), H64_LDS_BYTES, st, P);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
+// conv_gate64 (bit 0: the gate epilogues, bit 1: relu / linear / sigmoid layers): a layer that conv3x3_halo2_kernel would take, run on
+// 64-cout tiles by conv3x3_halo64_kernel at three workgroups per CU.  Same eligibility as halo2_ok (the halo2 weight layout, W == 64,
+// H % 4 == 0, 32-channel segments, staged epilogue); start values only in the accumulator-tile layout.
+template <int EPI>
+bool gate64_ok(const ConvParams& P);
+
+template <int EPI>
+int launch_gate64(const ConvParams& P0, hipStream_t st) {
+  ConvParams P = P0;
+  const long M = (long)P.N * P.H * P.W;
+  dim3 grid((unsigned)(M / BM), (unsigned)(P.CoutPad / 64));
+  P.ny = (int)grid.y;
+  if (opts().conv_xcd) { P.xcd_tiles = (int)((grid.x + 7) / 8); grid = dim3((unsigned)P.xcd_tiles * 8 * grid.y, 1); }
+  if (P.cinit) {
+    if constexpr (EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q) {
+      hipLaunchKernelGGL((conv3x3_halo64_kernel<EPI, 2>), grid, dim3(256), H64_LDS_BYTES, st, P);
+      DH_LAUNCH_CHECK();
+      return DH_OK;
+    }
+    return DH_ERR_UNSUPPORTED;
+  }
   hipLaunchKernelGGL((conv3x3_halo64_kernel<EPI>), grid, dim3(256), H64_LDS_BYTES, st, P);
   DH_LAUNCH_CHECK();
   return DH_OK;
@@ -2275,6 +2366,14 @@ bool halo2_ok(const ConvParams& P) {
   if (P.cinit && EPI != EPI_GRU_ZR && EPI != EPI_GRU_Q) return false;
   if (EPI == EPI_LINEAR && P.out_f32) return true;          // per-element fp32 stores (launch_halo2)
   return staged_epilogue_ok<EPI>(P);
+}
+
+template <int EPI>
+bool gate64_ok(const ConvParams& P) {
+  const int want = (EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q) ? 1 : 2;
+  if (!(opts().conv_gate64 & want) || P.out_f32 || P.glo_red) return false;       // (the fused global-context reduction needs all 128 channels in one workgroup)
+  if (P.cinit && P.cinit_stride >= 0) return false;
+  return halo2_ok<EPI>(P);
 }
 
 // Layout rule of `weights_halo` (the same rule is applied by the packer, droid_amd/update.py pack_conv_halo): 16-channel
@@ -2546,7 +2645,21 @@ extern "C" int dh_conv2d_nhwc_f16_ex2(const void* const* inputs, const int* in_c
                                       const float* gterm, const void* aux0, int aux0_stride, const void* aux1, int aux1_stride,
                                       float* red, const float* cinit, const int64_t* cinit_idx, int cinit_stride, int cinit_off,
                                       dh_stream_t stream) {
+  return dh_conv2d_nhwc_f16_ex3(inputs, in_channels, in_strides, n_inputs, weights, weights_halo, weights_layout, bias, N, H, W, KH, KW,
+                                Cout, CoutPad, Kpad, epilogue, out, out_is_f32, out_stride, gterm, aux0, aux0_stride, aux1, aux1_stride, red,
+                                cinit, cinit_idx, cinit_stride, cinit_off, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int dh_conv2d_nhwc_f16_ex3(const void* const* inputs, const int* in_channels, const int* in_strides, int n_inputs,
+                                      const void* weights, const void* weights_halo, int weights_layout, const float* bias,
+                                      int N, int H, int W, int KH, int KW, int Cout, int CoutPad, int Kpad, int epilogue,
+                                      void* out, int out_is_f32, int out_stride,
+                                      const float* gterm, const void* aux0, int aux0_stride, const void* aux1, int aux1_stride,
+                                      float* red, const float* cinit, const int64_t* cinit_idx, int cinit_stride, int cinit_off,
+                                      const void* glo_weights, const float* glo_bias, float* glo_red,
+                                      dh_stream_t stream) {
   if (weights_layout != DH_CONV_LAYOUT_AUTO && weights_layout != DH_CONV_LAYOUT_WINO) return DH_ERR_ARG;
+  if (glo_red && (epilogue != EPI_GRU_Q || !glo_weights || !glo_bias || Cout != 128 || CoutPad != 128 || ((uintptr_t)glo_weights) % 16)) return DH_ERR_ARG;
   if (n_inputs < 1 || n_inputs > MAXSEG || !inputs || !in_channels || !weights || !bias) return DH_ERR_ARG;
   if (N < 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0 || !(KH & 1) || !(KW & 1)) return DH_ERR_ARG;
   if (Cout <= 0 || CoutPad < Cout || CoutPad % 32 || Kpad <= 0 || Kpad % BK) return DH_ERR_ARG;
@@ -2581,7 +2694,8 @@ extern "C" int dh_conv2d_nhwc_f16_ex2(const void* const* inputs, const int* in_c
   P.out = out; P.out_f32 = out_is_f32; P.out_stride = out_stride;
 #ifdef DH_ABLATION
   {
-    const long nwg = ((long)N * H * W / 256) * ((CoutPad + 127) / 128);
+    const int ct = (opts().conv_gate64 && KH == 3 && CoutPad % 128 == 0) ? 64 : 128;      // (conv_gate64: 64-cout tiles, launch_gate64)
+    const long nwg = ((long)N * H * W / 256) * ((CoutPad + ct - 1) / ct);
     P.ts = nwg <= g_conv_ts_cap ? g_conv_ts : nullptr;
     // per-step stamps of 256 workgroups from the middle of the launch, in the 2048 rows behind the per-workgroup block
     P.ts_step = (P.ts && nwg + 2048 <= g_conv_ts_cap) ? g_conv_ts + nwg * 8 : nullptr;
@@ -2590,13 +2704,20 @@ extern "C" int dh_conv2d_nhwc_f16_ex2(const void* const* inputs, const int* in_c
 #endif
   P.gterm = gterm; P.aux0 = (const __half*)aux0; P.aux0_stride = aux0_stride;
   P.aux1 = (const __half*)aux1; P.aux1_stride = aux1_stride; P.red = red;
+  P.glo_wt = (const __half*)glo_weights; P.glo_bias = glo_bias; P.glo_red = glo_red;
   hipStream_t st = (hipStream_t)stream;
+  if (P.glo_red) {                                           // the fused reduction exists in conv3x3_halo2_kernel's q-gate form only
+    if (weights_layout != DH_CONV_LAYOUT_AUTO || !halo2_ok<EPI_GRU_Q>(P)) return DH_ERR_UNSUPPORTED;
+    return launch_halo2<EPI_GRU_Q>(P, st);
+  }
   if ((P.cinit && P.cinit_stride < 0) || P.out_f32 == 3) {    // accumulator-tile layout: conv3x3_halo2_kernel only (writer and reader share its tiling)
     if (weights_layout != DH_CONV_LAYOUT_AUTO) return DH_ERR_UNSUPPORTED;
     switch (P.epi) {
       case EPI_LINEAR: if (P.out_f32 == 3 && !P.cinit && halo2_ok<EPI_LINEAR>(P)) return launch_halo2<EPI_LINEAR>(P, st); break;
-      case EPI_GRU_ZR: if (P.out_f32 != 3 && halo2_ok<EPI_GRU_ZR>(P)) return launch_halo2<EPI_GRU_ZR>(P, st); break;
-      case EPI_GRU_Q: if (P.out_f32 != 3 && halo2_ok<EPI_GRU_Q>(P)) return launch_halo2<EPI_GRU_Q>(P, st); break;
+      case EPI_GRU_ZR: if (P.out_f32 != 3 && gate64_ok<EPI_GRU_ZR>(P)) return launch_gate64<EPI_GRU_ZR>(P, st);
+                       if (P.out_f32 != 3 && halo2_ok<EPI_GRU_ZR>(P)) return launch_halo2<EPI_GRU_ZR>(P, st); break;
+      case EPI_GRU_Q: if (P.out_f32 != 3 && gate64_ok<EPI_GRU_Q>(P)) return launch_gate64<EPI_GRU_Q>(P, st);
+                      if (P.out_f32 != 3 && halo2_ok<EPI_GRU_Q>(P)) return launch_halo2<EPI_GRU_Q>(P, st); break;
       default: break;
     }
     return DH_ERR_UNSUPPORTED;
@@ -2650,6 +2771,16 @@ extern "C" int dh_conv2d_nhwc_f16_ex2(const void* const* inputs, const int* in_c
     }
   }
 #endif
+  if (opts().conv_gate64) {                                  // 64-cout tiles, three workgroups per CU (A/B switch, see launch_gate64)
+    switch (P.epi) {
+      case EPI_LINEAR: if (gate64_ok<EPI_LINEAR>(P)) return launch_gate64<EPI_LINEAR>(P, st); break;
+      case EPI_RELU: if (gate64_ok<EPI_RELU>(P)) return launch_gate64<EPI_RELU>(P, st); break;
+      case EPI_SIGMOID: if (gate64_ok<EPI_SIGMOID>(P)) return launch_gate64<EPI_SIGMOID>(P, st); break;
+      case EPI_GRU_ZR: if (gate64_ok<EPI_GRU_ZR>(P)) return launch_gate64<EPI_GRU_ZR>(P, st); break;
+      case EPI_GRU_Q: if (gate64_ok<EPI_GRU_Q>(P)) return launch_gate64<EPI_GRU_Q>(P, st); break;
+      default: break;
+    }
+  }
   switch (P.epi) {
     case EPI_LINEAR: if (halo2_ok<EPI_LINEAR>(P)) return launch_halo2<EPI_LINEAR>(P, st); break;
     case EPI_RELU: if (halo2_ok<EPI_RELU>(P)) return launch_halo2<EPI_RELU>(P, st); break;

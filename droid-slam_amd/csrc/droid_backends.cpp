@@ -587,7 +587,8 @@ void conv2d_nhwc(std::vector<torch::Tensor> inputs, torch::Tensor weight, c10::o
                  int64_t Cout, int64_t epilogue, c10::optional<torch::Tensor> out, int64_t out_stride,
                  c10::optional<torch::Tensor> gterm, c10::optional<torch::Tensor> aux0, c10::optional<torch::Tensor> aux1,
                  c10::optional<torch::Tensor> red, c10::optional<torch::Tensor> cinit, c10::optional<torch::Tensor> cinit_idx,
-                 int64_t cinit_off, bool out_raw_f32, int64_t weights_layout, bool out_tiled, bool cinit_tiled) {
+                 int64_t cinit_off, bool out_raw_f32, int64_t weights_layout, bool out_tiled, bool cinit_tiled,
+                 c10::optional<torch::Tensor> glo_weight, c10::optional<torch::Tensor> glo_bias, c10::optional<torch::Tensor> glo_red) {
   TORCH_CHECK(!inputs.empty() && inputs.size() <= 4, "conv2d_nhwc: 1..4 inputs");
   const void* ptrs[4]; int chans[4], strides[4];
   const int64_t N = inputs[0].size(0), H = inputs[0].size(1), W = inputs[0].size(2);
@@ -626,13 +627,22 @@ void conv2d_nhwc(std::vector<torch::Tensor> inputs, torch::Tensor weight, c10::o
   }
   TORCH_CHECK(!out_raw_f32 || out_f32, "conv2d_nhwc: out_raw_f32 needs a float32 output");
   TORCH_CHECK(!out_tiled || (out_f32 && out_raw_f32), "conv2d_nhwc: out_tiled needs a raw float32 output");
-  check_status(dh_conv2d_nhwc_f16_ex2(ptrs, chans, strides, (int)inputs.size(), weight.data_ptr(), opt_ptr(weight_halo), (int)weights_layout, bias.data_ptr<float>(),
+  const void* gw = nullptr; const float* gb = nullptr; float* gr = nullptr;
+  if (glo_red.has_value()) {          // the next iteration's global-context reduction behind the q gate (dh_conv2d_nhwc_f16_ex3)
+    TORCH_CHECK(glo_weight.has_value() && glo_bias.has_value(), "conv2d_nhwc: glo_red needs glo_weight and glo_bias");
+    const torch::Tensor& w = *glo_weight; const torch::Tensor& b = *glo_bias; const torch::Tensor& r = *glo_red;
+    CHECK_INPUT(w); CHECK_INPUT(b); CHECK_F32(b); CHECK_INPUT(r); CHECK_F32(r);
+    TORCH_CHECK(w.scalar_type() == torch::kFloat16 && w.dim() == 2 && w.size(0) == 128 && w.size(1) == 128 && b.numel() == 128 &&
+                r.dim() == 2 && r.size(0) == N && r.size(1) == 128, "conv2d_nhwc: glo_weight [128,128] f16, glo_bias [128] f32, glo_red [N,128] f32");
+    gw = w.data_ptr(); gb = b.data_ptr<float>(); gr = r.data_ptr<float>();
+  }
+  check_status(dh_conv2d_nhwc_f16_ex3(ptrs, chans, strides, (int)inputs.size(), weight.data_ptr(), opt_ptr(weight_halo), (int)weights_layout, bias.data_ptr<float>(),
                                      (int)N, (int)H, (int)W, (int)KH, (int)KW, (int)Cout, (int)weight.size(0), (int)weight.size(1),
                                      (int)epilogue, opt_ptr(out), out_f32 ? (out_tiled ? 3 : out_raw_f32 ? 2 : 1) : 0, (int)out_stride,
                                      gterm.has_value() ? gterm->data_ptr<float>() : nullptr,
                                      opt_ptr(aux0), last(aux0), opt_ptr(aux1), last(aux1),
                                      red.has_value() ? red->data_ptr<float>() : nullptr, ci, cidx, cstride, (int)cinit_off,
-                                     cur_stream()),
+                                     gw, gb, gr, cur_stream()),
                "conv2d_nhwc");
 }
 
@@ -824,7 +834,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         py::arg("inputs"), py::arg("weight"), py::arg("weight_halo"), py::arg("bias"), py::arg("KH"), py::arg("KW"), py::arg("Cout"),
         py::arg("epilogue"), py::arg("out"), py::arg("out_stride"), py::arg("gterm"), py::arg("aux0"), py::arg("aux1"), py::arg("red"),
         py::arg("cinit") = py::none(), py::arg("cinit_idx") = py::none(), py::arg("cinit_off") = 0, py::arg("out_raw_f32") = false,
-        py::arg("weights_layout") = 0, py::arg("out_tiled") = false, py::arg("cinit_tiled") = false);
+        py::arg("weights_layout") = 0, py::arg("out_tiled") = false, py::arg("cinit_tiled") = false,
+        py::arg("glo_weight") = py::none(), py::arg("glo_bias") = py::none(), py::arg("glo_red") = py::none());
   m.def("conv_set_timestamps", [](c10::optional<torch::Tensor> buf) {
     if (buf.has_value() && buf->defined()) {
       CHECK_INPUT((*buf));

@@ -39,6 +39,8 @@ Options& opts() {
     v.conv_halo4 = env_int("DH_CONV_HALO4", 0);
     v.conv_halo64 = env_int("DH_CONV_HALO64", 1);
     v.cinit_tiled = env_int("DH_CINIT_TILED", 1);
+    v.conv_gate64 = env_int("DH_CONV_GATE64", 0);
+    v.glo_fused = env_int("DH_GLO_FUSED", 1);
 #ifndef DH_ABLATION
     // release build: the prototype / timing-ablation kernels are not compiled in; a stray environment variable cannot
     // select a variant that returns wrong results (lookup_mode 2-5) or does not exist
@@ -94,6 +96,8 @@ static int* slot(const char* name) {
   if (!strcmp(name, "conv_halo4")) return &o.conv_halo4;
   if (!strcmp(name, "conv_halo64")) return &o.conv_halo64;
   if (!strcmp(name, "cinit_tiled")) return &o.cinit_tiled;
+  if (!strcmp(name, "conv_gate64")) return &o.conv_gate64;
+  if (!strcmp(name, "glo_fused")) return &o.glo_fused;
   return nullptr;
 }
 

@@ -41,6 +41,7 @@ class FactorGraph:
         self.ii = torch.zeros(0, **lt); self.jj = torch.zeros(0, **lt); self.age = torch.zeros(0, **lt)
         self.corr = None
         self._net = None                                              # [E,h,w,128] fp16, channel-last
+        self._glo = None                                              # (the _net object, its global-context sums [E,128] f32): see _operator
         self.damping = 1e-6 * torch.ones_like(self.video.disps)
         self.target = torch.zeros(1, 0, ht, wd, 2, device=self.device)
         self.weight = torch.zeros(1, 0, ht, wd, 2, device=self.device)
@@ -101,6 +102,7 @@ class FactorGraph:
     # ---- reference-shaped views of the channel-last state ---------------------------------------------------------
     @property
     def net(self):
+        self._glo = None        # (a caller holding this view may write through it: the sums kept for the next iteration are dropped)
         return None if self._net is None else self._net.permute(0, 3, 1, 2)[None]        # [1,E,128,h,w]
 
     @property
@@ -191,8 +193,16 @@ class FactorGraph:
         """motion features + update operator on a set of edges -> (dw [E,h,w,4], damping [K,h,w], upmask, uniq)"""
         flow = db.motion_features(coords1, target_prev)
         uniq, ix, inp_frames, ctx = self._context(ii)
+        # Round 6: the ConvGRU's global-context reduction of the state this call writes is computed inside its q-gate launch and handed
+        # to the NEXT call on the same tensor (gru.py:23-24 reads what gru.py:31 wrote).  The pair (tensor object, sums) is only reused
+        # while `net` IS that object: every edit of the edge set replaces self._net (cat / mask indexing in _append_factors / _drop_state),
+        # and nothing but the operator writes into it in place; chunk views (update_lowmem) are new objects and never match.
+        chain = net is self._net and hasattr(self.update_op, "fuses_next_glo")        # (an operator object without the extension: plain call)
+        glo = self._glo[1] if (chain and self._glo is not None and self._glo[0] is net) else None
+        kw = dict(glo_red=glo, glo_next=True) if chain else {}
         _, _, _, damping, upmask = self.update_op.forward_nhwc(net, None, feats, flow, ii, inp_frames=inp_frames, inp_index=ix, ctx=ctx,
-                                                               corr0=corr0)
+                                                               corr0=corr0, **kw)
+        self._glo = (net, self.update_op.last_glo) if (chain and self.update_op.last_glo is not None) else None
         return self.update_op.last_dw, damping, upmask, uniq
 
     def _pyramid_features(self, block, coords1):

@@ -214,10 +214,12 @@ class _Conv:
             self._epoch = epoch
 
     def __call__(self, inputs, epi, out=None, out_stride=None, gterm=None, aux0=None, aux1=None, red=None,
-                 cinit=None, cinit_idx=None, cinit_off=0, out_raw_f32=False, out_tiled=False):
+                 cinit=None, cinit_idx=None, cinit_off=0, out_raw_f32=False, out_tiled=False, glo=None):
         """out_tiled (with out_raw_f32): the fp32 output in the accumulator-tile layout of csrc/conv.hip (ConvParams::cinit_stride < 0),
         returned as [N, h*w/256 pixel tiles, cout/128 cout tiles, 32768 floats per tile] (frame-major: slices of whole frames stay
-        valid); a `cinit` tensor of that shape is read back in that layout"""
+        valid); a `cinit` tensor of that shape is read back in that layout.
+        glo = (weight [128,128] f16, bias [128] f32, red [N,128] f32 zeroed), EPI_GRU_Q only: the next iteration's global-context
+        reduction on the new hidden state, fused behind the gate (dh_conv2d_nhwc_f16_ex3)"""
         self._check_layout()
         x0 = inputs[0]
         if out is None and out_tiled:
@@ -229,7 +231,8 @@ class _Conv:
         stride = 0 if out is None else (self.cout if out_tiled else out.shape[-1] if out_stride is None else out_stride)
         cinit_tiled = cinit is not None and cinit.dim() == 4 and cinit.shape[-1] == 32768 and cinit.shape[1] * 256 == x0.shape[1] * x0.shape[2]
         droid_backends.conv2d_nhwc(list(inputs), self.w, self.wh, self.b, self.k, self.k, self.cout, epi, out, stride,
-                                   gterm, aux0, aux1, red, cinit, cinit_idx, cinit_off, out_raw_f32, self.layout, out_tiled, cinit_tiled)
+                                   gterm, aux0, aux1, red, cinit, cinit_idx, cinit_off, out_raw_f32, self.layout, out_tiled, cinit_tiled,
+                                   *(glo if glo is not None else (None, None, None)))
         return out
 
 
@@ -269,6 +272,7 @@ class UpdateModule:
         self.device = torch.device(device)
         self.params = None
         self.last_dw = None
+        self.last_glo = None                   # forward_nhwc(glo_next=True): the new hidden state's global-context sums [E,128] f32
         # image sizes outside the production tiling of csrc/conv.hip (64-pixel rows, four-row tiles) run on a zero-padded
         # 64-column canvas through the SAME kernels (forward_nhwc); False = the generic implicit-GEMM loop on the image itself
         self.canvas = canvas
@@ -410,7 +414,16 @@ class UpdateModule:
             self._seg_key, self._seg = key, (order, seg_off, ii)       # (ii kept alive: its address is part of the key)
         return self._seg[0], self._seg[1]
 
-    def forward_nhwc(self, net, inp, corr, flow, ii, inp_frames=None, inp_index=None, ctx=None, corr0=None, _mask=None):
+    def fuses_next_glo(self, h, w):
+        """True where forward_nhwc(glo_next=True) computes the next iteration's global-context reduction inside the q gate's launch
+        (the production 3x3 kernel on a 64-column image with staged epilogues; not on canvases, whose padding is re-zeroed after the gate)"""
+        P = self.params
+        return bool(w == 64 and h % 4 == 0 and droid_backends.get_option("conv_halo") == 1 and droid_backends.get_option("conv_halo2") == 1
+                    and droid_backends.get_option("conv_epi_staged") == 1 and droid_backends.get_option("glo_fused") == 1
+                    and P["q_e"].layout == LAYOUT_AUTO and P["q_e"].wh is not None and P["q"].wh is not None)
+
+    def forward_nhwc(self, net, inp, corr, flow, ii, inp_frames=None, inp_index=None, ctx=None, corr0=None, _mask=None,
+                     glo_red=None, glo_next=False):
         """net [E,h,w,128] f16 (updated IN PLACE), corr = [E,196,h,w] f16 in the reference's layout (pixel counts that are a
         multiple of 128) or [4,E,h,w,56] f16, the level-planar channel-last output of
         droid_backends.corr_pyramid_lookup_nhwc (channel order: corr_channel_map), flow [E,h,w,8] f16 (4 + zero pad),
@@ -421,9 +434,16 @@ class UpdateModule:
             of one per-frame convolution (`context_term`, passed in as `ctx` [K',h,w,384] f32 if the caller keeps it).
         corr0 [E,h,w,128] f16 (then corr is ignored): the output of the correlation encoder's first layer, as
         CorrBlock.lookup_corr0 produces it inside the lookup kernel.
+        Round 6, the global-context reduction across iterations (gru.py:23-24 reads the state the previous iteration wrote):
+          glo_next = True: the q gate's launch also reduces the NEW hidden state (csrc/conv.hip ConvParams::glo_red); the sums are left in
+            self.last_glo ([E,128] f32, or None where fuses_next_glo() is False);
+          glo_red = those sums, handed back by a caller that KNOWS `net` is still the tensor the previous call wrote (FactorGraph keeps the
+            pair together): the stand-alone reduction -- a pass over the whole hidden state -- is then not launched.  Same values up to the
+            order of the per-tile atomics, which is not fixed in either form.
         -> (net, delta [E,h,w,2] f32, weight [E,h,w,2] f32, eta [K,h,w] f32, upmask [K,h,w,576] f16)."""
         P = self.params
         E, h, w, _ = net.shape
+        self.last_glo = None
         if self.canvas and not (w == 64 and h % 4 == 0) and w <= 64 and _mask is None:
             return self._forward_canvas(net, inp, corr, flow, ii, inp_frames, inp_index, corr0)
         if self.canvas and w > 64 and h <= 64 and _mask is None:
@@ -444,8 +464,11 @@ class UpdateModule:
             f = mk(P["flow2"]([mk(P["flow0"]([flow], EPI_RELU))], EPI_RELU))
         with _Fork(side[1], main) as gb:
             # global context: mean over pixels of sigmoid(w(net)) * net, then three 128x128 GEMVs per edge
-            red = torch.zeros(E, 128, dtype=torch.float32, device=net.device)
-            P["gru_w"]([net], EPI_GLO, aux0=net, red=red)
+            if glo_red is not None and _mask is None:
+                red = glo_red
+            else:
+                red = torch.zeros(E, 128, dtype=torch.float32, device=net.device)
+                P["gru_w"]([net], EPI_GLO, aux0=net, red=red)
             gzr = droid_backends.glo_gemv(red, P["glo_zr_t"][0], P["glo_zr_t"][1], 1.0 / npix)     # [E,256] z | r
             gq = droid_backends.glo_gemv(red, P["glo_q_t"][0], P["glo_q_t"][1], 1.0 / npix)        # [E,128]
             if inp is None and ctx is None:
@@ -453,13 +476,17 @@ class UpdateModule:
         c = mk(P["corr2"]([mk(c0)], EPI_RELU))
         fb.join(f)
         gb.join(gzr, gq, ctx)
+        glo = None
+        if glo_next and _mask is None and self.fuses_next_glo(h, w):
+            self.last_glo = torch.zeros(E, 128, dtype=torch.float32, device=net.device)
+            glo = (P["gru_w"].w, P["gru_w"].b, self.last_glo)
         if inp is not None:
             zr = P["zr"]([net, inp, c, f], EPI_GRU_ZR, gterm=gzr, aux0=net)             # [E,h,w,256] = z | r*net
-            P["q"]([zr[..., 128:], inp, c, f], EPI_GRU_Q, out=net, gterm=gq, aux0=net, aux1=zr)
+            P["q"]([zr[..., 128:], inp, c, f], EPI_GRU_Q, out=net, gterm=gq, aux0=net, aux1=zr, glo=glo)
         else:
             zr = P["zr_e"]([net, c, f], EPI_GRU_ZR, gterm=gzr, aux0=net, cinit=ctx, cinit_idx=inp_index, cinit_off=0)
             P["q_e"]([zr[..., 128:], c, f], EPI_GRU_Q, out=net, gterm=gq, aux0=net, aux1=zr,
-                     cinit=ctx, cinit_idx=inp_index, cinit_off=256)
+                     cinit=ctx, cinit_idx=inp_index, cinit_off=256, glo=glo)
         mk(net)
         with _Fork(side[0], main) as ab:
             # GraphAgg: conv -> mean over the edges of each source frame -> conv -> eta / upmask

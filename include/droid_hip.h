@@ -375,6 +375,23 @@ int dh_conv2d_nhwc_f16_ex2(const void* const* inputs, const int* in_channels, co
                           const float* gterm, const void* aux0, int aux0_stride, const void* aux1, int aux1_stride,
                           float* red, const float* cinit, const int64_t* cinit_idx, int cinit_stride, int cinit_off,
                           dh_stream_t stream);
+/* Round 6: the same, with the NEXT iteration's global-context reduction of the ConvGRU fused behind the q gate (epilogue 4 only).
+ * The reference's ConvGRU.forward begins with glo = mean_px(sigmoid(w(net)) * net) (droid_slam/modules/gru.py:23-24) on the hidden state
+ * the previous iteration's last statement wrote (gru.py:31: net = (1-z) * net + z * q).  With glo_red != NULL the q-gate launch, whose
+ * workgroups hold the new state of their 256 pixels x 128 channels in LDS, also adds
+ *     glo_red[image][c] += sum over the tile's pixels of fp16(fp16(sigmoid(glo_weights[c] . net' + glo_bias[c])) * net'[c])
+ * (glo_weights [128][128] f16, k contiguous = the packed 1x1 layer `gru.w`; glo_bias [128] f32; glo_red [N][128] f32, zeroed by the caller)
+ * -- exactly what epilogue 5 (EPI_GLO) computes from HBM on the same values, so that the next iteration's standalone reduction (3.2 GB of
+ * reads at 4096 edges) is not launched.  Cout == CoutPad == 128; production 3x3 kernel only (W == 64, H % 4 == 0, 32-channel segments,
+ * staged epilogue), DH_ERR_UNSUPPORTED elsewhere; glo_red == NULL: dh_conv2d_nhwc_f16_ex2. */
+int dh_conv2d_nhwc_f16_ex3(const void* const* inputs, const int* in_channels, const int* in_strides, int n_inputs,
+                          const void* weights, const void* weights_halo, int weights_layout, const float* bias,
+                          int N, int H, int W, int KH, int KW, int Cout, int CoutPad, int Kpad, int epilogue,
+                          void* out, int out_is_f32, int out_stride,
+                          const float* gterm, const void* aux0, int aux0_stride, const void* aux1, int aux1_stride,
+                          float* red, const float* cinit, const int64_t* cinit_idx, int cinit_stride, int cinit_off,
+                          const void* glo_weights, const float* glo_bias, float* glo_red,
+                          dh_stream_t stream);
 
 /* Measurement hook (-DDH_ABLATION builds; DH_ERR_UNSUPPORTED in the shipped library): per-workgroup phase timestamps of the 3x3
  * convolution kernels -- 8 x uint64 per workgroup: 100 MHz wall clock at kernel entry / first fetches issued / first barrier passed /

@@ -23,6 +23,8 @@ from oracle import update as oupd          # (shape template of the state dict o
 ap = argparse.ArgumentParser()
 ap.add_argument("--edges", type=int, default=1024)
 ap.add_argument("--out", default=None)
+ap.add_argument("--gate64", action="store_true", help="round 6: the product form against the SAME launches on 64-cout tiles at three workgroups "
+                "per CU (conv3x3_halo64_kernel, option conv_gate64) instead of against the 512-pixel form")
 a = ap.parse_args()
 E, K, h, w = a.edges, max(1, a.edges // 8), 48, 64
 
@@ -44,7 +46,7 @@ ctx_pm = upd.context_term(inp_frames, tiled=False)          # pixel-major [K,h,w
 ctx_tl = upd.context_term(inp_frames, tiled=True)           # accumulator-tile layout (round 5 default)
 gzr = torch.randn(E, 256, device="cuda") * 0.1
 zr = torch.empty(E, h, w, 256, device="cuda", dtype=torch.float16)
-nwg = (E * h * w // 256) * 2
+nwg = (E * h * w // 256) * (4 if a.gate64 else 2)
 buf = torch.zeros(nwg + 2048, 8, dtype=torch.int64, device="cuda")          # + 256 workgroups x 64 per-step stamps
 
 
@@ -82,8 +84,11 @@ def analyse(t, n):
 
 
 res = {"edges": E, "what": __doc__.split("\n\n")[0], "cases": []}
-for halo3 in (0, 1):
+for variant in (0, 1):
+    halo3 = variant if not a.gate64 else 0
+    gate64 = variant if a.gate64 else 0
     db.set_option("conv_halo3", halo3)
+    db.set_option("conv_gate64", 3 if gate64 else 0)
     upd = UpdateModule("cuda").load_state_dict(deterministic_state_dict(_SD(), seed=7)); P = upd.params       # (weights packed under the option)
     cases = {"relu (bare convolution, plain staged epilogue)": lambda: P["zr_e"]([net, c, f], EPI_RELU, out=zr),
              "gru (GRU epilogue, accumulators from zero)": lambda: P["zr_e"]([net, c, f], EPI_GRU_ZR, out=zr, gterm=gzr, aux0=net),
@@ -97,7 +102,11 @@ for halo3 in (0, 1):
         cases["q: relu (bare convolution 320 -> 128)"] = lambda: P["q_e"]([zr_in[..., 128:], c, f], EPI_RELU, out=outq)
         cases["q: gru (tanh + state update, accumulators from zero)"] = lambda: P["q_e"]([zr_in[..., 128:], c, f], EPI_GRU_Q, out=outq, gterm=gq, aux0=net, aux1=zr_in)
         cases["q: gru+cinit, accumulator-tile context term (the product's q launch)"] = lambda: P["q_e"]([zr_in[..., 128:], c, f], EPI_GRU_Q, out=outq, gterm=gq, aux0=net, aux1=zr_in, cinit=ctx_tl, cinit_idx=idx, cinit_off=256)
-    if not halo3:             # the other 3x3 launches of the operator that run in this kernel
+    if gate64:                # (launches that stay in conv3x3_halo2_kernel under the option are not repeated)
+        cases = {k: v for k, v in cases.items() if "pixel-major" not in k}
+        x128 = torch.empty(E, h, w, 128, device="cuda", dtype=torch.float16)
+        cases["128 -> 128 relu (corr_encoder.2 / agg.conv1)"] = lambda: P["agg1"]([net], EPI_RELU, out=x128)
+    if not halo3 and not gate64:             # the other 3x3 launches of the operator that run in this kernel
         part = torch.empty(2, E * h // 4, 6, 64, 4, dtype=torch.float32, device="cuda")
         w2p = P["heads2_fused"][0]
         x128 = torch.empty(E, h, w, 128, device="cuda", dtype=torch.float16)
@@ -105,7 +114,7 @@ for halo3 in (0, 1):
         cases["heads: 128 -> 256 + the fused second layer (EPI_HEADS0)"] = lambda: P["heads0"]([net], EPI_HEADS0, aux1=w2p, red=part)
         cases["context term 128 -> 384, accumulator-tile output (512 frames at E = 4096)"] = lambda: upd.context_term(inp_frames, tiled=True)
     tiles = E * h * w // 256
-    nwg_of = lambda name: (tiles if name.startswith(("q:", "128 -> 128")) else (K * h * w // 256) * 3 if name.startswith("context term") else 2 * tiles) // (2 if halo3 else 1)
+    nwg_of = lambda name: (tiles if name.startswith(("q:", "128 -> 128")) else (K * h * w // 256) * 3 if name.startswith("context term") else 2 * tiles) * (2 if gate64 else 1) // (2 if halo3 else 1)
     for name, fn in cases.items():
         db.conv_set_timestamps(None)
         for _ in range(3):
@@ -130,7 +139,7 @@ for halo3 in (0, 1):
                 r["steps"] = ns
                 r["step_us_median_by_index"] = [float(x) for x in np.median(d, axis=0)]
                 r["step_us_mean"] = float(d.mean()); r["step_us_p90"] = float(np.quantile(d, 0.9)); r["step_us_min"] = float(d.min())
-        r.update({"kernel": "conv3x3_halo3_kernel (512-px tile, one workgroup per CU)" if halo3 else "conv3x3_halo2_kernel (256-px tile, two workgroups per CU)",
+        r.update({"kernel": "conv3x3_halo64_kernel (256 px x 64 couts, three workgroups per CU)" if gate64 else "conv3x3_halo3_kernel (512-px tile, one workgroup per CU)" if halo3 else "conv3x3_halo2_kernel (256-px tile, two workgroups per CU)",
                   "launch": name, "ms_without_timestamps": ms_plain, "ms_with_timestamps": ms_ts})
         res["cases"].append(r)
         print("%-58s %-70s %.3f ms (%.3f with timestamps): prologue %.1f us (p90 %.1f), main loop %.1f us, epilogue %.1f us (p90 %.1f); per CU: "
@@ -141,6 +150,6 @@ for halo3 in (0, 1):
         if "steps" in r:
             print("      per step (us, median over 256 workgroups, step 0 -> 1 first): %s | mean %.2f p90 %.2f min %.2f" % (
                 " ".join("%.1f" % x for x in r["step_us_median_by_index"]), r["step_us_mean"], r["step_us_p90"], r["step_us_min"]), flush=True)
-db.set_option("conv_halo3", 0)
+db.set_option("conv_halo3", 0); db.set_option("conv_gate64", 0)
 if a.out:
     json.dump(res, open(a.out, "w"), indent=1)

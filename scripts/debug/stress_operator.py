@@ -26,7 +26,7 @@ def worker(rank, nproc, reps, E, opts):
     nbad = {"net": 0, "delta": 0, "weight": 0, "damping": 0, "corr0": 0}
     worst = {"net": 0.0, "delta": 0.0, "weight": 0.0, "damping": 0.0, "corr0": 0.0}
     for it in range(reps):
-        graph._net.copy_(net0)
+        graph._net.copy_(net0); graph._glo = None
         feats, corr0 = graph._pyramid_features(graph.corr, coords1)
         c0 = (corr0 if corr0 is not None else feats).float().clone()
         dw, damping, upmask, uniq = graph._operator(graph._net, coords1, tprev, feats, ii, corr0)

@@ -859,6 +859,103 @@ def test_context_term_in_the_accumulator_tile_layout_is_the_same_numbers(db, opt
     assert torch.equal(r[0], outs[0][0][sel]) and torch.equal(r[1], outs[0][1][sel]) and torch.equal(r[2], outs[0][2][sel])
 
 
+def test_gates_on_64_cout_tiles_three_workgroups_per_cu_are_bit_identical(db, option):
+    """round 6 (option conv_gate64, an A/B switch, off by default): the 3x3 / 128-cout layers -- the GRU gates with their epilogues and the
+    accumulator-tile start values (bit 0), the relu layers (bit 1) -- through conv3x3_halo64_kernel on 64-cout tiles (three workgroups
+    per CU) instead of conv3x3_halo2_kernel: the same MFMAs in the same k order on the same start values, so every output of the update
+    operator is EQUAL bit for bit; also at the image borders and with a pixel-tile count that is not a multiple of 8."""
+    from droid_amd.update import UpdateModule
+    from droid_amd.weights import deterministic_state_dict
+    from oracle import update as oupd
+
+    class _SD:
+        def state_dict(self):
+            return oupd.empty_state_dict()
+    torch.manual_seed(11)
+    upd = UpdateModule("cuda").load_state_dict(deterministic_state_dict(_SD(), seed=4))
+    assert db.get_option("conv_gate64") == 0
+    for (K, E, h, w) in [(3, 7, 12, 64), (2, 5, 48, 64)]:
+        inp_frames = torch.relu(torch.randn(K, h, w, 128, device="cuda")).half()
+        ii = (torch.arange(E, device="cuda") * K // E).contiguous()
+        net0 = torch.tanh(torch.randn(E, h, w, 128, device="cuda")).half()
+        corr = torch.randn(E, 196, h, w, device="cuda").half()
+        flow = torch.zeros(E, h, w, 8, device="cuda", dtype=torch.float16); flow[..., :4] = torch.randn(E, h, w, 4, device="cuda").half()
+        outs = []
+        for v in (0, 1, 2, 3):
+            option("conv_gate64", v)
+            for tiled in (True, False) if v in (0, 1) else (True,):
+                n = net0.clone()
+                ctx = upd.context_term(inp_frames, tiled=tiled)
+                r = upd.forward_nhwc(n, None, corr, flow, ii, inp_frames=inp_frames, inp_index=ii, ctx=ctx)
+                torch.cuda.synchronize()
+                outs.append([x.clone() for x in r])
+        option("conv_gate64", 0)
+        for other in outs[1:]:
+            for x, y in zip(outs[0], other):
+                assert torch.equal(x, y)
+
+
+def test_next_iterations_global_context_sums_from_inside_the_q_gate(db, option):
+    """round 6 (dh_conv2d_nhwc_f16_ex3, option glo_fused): the ConvGRU starts with glo = mean(sigmoid(w(net)) * net) of the state the
+    PREVIOUS iteration wrote (gru.py:23-24, :31).  forward_nhwc(glo_next=True) reduces the new state inside the q gate's launch:
+    (a) those sums equal the stand-alone kernel's on the state that was written (same arithmetic per 256-pixel tile; the order of the
+    per-tile atomics is free in both); (b) handing them to the next call gives the outputs of a call that recomputes them; (c) the state
+    and every other output of the call that produced them are EQUAL to a call without the fused reduction; (d) both context forms
+    (per-frame term / per-edge features); (e) a canvas image never fuses."""
+    from droid_amd.update import UpdateModule, EPI_GLO
+    from droid_amd.weights import deterministic_state_dict
+    from oracle import update as oupd
+
+    class _SD:
+        def state_dict(self):
+            return oupd.empty_state_dict()
+    torch.manual_seed(21)
+    upd = UpdateModule("cuda").load_state_dict(deterministic_state_dict(_SD(), seed=6))
+    P = upd.params
+    assert db.get_option("glo_fused") == 1
+    for (K, E, h, w) in [(3, 7, 12, 64), (2, 9, 48, 64)]:
+        assert upd.fuses_next_glo(h, w)
+        inp_frames = torch.relu(torch.randn(K, h, w, 128, device="cuda")).half()
+        ii = (torch.arange(E, device="cuda") * K // E).contiguous()
+        net0 = torch.tanh(torch.randn(E, h, w, 128, device="cuda")).half()
+        corr = [torch.randn(E, 196, h, w, device="cuda").half() for _ in range(2)]
+        flow = torch.zeros(E, h, w, 8, device="cuda", dtype=torch.float16); flow[..., :4] = torch.randn(E, h, w, 4, device="cuda").half()
+        for per_edge in (False, True):
+            kw = dict(inp_frames=inp_frames, inp_index=ii) if not per_edge else {}
+            inp = inp_frames[ii].contiguous() if per_edge else None
+            # two iterations, plain
+            n_a = net0.clone()
+            r1a = [x.clone() for x in upd.forward_nhwc(n_a, inp, corr[0], flow, ii, **kw)]
+            assert upd.last_glo is None
+            r2a = [x.clone() for x in upd.forward_nhwc(n_a, inp, corr[1], flow, ii, **kw)]
+            # two iterations, chained
+            n_b = net0.clone()
+            r1b = [x.clone() for x in upd.forward_nhwc(n_b, inp, corr[0], flow, ii, glo_next=True, **kw)]
+            glo = upd.last_glo
+            assert glo is not None and tuple(glo.shape) == (E, 128)
+            for x, y in zip(r1a, r1b):                                                    # (c)
+                assert torch.equal(x, y)
+            red = torch.zeros(E, 128, device="cuda")
+            P["gru_w"]([n_b], EPI_GLO, aux0=n_b, red=red)                                 # (a)
+            torch.cuda.synchronize()
+            assert (glo - red).abs().max().item() <= 1e-5 * max(1.0, red.abs().max().item())
+            r2b = [x.clone() for x in upd.forward_nhwc(n_b, inp, corr[1], flow, ii, glo_red=glo, glo_next=True, **kw)]
+            assert upd.last_glo is not None and upd.last_glo is not glo
+            for x, y in zip(r2a, r2b):                                                    # (b)
+                assert (x.float() - y.float()).abs().max().item() <= 2.0 ** -9 * max(1.0, x.float().abs().max().item())
+            option("glo_fused", 0)
+            upd.forward_nhwc(net0.clone(), inp, corr[0], flow, ii, glo_next=True, **kw)
+            assert upd.last_glo is None
+            option("glo_fused", 1)
+    # (e) 30 x 40 runs on a canvas: the reduction stays a kernel of its own (the padding is re-zeroed after the gate)
+    E, h, w = 3, 30, 40
+    net = torch.tanh(torch.randn(E, h, w, 128, device="cuda")).half()
+    inp = torch.relu(torch.randn(E, h, w, 128, device="cuda")).half()
+    flow = torch.zeros(E, h, w, 8, device="cuda", dtype=torch.float16)
+    upd.forward_nhwc(net, inp, torch.randn(E, 196, h, w, device="cuda").half(), flow, torch.arange(E, device="cuda"), glo_next=True)
+    assert upd.last_glo is None
+
+
 def test_conv7x7_on_four_channels_and_global_context_kernels(db):
     """the two single-purpose kernels of the update operator against torch: flow_encoder.0 (7x7 on the 4 motion
     channels, droid_net.py:89) and the ConvGRU's global-context reduction mean(sigmoid(w(net)) * net) (gru.py:23-24)"""
