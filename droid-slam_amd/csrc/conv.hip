@@ -1086,7 +1086,12 @@ constexpr int H2_LDS_BYTES = H2A_BYTES + 2 * H2B_BYTES;  // 74,496 (the staged e
 // ABL (only instantiated != 0 in -DDH_ABLATION builds, option "conv_abl", WRONG results by construction): timing / power
 // attribution of the main loop.  bit 0: fragment reads only in the first step (operands stay in registers); bit 1: no weight
 // DMA after the first two groups; bit 2: no halo fetch after the first chunk; bit 3: no epilogue; bit 4: no MFMAs.
-template <int EPI, bool STAGED = true, int CINIT = 0, int ABL = 0, bool GLO = false>      // CINIT: 0 zero, 1 pixel-major start values, 2 start values in the accumulator-tile
+// TWO (round 6, CINIT == 0 only; option conv_two_tiles): a workgroup computes TWO vertically adjacent pixel tiles one after the other.  The layers
+// with 128 input channels (corr_encoder.2, agg.conv1, the heads' first layer) run 12 steps between a 4.8 us prologue and a 5.3 / 8.3 us
+// epilogue (profiles/r05_n_conv_phase_timeline.txt: 1.3-1.5 of the CU's two workgroups in their main loop): here the second tile's halo
+// fetch is issued BEFORE the first tile's epilogue (three 16-byte loads per thread that land under it), its first weight group as soon as the
+// staged tile has been read, and the workgroup re-enters the main loop without a dispatch in between.  Same MFMAs per tile: same results.
+template <int EPI, bool STAGED = true, int CINIT = 0, int ABL = 0, bool GLO = false, bool TWO = false>      // CINIT: 0 zero, 1 pixel-major start values, 2 start values in the accumulator-tile
                                                                          // layout, 3 (STAGED = false) zero start, OUTPUT in that layout (out_f32 == 3)
                                                                          // GLO (EPI_GRU_Q): the next iteration's global-context reduction behind the state update
 __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
@@ -1098,29 +1103,29 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wrow = wave & 3, wn0 = (wave >> 2) * 64, wm0 = wrow * 64;
   long m0; int n0;
-  if (!xcd_decode(P, m0, n0, 128)) return;
+  if (!xcd_decode(P, m0, n0, 128, TWO ? 2 * BM : BM)) return;
   const int HW = P.H * P.W;
-  const int img = (int)(m0 / HW), y0 = (int)((m0 - (long)img * HW) / 64);
+  int img = (int)(m0 / HW), y0 = (int)((m0 - (long)img * HW) / 64);
   const int nchunks = P.Ctot / H2CK, nsteps = nchunks * 3;
 
   // halo roles.  The first and last column of the 6 x 66 halo lie outside the 64-pixel-wide image for every tile: they are
   // zeroed once, and the 6 x 64 interior is exactly 3 pieces per thread: piece id = tid + 512*i -> (row 2i + (tid >> 8),
   // column (tid >> 2) & 63, 16-byte slot tid & 3 of the pixel's 64-byte run)
   constexpr int A_PIECES = 3;
-  const int aq = tid & 3, ax = (tid >> 2) & 63, ahy = tid >> 8;
+  int aq = tid & 3, ax = (tid >> 2) & 63, ahy = tid >> 8;
   // (offsets are recomputed from these three where they are used: the kernel sits at its 128-register budget, and a
   // spilled address register is reloaded with a vmcnt(0) wait that serialises the halo loads)
-  const int a_pix0 = (img * P.H + y0 - 1 + ahy) * 64 + ax;      // image pixel of piece 0; piece i is two rows further down
+  int a_pix0 = (img * P.H + y0 - 1 + ahy) * 64 + ax;      // image pixel of piece 0; piece i is two rows further down
   if (tid < 48) {                                        // 12 edge pixels x 4 slots
     const int hp = (tid >> 3) * HCOLS + ((tid >> 2) & 1) * (HCOLS - 1);
     *reinterpret_cast<uint4*>(lds + hp * 64 + aq * 16) = uint4{0u, 0u, 0u, 0u};
   }
   // weight DMA: per-lane offset (one register for every piece) + wave-uniform base pointer in SGPRs
-  const int b_voff = lane * 16;
+  int b_voff = lane * 16;
   const char* const bsrc = reinterpret_cast<const char*>(P.wt_halo) + (long)(n0 >> 7) * nsteps * H2B_BYTES;
 
   // fragment addressing: 16-byte slot s of row r sits at r*64 + ((s ^ ((r >> 2) & 3)) << 4)
-  const int pl = wrow * HCOLS + (lane & 31), kh = lane >> 5;
+  int pl = wrow * HCOLS + (lane & 31), kh = lane >> 5;
   int b_row[2], b_x[2];
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
@@ -1171,6 +1176,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
   H2_FETCH_A(0)
   H2_DMA_B(0)
   DH_CTS(1);
+  for (int tile2 = 0; tile2 < (TWO ? 2 : 1); ++tile2) {
   for (int c = 0; c < nchunks; ++c) {
     // every wave has finished the previous chunk's reads of the halo tile
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1236,9 +1242,49 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo2_kernel(ConvParams P) {
       }
     }
   }
+  if constexpr (TWO) {
+    // second tile: its first halo chunk is requested now and lands under the first tile's epilogue
+    const long m0_done = m0;
+    const bool more = tile2 == 0 && m0 + BM < (long)P.N * HW;
+    if (more) {
+      m0 += BM;
+      img = (int)(m0 / HW); y0 = (int)((m0 - (long)img * HW) / 64);
+      a_pix0 = (img * P.H + y0 - 1 + ahy) * 64 + ax;
+      H2_FETCH_A(0)
+    }
+    if (tile2 == 0) DH_CTS(3);
+    int tid_e = tid;                                     // opaque: the epilogue now sits in a loop, and its per-thread addresses hoisted out of
+    asm volatile("" : "+v"(tid_e));                      // that loop as invariants are kept across the main loop -- in scratch
+    if constexpr (EPI == EPI_HEADS0) staged_heads0_epilogue(P, acc, s_conv, m0_done, n0, wm0, wn0, tid_e);
+    else staged_epilogue<EPI, 2, 128>(P, acc, s_conv, m0_done, n0, wm0, wn0, tid_e, HW);
+    if (!more) break;
+    __syncthreads();                                     // the staged tile has been read by everybody: the operand buffers are free again
+    {
+      // the per-lane constants of the main loop are formed AGAIN from an opaque copy of the thread index: kept alive across the
+      // epilogue (a dozen registers next to the accumulators, the three halo pieces in flight and the epilogue's own pieces) they spill
+      int t_o = tid;
+      asm volatile("" : "+v"(t_o));
+      const int l_o = t_o & 63;
+      aq = t_o & 3; ax = (t_o >> 2) & 63; ahy = t_o >> 8; b_voff = l_o * 16;
+      pl = wrow * HCOLS + (l_o & 31); kh = l_o >> 5;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int r = wn0 + b * 32 + (l_o & 31);
+        b_row[b] = r * 64; b_x[b] = ((r >> 2) & 3) ^ kh;
+      }
+      if (t_o < 48) {                                    // (the staged tile lay over the halo's zero columns)
+        const int hp = (t_o >> 3) * HCOLS + ((t_o >> 2) & 1) * (HCOLS - 1);
+        *reinterpret_cast<uint4*>(lds + hp * 64 + aq * 16) = uint4{0u, 0u, 0u, 0u};
+      }
+    }
+    H2_DMA_B(0)
+    zero_acc<2, 2>(acc);
+  }
+  }
 #undef H2_FETCH_A
 #undef H2_DMA_B
 #undef GLDS16S
+  if constexpr (TWO) { DH_CTS(4); return; }
   DH_CTS(3);
   if constexpr ((ABL & 8) != 0) {                        // no epilogue: one never-taken store keeps the accumulators live
     float sum = 0.f;
@@ -2200,6 +2246,19 @@ int launch_halo2(const ConvParams& P0, hipStream_t st) {
 #undef H2_ABL
   }
 #endif
+  if constexpr (EPI == EPI_RELU || EPI == EPI_HEADS0) {
+    // two vertically adjacent pixel tiles per workgroup for the layers with a short main loop (see the kernel's TWO parameter)
+    if (opts().conv_two_tiles && !P.cinit && P.Ctot <= opts().conv_two_tiles_maxc && M / BM >= 2048) {
+      const unsigned pairs = (unsigned)((M / BM + 1) / 2);
+      dim3 g2(pairs, (unsigned)P.ny);
+      if (opts().conv_xcd) { P.xcd_tiles = (int)((pairs + 7) / 8); g2 = dim3((unsigned)P.xcd_tiles * 8 * P.ny, 1); }
+      else P.xcd_tiles = 0;
+      DH_LDS_OPTIN((&conv3x3_halo2_kernel<EPI, true, 0, 0, false, true>), 80 * 1024);
+      hipLaunchKernelGGL((conv3x3_halo2_kernel<EPI, true, 0, 0, false, true>), g2, dim3(512), H2_LDS_BYTES, st, P);
+      DH_LAUNCH_CHECK();
+      return DH_OK;
+    }
+  }
   DH_LDS_OPTIN((&conv3x3_halo2_kernel<EPI>), 80 * 1024);
   hipLaunchKernelGGL((conv3x3_halo2_kernel<EPI>), grid, dim3(512), H2_LDS_BYTES, st, P);
   DH_LAUNCH_CHECK();

@@ -29,6 +29,8 @@ struct Options {
   int conv_halo64;      // DH_CONV_HALO64 (1): 3x3 layers with 64 couts through conv3x3_halo64_kernel (0 = first halo kernel); read by the weight packer too
   int conv_gate64;      // DH_CONV_GATE64 (0; round-6 A/B): layers conv3x3_halo2_kernel takes, on 64-cout tiles in conv3x3_halo64_kernel at THREE workgroups per CU: bit 0 = the GRU gates, bit 1 = relu / linear / sigmoid layers; bit-identical results
   int glo_fused;        // DH_GLO_FUSED (1): host side (UpdateModule / FactorGraph / bench.py): the next iteration's global-context reduction inside the q gate's launch (dh_conv2d_nhwc_f16_ex3) instead of a pass over the hidden state at the start of that iteration; 0 = always the stand-alone kernel
+  int conv_two_tiles;   // DH_CONV_TWO_TILES (0; round 6): relu / heads layers of conv3x3_halo2_kernel with at most conv_two_tiles_maxc input channels (128) and at least 2048 pixel tiles: TWO vertically adjacent pixel tiles per workgroup, the second tile's first fetches under the first tile's epilogue; same results
+  int conv_two_tiles_maxc;
   int conv_halo4;       // DH_CONV_HALO4 (0): -DDH_ABLATION builds only: the second kernel with four 64 x 128 waves per workgroup
   int conv_abl;         // DH_CONV_ABL (0): -DDH_ABLATION builds only: timing-ablation mask of conv3x3_halo2_kernel (wrong results)
   int ba_strict;        // DH_BA_STRICT (1): dh_ba / dh_ba_build synchronise and return DH_ERR_ARG on bad indices / eta rows; 0 = asynchronous, such calls apply no update

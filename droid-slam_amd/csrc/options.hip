@@ -41,6 +41,8 @@ Options& opts() {
     v.cinit_tiled = env_int("DH_CINIT_TILED", 1);
     v.conv_gate64 = env_int("DH_CONV_GATE64", 0);
     v.glo_fused = env_int("DH_GLO_FUSED", 1);
+    v.conv_two_tiles = env_int("DH_CONV_TWO_TILES", 0);
+    v.conv_two_tiles_maxc = env_int("DH_CONV_TWO_TILES_MAXC", 128);
 #ifndef DH_ABLATION
     // release build: the prototype / timing-ablation kernels are not compiled in; a stray environment variable cannot
     // select a variant that returns wrong results (lookup_mode 2-5) or does not exist
@@ -98,6 +100,8 @@ static int* slot(const char* name) {
   if (!strcmp(name, "cinit_tiled")) return &o.cinit_tiled;
   if (!strcmp(name, "conv_gate64")) return &o.conv_gate64;
   if (!strcmp(name, "glo_fused")) return &o.glo_fused;
+  if (!strcmp(name, "conv_two_tiles")) return &o.conv_two_tiles;
+  if (!strcmp(name, "conv_two_tiles_maxc")) return &o.conv_two_tiles_maxc;
   return nullptr;
 }
 

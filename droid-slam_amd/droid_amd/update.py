@@ -379,8 +379,11 @@ class UpdateModule:
         MFMA).  Same values; the tensor then has the shape [K, h*w/256, 3, 32768] and is only meaningful as `cinit=` of the gate convolutions."""
         P = self.params
         if tiled is None:
+            # (the same conditions as csrc/conv.hip halo2_ok<EPI_GRU_ZR / Q> + staged_epilogue_ok: a gate launch that cannot take the
+            # production kernel reads pixel-major start values only)
             tiled = (droid_backends.get_option("cinit_tiled") == 1 and droid_backends.get_option("conv_halo") == 1
-                     and droid_backends.get_option("conv_halo2") == 1 and P["zr_e"].layout == LAYOUT_AUTO and P["ctx"].wh is not None
+                     and droid_backends.get_option("conv_halo2") == 1 and droid_backends.get_option("conv_epi_staged") == 1
+                     and P["zr_e"].layout == LAYOUT_AUTO and P["ctx"].wh is not None
                      and inp_frames.shape[2] == 64 and inp_frames.shape[1] % 4 == 0)
         return P["ctx"]([inp_frames], EPI_LINEAR, out_raw_f32=True, out_tiled=bool(tiled))
 

@@ -895,6 +895,41 @@ def test_gates_on_64_cout_tiles_three_workgroups_per_cu_are_bit_identical(db, op
                 assert torch.equal(x, y)
 
 
+def test_two_pixel_tiles_per_workgroup_are_bit_identical(db, option):
+    """round 6 (option conv_two_tiles): the relu layers with 128 input channels and the heads' first layer with TWO vertically adjacent
+    pixel tiles per workgroup of conv3x3_halo2_kernel (the second tile's first fetches under the first tile's epilogue).  Same MFMAs per
+    tile: every output EQUAL to the one-tile form -- an even and an ODD number of pixel tiles (the last workgroup then has one tile), tile
+    pairs that straddle two images (3 tiles per image), image borders; and against torch's fp32 convolution on the first images."""
+    from droid_amd.update import UpdateModule, pack_conv, pack_conv_halo, EPI_RELU, EPI_HEADS0
+    from droid_amd.weights import deterministic_state_dict
+    from oracle import update as oupd
+
+    class _SD:
+        def state_dict(self):
+            return oupd.empty_state_dict()
+    torch.manual_seed(31)
+    upd = UpdateModule("cuda").load_state_dict(deterministic_state_dict(_SD(), seed=8))
+    P = upd.params
+    saved = db.get_option("conv_two_tiles")
+    for (E, h) in [(683, 12), (172, 48)]:                      # 2049 (odd) / 2064 pixel tiles: at least 2048 take the two-tile form
+        x = torch.tanh(torch.randn(E, h, 64, 128, device="cuda")).half()
+        outs = []
+        for v in (0, 1):
+            option("conv_two_tiles", v)
+            y = P["agg1"]([x], EPI_RELU)
+            part = torch.empty(2, E * h // 4, 6, 64, 4, dtype=torch.float32, device="cuda")
+            P["heads0"]([x], EPI_HEADS0, aux1=P["heads2_fused"][0], red=part)
+            torch.cuda.synchronize()
+            outs.append((y.clone(), part.clone()))
+        option("conv_two_tiles", saved)
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        sd = deterministic_state_dict(_SD(), seed=8)
+        wgt, bias = sd["agg.conv1.weight"].cuda().float(), sd["agg.conv1.bias"].cuda().float()
+        for sl in (slice(0, 2), slice(E - 2, E)):
+            ref = torch.nn.functional.conv2d(x[sl].float().permute(0, 3, 1, 2), wgt.half().float(), bias, padding=1).permute(0, 2, 3, 1).clamp_min(0)
+            assert (outs[1][0][sl].float() - ref).abs().max() <= 1e-2 * max(1.0, ref.abs().max().item())
+
+
 def test_next_iterations_global_context_sums_from_inside_the_q_gate(db, option):
     """round 6 (dh_conv2d_nhwc_f16_ex3, option glo_fused): the ConvGRU starts with glo = mean(sigmoid(w(net)) * net) of the state the
     PREVIOUS iteration wrote (gru.py:23-24, :31).  forward_nhwc(glo_next=True) reduces the new state inside the q gate's launch:
