@@ -273,11 +273,11 @@ inline bool staged_epilogue_ok(const ConvParams& P) {
 
 // second phase of the staged epilogues: the workgroup walks the fp16 tile [256 px][BNT couts] in 16-byte pieces (8 couts of
 // one pixel), applies the gate algebra with 16-byte operand loads and stores a pixel's couts as one run
-template <int EPI, int BNT, int NT = 512, bool KEEP = false>      // KEEP: the finished pieces are also written back into the LDS tile
+template <int EPI, int BNT, int NT = 512, bool KEEP = false, int ROWS = 256>      // KEEP: the finished pieces are also written back into the LDS tile
 __device__ __forceinline__ void staged_tile_store(const ConvParams& P, __half* __restrict__ sT, long m0, int n0, int tid) {
   constexpr int ELD = BNT + 8;
   constexpr int PPR = BNT / 8;
-  constexpr int NIT = 256 * PPR / NT;
+  constexpr int NIT = ROWS * PPR / NT;
   // 256 px x PPR pieces; thread -> (pixel row, piece): PPR consecutive lanes cover the couts of one pixel (NT = threads of the workgroup)
   // Round 5: the GRU operands of ALL the thread's pieces are requested first.  The q gate updates the hidden state in place (out ==
   // aux0), so with the loads inside the store loop the compiler had to keep every load behind the previous piece's store: eight
@@ -335,7 +335,7 @@ __device__ __forceinline__ void staged_tile_store(const ConvParams& P, __half* _
 }
 
 // TN = 32-cout accumulator tiles per wave, BNT = couts of the workgroup tile (128 or 64)
-template <int EPI, int TN, int BNT, int NT = 512, bool KEEP = false>
+template <int EPI, int TN, int BNT, int NT = 512, bool KEEP = false, int ROWS = 256>
 __device__ __forceinline__ void staged_epilogue(const ConvParams& P, f32x16 (&acc)[2][TN], __half* __restrict__ sT, long m0, int n0,
                                                 int wm0, int wn0, int tid, int HW) {
   constexpr int ELD = BNT + 8;            // LDS row stride of the staged tile (halves)
@@ -363,7 +363,7 @@ __device__ __forceinline__ void staged_epilogue(const ConvParams& P, f32x16 (&ac
       }
   }
   __syncthreads();
-  staged_tile_store<EPI, BNT, NT, KEEP>(P, sT, m0, n0, tid);
+  staged_tile_store<EPI, BNT, NT, KEEP, ROWS>(P, sT, m0, n0, tid);
 }
 
 // EPI_HEADS0: first layer of the delta | weight heads (3x3, 128 -> 256, relu) FUSED with the second layer's channel
@@ -1941,21 +1941,31 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(ConvParams P) {
 constexpr int C7_COLS = 72, C7_ROWS = 10, C7_K = 224, C7_WLD = C7_K + 8;
 constexpr int C7_A_BYTES = C7_ROWS * C7_COLS * 8, C7_W_BYTES = 128 * C7_WLD * 2;
 constexpr int C7_LDS_BYTES = (C7_A_BYTES + C7_W_BYTES) > BM * (128 + 8) * 2 ? (C7_A_BYTES + C7_W_BYTES) : BM * (128 + 8) * 2;
+constexpr int C7_W64_BYTES = 64 * C7_WLD * 2;             // 29,696: the weights of 64 couts
+constexpr int C7_LDS64_BYTES = (C7_A_BYTES + C7_W64_BYTES) > BM * (64 + 8) * 2 ? (C7_A_BYTES + C7_W64_BYTES) : BM * (64 + 8) * 2;      // 36,864
 
-template <int EPI>
-__global__ __launch_bounds__(512, 4) void conv7x7_c4_kernel(ConvParams P) {
+// Round 6: BN = 64 (option conv_c7_split, default): a workgroup of FOUR waves computes 256 px x 64 couts -- half the weights (29.7 KB),
+// a staged tile of 36.9 KB -- so that FOUR workgroups fit a CU instead of two.  The kernel runs far from either roof (0.63 PFLOP/s, 2.8 TB/s
+// of stores): its workgroups spend most of their life in a prologue (weights L2 -> registers -> LDS) and an epilogue with nothing of their
+// own to overlap, and unlike the gate convolutions more residency is what it lacks.  Same MFMAs per output element: same results.
+template <int EPI, int BN = 128>
+__global__ __launch_bounds__(BN == 128 ? 512 : 256, BN == 128 ? 4 : 4) void conv7x7_c4_kernel(ConvParams P) {
+  constexpr int NT = BN == 128 ? 512 : 256;              // threads
   extern __shared__ __half s_conv[];
   char* const lds = reinterpret_cast<char*>(s_conv);
   char* const sW = lds + C7_A_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wrow = wave & 3, wn0 = (wave >> 2) * 64, wm0 = wrow * 64;
-  const long m0 = (long)blockIdx.x * BM;
+  // BN == 64: 1-D grid, workgroup id -> (pixel tile id >> 1, cout half id & 1)
+  const long m0 = (BN == 128 ? (long)blockIdx.x : (long)(blockIdx.x >> 1)) * BM;
+  const int n0 = BN == 128 ? 0 : (int)(blockIdx.x & 1) * 64;
   const int HW = P.H * P.W;
   const int img = (int)(m0 / HW), y0 = (int)((m0 - (long)img * HW) / 64);
+  DH_CTS(0); DH_CTS_ID();
   // halo: column c holds image column c - 4, row r holds image row y0 - 3 + r; 8 bytes (4 channels) per pixel
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int id = tid + 512 * i;
+  for (int i = 0; i < (C7_ROWS * C7_COLS + NT - 1) / NT; ++i) {
+    const int id = tid + NT * i;
     if (id < C7_ROWS * C7_COLS) {
       const int r = id / C7_COLS, c = id - r * C7_COLS;
       const int y = y0 - 3 + r, x = c - 4;
@@ -1966,13 +1976,15 @@ __global__ __launch_bounds__(512, 4) void conv7x7_c4_kernel(ConvParams P) {
     }
   }
 #pragma unroll
-  for (int i = 0; i < 7; ++i) {                            // 128 rows x 28 pieces of 16 bytes
-    const int id = tid + 512 * i, row = id / 28, pc = id - row * 28;
-    *reinterpret_cast<uint4*>(sW + row * (C7_WLD * 2) + pc * 16) = *reinterpret_cast<const uint4*>(P.wt_halo + (long)row * C7_K + pc * 8);
+  for (int i = 0; i < 7; ++i) {                            // BN rows x 28 pieces of 16 bytes (BN * 28 = 7 * NT)
+    const int id = tid + NT * i, row = id / 28, pc = id - row * 28;
+    *reinterpret_cast<uint4*>(sW + row * (C7_WLD * 2) + pc * 16) = *reinterpret_cast<const uint4*>(P.wt_halo + (long)(n0 + row) * C7_K + pc * 8);
   }
   f32x16 acc[2][2];
   zero_acc<2, 2>(acc);
+  DH_CTS(1);
   __syncthreads();
+  DH_CTS(2);
   const int p = lane & 31, kh = lane >> 5;
 #pragma unroll
   for (int dy = 0; dy < 7; ++dy) {
@@ -1996,7 +2008,9 @@ __global__ __launch_bounds__(512, 4) void conv7x7_c4_kernel(ConvParams P) {
         for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
     }
   }
-  staged_epilogue<EPI, 2, 128>(P, acc, s_conv, m0, 0, wm0, wn0, tid, HW);
+  DH_CTS(3);
+  staged_epilogue<EPI, 2, BN, NT>(P, acc, s_conv, m0, n0, wm0, wn0, tid, HW);
+  DH_CTS(4);
 }
 
 // ---- 1x1 on 128 input channels with many outputs (GraphAgg's upmask head: 128 -> 576 on the source frames, droid_net.py:62) -------
@@ -2009,40 +2023,44 @@ __global__ __launch_bounds__(512, 4) void conv7x7_c4_kernel(ConvParams P) {
 constexpr int K1_LD = 128 + 8;
 constexpr int K1_A_BYTES = BM * K1_LD * 2, K1_B_BYTES = 64 * K1_LD * 2, K1_T_BYTES = BM * (64 + 8) * 2;
 constexpr int K1_LDS_BYTES = K1_A_BYTES + K1_B_BYTES + K1_T_BYTES;
-template <int EPI>
-__global__ __launch_bounds__(512, 1) void conv1x1_c128_kernel(ConvParams P) {
+// Round 6: TM = 128 (option conv_k1_half, default): 128-pixel tiles by FOUR waves -- 34.8 (A) + 17.4 (B) + 18.4 (staged tile) = 70.6 KB, TWO
+// workgroups per CU, so that one workgroup's activation fetch and stores run under the other's cout-tile walk (the 256-pixel form has the
+// CU to itself: its 64 KB fetch is exposed).  Same MFMAs per output element: same results.
+template <int EPI, int TM = 256>
+__global__ __launch_bounds__(TM * 2, TM == 256 ? 1 : 2) void conv1x1_c128_kernel(ConvParams P) {
+  constexpr int NT = TM * 2, AIT = TM * 16 / NT, BIT = 64 * 16 / NT;        // threads; 16-byte pieces per thread of the A / B tiles
   extern __shared__ __half s_conv[];
   __half* sA = s_conv;
-  __half* sB = s_conv + K1_A_BYTES / 2;
-  __half* sT = s_conv + (K1_A_BYTES + K1_B_BYTES) / 2;
+  __half* sB = s_conv + TM * K1_LD;
+  __half* sT = s_conv + (TM + 64) * K1_LD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm0 = (wave & 3) * 64, wn0 = (wave >> 2) * 32;
-  const long m0 = (long)blockIdx.x * BM;
+  const int wm0 = (wave % (TM / 64)) * 64, wn0 = (wave / (TM / 64)) * 32;
+  const long m0 = (long)blockIdx.x * TM;
   const int HW = P.H * P.W;
-  uint4 ra[8], rb[2];
+  uint4 ra[AIT], rb[BIT];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int id = tid + 512 * i;
+  for (int i = 0; i < AIT; ++i) {
+    const int id = tid + NT * i;
     ra[i] = *reinterpret_cast<const uint4*>(P.in[0] + (m0 + (id >> 4)) * P.segS[0] + (id & 15) * 8);
   }
   auto fetch_b = [&](int n0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int id = tid + 512 * i, row = id >> 4;
+    for (int i = 0; i < BIT; ++i) {
+      const int id = tid + NT * i, row = id >> 4;
       rb[i] = n0 + row < P.CoutPad ? *reinterpret_cast<const uint4*>(P.wt + (long)(n0 + row) * P.Kpad + (id & 15) * 8) : uint4{0u, 0u, 0u, 0u};
     }
   };
   fetch_b(0);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int id = tid + 512 * i;
+  for (int i = 0; i < AIT; ++i) {
+    const int id = tid + NT * i;
     *reinterpret_cast<uint4*>(sA + (id >> 4) * K1_LD + (id & 15) * 8) = ra[i];
   }
   const int p = lane & 31, kh = lane >> 5;
   for (int n0 = 0; n0 < P.CoutPad; n0 += 64) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {          // (the previous cout tile's B fragments are read: two barriers in its epilogue)
-      const int id = tid + 512 * i;
+    for (int i = 0; i < BIT; ++i) {        // (the previous cout tile's B fragments are read: two barriers in its epilogue)
+      const int id = tid + NT * i;
       *reinterpret_cast<uint4*>(sB + (id >> 4) * K1_LD + (id & 15) * 8) = rb[i];
     }
     __syncthreads();                       // A (first cout tile) and B staged
@@ -2058,7 +2076,7 @@ __global__ __launch_bounds__(512, 1) void conv1x1_c128_kernel(ConvParams P) {
         acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[a][0], 0, 0, 0);
       }
     }
-    staged_epilogue<EPI, 1, 64>(P, acc, sT, m0, n0, wm0, wn0, tid, HW);      // (its first barrier: the previous tile's pieces are read)
+    staged_epilogue<EPI, 1, 64, NT, false, TM>(P, acc, sT, m0, n0, wm0, wn0, tid, HW);      // (its first barrier: the previous tile's pieces are read)
   }
 }
 
@@ -2246,6 +2264,7 @@ int launch_halo2(const ConvParams& P0, hipStream_t st) {
 #undef H2_ABL
   }
 #endif
+#ifndef DH_ABLATION       // (the measurement build's phase timestamps do not fit next to the second tile's registers: one-tile form there)
   if constexpr (EPI == EPI_RELU || EPI == EPI_HEADS0) {
     // two vertically adjacent pixel tiles per workgroup for the layers with a short main loop (see the kernel's TWO parameter)
     if (opts().conv_two_tiles && !P.cinit && P.Ctot <= opts().conv_two_tiles_maxc && M / BM >= 2048) {
@@ -2259,6 +2278,7 @@ int launch_halo2(const ConvParams& P0, hipStream_t st) {
       return DH_OK;
     }
   }
+#endif
   DH_LDS_OPTIN((&conv3x3_halo2_kernel<EPI>), 80 * 1024);
   hipLaunchKernelGGL((conv3x3_halo2_kernel<EPI>), grid, dim3(512), H2_LDS_BYTES, st, P);
   DH_LAUNCH_CHECK();
@@ -2859,6 +2879,19 @@ extern "C" int dh_conv2d_nhwc_f16_ex3(const void* const* inputs, const int* in_c
       default: break;
     }
   }
+  if (k1_ok(P) && opts().conv_k1_half) {                     // 128-pixel tiles, two workgroups per CU
+    const dim3 grid((unsigned)((long)P.N * P.H * P.W / 128));
+    constexpr int lds = (128 + 64) * K1_LD * 2 + 128 * (64 + 8) * 2;
+    if (P.epi == EPI_LINEAR) {
+      DH_LDS_OPTIN((&conv1x1_c128_kernel<EPI_LINEAR, 128>), 80 * 1024);
+      hipLaunchKernelGGL((conv1x1_c128_kernel<EPI_LINEAR, 128>), grid, dim3(256), lds, st, P);
+    } else {
+      DH_LDS_OPTIN((&conv1x1_c128_kernel<EPI_RELU, 128>), 80 * 1024);
+      hipLaunchKernelGGL((conv1x1_c128_kernel<EPI_RELU, 128>), grid, dim3(256), lds, st, P);
+    }
+    DH_LAUNCH_CHECK();
+    return DH_OK;
+  }
   if (k1_ok(P)) {
     const dim3 grid((unsigned)((long)P.N * P.H * P.W / BM));
     if (P.epi == EPI_LINEAR) {
@@ -2874,6 +2907,11 @@ extern "C" int dh_conv2d_nhwc_f16_ex3(const void* const* inputs, const int* in_c
   if (glo_ok(P)) {
     DH_LDS_OPTIN(&glo_reduce_kernel, 80 * 1024);
     hipLaunchKernelGGL(glo_reduce_kernel, dim3((unsigned)((long)P.N * P.H * P.W / BM)), dim3(512), BM * GLD * 2, st, P);
+    DH_LAUNCH_CHECK();
+    return DH_OK;
+  }
+  if (c7_ok(P) && opts().conv_c7_split) {                    // 64-cout halves, four workgroups per CU
+    hipLaunchKernelGGL((conv7x7_c4_kernel<EPI_RELU, 64>), dim3((unsigned)((long)P.N * P.H * P.W / BM) * 2), dim3(256), C7_LDS64_BYTES, st, P);
     DH_LAUNCH_CHECK();
     return DH_OK;
   }

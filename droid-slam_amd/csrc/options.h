@@ -31,6 +31,8 @@ struct Options {
   int glo_fused;        // DH_GLO_FUSED (1): host side (UpdateModule / FactorGraph / bench.py): the next iteration's global-context reduction inside the q gate's launch (dh_conv2d_nhwc_f16_ex3) instead of a pass over the hidden state at the start of that iteration; 0 = always the stand-alone kernel
   int conv_two_tiles;   // DH_CONV_TWO_TILES (0; round 6): relu / heads layers of conv3x3_halo2_kernel with at most conv_two_tiles_maxc input channels (128) and at least 2048 pixel tiles: TWO vertically adjacent pixel tiles per workgroup, the second tile's first fetches under the first tile's epilogue; same results
   int conv_two_tiles_maxc;
+  int conv_k1_half;     // DH_CONV_K1_HALF (round 6): the 128 -> 576 upmask head on 128-pixel tiles by four waves, two workgroups per CU (conv1x1_c128_kernel<.., 128>) instead of one 256-pixel workgroup; same results
+  int conv_c7_split;    // DH_CONV_C7_SPLIT (round 6): the flow encoder's 7x7 stem as 64-cout halves, four workgroups of four waves per CU (conv7x7_c4_kernel<.., 64>) instead of two of eight; same results
   int conv_halo4;       // DH_CONV_HALO4 (0): -DDH_ABLATION builds only: the second kernel with four 64 x 128 waves per workgroup
   int conv_abl;         // DH_CONV_ABL (0): -DDH_ABLATION builds only: timing-ablation mask of conv3x3_halo2_kernel (wrong results)
   int ba_strict;        // DH_BA_STRICT (1): dh_ba / dh_ba_build synchronise and return DH_ERR_ARG on bad indices / eta rows; 0 = asynchronous, such calls apply no update

@@ -42,6 +42,8 @@ Options& opts() {
     v.conv_gate64 = env_int("DH_CONV_GATE64", 0);
     v.glo_fused = env_int("DH_GLO_FUSED", 1);
     v.conv_two_tiles = env_int("DH_CONV_TWO_TILES", 0);
+    v.conv_c7_split = env_int("DH_CONV_C7_SPLIT", 0);
+    v.conv_k1_half = env_int("DH_CONV_K1_HALF", 0);
     v.conv_two_tiles_maxc = env_int("DH_CONV_TWO_TILES_MAXC", 128);
 #ifndef DH_ABLATION
     // release build: the prototype / timing-ablation kernels are not compiled in; a stray environment variable cannot
@@ -101,6 +103,8 @@ static int* slot(const char* name) {
   if (!strcmp(name, "conv_gate64")) return &o.conv_gate64;
   if (!strcmp(name, "glo_fused")) return &o.glo_fused;
   if (!strcmp(name, "conv_two_tiles")) return &o.conv_two_tiles;
+  if (!strcmp(name, "conv_c7_split")) return &o.conv_c7_split;
+  if (!strcmp(name, "conv_k1_half")) return &o.conv_k1_half;
   if (!strcmp(name, "conv_two_tiles_maxc")) return &o.conv_two_tiles_maxc;
   return nullptr;
 }

@@ -23,6 +23,7 @@ from oracle import update as oupd          # (shape template of the state dict o
 ap = argparse.ArgumentParser()
 ap.add_argument("--edges", type=int, default=1024)
 ap.add_argument("--out", default=None)
+ap.add_argument("--only", default=None, help="substring filter on the case names")
 ap.add_argument("--gate64", action="store_true", help="round 6: the product form against the SAME launches on 64-cout tiles at three workgroups "
                 "per CU (conv3x3_halo64_kernel, option conv_gate64) instead of against the 512-pixel form")
 a = ap.parse_args()
@@ -102,6 +103,10 @@ for variant in (0, 1):
         cases["q: relu (bare convolution 320 -> 128)"] = lambda: P["q_e"]([zr_in[..., 128:], c, f], EPI_RELU, out=outq)
         cases["q: gru (tanh + state update, accumulators from zero)"] = lambda: P["q_e"]([zr_in[..., 128:], c, f], EPI_GRU_Q, out=outq, gterm=gq, aux0=net, aux1=zr_in)
         cases["q: gru+cinit, accumulator-tile context term (the product's q launch)"] = lambda: P["q_e"]([zr_in[..., 128:], c, f], EPI_GRU_Q, out=outq, gterm=gq, aux0=net, aux1=zr_in, cinit=ctx_tl, cinit_idx=idx, cinit_off=256)
+    if not halo3 and not gate64:             # the flow encoder's 7x7 stem (conv7x7_c4_kernel: stamps 1 = staging issued, 2 = staged, 3 = MFMAs done)
+        flow8 = torch.zeros(E, h, w, 8, device="cuda", dtype=torch.float16); flow8[..., :4] = torch.randn(E, h, w, 4, device="cuda").half()
+        xs = torch.empty(E, h, w, 128, device="cuda", dtype=torch.float16)
+        cases["stem: 7x7 on 4 channels -> 128 (flow_encoder.0)"] = lambda: P["flow0"]([flow8], EPI_RELU, out=xs)
     if gate64:                # (launches that stay in conv3x3_halo2_kernel under the option are not repeated)
         cases = {k: v for k, v in cases.items() if "pixel-major" not in k}
         x128 = torch.empty(E, h, w, 128, device="cuda", dtype=torch.float16)
@@ -114,8 +119,10 @@ for variant in (0, 1):
         cases["heads: 128 -> 256 + the fused second layer (EPI_HEADS0)"] = lambda: P["heads0"]([net], EPI_HEADS0, aux1=w2p, red=part)
         cases["context term 128 -> 384, accumulator-tile output (512 frames at E = 4096)"] = lambda: upd.context_term(inp_frames, tiled=True)
     tiles = E * h * w // 256
-    nwg_of = lambda name: (tiles if name.startswith(("q:", "128 -> 128")) else (K * h * w // 256) * 3 if name.startswith("context term") else 2 * tiles) * (2 if gate64 else 1) // (2 if halo3 else 1)
+    nwg_of = lambda name: (tiles if name.startswith(("q:", "128 -> 128", "stem:")) else (K * h * w // 256) * 3 if name.startswith("context term") else 2 * tiles) * (2 if gate64 else 1) // (2 if halo3 else 1)
     for name, fn in cases.items():
+        if a.only and a.only not in name:
+            continue
         db.conv_set_timestamps(None)
         for _ in range(3):
             fn()

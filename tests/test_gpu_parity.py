@@ -1009,6 +1009,17 @@ def test_conv7x7_on_four_channels_and_global_context_kernels(db):
     gen = torch.empty_like(out)                          # generic loop on the same inputs
     db.conv2d_nhwc([x], wp, None, bp, 7, 7, 128, EPI_RELU, gen, 128, None, None, None, None)
     assert (out.float() - gen.float()).abs().max() <= 2.0 ** -9 * max(1.0, ref.abs().max().item())
+    # the two forms of the stem kernel (option conv_c7_split: 64-cout halves, four workgroups per CU): the same MFMAs -> EQUAL
+    saved = db.get_option("conv_c7_split")
+    both = []
+    for v in (0, 1):
+        db.set_option("conv_c7_split", v)
+        o = torch.empty_like(out)
+        db.conv2d_nhwc([x], wp, pack_conv_7x7_c4(wgt), bp, 7, 7, 128, EPI_RELU, o, 128, None, None, None, None)
+        torch.cuda.synchronize()
+        both.append(o)
+    db.set_option("conv_c7_split", saved)
+    assert torch.equal(both[0], both[1]) and torch.equal(both[0], out if saved == 0 else both[saved])
     # global context
     net = torch.tanh(torch.randn(N, H, W, 128, device="cuda")).half()
     w1 = torch.randn(128, 128, 1, 1, device="cuda") / 11.0
