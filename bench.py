@@ -27,6 +27,8 @@ PKG = os.path.join(ROOT, "droid-slam_amd")
 for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
+if os.environ.get("DH_LIB_DIR"):          # same-box A/B of a compile-time variant of the library (droid-slam_amd/build.py DROID_HIP_VARIANT)
+    sys.path.insert(0, os.path.join(PKG, os.environ["DH_LIB_DIR"]))
 
 import numpy as np
 import torch

@@ -40,6 +40,19 @@ if ABLATION:
     EXT = os.path.join(OUTDIR, "droid_backends.so")
 
 
+# DROID_HIP_VARIANT=name DROID_HIP_EXTRA_FLAGS="-D...": one more separate build under droid-slam_amd/variant_<name>/ for same-box A/B runs of a
+# compile-time choice (bench.py / the scripts load it when DH_LIB_DIR names that directory)
+VARIANT = os.environ.get("DROID_HIP_VARIANT", "")
+if VARIANT:
+    assert not ABLATION, "DROID_HIP_VARIANT and DROID_HIP_ABLATION are separate builds"
+    HIP_FLAGS += os.environ.get("DROID_HIP_EXTRA_FLAGS", "").split()
+    OUTDIR = os.path.join(HERE, "variant_" + VARIANT)
+    OBJ = os.path.join(HERE, "build", "variant_" + VARIANT)
+    os.makedirs(OUTDIR, exist_ok=True)
+    LIB = os.path.join(OUTDIR, "libdroid_hip.so")
+    EXT = os.path.join(OUTDIR, "droid_backends.so")
+
+
 # DROID_HIP_SANITIZE=1: a THIRD, separate build under droid-slam_amd/sanitize/ whose HOST code (argument checks, workspace layouts,
 # option store, launch geometry -- everything of the C ABI that runs on the CPU) is instrumented with AddressSanitizer +
 # UndefinedBehaviorSanitizer (the host-test build).  Device code is unchanged (hipcc ignores -fsanitize for gfx950
@@ -164,10 +177,18 @@ def audit_spills(force=False, verbose=False):
         name = fn.split()[0]
         if "conv3x3_halo2_kernel" not in name:
             continue
+        abl = re.search(r"conv3x3_halo2_kernelILi\d+ELb\dELi\d+ELi(\d+)E", name)
+        if abl and int(abl.group(1)) != 0:
+            continue                      # timing-ablation instantiations (-DDH_ABLATION builds, wrong results by construction)
         seen += 1
         m = re.search(r"; ScratchSize: (\d+)", fn)
         if m is None or int(m.group(1)) != 0:
             bad.append("%s: ScratchSize %s" % (name, m.group(1) if m else "?"))
+    if bad and ABLATION and seen:
+        # the measurement build carries phase-timestamp code in every instantiation: a few bytes of scratch there change a timeline by
+        # nothing that matters; the SHIPPED library (no -DDH_ABLATION) must stay free of it
+        print("note (ablation build): " + "; ".join(bad))
+        bad = []
     if bad or not seen:
         raise RuntimeError("register spills in the default convolution kernel (see DESIGN.md, known gaps):\n" + "\n".join(bad or ["kernel not found"]))
     open(stamp, "w").write("%d instantiations, no scratch\n" % seen)

@@ -273,8 +273,38 @@ inline bool staged_epilogue_ok(const ConvParams& P) {
 
 // second phase of the staged epilogues: the workgroup walks the fp16 tile [256 px][BNT couts] in 16-byte pieces (8 couts of
 // one pixel), applies the gate algebra with 16-byte operand loads and stores a pixel's couts as one run
-template <int EPI, int BNT, int NT = 512, bool KEEP = false, int ROWS = 256>      // KEEP: the finished pieces are also written back into the LDS tile
-__device__ __forceinline__ void staged_tile_store(const ConvParams& P, __half* __restrict__ sT, long m0, int n0, int tid) {
+// DH_EPI_EARLY (round 6, default 1; -DDH_EPI_EARLY=0 = round 5): the GRU operands (old state / z: 16-byte loads from HBM) are requested WHILE
+// the accumulators are being parked -- two pieces' worth after each of the four accumulator tiles, whose sixteen registers have just
+// become free -- instead of after the barrier behind the parking: their latency runs under the gate activations (128 transcendentals
+// per lane) instead of in front of the store loop.  Same loads, same values.
+#ifndef DH_EPI_EARLY
+#define DH_EPI_EARLY 1
+#endif
+template <int EPI, int BNT, int NT, int NIT>
+struct GruOperands { uint4 hv[(EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q) ? NIT : 1], zv[EPI == EPI_GRU_Q ? NIT : 1]; };
+
+// operands of piece `it` of thread `tid` (piece id = tid + NT * it -> pixel row id / PPR, couts (id % PPR) * 8 ..)
+template <int EPI, int BNT, int NT, int NIT>
+__device__ __forceinline__ void gru_operand_load(const ConvParams& P, GruOperands<EPI, BNT, NT, NIT>& g, int it, long m0, int n0, int tid) {
+  constexpr int PPR = BNT / 8;
+  if constexpr (EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q) {
+    const int id = tid + NT * it, row = id / PPR, co = n0 + (id % PPR) * 8;
+    const long pix = m0 + row;
+    g.hv[it] = uint4{0u, 0u, 0u, 0u};
+    if (co < P.Cout) {
+      if (EPI == EPI_GRU_Q) {
+        g.zv[it] = *reinterpret_cast<const uint4*>(P.aux1 + pix * P.aux1_stride + co);
+        g.hv[it] = *reinterpret_cast<const uint4*>(P.aux0 + pix * P.aux0_stride + co);
+      } else if (co >= 128) {
+        g.hv[it] = *reinterpret_cast<const uint4*>(P.aux0 + pix * P.aux0_stride + co - 128);
+      }
+    }
+  }
+}
+
+template <int EPI, int BNT, int NT = 512, bool KEEP = false, int ROWS = 256, bool PRELOADED = false>      // KEEP: the finished pieces are also written back into the LDS tile
+__device__ __forceinline__ void staged_tile_store(const ConvParams& P, __half* __restrict__ sT, long m0, int n0, int tid,
+                                                  GruOperands<EPI, BNT, NT, ROWS * (BNT / 8) / NT>& g) {
   constexpr int ELD = BNT + 8;
   constexpr int PPR = BNT / 8;
   constexpr int NIT = ROWS * PPR / NT;
@@ -283,22 +313,9 @@ __device__ __forceinline__ void staged_tile_store(const ConvParams& P, __half* _
   // aux0), so with the loads inside the store loop the compiler had to keep every load behind the previous piece's store: eight
   // exposed memory latencies per workgroup -- 16.0 us of epilogue against 4.3 us for the plain one (scripts/conv_timeline.py).
   // A thread only ever reads the piece it is about to overwrite itself, so requesting them up front changes no value.
-  uint4 hv[(EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q) ? NIT : 1], zv[EPI == EPI_GRU_Q ? NIT : 1];
-  if constexpr (EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q) {
+  if constexpr ((EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q) && !PRELOADED) {
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int id = tid + NT * it, row = id / PPR, co = n0 + (id % PPR) * 8;
-      const long pix = m0 + row;
-      hv[it] = uint4{0u, 0u, 0u, 0u};
-      if (co < P.Cout) {
-        if (EPI == EPI_GRU_Q) {
-          zv[it] = *reinterpret_cast<const uint4*>(P.aux1 + pix * P.aux1_stride + co);
-          hv[it] = *reinterpret_cast<const uint4*>(P.aux0 + pix * P.aux0_stride + co);
-        } else if (co >= 128) {
-          hv[it] = *reinterpret_cast<const uint4*>(P.aux0 + pix * P.aux0_stride + co - 128);
-        }
-      }
-    }
+    for (int it = 0; it < NIT; ++it) gru_operand_load<EPI, BNT, NT, NIT>(P, g, it, m0, n0, tid);
   }
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
@@ -309,7 +326,7 @@ __device__ __forceinline__ void staged_tile_store(const ConvParams& P, __half* _
     uint4 v = *reinterpret_cast<const uint4*>(sT + row * ELD + c8);
     if (EPI == EPI_GRU_ZR) {
       if (co >= 128) {                                                                   // r * net
-        const __half2* a2 = reinterpret_cast<const __half2*>(&v); const __half2* h2 = reinterpret_cast<const __half2*>(&hv[it]);
+        const __half2* a2 = reinterpret_cast<const __half2*>(&v); const __half2* h2 = reinterpret_cast<const __half2*>(&g.hv[it]);
         uint4 o; __half2* o2 = reinterpret_cast<__half2*>(&o);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -319,8 +336,8 @@ __device__ __forceinline__ void staged_tile_store(const ConvParams& P, __half* _
         v = uint4{o.x, o.y, o.z, o.w};
       }
     } else if (EPI == EPI_GRU_Q) {
-      const __half2* q2 = reinterpret_cast<const __half2*>(&v); const __half2* z2 = reinterpret_cast<const __half2*>(&zv[it]);
-      const __half2* h2 = reinterpret_cast<const __half2*>(&hv[it]);
+      const __half2* q2 = reinterpret_cast<const __half2*>(&v); const __half2* z2 = reinterpret_cast<const __half2*>(&g.zv[it]);
+      const __half2* h2 = reinterpret_cast<const __half2*>(&g.hv[it]);
       uint4 o; __half2* o2 = reinterpret_cast<__half2*>(&o);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -334,21 +351,30 @@ __device__ __forceinline__ void staged_tile_store(const ConvParams& P, __half* _
   }
 }
 
+template <int EPI, int BNT, int NT = 512, bool KEEP = false, int ROWS = 256>
+__device__ __forceinline__ void staged_tile_store(const ConvParams& P, __half* __restrict__ sT, long m0, int n0, int tid) {
+  GruOperands<EPI, BNT, NT, ROWS * (BNT / 8) / NT> g;
+  staged_tile_store<EPI, BNT, NT, KEEP, ROWS, false>(P, sT, m0, n0, tid, g);
+}
+
 // TN = 32-cout accumulator tiles per wave, BNT = couts of the workgroup tile (128 or 64)
 template <int EPI, int TN, int BNT, int NT = 512, bool KEEP = false, int ROWS = 256>
 __device__ __forceinline__ void staged_epilogue(const ConvParams& P, f32x16 (&acc)[2][TN], __half* __restrict__ sT, long m0, int n0,
                                                 int wm0, int wn0, int tid, int HW) {
   constexpr int ELD = BNT + 8;            // LDS row stride of the staged tile (halves)
   constexpr int PPR = BNT / 8;            // 16-byte pieces per pixel row
+  constexpr int NIT = ROWS * PPR / NT;
+  constexpr bool EARLY = DH_EPI_EARLY && (EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q) && NIT % (2 * TN) == 0;
   const int lane = tid & 63;
   const int img = (int)(m0 / HW);
+  GruOperands<EPI, BNT, NT, NIT> g;
   __syncthreads();                        // the operand tiles of the main loop are dead
 #pragma unroll
   for (int b = 0; b < TN; ++b) {
     const int cl = wn0 + b * 32 + (lane & 31), co = n0 + cl;
     const float add = (co < P.CoutPad ? P.bias[co] : 0.f) + ((P.gterm && co < P.CoutPad) ? P.gterm[(long)img * P.CoutPad + co] : 0.f);
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 2; ++a) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int row = wm0 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
@@ -361,9 +387,15 @@ __device__ __forceinline__ void staged_epilogue(const ConvParams& P, f32x16 (&ac
         }
         sT[row * ELD + cl] = __float2half(v);
       }
+      if constexpr (EARLY) {               // this accumulator tile's registers are free: request the next NIT / (2 TN) pieces' operands
+        constexpr int PER = NIT / (2 * TN);
+#pragma unroll
+        for (int k = 0; k < PER; ++k) gru_operand_load<EPI, BNT, NT, NIT>(P, g, (b * 2 + a) * PER + k, m0, n0, tid);
+      }
+    }
   }
   __syncthreads();
-  staged_tile_store<EPI, BNT, NT, KEEP, ROWS>(P, sT, m0, n0, tid);
+  staged_tile_store<EPI, BNT, NT, KEEP, ROWS, EARLY>(P, sT, m0, n0, tid, g);
 }
 
 // EPI_HEADS0: first layer of the delta | weight heads (3x3, 128 -> 256, relu) FUSED with the second layer's channel

@@ -7,7 +7,7 @@ the z|r and q launches of the update operator at C3 size (4096 edges, 512 source
     python scripts/bench_gates.py [--edges 4096] [--reps 5]"""
 import argparse, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "droid-slam_amd")]
+sys.path[:0] = [ROOT] + ([os.path.join(ROOT, "droid-slam_amd", os.environ["DH_LIB_DIR"])] if os.environ.get("DH_LIB_DIR") else []) + [os.path.join(ROOT, "droid-slam_amd")]
 import torch
 import droid_backends as db
 from droid_amd.update import UpdateModule, EPI_RELU, EPI_GRU_ZR, EPI_GRU_Q
