@@ -426,7 +426,7 @@ class UpdateModule:
                     and P["q_e"].layout == LAYOUT_AUTO and P["q_e"].wh is not None and P["q"].wh is not None)
 
     def forward_nhwc(self, net, inp, corr, flow, ii, inp_frames=None, inp_index=None, ctx=None, corr0=None, _mask=None,
-                     glo_red=None, glo_next=False):
+                     glo_red=None, glo_next=False, _glo=None):
         """net [E,h,w,128] f16 (updated IN PLACE), corr = [E,196,h,w] f16 in the reference's layout (pixel counts that are a
         multiple of 128) or [4,E,h,w,56] f16, the level-planar channel-last output of
         droid_backends.corr_pyramid_lookup_nhwc (channel order: corr_channel_map), flow [E,h,w,8] f16 (4 + zero pad),
@@ -448,13 +448,17 @@ class UpdateModule:
         E, h, w, _ = net.shape
         self.last_glo = None
         if self.canvas and not (w == 64 and h % 4 == 0) and w <= 64 and _mask is None:
-            return self._forward_canvas(net, inp, corr, flow, ii, inp_frames, inp_index, corr0)
+            return self._forward_canvas(net, inp, corr, flow, ii, inp_frames, inp_index, corr0, _glo=_glo)
         if self.canvas and w > 64 and h <= 64 and _mask is None:
             return self._forward_transposed(net, inp, corr, flow, ii, inp_frames, inp_index, corr0)
+        if self.canvas and w > 64 and h > 64 and _mask is None:
+            return self._forward_strips(net, inp, corr, flow, ii, inp_frames, inp_index, corr0)
         # canvas mode (_mask = (h_img, w_img)): the tensors are canvases; every activation that feeds a 3x3 layer gets the pixels
         # outside the image zeroed again, which is the zero border the reference's padded convolutions see there
         mk = (lambda t: t) if _mask is None else (lambda t: (droid_backends.canvas_mask_(t, _mask[0], _mask[1]), t)[1])
         npix = float(h * w) if _mask is None else float(_mask[0] * _mask[1])
+        if _glo is not None:                   # (strip mode: the global context is a mean over the WHOLE image, reduced by the caller)
+            glo_red, npix = _glo[0], float(_glo[1])
         main, side = torch.cuda.current_stream(net.device), (None, None)
         if self.streams and net.is_cuda and E * h * w >= (1 << 18):          # (small problems are launch-bound: nothing to overlap)
             if self._side is None:
@@ -467,7 +471,7 @@ class UpdateModule:
             f = mk(P["flow2"]([mk(P["flow0"]([flow], EPI_RELU))], EPI_RELU))
         with _Fork(side[1], main) as gb:
             # global context: mean over pixels of sigmoid(w(net)) * net, then three 128x128 GEMVs per edge
-            if glo_red is not None and _mask is None:
+            if glo_red is not None and (_mask is None or _glo is not None):
                 red = glo_red
             else:
                 red = torch.zeros(E, 128, dtype=torch.float32, device=net.device)
@@ -529,7 +533,7 @@ class UpdateModule:
         self._derived[slot] = (key, val, src)
         return val
 
-    def _forward_canvas(self, net, inp, corr, flow, ii, inp_frames, inp_index, corr0):
+    def _forward_canvas(self, net, inp, corr, flow, ii, inp_frames, inp_index, corr0, _glo=None):
         """forward_nhwc for an image that is not 64 pixels wide / a multiple of four rows high (TUM's 30x40, 16x32, ...): the
         tensors are embedded into zero-padded canvases [.., ceil4(h), 64, C], the production kernels run on the canvases with
         the padding re-zeroed between the layers (forward_nhwc, _mask), and the results are cropped.  Same arithmetic per
@@ -550,10 +554,70 @@ class UpdateModule:
         inpf_c = self._cached("canvas_inp_%dx%d" % (h, w), inp_frames, pad)
         ctx = self._cached("canvas_ctx_%dx%d" % (h, w), inpf_c, self.context_term) if (inp is None and inpf_c is not None) else None
         n, delta, weight, eta, upmask = self.forward_nhwc(net_c, pad(inp), corr_c, pad(flow), ii, inp_frames=inpf_c,
-                                                          inp_index=inp_index, ctx=ctx, corr0=corr0_c, _mask=(h, w))
+                                                          inp_index=inp_index, ctx=ctx, corr0=corr0_c, _mask=(h, w), _glo=_glo)
         net.copy_(n[:, :h, :w])
         self.last_dw = crop(self.last_dw)
         return net, self.last_dw[..., :2], self.last_dw[..., 2:], eta[:, :h, :w].contiguous(), crop(upmask)
+
+    # ---- images with more than 64 columns AND more than 64 rows (72x96 = a 576x768 video, ...) ---------------------------------
+    STRIP_OVERLAP = 9       # columns a strip's results are contaminated from an INNER strip border: the longest 3x3 / 7x7 chain of one
+                            # call is flow_encoder (3 + 1) -> z|r (1) -> q (1) -> agg.conv1 (1) -> agg.conv2 (1) -> eta (1) = 9
+                            # (heads: 6 + 1 + 1 = 8; the new hidden state: 6)
+
+    @classmethod
+    def strip_plan(cls, w):
+        """64-column strips that cover w > 64 columns: [(start, first valid column, one past the last valid column)] -- a strip's results
+        are used outside STRIP_OVERLAP columns from its borders that are not image borders"""
+        V, plan, lo = cls.STRIP_OVERLAP, [], 0
+        while True:
+            start = 0 if lo == 0 else lo - V
+            if start + 64 >= w:
+                start = w - 64
+                plan.append((start, lo, w))
+                return plan
+            plan.append((start, lo, start + 64 - V))
+            lo = start + 64 - V
+
+    def _forward_strips(self, net, inp, corr, flow, ii, inp_frames, inp_index, corr0):
+        """forward_nhwc for an image wider AND higher than 64 (round 6; rounds 1-5 ran these sizes through the generic convolution loop).
+        The production kernels want 64-column images, and every layer of the operator is local except the ConvGRU's global context.  So:
+        the global-context sums are reduced over the WHOLE image first (stand-alone kernel, any size); the image is cut into 64-column
+        strips that overlap by 2 x STRIP_OVERLAP columns; the strips of all edges run through forward_nhwc as ONE batch of 64-column
+        images (each strip's zero padding at an inner border is wrong, and what it contaminates -- at most STRIP_OVERLAP columns, the
+        receptive field of the longest convolution chain -- is thrown away); the valid columns are stitched.  GraphAgg's mean over the
+        edges of a source frame is per pixel, so frame k of strip s is segment s * K + k of the batch.  Same arithmetic per valid pixel
+        as on a 64-column image; 64 / (64 - 2 x 9) more work than the image has."""
+        P = self.params
+        E, h, w, _ = net.shape
+        plan = self.strip_plan(w)
+        S = len(plan)
+        red = torch.zeros(E, 128, dtype=torch.float32, device=net.device)
+        P["gru_w"]([net], EPI_GLO, aux0=net, red=red)
+        c0 = corr0 if corr0 is not None else self.corr0_layer(corr)
+        cut = lambda t: None if t is None else torch.cat([t[:, :, a:a + 64] for a, _, _ in plan], 0).contiguous()      # [S*N,h,64,C], strip-major
+        uniq, ix = torch.unique(ii, return_inverse=True)
+        K = uniq.numel()
+        ii_b = torch.cat([ix + s_ * K for s_ in range(S)]).contiguous()
+        kw = {}
+        if inp is None:
+            Kp = inp_frames.shape[0]
+            kw = dict(inp_frames=self._cached("strips_inp_%dx%d" % (h, w), inp_frames, cut),
+                      inp_index=torch.cat([inp_index + s_ * Kp for s_ in range(S)]).contiguous())
+            if h % 4 == 0:                     # (other heights: the strips run on canvases, which keep their own padded copy and term)
+                kw["ctx"] = self._cached("strips_ctx_%dx%d" % (h, w), kw["inp_frames"], self.context_term)
+        net_b = cut(net)
+        n_b, _, _, eta_b, up_b = self.forward_nhwc(net_b, cut(inp), None, cut(flow), ii_b, corr0=cut(c0), _glo=(red.repeat(S, 1), h * w), **kw)
+        dw_b = self.last_dw
+        dw = torch.empty(E, h, w, 4, dtype=dw_b.dtype, device=net.device)
+        eta = torch.empty(K, h, w, dtype=eta_b.dtype, device=net.device)
+        upmask = torch.empty(K, h, w, up_b.shape[-1], dtype=up_b.dtype, device=net.device)
+        for s_, (a, lo, hi) in enumerate(plan):
+            net[:, :, lo:hi] = n_b[s_ * E:(s_ + 1) * E, :, lo - a:hi - a]
+            dw[:, :, lo:hi] = dw_b[s_ * E:(s_ + 1) * E, :, lo - a:hi - a]
+            eta[:, :, lo:hi] = eta_b[s_ * K:(s_ + 1) * K, :, lo - a:hi - a]
+            upmask[:, :, lo:hi] = up_b[s_ * K:(s_ + 1) * K, :, lo - a:hi - a]
+        self.last_dw, self.last_glo = dw, None
+        return net, dw[..., :2], dw[..., 2:], eta, upmask
 
     # ---- images wider than 64 columns but at most 64 rows high (41x73 from a 16:9 video, 60x80, ...) -------------------------
     def transposed_twin(self):

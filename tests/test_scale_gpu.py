@@ -626,7 +626,9 @@ def test_canvas_pyramid_and_operator_equal_the_general_paths(db, shape):
     16:9 video at the reference's demo resolution, 60x80, ...) run TRANSPOSED on the canvases (CorrBlock.transposed,
     UpdateModule.transposed_twin): same comparisons, plus the operator fed by the fused lookup.  Shapes with more than 64 columns
     AND rows (72x96, 65x70, 80x136: two and three strips) keep the pyramid in 64-column strips (CorrBlock.strips: lookups summed
-    over the target strips); their operator is the generic loop on both sides, fed by the strip lookup."""
+    over the target strips); round 6: their operator runs the production kernels on overlapping 64-column strips of the image
+    (UpdateModule._forward_strips: global context reduced over the whole image, contaminated columns discarded) against the generic
+    loop on the image itself -- 65x70 additionally on row-padded canvases."""
     from droid_amd.corr import CorrBlock, CorrBlockRef
     from droid_amd.update import UpdateModule, pack_corr0_fused
     from droid_amd.weights import deterministic_state_dict
@@ -673,8 +675,8 @@ def test_canvas_pyramid_and_operator_equal_the_general_paths(db, shape):
             assert (x - y).abs().max().item() <= (tol if k == 0 else 4 * tol) * max(1.0, y.abs().max().item()), (k, shape)
     # the canvas / transposed paths keep the padded context features and the gates' context term per source tensor (identity +
     # version): the calls above hit that cache; an IN-PLACE change of the frames' context features must refresh it
-    if (h, w) != (44, 64) and not (h > 64 and w > 64):             # (44x64 is inside the production tiling: no canvas; strips: generic loop)
-        assert any(k.startswith(("canvas_ctx", "transposed_inp")) for k in upd._derived)
+    if (h, w) != (44, 64):                                         # (44x64 is inside the production tiling: no canvas)
+        assert any(k.startswith(("canvas_ctx", "transposed_inp", "strips_inp")) for k in upd._derived)
     inp_frames.mul_(0.5)
     outs2 = []
     for m in (upd, gen):
