@@ -127,6 +127,7 @@ class FactorGraph:
     def clear_edges(self):
         self.rm_factors(self.ii >= 0)
         self._net = None
+        self._glo = None
 
     def add_factors(self, ii, jj, remove=False):
         as_t = lambda x: x.to(self.device, torch.long) if isinstance(x, torch.Tensor) else torch.as_tensor(x, dtype=torch.long, device=self.device)
@@ -152,6 +153,7 @@ class FactorGraph:
             self.corr = corr if self.corr is None else self.corr.cat(corr)
         target, _ = self.video.reproject(ii, jj)
         self._net = net if self._net is None else torch.cat([self._net, net], 0)
+        self._glo = None                                              # (sums of the replaced state tensor: release it)
         self.target = torch.cat([self.target, target], 1)
         self.weight = torch.cat([self.weight, torch.zeros_like(target)], 1)
 
@@ -170,6 +172,7 @@ class FactorGraph:
             self.corr = self.corr[~mask]
         if self._net is not None:
             self._net = self._net[~mask]
+            self._glo = None
         self.target = self.target[:, ~mask]; self.weight = self.weight[:, ~mask]
 
     def rm_keyframe(self, ix):
@@ -237,7 +240,9 @@ class FactorGraph:
         if key is not None and key == self._coherence_key:
             return
         self._coherence_key, self._coherence_ii = key, (ii, jj)                    # (kept alive: their addresses are in the key)
-        self.last_window_spread = spread = CorrBlock.window_spread(coords1)
+        # (a mean over at most 256 evenly spaced edges: the figure decides between two layouts a factor 6 apart, and the frontend
+        # changes its edge list -- and so comes through here -- at every keyframe)
+        self.last_window_spread = spread = CorrBlock.window_spread(coords1[::max(1, coords1.shape[0] // 256)])
         if spread <= CorrBlock.SPREAD_LIMIT:
             return
         c = (ii == jj).long()

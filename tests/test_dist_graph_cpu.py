@@ -294,3 +294,55 @@ def test_sharded_graph_two_ranks_equals_single_process_graph(tmp_path, lowmem, w
         net[r["local_index"]] = r["net_local"]; tgt[r["local_index"]] = r["target_local"]; seen[r["local_index"]] += 1
     assert np.all(seen == 1)
     assert np.abs(net - graph._net.numpy()).max() < 1e-5 and np.abs(tgt - graph.target[0].numpy()).max() < 1e-4
+
+
+def test_global_context_sums_follow_the_state_tensor_they_were_reduced_from():
+    """host logic of round 6's chain (FactorGraph._operator): the sums the update operator leaves behind (last_glo) are handed to the next call
+    only while the graph's hidden-state tensor IS the object they were reduced from -- not after rm_factors / add_factors (new tensor),
+    not after a caller took the reference-shaped `net` view (it may write through it), never for update_lowmem's chunk copies."""
+    _install_fakes()
+    from droid_amd import depth_video as dv_mod
+    from droid_amd.factor_graph import FactorGraph
+    g = _scenario()
+    v = _make_video(g, False)
+    fake = type("DB", (FakeDB,), {})
+    fake.ba = staticmethod(OracleVideoBA(None))
+    dv_mod.db = fake
+    calls = []
+
+    class ChainUpdate(FakeUpdate):
+        last_glo = None
+
+        def fuses_next_glo(self, h, w):
+            return True
+
+        def forward_nhwc(self, net, inp, feats, flow, ii, inp_frames=None, inp_index=None, ctx=None, corr0=None, glo_red=None, glo_next=False):
+            calls.append((net, glo_red, glo_next))
+            out = FakeUpdate.forward_nhwc(self, net, inp, feats, flow, ii, inp_frames=inp_frames, inp_index=inp_index, ctx=ctx, corr0=corr0)
+            self.last_glo = net.float().sum((1, 2)) if glo_next else None      # "sums of the state this call wrote"
+            return out
+    graph = FactorGraph(v, ChainUpdate(), device="cpu", corr_impl="volume", native_corr=False)
+    graph.add_neighborhood_factors(0, NF, r=2)
+    graph.update(1)
+    graph.update(1)
+    graph.update(1)
+    assert calls[0][1] is None and all(c[2] for c in calls)
+    assert calls[1][1] is not None and tuple(calls[1][1].shape) == (calls[0][0].shape[0], 16)            # what call 0 left behind
+    assert calls[2][1] is not calls[1][1] and calls[2][0] is calls[1][0] is graph._net
+    graph.rm_factors(graph.ii < 1, store=False)                   # the state tensor is replaced: nothing to hand over
+    graph.update(1)
+    assert calls[3][1] is None and calls[3][0] is graph._net and calls[3][0] is not calls[2][0]
+    graph.update(1)
+    assert calls[4][1] is not None
+    _ = graph.net                                                  # reference-shaped view handed out: the caller may write through it
+    graph.update(1)
+    assert calls[5][1] is None
+    graph.add_factors([0, 6], [4, 2])
+    graph.update(1)
+    assert calls[6][1] is None
+    # update_lowmem's alt-correlation loop works on chunk COPIES of the state: never chained, and the kept sums are dropped
+    n = len(calls)
+    g2 = FactorGraph(v, ChainUpdate(), device="cpu", corr_impl="alt", native_corr=False)
+    g2.add_neighborhood_factors(0, NF, r=2)
+    g2.update_lowmem(steps=2, corr="alt")
+    assert len(calls) > n and all(c[1] is None and not c[2] for c in calls[n:]) and g2._glo is None
