@@ -263,7 +263,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& P, f32x16 (&acc)
 template <int EPI>
 inline bool staged_epilogue_ok(const ConvParams& P) {
   if (!opts().conv_epi_staged) return false;                // 0: per-element epilogue everywhere (A/B runs)
-  if (EPI == EPI_HEADS0) return P.aux1 && P.red && P.Cout == P.CoutPad && P.CoutPad % 128 == 0 && ((uintptr_t)P.aux1) % 16 == 0;
+  if (EPI == EPI_HEADS0) return P.aux1 && P.red && P.Cout == P.CoutPad && P.CoutPad % 128 == 0 && ((uintptr_t)P.aux1) % 16 == 0 &&
+                                (!P.out || (!P.out_f32 && P.out_stride % 8 == 0 && ((uintptr_t)P.out) % 16 == 0));
   if (EPI == EPI_GLO) return P.Cout % 8 == 0 && P.aux0_stride % 8 == 0 && ((uintptr_t)P.aux0) % 16 == 0;
   if (P.out_f32 || P.Cout % 8 || P.out_stride % 8 || ((uintptr_t)P.out) % 16) return false;
   if (EPI == EPI_GRU_ZR && (P.aux0_stride % 8 || ((uintptr_t)P.aux0) % 16)) return false;
@@ -425,6 +426,9 @@ __device__ __forceinline__ void staged_heads0_epilogue(const ConvParams& P, f32x
       }
   }
   __syncthreads();
+  // round 6: P.out != nullptr -- the relu'd activations ALSO leave the kernel (GraphAgg's second convolution: the upmask head reads them,
+  // and the 3x3 eta head is the fused second layer here; for the delta | weight heads nothing else reads them and P.out is null)
+  if (P.out) staged_tile_store<EPI_RELU, 128>(P, sT, m0, n0, tid);
   const int mrow = (wave & 3) * 64, nh = (wave >> 2) * 32, p = lane & 31, kh = lane >> 5;
   const int tile = n0 >> 7;
   const __half* wsrc = P.aux1 + ((long)tile * 64 + nh + p) * 128 + kh * 8;
@@ -484,6 +488,8 @@ __device__ __forceinline__ void staged_heads0_epilogue(const ConvParams& P, f32x
 // o(p) = bias + sum over cout tiles of (own tile's row partial + the row the tile above / below contributes, same image), then the
 // heads' activation (delta_x, delta_y raw; sigmoid on the two confidence outputs), values rounded to fp16 like the convolution it
 // replaces.  part = [cout tiles][pixel tiles of 4 rows][6 output rows: -1 .. 4][64][4] f32 (staged_heads0_epilogue); W = 64.
+// MODE 1 (round 6): GraphAgg's eta head -- output 0 only, 0.01 * softplus of the fp16-rounded sum (EPI_SOFTPLUS_001), one float per pixel
+template <int MODE>
 __global__ __launch_bounds__(256) void heads_gather_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ dw,
                                                            long M, int ntiles, int H) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -502,10 +508,15 @@ __global__ __launch_bounds__(256) void heads_gather_kernel(const float* __restri
     if (ry == 0 && y > 0) add(t0 - 1, 5);
     if (ry == 3 && y < H - 1) add(t0 + 1, 0);
   }
-  float4 res;
-  res.x = round_h(o[0]); res.y = round_h(o[1]);
-  res.z = round_h(sigmoidf_(round_h(o[2]))); res.w = round_h(sigmoidf_(round_h(o[3])));
-  reinterpret_cast<float4*>(dw)[i] = res;
+  if constexpr (MODE == 1) {
+    const float hv = round_h(o[0]);
+    dw[i] = 0.01f * (hv > 20.f ? hv : log1pf(__expf(hv)));
+  } else {
+    float4 res;
+    res.x = round_h(o[0]); res.y = round_h(o[1]);
+    res.z = round_h(sigmoidf_(round_h(o[2]))); res.w = round_h(sigmoidf_(round_h(o[3])));
+    reinterpret_cast<float4*>(dw)[i] = res;
+  }
 }
 
 // EPI_GLO through the same staged tile: sigmoid gate -> LDS, gate * feature with 16-byte operand loads, per-cout sum
@@ -3035,12 +3046,18 @@ extern "C" int dh_glo_gemv(const float* red, const float* wt, const float* bias,
 }
 
 extern "C" int dh_heads_gather(const float* partials, const float* bias4, float* dw, int N, int H, int W, int n_cout_tiles, dh_stream_t stream) {
+  return dh_heads_gather_ex(partials, bias4, dw, N, H, W, n_cout_tiles, 0, stream);
+}
+
+extern "C" int dh_heads_gather_ex(const float* partials, const float* bias4, float* dw, int N, int H, int W, int n_cout_tiles, int mode, dh_stream_t stream) {
+  if (mode != 0 && mode != 1) return DH_ERR_ARG;
   if (N < 0 || H <= 0 || W <= 0 || n_cout_tiles < 1) return DH_ERR_ARG;
   if (W != 64 || H % 4) return DH_ERR_UNSUPPORTED;           // the partials are per tile of four full 64-pixel rows (EPI_HEADS0)
   if (N == 0) return DH_OK;
   if (!partials || !bias4 || !dw) return DH_ERR_ARG;
   const long M = (long)N * H * W;
-  hipLaunchKernelGGL(heads_gather_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partials, bias4, dw, M, n_cout_tiles, H);
+  if (mode == 1) hipLaunchKernelGGL(heads_gather_kernel<1>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partials, bias4, dw, M, n_cout_tiles, H);
+  else hipLaunchKernelGGL(heads_gather_kernel<0>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partials, bias4, dw, M, n_cout_tiles, H);
   DH_LAUNCH_CHECK();
   return DH_OK;
 }

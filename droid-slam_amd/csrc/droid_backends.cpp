@@ -706,15 +706,16 @@ std::vector<torch::Tensor> proximity_nms(torch::Tensor dist, torch::Tensor edges
   return {out, count};
 }
 
-torch::Tensor heads_gather(torch::Tensor partials, torch::Tensor bias4, int64_t H, int64_t W) {
+torch::Tensor heads_gather(torch::Tensor partials, torch::Tensor bias4, int64_t H, int64_t W, int64_t mode) {
   CHECK_INPUT(partials); CHECK_INPUT(bias4); CHECK_F32(partials); CHECK_F32(bias4);
   TORCH_CHECK(partials.dim() == 5 && partials.size(2) == 6 && partials.size(3) == 64 && partials.size(4) == 4 && bias4.numel() >= 4 && W == 64 &&
               H % 4 == 0 && (partials.size(1) * 4) % H == 0,
               "heads_gather: partials [cout tiles, N*H/4 pixel tiles, 6, 64, 4] f32 of images with 64 columns");
   const int N = (int)(partials.size(1) * 4 / H);
-  torch::Tensor dw = torch::empty({N, H, W, 4}, partials.options());
-  check_status(dh_heads_gather(partials.data_ptr<float>(), bias4.data_ptr<float>(), dw.data_ptr<float>(), N, (int)H, (int)W,
-                               (int)partials.size(0), cur_stream()), "heads_gather");
+  // mode 1: GraphAgg's eta head (one output, 0.01 * softplus) -> [N,H,W]
+  torch::Tensor dw = mode == 1 ? torch::empty({N, H, W}, partials.options()) : torch::empty({N, H, W, 4}, partials.options());
+  check_status(dh_heads_gather_ex(partials.data_ptr<float>(), bias4.data_ptr<float>(), dw.data_ptr<float>(), N, (int)H, (int)W,
+                                  (int)partials.size(0), (int)mode, cur_stream()), "heads_gather");
   return dw;
 }
 
@@ -850,7 +851,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("ba_inputs", &ba_inputs, "target = coords1 + delta, weight; also in ba's [E,2,h,w] layout");
   m.def("cvx_upsample", &cvx_upsample, "convex 8x upsampling of depth maps");
   m.def("proximity_nms", &proximity_nms, "candidate masking + greedy NMS of add_proximity_factors on the device");
-  m.def("heads_gather", &heads_gather, "second head layer from the fused first layer's partial products");
+  m.def("heads_gather", &heads_gather, "second head layer from the fused first layer's partial products",
+        py::arg("partials"), py::arg("bias4"), py::arg("H"), py::arg("W"), py::arg("mode") = 0);
   m.def("norm_act", &norm_act, "instance norm / residual add + activation on channel-last fp16 (encoders)");
   m.def("reproject", &reproject, "fused reprojection (Python thresholds)");
   m.def("se3_op", &se3_op, "SE3 inv/mul/exp/retr");

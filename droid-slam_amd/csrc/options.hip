@@ -41,6 +41,7 @@ Options& opts() {
     v.cinit_tiled = env_int("DH_CINIT_TILED", 1);
     v.conv_gate64 = env_int("DH_CONV_GATE64", 0);
     v.glo_fused = env_int("DH_GLO_FUSED", 1);
+    v.eta_fused = env_int("DH_ETA_FUSED", 1);
     v.conv_two_tiles = env_int("DH_CONV_TWO_TILES", 0);
     v.conv_c7_split = env_int("DH_CONV_C7_SPLIT", 0);
     v.conv_k1_half = env_int("DH_CONV_K1_HALF", 0);
@@ -102,6 +103,7 @@ static int* slot(const char* name) {
   if (!strcmp(name, "cinit_tiled")) return &o.cinit_tiled;
   if (!strcmp(name, "conv_gate64")) return &o.conv_gate64;
   if (!strcmp(name, "glo_fused")) return &o.glo_fused;
+  if (!strcmp(name, "eta_fused")) return &o.eta_fused;
   if (!strcmp(name, "conv_two_tiles")) return &o.conv_two_tiles;
   if (!strcmp(name, "conv_c7_split")) return &o.conv_c7_split;
   if (!strcmp(name, "conv_k1_half")) return &o.conv_k1_half;

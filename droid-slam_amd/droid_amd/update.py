@@ -355,6 +355,12 @@ class UpdateModule:
         P["agg1"] = conv("agg.conv1")
         P["agg2"] = conv("agg.conv2")
         P["eta"] = conv("agg.eta.0")
+        # round 6: the eta head (3x3, 128 -> 1) as the fused second layer of agg.conv2's launch (csrc/conv.hip EPI_HEADS0 with an `out`
+        # pointer): weights in the heads' layout [cout tile][tap*4 + output (output 0 only)][128 channels]
+        we = torch.zeros(1, 64, 128, device=self.device)
+        we[0, 0:36:4] = g("agg.eta.0.weight").float().reshape(128, 9).t()
+        be = torch.zeros(4, device=self.device); be[0] = g("agg.eta.0.bias").float()[0]
+        P["eta_fused"] = (we.half().contiguous(), be.contiguous())
         P["upmask"] = conv("agg.upmask.0")
         self.params = P
         return self
@@ -500,10 +506,19 @@ class UpdateModule:
             x = P["agg1"]([net], EPI_RELU)
             order, seg_off = self.segments(ii)
             xm = mk(droid_backends.segment_mean(x, order, seg_off))
-            x2 = mk(P["agg2"]([xm], EPI_RELU))
             K = xm.shape[0]
-            eta = torch.empty(K, h, w, 1, dtype=torch.float32, device=net.device)
-            P["eta"]([x2], EPI_SOFTPLUS_001, out=eta)
+            if (_mask is None and w == 64 and h % 4 == 0 and droid_backends.get_option("conv_halo") and droid_backends.get_option("conv_halo2")
+                    and droid_backends.get_option("conv_epi_staged") and droid_backends.get_option("eta_fused")):
+                # the eta head never runs as a convolution of its own: agg.conv2's workgroups multiply their relu'd tile with its nine
+                # tap vectors (the heads' fused second layer), and the gather adds the taps and applies 0.01 * softplus
+                x2 = torch.empty(K, h, w, 128, dtype=torch.float16, device=net.device)
+                part = torch.empty(1, K * h // 4, 6, 64, 4, dtype=torch.float32, device=net.device)
+                P["agg2"]([xm], EPI_HEADS0, out=x2, aux1=P["eta_fused"][0], red=part)
+                eta = droid_backends.heads_gather(part, P["eta_fused"][1], h, w, 1)[..., None]
+            else:
+                x2 = mk(P["agg2"]([xm], EPI_RELU))
+                eta = torch.empty(K, h, w, 1, dtype=torch.float32, device=net.device)
+                P["eta"]([x2], EPI_SOFTPLUS_001, out=eta)
             upmask = P["upmask"]([x2], EPI_LINEAR)
         if _mask is None and w == 64 and h % 4 == 0 and droid_backends.get_option("conv_halo") and droid_backends.get_option("conv_halo2"):
             # heads: the 256-channel activations never leave the first layer's kernel (see csrc/conv.hip EPI_HEADS0)

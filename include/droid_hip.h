@@ -341,6 +341,11 @@ int dh_conv2d_s2_nhwc_f16(const void* input, int C, int in_stride, const void* w
  * tiles the pixel's own four-row tile's row + the row the tile above / below contributes (same image)
  * (= the heads' second 3x3 convolution, reference droid_slam/droid_net.py:95-106).  W == 64, H % 4 == 0, else DH_ERR_UNSUPPORTED. */
 int dh_heads_gather(const float* partials, const float* bias4, float* dw, int N, int H, int W, int n_cout_tiles, dh_stream_t stream);
+/* Round 6, mode 1: the same gather for a ONE-output second layer with the softplus of GraphAgg's eta head (reference
+ * droid_slam/droid_net.py:57-60 `eta`: Conv2d(128, 1, 3) + GradientClip + Softplus, scaled by 0.01 at :71): partials as above (outputs 1..3
+ * of every tap unused), dw [N*H*W] f32 = 0.01 * softplus(fp16(bias4[0] + sum)).  The first layer is then GraphAgg's conv2 launched with
+ * epilogue 8 AND an `out` pointer: its relu'd activations are stored as well (the upmask head reads them).  mode 0 = dh_heads_gather. */
+int dh_heads_gather_ex(const float* partials, const float* bias4, float* dw, int N, int H, int W, int n_cout_tiles, int mode, dh_stream_t stream);
 /* The same convolution with accumulator start values:  acc(image n, pixel r, cout) starts from
  *   cinit[(cinit_idx[n] * H*W + r) * cinit_stride + cinit_off + cout]   (fp32; cinit_idx [N] i64)
  * instead of zero, and out_is_f32 == 2 stores unrounded fp32.  This is how the per-source-frame context features of the
