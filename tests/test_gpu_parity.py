@@ -837,14 +837,15 @@ def test_context_term_in_the_accumulator_tile_layout_is_the_same_numbers(db, opt
     corr = torch.randn(E, 196, h, w, device="cuda").half()
     flow = torch.zeros(E, h, w, 8, device="cuda", dtype=torch.float16); flow[..., :4] = torch.randn(E, h, w, 4, device="cuda").half()
     outs = []
+    red = _glo_sums(upd, net0)                   # (reduced ONCE: the order of the reduction's atomics is free)
     for ctx in (t, p, None):
         n = net0.clone()
-        r = upd.forward_nhwc(n, None, corr, flow, ii, inp_frames=inp_frames, inp_index=ii, ctx=ctx)
+        r = upd.forward_nhwc(n, None, corr, flow, ii, inp_frames=inp_frames, inp_index=ii, ctx=ctx, glo_red=red)
         torch.cuda.synchronize()
         outs.append([x.clone() for x in r])
     option("cinit_tiled", 0)
     n = net0.clone()
-    r = upd.forward_nhwc(n, None, corr, flow, ii, inp_frames=inp_frames, inp_index=ii)
+    r = upd.forward_nhwc(n, None, corr, flow, ii, inp_frames=inp_frames, inp_index=ii, glo_red=red)
     torch.cuda.synchronize()
     outs.append([x.clone() for x in r])
     for other in outs[1:]:
@@ -854,9 +855,19 @@ def test_context_term_in_the_accumulator_tile_layout_is_the_same_numbers(db, opt
     option("cinit_tiled", 1)
     sel = ii >= 1
     n = net0[sel].clone()
-    r = upd.forward_nhwc(n, None, corr[sel].contiguous(), flow[sel].contiguous(), ii[sel].contiguous(), inp_frames=inp_frames[1:], inp_index=(ii[sel] - 1).contiguous(), ctx=t[1:])
+    r = upd.forward_nhwc(n, None, corr[sel].contiguous(), flow[sel].contiguous(), ii[sel].contiguous(), inp_frames=inp_frames[1:], inp_index=(ii[sel] - 1).contiguous(), ctx=t[1:],
+                         glo_red=red[sel].contiguous())
     torch.cuda.synchronize()
     assert torch.equal(r[0], outs[0][0][sel]) and torch.equal(r[1], outs[0][1][sel]) and torch.equal(r[2], outs[0][2][sel])
+
+
+def _glo_sums(upd, net):
+    """the ConvGRU's global-context sums of `net` [E,h,w,128] by the stand-alone kernel -> [E,128] f32 (forward_nhwc(glo_red=...))"""
+    from droid_amd.update import EPI_GLO
+    red = torch.zeros(net.shape[0], 128, dtype=torch.float32, device=net.device)
+    upd.params["gru_w"]([net], EPI_GLO, aux0=net, red=red)
+    torch.cuda.synchronize()
+    return red
 
 
 def test_gates_on_64_cout_tiles_three_workgroups_per_cu_are_bit_identical(db, option):
@@ -881,12 +892,13 @@ def test_gates_on_64_cout_tiles_three_workgroups_per_cu_are_bit_identical(db, op
         corr = torch.randn(E, 196, h, w, device="cuda").half()
         flow = torch.zeros(E, h, w, 8, device="cuda", dtype=torch.float16); flow[..., :4] = torch.randn(E, h, w, 4, device="cuda").half()
         outs = []
+        red = _glo_sums(upd, net0)               # (reduced ONCE: the order of the reduction's atomics is free, two runs of it may differ in the last fp32 bit)
         for v in (0, 1, 2, 3):
             option("conv_gate64", v)
             for tiled in (True, False) if v in (0, 1) else (True,):
                 n = net0.clone()
                 ctx = upd.context_term(inp_frames, tiled=tiled)
-                r = upd.forward_nhwc(n, None, corr, flow, ii, inp_frames=inp_frames, inp_index=ii, ctx=ctx)
+                r = upd.forward_nhwc(n, None, corr, flow, ii, inp_frames=inp_frames, inp_index=ii, ctx=ctx, glo_red=red)
                 torch.cuda.synchronize()
                 outs.append([x.clone() for x in r])
         option("conv_gate64", 0)
@@ -958,14 +970,15 @@ def test_next_iterations_global_context_sums_from_inside_the_q_gate(db, option):
         for per_edge in (False, True):
             kw = dict(inp_frames=inp_frames, inp_index=ii) if not per_edge else {}
             inp = inp_frames[ii].contiguous() if per_edge else None
+            red0 = _glo_sums(upd, net0)          # (the first iteration's sums, reduced ONCE: two runs of the reduction may differ in the last fp32 bit)
             # two iterations, plain
             n_a = net0.clone()
-            r1a = [x.clone() for x in upd.forward_nhwc(n_a, inp, corr[0], flow, ii, **kw)]
+            r1a = [x.clone() for x in upd.forward_nhwc(n_a, inp, corr[0], flow, ii, glo_red=red0, **kw)]
             assert upd.last_glo is None
             r2a = [x.clone() for x in upd.forward_nhwc(n_a, inp, corr[1], flow, ii, **kw)]
             # two iterations, chained
             n_b = net0.clone()
-            r1b = [x.clone() for x in upd.forward_nhwc(n_b, inp, corr[0], flow, ii, glo_next=True, **kw)]
+            r1b = [x.clone() for x in upd.forward_nhwc(n_b, inp, corr[0], flow, ii, glo_red=red0, glo_next=True, **kw)]
             glo = upd.last_glo
             assert glo is not None and tuple(glo.shape) == (E, 128)
             for x, y in zip(r1a, r1b):                                                    # (c)
@@ -1317,7 +1330,8 @@ def test_update_forward_leaves_a_channel_last_hidden_state_untouched(db):
     out1 = mod(net, inp, corr)[0].clone()
     assert torch.equal(net, before)
     out2 = mod(net, inp, corr)[0]
-    assert torch.equal(out1, out2)
+    # (not torch.equal: the global-context reduction adds its per-tile sums with atomics, whose order -- and so the last fp32 bit -- is free)
+    assert (out1.float() - out2.float()).abs().max().item() <= 2.0 ** -9
 
 
 @pytest.mark.parametrize("variant", ["conv_halo3", "conv_halo4"])
