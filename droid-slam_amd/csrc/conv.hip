@@ -2056,6 +2056,141 @@ __global__ __launch_bounds__(BN == 128 ? 512 : 256, BN == 128 ? 4 : 4) void conv
   DH_CTS(4);
 }
 
+// ---- the stem as PERSISTENT workgroups (round 6, option conv_c7_pp) ---------------------------------------------------------------------
+// conv7x7_c4_kernel writes 3.2 GB per launch at 2.9-3.0 TB/s where a write-only stream reaches 6.9 TB/s (scripts/ubench/hbm_rw.py): its
+// workgroups live 11 us -- weights L2 -> registers -> LDS, 2.8 us of MFMAs, 5 us of parking and storing -- with nothing of their own to
+// overlap and 16 waves per CU whatever the workgroup size.  Here ONE workgroup of 16 waves per CU walks pixel tiles: the 57 KB of weights are
+// staged once; the waves form two groups of eight with the roles of the kernel above, and in every "super-step" one group multiplies its
+// tile while the other parks and stores the tile it multiplied in the previous super-step and stages the halo of its next one; then
+// the roles swap.  The groups meet at four workgroup barriers per super-step (the parking group needs them around its two 128-pixel
+// halves of the staged tile; the multiplying group passes them between its kernel rows).  LDS: weights 59.4 KB + 2 x (halo 5.8 KB +
+// half a staged tile 34.8 KB) = 140.5 KB.  Same MFMAs in the same order per output element, same epilogue arithmetic: EQUAL results.
+constexpr int C7P_S_BYTES = 128 * (128 + 8) * 2;               // 34,816: half a staged tile [128 px][128 couts + 8]
+constexpr int C7P_G_BYTES = C7_A_BYTES + C7P_S_BYTES;          // per wave group
+constexpr int C7P_LDS_BYTES = C7_W_BYTES + 2 * C7P_G_BYTES;    // 140,544
+template <int EPI>
+__global__ __launch_bounds__(1024, 4) void conv7x7_c4_pp_kernel(ConvParams P) {
+  extern __shared__ __half s_conv[];
+  char* const lds = reinterpret_cast<char*>(s_conv);
+  char* const sW = lds;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 3, w8 = wave & 7, tg = tid & 511;           // wave group, wave inside it, thread inside it
+  const int wrow = w8 & 3, wn0 = (w8 >> 2) * 64, wm0 = wrow * 64;
+  char* const sH = lds + C7_W_BYTES + grp * C7P_G_BYTES;              // this group's halo
+  __half* const sS = reinterpret_cast<__half*>(sH + C7_A_BYTES);     // this group's half staged tile
+  const int HW = P.H * P.W;
+  const long ntiles = (long)P.N * HW / BM;
+  // weights once: 128 rows x 28 pieces of 16 bytes
+  for (int id = tid; id < 128 * 28; id += 1024) {
+    const int row = id / 28, pc = id - row * 28;
+    *reinterpret_cast<uint4*>(sW + row * (C7_WLD * 2) + pc * 16) = *reinterpret_cast<const uint4*>(P.wt_halo + (long)row * C7_K + pc * 8);
+  }
+  // halo of tile t into this group's buffer: column c holds image column c - 4, row r image row y0 - 3 + r; 8 bytes per pixel
+  auto halo_fetch = [&](long t, uint2 (&v)[2], int tg) {
+    const long m0 = t * BM;
+    const int img = (int)(m0 / HW), y0 = (int)((m0 - (long)img * HW) / 64);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int id = tg + 512 * i;
+      v[i] = uint2{0u, 0u};
+      if (id < C7_ROWS * C7_COLS) {
+        const int r = id / C7_COLS, c = id - r * C7_COLS;
+        const int y = y0 - 3 + r, x = c - 4;
+        if ((unsigned)y < (unsigned)P.H && (unsigned)x < 64u)
+          v[i] = *reinterpret_cast<const uint2*>(P.in[0] + ((long)(img * P.H + y) * 64 + x) * P.segS[0]);
+      }
+    }
+  };
+  auto halo_store = [&](const uint2 (&v)[2], int tg) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int id = tg + 512 * i;
+      if (id < C7_ROWS * C7_COLS) *reinterpret_cast<uint2*>(sH + id * 8) = v[i];
+    }
+  };
+  // tile s of this workgroup's sequence; group (s & 1) owns it
+  auto tile_of = [&](long sidx) { return (long)blockIdx.x + sidx * gridDim.x; };
+  f32x16 acc[2][2];
+  const int p = lane & 31, kh = lane >> 5;
+  {
+    uint2 v[2];
+    if (tile_of(grp) < ntiles) { halo_fetch(tile_of(grp), v, tg); halo_store(v, tg); }       // each group's first tile
+  }
+  __syncthreads();
+  // super-step k: group (k & 1) multiplies tile k; the other group finishes tile k - 1 and stages the halo of tile k + 1
+  for (long k = 0; tile_of(k > 0 ? k - 1 : 0) < ntiles; ++k) {
+    const bool mul = (int)(k & 1) == grp;
+    const long t_mul = tile_of(k), t_epi = tile_of(k - 1), t_next = tile_of(k + 1);
+    const bool do_mul = mul && t_mul < ntiles, do_epi = !mul && k > 0 && t_epi < ntiles;
+    // (opaque per super-step: the per-thread addresses of the halo / parking / store code would otherwise be hoisted out of the tile loop
+    // as invariants and kept -- in scratch -- across the multiply phase)
+    int lane_o = lane, tg_o = tg;
+    asm volatile("" : "+v"(lane_o), "+v"(tg_o));
+    uint2 hv[2];
+    const bool do_halo = !mul && k > 0 && t_next < ntiles;                              // (k == 0: both first halos were staged above)
+    if (do_halo) halo_fetch(t_next, hv, tg_o);
+    if (do_mul) zero_acc<2, 2>(acc);
+    const long m0e = t_epi * BM;
+#pragma unroll
+    for (int seg = 0; seg < 4; ++seg) {
+      if (do_mul) {
+        // kernel rows 2 seg, 2 seg + 1 (the last segment: row 6 only)
+#pragma unroll
+        for (int d2 = 0; d2 < 2; ++d2) {
+          const int dy = 2 * seg + d2;
+          if (dy < 7) {
+#pragma unroll
+            for (int hx = 0; hx < 2; ++hx) {
+              const int ks = dy * 2 + hx;
+              half8 af[2], bf[2];
+#pragma unroll
+              for (int a = 0; a < 2; ++a) {
+                const char* src = sH + ((wrow + dy) * C7_COLS + a * 32 + p + hx * 4 + kh * 2 + 1) * 8;
+                const uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 8);
+                const uint4 v{lo.x, lo.y, hi.x, hi.y};
+                af[a] = *reinterpret_cast<const half8*>(&v);
+              }
+#pragma unroll
+              for (int b = 0; b < 2; ++b)
+                bf[b] = *reinterpret_cast<const half8*>(sW + (wn0 + b * 32 + p) * (C7_WLD * 2) + ks * 32 + kh * 16);
+#pragma unroll
+              for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+            }
+          }
+        }
+      } else if (do_epi) {
+        const int half = seg >> 1;
+        if ((seg & 1) == 0) {
+          // park: the waves that own image rows 2 half, 2 half + 1 of the tile write their 64 x 64 sub-tiles (bias, activation, fp16)
+          if ((wrow >> 1) == half) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+              const int cl = wn0 + b * 32 + (lane_o & 31);
+              const float add = P.bias[cl];
+#pragma unroll
+              for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                  const int row = (wrow & 1) * 64 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane_o >> 5);
+                  float v = acc[a][b][q] + add;
+                  if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
+                  sS[row * (128 + 8) + cl] = __float2half(v);
+                }
+            }
+          }
+        } else {
+          staged_tile_store<EPI, 128, 512, false, 128>(P, sS, m0e + half * 128, 0, tg_o);
+          if (seg == 3 && do_halo) halo_store(hv, tg_o);
+        }
+      } else if (seg == 3 && do_halo) halo_store(hv, tg_o);
+      __syncthreads();
+    }
+  }
+}
+
 // ---- 1x1 on 128 input channels with many outputs (GraphAgg's upmask head: 128 -> 576 on the source frames, droid_net.py:62) -------
 // The generic loop runs this shape as 5 independent cout tiles per pixel tile, each with a two-chunk main loop between a cold
 // prologue and a full epilogue (0.80 ms at 512 frames for 2.2 GB of traffic).  Here the pixel tile's activations [256 px][128 ch] are
@@ -2950,6 +3085,14 @@ extern "C" int dh_conv2d_nhwc_f16_ex3(const void* const* inputs, const int* in_c
   if (glo_ok(P)) {
     DH_LDS_OPTIN(&glo_reduce_kernel, 80 * 1024);
     hipLaunchKernelGGL(glo_reduce_kernel, dim3((unsigned)((long)P.N * P.H * P.W / BM)), dim3(512), BM * GLD * 2, st, P);
+    DH_LAUNCH_CHECK();
+    return DH_OK;
+  }
+  if (c7_ok(P) && opts().conv_c7_pp && P.epi == EPI_RELU) {  // persistent workgroups, two wave groups alternating roles
+    const long ntiles = (long)P.N * P.H * P.W / BM;
+    const unsigned grid = (unsigned)std::min<long>((ntiles + 1) / 2, device_cus());
+    DH_LDS_OPTIN((&conv7x7_c4_pp_kernel<EPI_RELU>), 160 * 1024);
+    hipLaunchKernelGGL((conv7x7_c4_pp_kernel<EPI_RELU>), dim3(grid), dim3(1024), C7P_LDS_BYTES, st, P);
     DH_LAUNCH_CHECK();
     return DH_OK;
   }

@@ -44,6 +44,7 @@ Options& opts() {
     v.eta_fused = env_int("DH_ETA_FUSED", 1);
     v.conv_two_tiles = env_int("DH_CONV_TWO_TILES", 0);
     v.conv_c7_split = env_int("DH_CONV_C7_SPLIT", 0);
+    v.conv_c7_pp = env_int("DH_CONV_C7_PP", 0);
     v.conv_k1_half = env_int("DH_CONV_K1_HALF", 0);
     v.conv_two_tiles_maxc = env_int("DH_CONV_TWO_TILES_MAXC", 128);
 #ifndef DH_ABLATION
@@ -106,6 +107,7 @@ static int* slot(const char* name) {
   if (!strcmp(name, "eta_fused")) return &o.eta_fused;
   if (!strcmp(name, "conv_two_tiles")) return &o.conv_two_tiles;
   if (!strcmp(name, "conv_c7_split")) return &o.conv_c7_split;
+  if (!strcmp(name, "conv_c7_pp")) return &o.conv_c7_pp;
   if (!strcmp(name, "conv_k1_half")) return &o.conv_k1_half;
   if (!strcmp(name, "conv_two_tiles_maxc")) return &o.conv_two_tiles_maxc;
   return nullptr;
