@@ -2056,6 +2056,79 @@ __global__ __launch_bounds__(BN == 128 ? 512 : 256, BN == 128 ? 4 : 4) void conv
   DH_CTS(4);
 }
 
+// ---- the stem with SIXTEEN waves of 32 px x 64 couts per workgroup (round 6, option conv_c7_w16) ---------------------------------------------
+// The stem is latency-bound with its SIMDs issuing ~45 % of the time (670 instructions per wave and tile in chains of LDS / memory latencies,
+// four waves per SIMD): the same tile, the same LDS image and the same two workgroups per CU, but 32 accumulators per wave instead of 64
+// (<= 64 registers) double the waves per SIMD to eight.  A wave owns pixel columns 32 a .. 32 a + 31 of one image row and 64 couts.  Same
+// MFMAs per output element in the same order: EQUAL results.
+template <int EPI>
+__global__ __launch_bounds__(1024, 8) void conv7x7_c4_w16_kernel(ConvParams P) {
+  extern __shared__ __half s_conv[];
+  char* const lds = reinterpret_cast<char*>(s_conv);
+  char* const sW = lds + C7_A_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wrow = wave & 3, ah = (wave >> 2) & 1, wn0 = (wave >> 3) * 64;
+  const long m0 = (long)blockIdx.x * BM;
+  const int HW = P.H * P.W;
+  const int img = (int)(m0 / HW), y0 = (int)((m0 - (long)img * HW) / 64);
+  if (tid < C7_ROWS * C7_COLS) {
+    const int r = tid / C7_COLS, c = tid - r * C7_COLS;
+    const int y = y0 - 3 + r, x = c - 4;
+    uint2 v{0u, 0u};
+    if ((unsigned)y < (unsigned)P.H && (unsigned)x < 64u)
+      v = *reinterpret_cast<const uint2*>(P.in[0] + ((long)(img * P.H + y) * 64 + x) * P.segS[0]);
+    *reinterpret_cast<uint2*>(lds + tid * 8) = v;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {                            // 128 rows x 28 pieces of 16 bytes = 3584 = 3.5 x 1024
+    const int id = tid + 1024 * i;
+    if (id < 128 * 28) {
+      const int row = id / 28, pc = id - row * 28;
+      *reinterpret_cast<uint4*>(sW + row * (C7_WLD * 2) + pc * 16) = *reinterpret_cast<const uint4*>(P.wt_halo + (long)row * C7_K + pc * 8);
+    }
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[b][q] = 0.f;
+  __syncthreads();
+  const int p = lane & 31, kh = lane >> 5;
+#pragma unroll
+  for (int dy = 0; dy < 7; ++dy) {
+#pragma unroll
+    for (int hx = 0; hx < 2; ++hx) {
+      const int ks = dy * 2 + hx;
+      const char* src = lds + ((wrow + dy) * C7_COLS + ah * 32 + p + hx * 4 + kh * 2 + 1) * 8;
+      const uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 8);
+      const uint4 v{lo.x, lo.y, hi.x, hi.y};
+      const half8 af = *reinterpret_cast<const half8*>(&v);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const half8 bf = *reinterpret_cast<const half8*>(sW + (wn0 + b * 32 + p) * (C7_WLD * 2) + ks * 32 + kh * 16);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[b], 0, 0, 0);
+      }
+    }
+  }
+  // the staged epilogue of the other kernels with one 32-pixel accumulator tile per wave and 1024 threads
+  constexpr int ELD = 128 + 8;
+  __syncthreads();
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int cl = wn0 + b * 32 + (lane & 31);
+    const float add = P.bias[cl];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = wrow * 64 + ah * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+      float v = acc[b][q] + add;
+      if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
+      s_conv[row * ELD + cl] = __float2half(v);
+    }
+  }
+  __syncthreads();
+  staged_tile_store<EPI, 128, 1024>(P, s_conv, m0, 0, tid);
+}
+
 // ---- the stem as PERSISTENT workgroups (round 6, option conv_c7_pp) ---------------------------------------------------------------------
 // conv7x7_c4_kernel writes 3.2 GB per launch at 2.9-3.0 TB/s where a write-only stream reaches 6.9 TB/s (scripts/ubench/hbm_rw.py): its
 // workgroups live 11 us -- weights L2 -> registers -> LDS, 2.8 us of MFMAs, 5 us of parking and storing -- with nothing of their own to
@@ -3085,6 +3158,12 @@ extern "C" int dh_conv2d_nhwc_f16_ex3(const void* const* inputs, const int* in_c
   if (glo_ok(P)) {
     DH_LDS_OPTIN(&glo_reduce_kernel, 80 * 1024);
     hipLaunchKernelGGL(glo_reduce_kernel, dim3((unsigned)((long)P.N * P.H * P.W / BM)), dim3(512), BM * GLD * 2, st, P);
+    DH_LAUNCH_CHECK();
+    return DH_OK;
+  }
+  if (c7_ok(P) && opts().conv_c7_w16) {                      // sixteen 32 px x 64 cout waves per workgroup: eight waves per SIMD
+    DH_LDS_OPTIN((&conv7x7_c4_w16_kernel<EPI_RELU>), 80 * 1024);
+    hipLaunchKernelGGL((conv7x7_c4_w16_kernel<EPI_RELU>), dim3((unsigned)((long)P.N * P.H * P.W / BM)), dim3(1024), C7_LDS_BYTES, st, P);
     DH_LAUNCH_CHECK();
     return DH_OK;
   }

@@ -33,6 +33,7 @@ struct Options {
   int conv_two_tiles_maxc;
   int conv_k1_half;     // DH_CONV_K1_HALF (round 6): the 128 -> 576 upmask head on 128-pixel tiles by four waves, two workgroups per CU (conv1x1_c128_kernel<.., 128>) instead of one 256-pixel workgroup; same results
   int conv_c7_pp;       // DH_CONV_C7_PP (round 6): the stem as persistent 16-wave workgroups whose two wave groups alternate between multiplying a tile and parking / storing the previous one (conv7x7_c4_pp_kernel); equal results
+  int conv_c7_w16;      // DH_CONV_C7_W16 (round 6): the stem with sixteen waves of 32 px x 64 couts per workgroup (<= 64 registers: eight waves per SIMD) instead of eight of 64 x 64; equal results
   int conv_c7_split;    // DH_CONV_C7_SPLIT (round 6): the flow encoder's 7x7 stem as 64-cout halves, four workgroups of four waves per CU (conv7x7_c4_kernel<.., 64>) instead of two of eight; same results
   int eta_fused;        // DH_ETA_FUSED (1): host side (UpdateModule): GraphAgg's eta head as the fused second layer of agg.conv2's launch (EPI_HEADS0 with an output pointer + dh_heads_gather_ex mode 1) instead of a 3x3 convolution with one output channel
   int conv_halo4;       // DH_CONV_HALO4 (0): -DDH_ABLATION builds only: the second kernel with four 64 x 128 waves per workgroup

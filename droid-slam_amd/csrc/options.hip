@@ -45,6 +45,7 @@ Options& opts() {
     v.conv_two_tiles = env_int("DH_CONV_TWO_TILES", 0);
     v.conv_c7_split = env_int("DH_CONV_C7_SPLIT", 0);
     v.conv_c7_pp = env_int("DH_CONV_C7_PP", 0);
+    v.conv_c7_w16 = env_int("DH_CONV_C7_W16", 0);
     v.conv_k1_half = env_int("DH_CONV_K1_HALF", 0);
     v.conv_two_tiles_maxc = env_int("DH_CONV_TWO_TILES_MAXC", 128);
 #ifndef DH_ABLATION
@@ -108,6 +109,7 @@ static int* slot(const char* name) {
   if (!strcmp(name, "conv_two_tiles")) return &o.conv_two_tiles;
   if (!strcmp(name, "conv_c7_split")) return &o.conv_c7_split;
   if (!strcmp(name, "conv_c7_pp")) return &o.conv_c7_pp;
+  if (!strcmp(name, "conv_c7_w16")) return &o.conv_c7_w16;
   if (!strcmp(name, "conv_k1_half")) return &o.conv_k1_half;
   if (!strcmp(name, "conv_two_tiles_maxc")) return &o.conv_two_tiles_maxc;
   return nullptr;

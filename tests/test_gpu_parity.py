@@ -1035,19 +1035,20 @@ def test_conv7x7_on_four_channels_and_global_context_kernels(db):
     assert torch.equal(both[0], both[1]) and torch.equal(both[0], out if saved == 0 else both[saved])
     # the persistent form (option conv_c7_pp: one 16-wave workgroup per CU, two wave groups alternating between multiplying a tile and
     # parking / storing the previous one): EQUAL -- 6 tiles (two per workgroup), 2 101 tiles (odd; eight or nine per workgroup), 1 tile
-    saved_pp = db.get_option("conv_c7_pp")
+    # ... and the form with sixteen 32 px x 64 cout waves per workgroup (option conv_c7_w16): EQUAL as well
+    saved_pp, saved_w16 = db.get_option("conv_c7_pp"), db.get_option("conv_c7_w16")
     for (n2, h2) in [(N, H), (191, 44), (1, 4)]:
         x2 = torch.zeros(n2, h2, W, 8, device="cuda", dtype=torch.float16)
         x2[..., :4] = (4 * torch.randn(n2, h2, W, 4, device="cuda")).half()
         res = []
-        for v in (0, 1):
-            db.set_option("conv_c7_pp", v)
+        for (pp, w16) in ((0, 0), (1, 0), (0, 1)):
+            db.set_option("conv_c7_pp", pp); db.set_option("conv_c7_w16", w16)
             o = torch.full((n2, h2, W, 128), -7.0, device="cuda", dtype=torch.float16)
             db.conv2d_nhwc([x2], wp, pack_conv_7x7_c4(wgt), bp, 7, 7, 128, EPI_RELU, o, 128, None, None, None, None)
             torch.cuda.synchronize()
             res.append(o)
-        db.set_option("conv_c7_pp", saved_pp)
-        assert torch.equal(res[0], res[1]), (n2, h2)
+        db.set_option("conv_c7_pp", saved_pp); db.set_option("conv_c7_w16", saved_w16)
+        assert torch.equal(res[0], res[1]) and torch.equal(res[0], res[2]), (n2, h2)
     # global context
     net = torch.tanh(torch.randn(N, H, W, 128, device="cuda")).half()
     w1 = torch.randn(128, 128, 1, 1, device="cuda") / 11.0
