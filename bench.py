@@ -1026,6 +1026,7 @@ def product_class_line(args, g, dev, upd, conf, _unused):
     video = _video_for(g, cfg, dev)
     _, ii, jj = _sorted_edges(g)                               # (g's edge arrays were permuted by main() already: identity here)
     graph = FactorGraph(video, upd, corr_impl="volume", max_factors=-1, upsample=False)
+    graph.compute_upmask = True                                # like the timed steps and the reference: every head of the operator in every iteration
     graph.add_factors(d(ii), d(jj))
     poses0, disps0 = d(g["poses"]), d(g["disps"])
     sync = torch.cuda.synchronize
@@ -1038,6 +1039,12 @@ def product_class_line(args, g, dev, upd, conf, _unused):
         res[key] = 1e3 * el / max(1, args.steps)
         if cache:
             res.update({"ms_corr_lookup": lk, "ms_update_operator": up, "ms_per_global_ba": ba})
+    # what the class does by default for a graph built with upsample=False (the reference's callers' default): GraphAgg's upmask head, whose
+    # only reader is DepthVideo.upsample, is not computed -- reported beside the figures above, never instead of them
+    graph.cache_context, graph.compute_upmask = True, None
+    el, _, up, _ = _timed_updates(graph, video, g, poses0, disps0, args.steps, sync)
+    res["ms_per_step_without_upmask_head"] = 1e3 * el / max(1, args.steps)
+    res["ms_update_operator_without_upmask_head"] = up
     res["steps"] = args.steps
     res["note"] = ("droid_amd.factor_graph.FactorGraph.update(1, N, itrs, lm, ep) on all edges, wall clock incl. its host logic; compare "
                    "ms_per_step with steady_state_cached_context.ms_per_step and ms_per_step_recomputing_context with the headline ms_per_step")
@@ -1071,6 +1078,7 @@ def main_dist(args, dev, world, rank, local):
     video = _video_for(g, cfg, dev)
     solver = DistBA(world, always_reduce=(world == 1))
     graph = DistFactorGraph(video, upd, corr_impl="volume", max_factors=-1, upsample=False, world=world, rank=rank, solver=solver)
+    graph.compute_upmask = True                                # every head of the operator in every iteration, like the N = 1 steps
     graph.cache_context = False
     torch.cuda.synchronize()
     e0, e1 = _ev(), _ev()

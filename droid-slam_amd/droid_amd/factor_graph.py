@@ -42,6 +42,9 @@ class FactorGraph:
         self.corr = None
         self._net = None                                              # [E,h,w,128] fp16, channel-last
         self._glo = None                                              # (the _net object, its global-context sums [E,128] f32): see _operator
+        # GraphAgg's upmask head is only read by DepthVideo.upsample: None = compute it iff this graph upsamples (the reference computes it
+        # in every iteration and drops it when upsample=False, its callers' default); True / False force it (bench.py forces True)
+        self.compute_upmask = None
         self.damping = 1e-6 * torch.ones_like(self.video.disps)
         self.target = torch.zeros(1, 0, ht, wd, 2, device=self.device)
         self.weight = torch.zeros(1, 0, ht, wd, 2, device=self.device)
@@ -203,6 +206,8 @@ class FactorGraph:
         chain = net is self._net and hasattr(self.update_op, "fuses_next_glo")        # (an operator object without the extension: plain call)
         glo = self._glo[1] if (chain and self._glo is not None and self._glo[0] is net) else None
         kw = dict(glo_red=glo, glo_next=True) if chain else {}
+        if hasattr(self.update_op, "fuses_next_glo"):
+            kw["want_upmask"] = bool(self.upsample if self.compute_upmask is None else self.compute_upmask)
         _, _, _, damping, upmask = self.update_op.forward_nhwc(net, None, feats, flow, ii, inp_frames=inp_frames, inp_index=ix, ctx=ctx,
                                                                corr0=corr0, **kw)
         self._glo = (net, self.update_op.last_glo) if (chain and self.update_op.last_glo is not None) else None

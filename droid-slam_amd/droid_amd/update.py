@@ -432,7 +432,7 @@ class UpdateModule:
                     and P["q_e"].layout == LAYOUT_AUTO and P["q_e"].wh is not None and P["q"].wh is not None)
 
     def forward_nhwc(self, net, inp, corr, flow, ii, inp_frames=None, inp_index=None, ctx=None, corr0=None, _mask=None,
-                     glo_red=None, glo_next=False, _glo=None):
+                     glo_red=None, glo_next=False, _glo=None, want_upmask=True):
         """net [E,h,w,128] f16 (updated IN PLACE), corr = [E,196,h,w] f16 in the reference's layout (pixel counts that are a
         multiple of 128) or [4,E,h,w,56] f16, the level-planar channel-last output of
         droid_backends.corr_pyramid_lookup_nhwc (channel order: corr_channel_map), flow [E,h,w,8] f16 (4 + zero pad),
@@ -449,12 +449,14 @@ class UpdateModule:
           glo_red = those sums, handed back by a caller that KNOWS `net` is still the tensor the previous call wrote (FactorGraph keeps the
             pair together): the stand-alone reduction -- a pass over the whole hidden state -- is then not launched.  Same values up to the
             order of the per-tile atomics, which is not fixed in either form.
+        want_upmask = False: GraphAgg's upmask head (1x1, 128 -> 576; only DepthVideo.upsample reads it, and the reference's callers
+        build their graphs with upsample=False unless asked: droid_frontend.py:18, droid_backend.py:30) is not computed; `upmask` is None.
         -> (net, delta [E,h,w,2] f32, weight [E,h,w,2] f32, eta [K,h,w] f32, upmask [K,h,w,576] f16)."""
         P = self.params
         E, h, w, _ = net.shape
         self.last_glo = None
         if self.canvas and not (w == 64 and h % 4 == 0) and w <= 64 and _mask is None:
-            return self._forward_canvas(net, inp, corr, flow, ii, inp_frames, inp_index, corr0, _glo=_glo)
+            return self._forward_canvas(net, inp, corr, flow, ii, inp_frames, inp_index, corr0, _glo=_glo)      # (always with the upmask head)
         if self.canvas and w > 64 and h <= 64 and _mask is None:
             return self._forward_transposed(net, inp, corr, flow, ii, inp_frames, inp_index, corr0)
         if self.canvas and w > 64 and h > 64 and _mask is None:
@@ -511,7 +513,7 @@ class UpdateModule:
                     and droid_backends.get_option("conv_epi_staged") and droid_backends.get_option("eta_fused")):
                 # the eta head never runs as a convolution of its own: agg.conv2's workgroups multiply their relu'd tile with its nine
                 # tap vectors (the heads' fused second layer), and the gather adds the taps and applies 0.01 * softplus
-                x2 = torch.empty(K, h, w, 128, dtype=torch.float16, device=net.device)
+                x2 = torch.empty(K, h, w, 128, dtype=torch.float16, device=net.device) if want_upmask else None     # (only the upmask head reads it)
                 part = torch.empty(1, K * h // 4, 6, 64, 4, dtype=torch.float32, device=net.device)
                 P["agg2"]([xm], EPI_HEADS0, out=x2, aux1=P["eta_fused"][0], red=part)
                 eta = droid_backends.heads_gather(part, P["eta_fused"][1], h, w, 1)[..., None]
@@ -519,7 +521,7 @@ class UpdateModule:
                 x2 = mk(P["agg2"]([xm], EPI_RELU))
                 eta = torch.empty(K, h, w, 1, dtype=torch.float32, device=net.device)
                 P["eta"]([x2], EPI_SOFTPLUS_001, out=eta)
-            upmask = P["upmask"]([x2], EPI_LINEAR)
+            upmask = P["upmask"]([x2], EPI_LINEAR) if want_upmask else None
         if _mask is None and w == 64 and h % 4 == 0 and droid_backends.get_option("conv_halo") and droid_backends.get_option("conv_halo2"):
             # heads: the 256-channel activations never leave the first layer's kernel (see csrc/conv.hip EPI_HEADS0)
             w2p, b4 = P["heads2_fused"]

@@ -316,8 +316,9 @@ def test_global_context_sums_follow_the_state_tensor_they_were_reduced_from():
         def fuses_next_glo(self, h, w):
             return True
 
-        def forward_nhwc(self, net, inp, feats, flow, ii, inp_frames=None, inp_index=None, ctx=None, corr0=None, glo_red=None, glo_next=False):
-            calls.append((net, glo_red, glo_next))
+        def forward_nhwc(self, net, inp, feats, flow, ii, inp_frames=None, inp_index=None, ctx=None, corr0=None, glo_red=None, glo_next=False,
+                         want_upmask=True):
+            calls.append((net, glo_red, glo_next, want_upmask))
             out = FakeUpdate.forward_nhwc(self, net, inp, feats, flow, ii, inp_frames=inp_frames, inp_index=inp_index, ctx=ctx, corr0=corr0)
             self.last_glo = net.float().sum((1, 2)) if glo_next else None      # "sums of the state this call wrote"
             return out
@@ -327,6 +328,11 @@ def test_global_context_sums_follow_the_state_tensor_they_were_reduced_from():
     graph.update(1)
     graph.update(1)
     assert calls[0][1] is None and all(c[2] for c in calls)
+    assert not any(c[3] for c in calls)                           # a graph that does not upsample does not ask for the upmask head ...
+    graph.compute_upmask = True
+    graph.update(1)
+    assert calls.pop()[3]                                         # ... unless told to (bench.py)
+    graph.compute_upmask = None
     assert calls[1][1] is not None and tuple(calls[1][1].shape) == (calls[0][0].shape[0], 16)            # what call 0 left behind
     assert calls[2][1] is not calls[1][1] and calls[2][0] is calls[1][0] is graph._net
     graph.rm_factors(graph.ii < 1, store=False)                   # the state tensor is replaced: nothing to hand over

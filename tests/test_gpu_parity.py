@@ -1004,6 +1004,37 @@ def test_next_iterations_global_context_sums_from_inside_the_q_gate(db, option):
     assert upd.last_glo is None
 
 
+def test_operator_without_the_upmask_head(db):
+    """forward_nhwc(want_upmask=False) -- what FactorGraph asks for when it does not upsample (the head's only reader is
+    DepthVideo.upsample; the reference computes and drops it): upmask is None, every other output EQUAL to the full call."""
+    from droid_amd.update import UpdateModule
+    from droid_amd.weights import deterministic_state_dict
+    from oracle import update as oupd
+
+    class _SD:
+        def state_dict(self):
+            return oupd.empty_state_dict()
+    torch.manual_seed(41)
+    upd = UpdateModule("cuda").load_state_dict(deterministic_state_dict(_SD(), seed=2))
+    for (K, E, h, w) in [(2, 5, 12, 64), (2, 3, 30, 40)]:
+        inp_frames = torch.relu(torch.randn(K, h, w, 128, device="cuda")).half()
+        ii = (torch.arange(E, device="cuda") * K // E).contiguous()
+        net0 = torch.tanh(torch.randn(E, h, w, 128, device="cuda")).half()
+        corr = torch.randn(E, 196, h, w, device="cuda").half()
+        flow = torch.zeros(E, h, w, 8, device="cuda", dtype=torch.float16); flow[..., :4] = torch.randn(E, h, w, 4, device="cuda").half()
+        red = _glo_sums(upd, net0) if w == 64 else None
+        full = upd.forward_nhwc(net0.clone(), None, corr, flow, ii, inp_frames=inp_frames, inp_index=ii, glo_red=red)
+        full = [x.clone() for x in full]
+        lean = upd.forward_nhwc(net0.clone(), None, corr, flow, ii, inp_frames=inp_frames, inp_index=ii, glo_red=red, want_upmask=False)
+        torch.cuda.synchronize()
+        if w == 64:
+            assert lean[4] is None and full[4] is not None
+            for x, y in zip(full[:4], lean[:4]):
+                assert torch.equal(x, y)
+        else:                                  # canvas sizes keep the head (their path is not the one FactorGraph's large graphs take)
+            assert lean[4] is not None
+
+
 def test_conv7x7_on_four_channels_and_global_context_kernels(db):
     """the two single-purpose kernels of the update operator against torch: flow_encoder.0 (7x7 on the 4 motion
     channels, droid_net.py:89) and the ConvGRU's global-context reduction mean(sigmoid(w(net)) * net) (gru.py:23-24)"""
