@@ -253,6 +253,27 @@ __global__ __launch_bounds__(256) void pyr_build_kernel(const __half* __restrict
 #ifndef DH_PYR_ABL
 #define DH_PYR_ABL 0        // timing ablations of the ring build (WRONG results; never in a shipped build): 1 = no record stores, 2 = no scatter into the ring,
 #endif                      // 4 = no B-fragment reads / MFMAs, 8 = no global loads of the target rows, 16 = no LDS writes of them
+#ifndef DH_PYR_V2
+#define DH_PYR_V2 1         // round 6, second pass (profiles/r06_v_pyr_build_pmc.txt: the SIMDs ISSUE 89 % of the kernel's time -- the build is bound by its
+#endif                      // instruction count, 124 per wave and step).  1 = (a) the ring's bank swizzle moves whole 16-byte quads only (bits 2-4 of the
+                            // pixel index instead of bits 0, 1, 4), so a finished row leaves LDS with ONE ds_read_b128 per lane and no 12-instruction
+                            // dword rotation; (b) the next target row's address is kept as a pointer that wraps instead of a `% h2` per fetch (22
+                            // scalar instructions).  Same MFMAs, same rounding, same records.  0 = rounds 2-6a (variant builds, for A/B runs).
+// dword swizzle of the ring: pixel p of cell pair `up` lives at dword up * 64 + (p ^ ring_f(up))
+__device__ __forceinline__ int ring_f(int up) { return DH_PYR_V2 ? ((up & 7) << 2) : ((up & 3) | ((up & 4) << 2)); }
+// one 16-byte piece (pixels p0 .. p0 + 3 of cell pair up) of a finished ring row, in HBM order
+__device__ __forceinline__ u32x4 ring_read_piece(const unsigned char* src, int up, int p0) {
+  const int f = ring_f(up);
+  if (DH_PYR_V2) return *reinterpret_cast<const u32x4*>(src + ((up * 64 + (p0 ^ f)) << 2));
+  const uint4 c = *reinterpret_cast<const uint4*>(src + ((up * 64 + (p0 ^ (f & 16))) << 2));
+  const int sw = f & 3;               /* out[i] = in[i ^ sw] */
+  u32x4 o;            /* a native vector: member-wise built HIP uint4 stores are split into 4 dword stores */
+  o[0] = sw == 0 ? c.x : sw == 1 ? c.y : sw == 2 ? c.z : c.w;
+  o[1] = sw == 0 ? c.y : sw == 1 ? c.x : sw == 2 ? c.w : c.z;
+  o[2] = sw == 0 ? c.z : sw == 1 ? c.w : sw == 2 ? c.x : c.y;
+  o[3] = sw == 0 ? c.w : sw == 1 ? c.z : sw == 2 ? c.y : c.x;
+  return o;
+}
 __device__ __forceinline__ void gload16_async(u32x4& dst, const __half* p) {
 #if DH_PYR_ABL & 8
   dst = u32x4{(uint32_t)(uintptr_t)p, 1u, 2u, 3u};
@@ -317,7 +338,7 @@ __device__ __forceinline__ void ring_level(const half8 (&afrag)[4], const __half
     for (int r = 0; r < 4; ++r) {
       const int x2 = (nt0 + nt) * 16 + j, x1l = (bx * 8 + xq + r) >> l;
       const int u = wrap(x2 - x1l, w2), up = u >> 1, p = yy * 8 + xq + r;
-      const int f = (up & 3) | ((up & 4) << 2);
+      const int f = ring_f(up);
       soff[nt][r] = x2 < w2 ? ((up * 64 + (p ^ f)) << 2) + ((u & 1) << 1) : -1;
     }
   // B staging role: piece id = tid + 256*q -> (target id>>4, quad id&15), q < NTL.  Target rows are fetched THREE steps
@@ -336,9 +357,14 @@ __device__ __forceinline__ void ring_level(const half8 (&afrag)[4], const __half
 #define RING_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
   // (DH_PYR_ASM & 1, the hand-counted waits: a row is fetched for EVERY k, also the three beyond the level's last step -- the row of
   // the last step again: every step then has exactly 2 x NQ loads issued behind the row it waits for)
+  // the row of fetch k is (ybase + k) % h2; fetches are issued in the order of k, so DH_PYR_V2 keeps a pointer that wraps
+  const __half* fetch_p = trow0 + (long)ybase * w2 * CH;
+  const __half* const fetch_end = trow0 + (long)h2 * w2 * CH;
 #define RING_FETCH_B(k_, s_)                                                                                         \
   if ((DH_PYR_ASM & 1) || (k_) < nsteps) {                                                                           \
-    const __half* trow = trow0 + (long)((ybase + min((k_), nsteps - 1)) % h2) * w2 * CH;                             \
+    const __half* trow = (DH_PYR_V2 && !(DH_PYR_ASM & 1)) ? fetch_p : trow0 + (long)((ybase + min((k_), nsteps - 1)) % h2) * w2 * CH; \
+    fetch_p += w2 * CH;                                                                                              \
+    fetch_p = fetch_p == fetch_end ? trow0 : fetch_p;                                                                \
     if (stages) { _Pragma("unroll") for (int q = 0; q < NQ; ++q) gload16_async(breg[s_][q], trow + b_src[q]); }         \
   }
 #define RING_STEP(k_, s_)                                                                                            \
@@ -378,15 +404,7 @@ __device__ __forceinline__ void ring_level(const half8 (&afrag)[4], const __half
       const unsigned char* src = ring + (vdone & (R - 1)) * rowbytes;                                                \
       __half* dst = lbase + (long)vdone * (rowbytes >> 1);                                                           \
       for (int n4 = tid; n4 < w2 * 8; n4 += NT) {                                                                    \
-        const int up = n4 >> 4, p0 = (n4 & 15) << 2;                                                                 \
-        const int f = (up & 3) | ((up & 4) << 2);                                                                    \
-        const uint4 c = *reinterpret_cast<const uint4*>(src + ((up * 64 + (p0 ^ (f & 16))) << 2));                   \
-        const int sw = f & 3;               /* out[i] = in[i ^ sw] */                                                \
-        u32x4 o;            /* a native vector: member-wise built HIP uint4 stores are split into 4 dword stores */ \
-        o[0] = sw == 0 ? c.x : sw == 1 ? c.y : sw == 2 ? c.z : c.w;                                                  \
-        o[1] = sw == 0 ? c.y : sw == 1 ? c.x : sw == 2 ? c.w : c.z;                                                  \
-        o[2] = sw == 0 ? c.z : sw == 1 ? c.w : sw == 2 ? c.x : c.y;                                                  \
-        o[3] = sw == 0 ? c.w : sw == 1 ? c.z : sw == 2 ? c.y : c.x;                                                  \
+        const u32x4 o = ring_read_piece(src, n4 >> 4, (n4 & 15) << 2);                                               \
         gstore16_async(dst + (long)n4 * 8, o);                                                                       \
       }                                                                                                              \
     }                                                                                                                \
@@ -444,7 +462,7 @@ __device__ __forceinline__ void ring_level0_tm(const __half* __restrict__ f1rows
   for (int r = 0; r < 4; ++r) {
     const int x2 = tile * 16 + j, x1l = bx * 8 + xq + r;
     const int u = wrap(x2 - x1l, w2), up = u >> 1, p = (lane >> 5) * 8 + xq + r;
-    const int f = (up & 3) | ((up & 4) << 2);
+    const int f = ring_f(up);
     soff0[r] = ((up * 64 + (p ^ f)) << 2) + ((u & 1) << 1);
   }
   constexpr int NQ = (NTL * 256 + NT - 1) / NT;
@@ -488,15 +506,7 @@ __device__ __forceinline__ void ring_level0_tm(const __half* __restrict__ f1rows
       const unsigned char* src = ring + (vdone & (R - 1)) * rowbytes;                                                \
       __half* dst = lbase + (long)vdone * (rowbytes >> 1);                                                           \
       for (int n4 = tid; n4 < w2 * 8; n4 += NT) {                                                                    \
-        const int up = n4 >> 4, p0 = (n4 & 15) << 2;                                                                 \
-        const int f = (up & 3) | ((up & 4) << 2);                                                                    \
-        const uint4 c = *reinterpret_cast<const uint4*>(src + ((up * 64 + (p0 ^ (f & 16))) << 2));                   \
-        const int sw = f & 3;                                                                                        \
-        u32x4 o;                                                                                                     \
-        o[0] = sw == 0 ? c.x : sw == 1 ? c.y : sw == 2 ? c.z : c.w;                                                  \
-        o[1] = sw == 0 ? c.y : sw == 1 ? c.x : sw == 2 ? c.w : c.z;                                                  \
-        o[2] = sw == 0 ? c.z : sw == 1 ? c.w : sw == 2 ? c.x : c.y;                                                  \
-        o[3] = sw == 0 ? c.w : sw == 1 ? c.z : sw == 2 ? c.y : c.x;                                                  \
+        const u32x4 o = ring_read_piece(src, n4 >> 4, (n4 & 15) << 2);                                               \
         gstore16_async(dst + (long)n4 * 8, o);                                                                       \
       }                                                                                                              \
     }                                                                                                                \
@@ -522,11 +532,20 @@ template <int W, int NT = 256, bool TM = false>
 __global__ __launch_bounds__(NT, TM ? (NT == 512 ? 4 : 2) : 1) void pyr_build_ring_kernel(const __half* __restrict__ f1T, const __half* __restrict__ f2T,
                                                              __half* __restrict__ pyr, PyrDims D, long f1_stride_e,
                                                              long f2_stride_e, const int64_t* __restrict__ idx1 = nullptr,
-                                                             const int64_t* __restrict__ idx2 = nullptr) {
+                                                             const int64_t* __restrict__ idx2 = nullptr, int xcd_edges = 0) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_ring_raw[];
   unsigned char* const ring = s_ring_raw;                          // [R][w2 * 32 dwords]
   unsigned char* const sB = s_ring_raw + (size_t)W * 1024;         // [target][256 B], 16-byte quads XOR-ed with row & 15
-  const int e = blockIdx.y, sb = blockIdx.x;
+  // Workgroups are dealt to the 8 XCDs round-robin in dispatch order (x fastest).  In the plain order the source blocks of ONE edge
+  // land on all eight XCDs and every L2 fetches that edge's target rows; with xcd_edges = 8 * (E / 8) > 0 (option pyr_build_xcd) the
+  // workgroups an XCD receives walk the source blocks of one edge after the other, so an edge's target rows (1 MB with the pooled
+  // levels) are read from HBM once and re-read by its other source blocks from ONE L2.  Edges >= xcd_edges keep the plain order.
+  int e = blockIdx.y, sb = blockIdx.x;
+  if (e < xcd_edges) {
+    const int n = e * (int)gridDim.x + sb, x = n & 7, loc = n >> 3;
+    e = (loc / (int)gridDim.x) * 8 + x;
+    sb = loc % (int)gridDim.x;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;
   constexpr int nbx = W / 8;
   const int by = sb / nbx, bx = sb - by * nbx;
@@ -1214,22 +1233,23 @@ int launch_ring(const __half* f1T, const __half* f2T, __half* pyramid, const Pyr
                 const int64_t* idx1, const int64_t* idx2, hipStream_t st) {
   const size_t lds = (size_t)w * 1024 + (size_t)(w > 16 ? w : 16) * 256;       // row ring + one staged target row
   const dim3 grid(D.nblk, E);
+  const int xe = (opts().pyr_build_xcd && (D.nblk * (long)E) % 8 == 0 && (long)D.nblk * E < (1L << 30)) ? (E / 8) * 8 : 0;
   if (w == 64 && opts().pyr_build_tm && opts().pyr_build_waves == 8) {
     DH_LDS_OPTIN((&pyr_build_ring_kernel<64, 512, true>), 80 * 1024);
-    hipLaunchKernelGGL((pyr_build_ring_kernel<64, 512, true>), grid, dim3(512), lds, st, f1T, f2T, pyramid, D, s1, s2, idx1, idx2);
+    hipLaunchKernelGGL((pyr_build_ring_kernel<64, 512, true>), grid, dim3(512), lds, st, f1T, f2T, pyramid, D, s1, s2, idx1, idx2, xe);
   } else if (w == 64 && opts().pyr_build_tm) {
     DH_LDS_OPTIN((&pyr_build_ring_kernel<64, 256, true>), 80 * 1024);
-    hipLaunchKernelGGL((pyr_build_ring_kernel<64, 256, true>), grid, dim3(256), lds, st, f1T, f2T, pyramid, D, s1, s2, idx1, idx2);
+    hipLaunchKernelGGL((pyr_build_ring_kernel<64, 256, true>), grid, dim3(256), lds, st, f1T, f2T, pyramid, D, s1, s2, idx1, idx2, xe);
   } else if (w == 64 && opts().pyr_build_waves == 8) {
     DH_LDS_OPTIN((&pyr_build_ring_kernel<64, 512>), 80 * 1024);
-    hipLaunchKernelGGL((pyr_build_ring_kernel<64, 512>), grid, dim3(512), lds, st, f1T, f2T, pyramid, D, s1, s2, idx1, idx2);
+    hipLaunchKernelGGL((pyr_build_ring_kernel<64, 512>), grid, dim3(512), lds, st, f1T, f2T, pyramid, D, s1, s2, idx1, idx2, xe);
   } else if (w == 64) {
     DH_LDS_OPTIN((&pyr_build_ring_kernel<64>), 80 * 1024);
-    hipLaunchKernelGGL(pyr_build_ring_kernel<64>, grid, dim3(256), lds, st, f1T, f2T, pyramid, D, s1, s2, idx1, idx2);
+    hipLaunchKernelGGL(pyr_build_ring_kernel<64>, grid, dim3(256), lds, st, f1T, f2T, pyramid, D, s1, s2, idx1, idx2, xe);
   } else if (w == 32) {
-    hipLaunchKernelGGL(pyr_build_ring_kernel<32>, grid, dim3(256), lds, st, f1T, f2T, pyramid, D, s1, s2, idx1, idx2);
+    hipLaunchKernelGGL(pyr_build_ring_kernel<32>, grid, dim3(256), lds, st, f1T, f2T, pyramid, D, s1, s2, idx1, idx2, xe);
   } else {
-    hipLaunchKernelGGL(pyr_build_ring_kernel<16>, grid, dim3(256), lds, st, f1T, f2T, pyramid, D, s1, s2, idx1, idx2);
+    hipLaunchKernelGGL(pyr_build_ring_kernel<16>, grid, dim3(256), lds, st, f1T, f2T, pyramid, D, s1, s2, idx1, idx2, xe);
   }
   return DH_OK;
 }

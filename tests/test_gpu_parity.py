@@ -585,6 +585,21 @@ def test_native_pyramid_build_kernels_are_bit_identical(db, option):
         assert torch.equal(b, d8) and torch.equal(b, d4)
 
 
+def test_pyramid_build_with_an_edges_workgroups_on_one_xcd_is_bit_identical(db, option):
+    """round 6 (option pyr_build_xcd): the build's workgroups are re-numbered so that the source blocks of one edge run on ONE XCD
+    (its target rows then come from one L2: fabric reads 11.1 -> 0.9 GB per 256 edges, profiles/r06_v_pyr_build_pmc.txt).  A pure
+    re-numbering: equal records, also when the edge count is no multiple of 8 (the last E % 8 edges keep the plain order)."""
+    torch.manual_seed(12)
+    for (E, h, w) in [(19, 16, 32), (8, 8, 16), (9, 48, 64), (16, 24, 64)]:
+        f1 = torch.randn(E, 128, h, w, device="cuda").half()
+        f2 = torch.randn(E, 128, h, w, device="cuda").half()
+        option("pyr_build_xcd", 0)
+        a = db.corr_pyramid_build(f1, f2)
+        option("pyr_build_xcd", 1)
+        b = db.corr_pyramid_build(f1, f2)
+        assert torch.equal(a, b), (E, h, w)
+
+
 @pytest.mark.parametrize("shape,rig", [((48, 64), 1), ((16, 32), 2), ((30, 40), 1), ((24, 16), 2), ((41, 73), 1), ((72, 96), 1)])
 def test_pyramid_from_frames_is_bit_identical_to_the_per_edge_build(db, shape, rig):
     """round 5: CorrBlock.from_frames(video.fmaps, ii, jj) -- features transposed and pooled once per frame
