@@ -260,6 +260,22 @@ __global__ __launch_bounds__(256) void pyr_build_kernel(const __half* __restrict
                             // dword rotation; (b) the next target row's address is kept as a pointer that wraps instead of a `% h2` per fetch (22
                             // scalar instructions).  Same MFMAs, same rounding, same records.  0 = rounds 2-6a (variant builds, for A/B runs).
 // dword swizzle of the ring: pixel p of cell pair `up` lives at dword up * 64 + (p ^ ring_f(up))
+#ifdef DH_PYR_TS            // scripts/ubench/pyr_ts.hip: phase timestamps (s_memtime) of two waves of ONE workgroup (blockIdx = (5, DH_PYR_TS)) at level 0,
+__device__ unsigned long long g_pyr_ts[2 * 16 * 8];      // steps 16 .. 31 (never defined in the library build)
+#define PYR_TS_DECL(l_)                                                                                              \
+  const int ts_w = ((l_) == 0 && blockIdx.x == 5 && blockIdx.y == DH_PYR_TS) ? (tid_all == 0 ? 0 : tid_all == DH_PYR_TS_WAVE * 64 ? 1 : -1) : -1; \
+  unsigned long long ts_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PYR_TS(i) ts_[i] = __builtin_readcyclecounter();
+#define PYR_TS_FLUSH(k_)                                                                                             \
+  if (ts_w >= 0 && (k_) >= 16 && (k_) < 32) { _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) g_pyr_ts[(ts_w * 16 + (k_) - 16) * 8 + i_] = ts_[i_]; }
+#else
+#define PYR_TS_DECL(l_)
+#define PYR_TS(i)
+#define PYR_TS_FLUSH(k_)
+#endif
+#ifndef DH_PYR_PIPE
+#define DH_PYR_PIPE 0       // (measured SLOWER: 2.44 vs 2.39 ms single, 2.43 vs 2.26 ms dual, profiles/r06_v_pyr_build_pmc.txt) 1 = the scatter of a step is issued between the MFMAs of the next one (ring_level, RING_ITER); 0 = RING_STEP (variant builds)
+#endif
 __device__ __forceinline__ int ring_f(int up) { return DH_PYR_V2 ? ((up & 7) << 2) : ((up & 3) | ((up & 4) << 2)); }
 // one 16-byte piece (pixels p0 .. p0 + 3 of cell pair up) of a finished ring row, in HBM order
 __device__ __forceinline__ u32x4 ring_read_piece(const unsigned char* src, int up, int p0) {
@@ -316,10 +332,16 @@ __device__ __forceinline__ void wait_vm_for(u32x4& a) {
 // one level of the ring build; NTL = 16-target tiles per target row (compile time: everything below stays in registers)
 // NT = threads of the workgroup: 256 (4 waves = 4 source row pairs, every wave all NTL target tiles) or 512 (8 waves: the
 // second four take the upper half of the target tiles -- twice the waves per CU on the same 80 KB of LDS)
-template <int NTL, int NT>
+// DUAL (round 6, option pyr_build_dual): a workgroup of 2 x NT threads builds TWO horizontally adjacent source blocks -- each half with
+// its own ring, its own records and the wave roles above -- from ONE staged copy of every target row: the row fetches (16 KB per step,
+// two thirds of what a step moves through the CU's vector-memory path) are shared by the two blocks.  `tid_all` = thread of the
+// workgroup (staging role), `tid` = thread of the half (all other roles).
+template <int NTL, int NT, bool DUAL = false>
 __device__ __forceinline__ void ring_level(const half8 (&afrag)[4], const __half* __restrict__ trow0, __half* __restrict__ lbase,
                                            unsigned char* __restrict__ ring, unsigned char* __restrict__ sB,
-                                           int l, int h2, int w2, int by, int bx, int tid) {
+                                           int l, int h2, int w2, int by, int bx, int tid_all) {
+  constexpr int NTS = DUAL ? 2 * NT : NT;                               // threads that stage a target row
+  const int tid = DUAL ? (tid_all & (NT - 1)) : tid_all;
   const int lane = tid & 63, wave = (tid >> 6) & 3, wt = tid >> 8;      // wave = source row pair, wt = target half (NT = 512)
   constexpr int NTW = (NT == 512 && NTL >= 2) ? NTL / 2 : NTL;           // target tiles of this wave: wt * NTW .. + NTW
   const bool has_tiles = NT == 256 || NTL >= 2 || wt == 0;
@@ -328,6 +350,7 @@ __device__ __forceinline__ void ring_level(const half8 (&afrag)[4], const __half
   const int R = 8 >> l, ybase = (by * 8) >> l;
   const int rowbytes = w2 * 128;                                  // one displacement row: w2/2 pairs x 64 px x 4 B
   const int nsteps = h2 + R - 1;
+  PYR_TS_DECL(l)
   const int d = ((by * 8 + yy) >> l) - ybase;                      // this lane's source row offset inside the block
   // byte offset inside a ring row of the value (tile nt, register r) of this lane -- the same at every step -- or -1
   // for the padding columns of a row shorter than 16 targets
@@ -344,13 +367,13 @@ __device__ __forceinline__ void ring_level(const half8 (&afrag)[4], const __half
   // B staging role: piece id = tid + 256*q -> (target id>>4, quad id&15), q < NTL.  Target rows are fetched THREE steps
   // ahead into registers.  (A __syncthreads() would drain vmcnt and with it the prefetch: the LDS traffic of a step only
   // needs lgkmcnt(0) + s_barrier.)
-  constexpr int NQ = (NTL * 256 + NT - 1) / NT;        // 16-byte pieces of a target row per thread
-  const bool stages = NTL * 256 >= NT || tid < NTL * 256;
+  constexpr int NQ = (NTL * 256 + NTS - 1) / NTS;      // 16-byte pieces of a target row per thread
+  const bool stages = NTL * 256 >= NTS || tid_all < NTL * 256;
   u32x4 breg[3][NQ];      // (native vectors: arrays of HIP's uint4 struct assigned under a condition end up in scratch)
   int b_src[NQ], b_dst[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
-    const int id = tid + NT * q, row = id >> 4, quad = id & 15;
+    const int id = tid_all + NTS * q, row = id >> 4, quad = id & 15;
     b_src[q] = min(row, w2 - 1) * CH + quad * 8;
     b_dst[q] = row * 256 + ((quad ^ (row & 15)) << 4);
   }
@@ -370,13 +393,17 @@ __device__ __forceinline__ void ring_level(const half8 (&afrag)[4], const __half
 #define RING_STEP(k_, s_)                                                                                            \
   if ((k_) < nsteps) {                                                                                               \
     const int k = (k_);                                                                                              \
+    PYR_TS(0)                                                                                                        \
     if (DH_PYR_ABL & 16) { _Pragma("unroll") for (int q = 0; q < NQ; ++q) asm volatile("" ::"v"(breg[s_][q])); }     \
     if (stages && !(DH_PYR_ABL & 16)) {                                                                              \
       _Pragma("unroll") for (int q = 0; q < NQ; ++q) wait_vm_for<2 * NQ>(breg[s_][q]);   /* the row fetched three steps ago */ \
       _Pragma("unroll") for (int q = 0; q < NQ; ++q) *reinterpret_cast<u32x4*>(sB + b_dst[q]) = breg[s_][q];           \
     }                                                                                                                \
+    PYR_TS(1)                                                                                                        \
     RING_BARRIER();                         /* target row staged; last step's completed row has been read out */    \
+    PYR_TS(2)                                                                                                        \
     RING_FETCH_B(k + 3, s_)                                                                                          \
+    PYR_TS(3)                                                                                                        \
     const int v = k - d;                    /* displacement row this lane's pixels contribute to */                  \
     const bool vok = v >= 0 && v < h2;                                                                               \
     unsigned char* const rslot = ring + (v & (R - 1)) * rowbytes;                                                    \
@@ -391,6 +418,7 @@ __device__ __forceinline__ void ring_level(const half8 (&afrag)[4], const __half
         acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag[ks], b[nt], acc[nt], 0, 0, 0);                        \
     }                                                                                                                \
     }                                                                                                                \
+    PYR_TS(4)                                                                                                        \
     if (DH_PYR_ABL & 2) { _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt) asm volatile("" ::"v"(acc[nt])); }      \
     if (vok && has_tiles && !(DH_PYR_ABL & 2)) {                                                                     \
       _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt)                                                             \
@@ -398,8 +426,57 @@ __device__ __forceinline__ void ring_level(const half8 (&afrag)[4], const __half
           if (NTL > 1 || soff[nt][r] >= 0)                                                                           \
             *reinterpret_cast<__half*>(rslot + soff[nt][r]) = __float2half(acc[nt][r] * 0.0625f);                    \
     }                                                                                                                \
+    PYR_TS(5)                                                                                                        \
     RING_BARRIER();                         /* scatter complete */                                                  \
+    PYR_TS(6)                                                                                                        \
     const int vdone = k - (R - 1);                                                                                   \
+    if (vdone >= 0 && vdone < h2) {                                                                                  \
+      const unsigned char* src = ring + (vdone & (R - 1)) * rowbytes;                                                \
+      __half* dst = lbase + (long)vdone * (rowbytes >> 1);                                                           \
+      for (int n4 = tid; n4 < w2 * 8; n4 += NT) {                                                                    \
+        const u32x4 o = ring_read_piece(src, n4 >> 4, (n4 & 15) << 2);                                               \
+        gstore16_async(dst + (long)n4 * 8, o);                                                                       \
+      }                                                                                                              \
+    }                                                                                                                \
+    PYR_TS(7)                                                                                                        \
+    PYR_TS_FLUSH(k)                                                                                                  \
+  }
+  // DH_PYR_PIPE (round 6): the scatter of step t - 1 is issued BETWEEN the MFMAs of step t (software pipelining inside the wave: the
+  // products of a step wait one iteration in 4 * NTW registers).  A workgroup's waves run the phases of a step in lockstep between
+  // its two barriers, so what a step costs is the SUM of its phases (B reads + MFMA chains ~ 600 cycles, conversion + scatter ~ 450,
+  // read-out, staging: profiles/r06_v_pyr_build_pmc.txt); here the 8 conversions / 8 address adds / 8 ds_write_b16 fill the issue
+  // slots the two dependent MFMA chains leave empty.  The scatter is unconditional per lane: a lane whose displacement row
+  // v = t - 1 - d lies outside [0, h2) writes into the slot of row v +- R at ITS OWN cells -- before that row's real values arrive
+  // (v < 0) or after the row has left (v >= h2) -- so no exec-mask branch splits the block.  Iteration t = nsteps only drains.
+  // Rows complete one iteration later than in RING_STEP; slot reuse keeps its one-barrier distance (row t - 1 takes the slot of
+  // row t - 1 - R, read out in iteration t - 1).  Same MFMAs, same conversion: same records.
+#define RING_ITER(t_, s_)                                                                                            \
+  if ((t_) <= nsteps) {                                                                                              \
+    const int t = (t_);                                                                                              \
+    if (stages) {                                                                                                    \
+      _Pragma("unroll") for (int q = 0; q < NQ; ++q) wait_vm_for<2 * NQ>(breg[s_][q]);                               \
+      _Pragma("unroll") for (int q = 0; q < NQ; ++q) *reinterpret_cast<u32x4*>(sB + b_dst[q]) = breg[s_][q];           \
+    }                                                                                                                \
+    RING_BARRIER();                         /* target row t staged; the row completed last iteration has been read out */ \
+    RING_FETCH_B(t + 3, s_)                                                                                          \
+    unsigned char* const rslot = ring + ((t - 1 - d) & (R - 1)) * rowbytes;                                          \
+    f32x4 acc[NTW];                                                                                                  \
+    _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};                          \
+    if (has_tiles) {                                                                                                 \
+      _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                             \
+        half8 b[NTW];                                                                                                \
+        _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt)                                                           \
+          b[nt] = *reinterpret_cast<const half8*>(sB + ((nt0 + nt) * 16 + j) * 256 + (((ks * 4 + (lane >> 4)) ^ j) << 4)); \
+        _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt)                                                           \
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag[ks], b[nt], acc[nt], 0, 0, 0);                      \
+        _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt)        /* register ks of last step's products */          \
+          if (NTL > 1 || soff[nt][ks] >= 0)                                                                          \
+            *reinterpret_cast<__half*>(rslot + soff[nt][ks]) = __float2half(prev[nt][ks] * 0.0625f);                 \
+      }                                                                                                              \
+    }                                                                                                                \
+    _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt) prev[nt] = acc[nt];                                           \
+    RING_BARRIER();                         /* scatter of step t - 1 complete */                                    \
+    const int vdone = t - R;                                                                                         \
     if (vdone >= 0 && vdone < h2) {                                                                                  \
       const unsigned char* src = ring + (vdone & (R - 1)) * rowbytes;                                                \
       __half* dst = lbase + (long)vdone * (rowbytes >> 1);                                                           \
@@ -410,11 +487,23 @@ __device__ __forceinline__ void ring_level(const half8 (&afrag)[4], const __half
     }                                                                                                                \
   }
   RING_FETCH_B(0, 0) RING_FETCH_B(1, 1) RING_FETCH_B(2, 2)
-  for (int k3 = 0; k3 < nsteps; k3 += 3) {
-    RING_STEP(k3, 0)
-    RING_STEP(k3 + 1, 1)
-    RING_STEP(k3 + 2, 2)
+  if (DH_PYR_PIPE && !DH_PYR_ABL && !(DH_PYR_ASM & 1)) {
+    f32x4 prev[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) prev[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t3 = 0; t3 <= nsteps; t3 += 3) {
+      RING_ITER(t3, 0)
+      RING_ITER(t3 + 1, 1)
+      RING_ITER(t3 + 2, 2)
+    }
+  } else {
+    for (int k3 = 0; k3 < nsteps; k3 += 3) {
+      RING_STEP(k3, 0)
+      RING_STEP(k3 + 1, 1)
+      RING_STEP(k3 + 2, 2)
+    }
   }
+#undef RING_ITER
 #undef RING_STEP
 #undef RING_FETCH_B
   // the three rows fetched past the level's end were never waited for: their data must have landed before the registers are anything
@@ -528,14 +617,15 @@ __device__ __forceinline__ void ring_level0_tm(const __half* __restrict__ f1rows
 
 // idx1 / idx2 (round 5, optional): edge e reads the prepared rows of FRAME idx1[e] / idx2[e] (dh_corr_pyramid_prepare_frames +
 // dh_corr_pyramid_build_indexed: features transposed and pooled once per frame instead of once per edge); nullptr = row e
-template <int W, int NT = 256, bool TM = false>
-__global__ __launch_bounds__(NT, TM ? (NT == 512 ? 4 : 2) : 1) void pyr_build_ring_kernel(const __half* __restrict__ f1T, const __half* __restrict__ f2T,
+template <int W, int NT = 256, bool TM = false, bool DUAL = false>
+__global__ __launch_bounds__(DUAL ? 2 * NT : NT, TM ? (NT == 512 ? 4 : 2) : 1) void pyr_build_ring_kernel(const __half* __restrict__ f1T, const __half* __restrict__ f2T,
                                                              __half* __restrict__ pyr, PyrDims D, long f1_stride_e,
                                                              long f2_stride_e, const int64_t* __restrict__ idx1 = nullptr,
                                                              const int64_t* __restrict__ idx2 = nullptr, int xcd_edges = 0) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_ring_raw[];
-  unsigned char* const ring = s_ring_raw;                          // [R][w2 * 32 dwords]
-  unsigned char* const sB = s_ring_raw + (size_t)W * 1024;         // [target][256 B], 16-byte quads XOR-ed with row & 15
+  const int half_id = DUAL ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x / NT)) : 0;      // DUAL: which of the workgroup's two source blocks (wave-uniform)
+  unsigned char* const ring = s_ring_raw + (size_t)half_id * W * 1024;      // [R][w2 * 32 dwords] (DUAL: one ring per half)
+  unsigned char* const sB = s_ring_raw + (size_t)(DUAL ? 2 : 1) * W * 1024; // [target][256 B], 16-byte quads XOR-ed with row & 15
   // Workgroups are dealt to the 8 XCDs round-robin in dispatch order (x fastest).  In the plain order the source blocks of ONE edge
   // land on all eight XCDs and every L2 fetches that edge's target rows; with xcd_edges = 8 * (E / 8) > 0 (option pyr_build_xcd) the
   // workgroups an XCD receives walk the source blocks of one edge after the other, so an edge's target rows (1 MB with the pooled
@@ -548,6 +638,7 @@ __global__ __launch_bounds__(NT, TM ? (NT == 512 ? 4 : 2) : 1) void pyr_build_ri
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;
   constexpr int nbx = W / 8;
+  if (DUAL) sb = (sb / (nbx / 2)) * nbx + (sb % (nbx / 2)) * 2 + half_id;      // blockIdx.x numbers PAIRS of blocks (bx, bx + 1)
   const int by = sb / nbx, bx = sb - by * nbx;
   // A fragments of this wave's 16 source pixels (rows yy = 2*wave, 2*wave+1): lane holds A[i = lane&15][k = (lane>>4)*8..+8]
   const __half* bbase = f2T + (idx2 ? (long)idx2[e] : (long)e) * f2_stride_e;
@@ -567,7 +658,7 @@ __global__ __launch_bounds__(NT, TM ? (NT == 512 ? 4 : 2) : 1) void pyr_build_ri
   {                                                                                                                  \
     constexpr int w2 = W >> (l_);                                                                                    \
     constexpr int NTL = w2 >= 16 ? w2 / 16 : 1;                                                                      \
-    ring_level<NTL, NT>(afrag, bbase + (long)D.tgt_off[l_] * CH, obase + D.lev_off[l_] + (long)sb * D.blk_elems[l_],     \
+    ring_level<NTL, NT, DUAL>(afrag, bbase + (long)D.tgt_off[l_] * CH, obase + D.lev_off[l_] + (long)sb * D.blk_elems[l_], \
                     ring, sB, l_, h >> (l_), w2, by, bx, tid);                                                       \
   }
   if constexpr (!(TM && W == 64)) {
@@ -1232,6 +1323,13 @@ namespace {
 int launch_ring(const __half* f1T, const __half* f2T, __half* pyramid, const PyrDims& D, long s1, long s2, int E, int w,
                 const int64_t* idx1, const int64_t* idx2, hipStream_t st) {
   const size_t lds = (size_t)w * 1024 + (size_t)(w > 16 ? w : 16) * 256;       // row ring + one staged target row
+  if (w == 64 && opts().pyr_build_dual && !opts().pyr_build_tm && opts().pyr_build_waves == 8) {
+    const int xe2 = opts().pyr_build_xcd && (long)D.nblk * E < (1L << 30) ? (E / 8) * 8 : 0;
+    DH_LDS_OPTIN((&pyr_build_ring_kernel<64, 512, false, true>), 160 * 1024);
+    hipLaunchKernelGGL((pyr_build_ring_kernel<64, 512, false, true>), dim3(D.nblk / 2, E), dim3(1024), (size_t)(2 * 64 * 1024 + 64 * 256), st,
+                       f1T, f2T, pyramid, D, s1, s2, idx1, idx2, xe2);
+    return DH_OK;
+  }
   const dim3 grid(D.nblk, E);
   const int xe = (opts().pyr_build_xcd && (D.nblk * (long)E) % 8 == 0 && (long)D.nblk * E < (1L << 30)) ? (E / 8) * 8 : 0;
   if (w == 64 && opts().pyr_build_tm && opts().pyr_build_waves == 8) {

@@ -18,15 +18,21 @@ prep = db.corr_pyramid_prepare_frames(fm, h, w)
 g = torch.Generator(device="cuda").manual_seed(1)
 i1 = torch.randint(0, F, (E,), device="cuda", generator=g); i2 = torch.randint(0, F, (E,), device="cuda", generator=g)
 out = torch.empty(E, db.corr_pyramid_build_indexed(prep, i1[:1], i2[:1], h, w, None).shape[1], dtype=torch.float16, device="cuda")
-variants = [("row-pair-major, 8 waves (rounds 2-5)", 0, 8, 0), ("row-pair-major, 8 waves, an edge's workgroups on one XCD", 0, 8, 1),
-            ("row-pair-major, 4 waves", 0, 4, 0), ("tile-major, 8 waves (32 px per wave)", 1, 8, 0),
-            ("tile-major, 8 waves, an edge's workgroups on one XCD", 1, 8, 1), ("tile-major, 4 waves (64 px per wave)", 1, 4, 0)]
+variants = [("row-pair-major, 8 waves (rounds 2-5)", 0, 8, 0, 0), ("row-pair-major, 8 waves, an edge's workgroups on one XCD", 0, 8, 1, 0),
+            ("two source blocks per workgroup (16 waves), plain order", 0, 8, 0, 1), ("two source blocks per workgroup (16 waves), one XCD per edge", 0, 8, 1, 1),
+            ("row-pair-major, 4 waves", 0, 4, 0, 0), ("tile-major, 8 waves (32 px per wave)", 1, 8, 0, 0),
+            ("tile-major, 8 waves, an edge's workgroups on one XCD", 1, 8, 1, 0), ("tile-major, 4 waves (64 px per wave)", 1, 4, 0, 0)]
 variants = [v for v in variants if only in v[0]]
 ref = None
 times = {v[0]: [] for v in variants}
 for r in range(rounds):
-    for name, tm, waves, xcd in variants:
+    for name, tm, waves, xcd, dual in variants:
         db.set_option("pyr_build_tm", tm); db.set_option("pyr_build_waves", waves); db.set_option("pyr_build_xcd", xcd)
+        try:
+            db.set_option("pyr_build_dual", dual)
+        except Exception:                      # (a variant build from before the option existed)
+            if dual:
+                continue
         db.corr_pyramid_build_indexed(prep, i1, i2, h, w, out); torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(); db.corr_pyramid_build_indexed(prep, i1, i2, h, w, out); b.record(); torch.cuda.synchronize()
@@ -41,6 +47,8 @@ for r in range(rounds):
             print("%-62s identical to the first variant: %s" % (name, torch.equal(cur, ref)))
 GB = out.numel() * 2 / 1e9
 for name, ts in times.items():
+    if not ts:
+        continue
     t = float(np.median(ts))
     print("%-62s %.3f ms per %d edges (median of %d, min %.3f)  %.2f TB/s of records written" % (name, t, E, rounds, min(ts), GB / t))
-db.set_option("pyr_build_tm", 0); db.set_option("pyr_build_waves", 8); db.set_option("pyr_build_xcd", 0)
+db.set_option("pyr_build_tm", 0); db.set_option("pyr_build_waves", 8)

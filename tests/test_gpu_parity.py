@@ -598,6 +598,12 @@ def test_pyramid_build_with_an_edges_workgroups_on_one_xcd_is_bit_identical(db, 
         option("pyr_build_xcd", 1)
         b = db.corr_pyramid_build(f1, f2)
         assert torch.equal(a, b), (E, h, w)
+        # two horizontally adjacent source blocks per workgroup sharing each staged target row (option pyr_build_dual, w = 64 only)
+        for xcd in (0, 1):
+            option("pyr_build_xcd", xcd); option("pyr_build_dual", 1)
+            c = db.corr_pyramid_build(f1, f2)
+            option("pyr_build_dual", 0)
+            assert torch.equal(a, c), (E, h, w, xcd)
 
 
 @pytest.mark.parametrize("shape,rig", [((48, 64), 1), ((16, 32), 2), ((30, 40), 1), ((24, 16), 2), ((41, 73), 1), ((72, 96), 1)])
