@@ -247,6 +247,7 @@ __global__ __launch_bounds__(256) void pyr_build_kernel(const __half* __restrict
 // reused if a wave never waits again, so the shipped build uses plain C++ (0).  DH_PYR_ABL removes one stage at a time (wrong results,
 // timing only): the stages' times ADD UP (stores 0.67 + row fetches 0.54 + B reads / MFMA 0.48 + scatter 0.19 + row staging 0.09 ms
 // of 2.57; bare loop 0.68): a step is a serial chain, and two thirds of it is the CU's vector-memory path (192 lines per block-step).
+// Second pass (counters, V2 / V3 / pipelined / two-block forms, phase timeline): profiles/r06_v_pyr_build_pmc.txt.
 #ifndef DH_PYR_ASM
 #define DH_PYR_ASM 0        // measurement switch (scripts/bench_pyr_build.py, profiles/r06_pyr_build_ab.txt): bit 0 = loads as asm, bit 1 = stores as asm; 0 = plain C++ (shipped)
 #endif
@@ -259,6 +260,10 @@ __global__ __launch_bounds__(256) void pyr_build_kernel(const __half* __restrict
                             // pixel index instead of bits 0, 1, 4), so a finished row leaves LDS with ONE ds_read_b128 per lane and no 12-instruction
                             // dword rotation; (b) the next target row's address is kept as a pointer that wraps instead of a `% h2` per fetch (22
                             // scalar instructions).  Same MFMAs, same rounding, same records.  0 = rounds 2-6a (variant builds, for A/B runs).
+__device__ __forceinline__ uint32_t pack_h2_scaled(float a, float b) {      // {fp16(a / 16), fp16(b / 16)}, round to nearest even like the 2-byte scatter
+  const __half2 h = __halves2half2(__float2half(a * 0.0625f), __float2half(b * 0.0625f));
+  return __builtin_bit_cast(uint32_t, h);
+}
 // dword swizzle of the ring: pixel p of cell pair `up` lives at dword up * 64 + (p ^ ring_f(up))
 #ifdef DH_PYR_TS            // scripts/ubench/pyr_ts.hip: phase timestamps (s_memtime) of two waves of ONE workgroup (blockIdx = (5, DH_PYR_TS)) at level 0,
 __device__ unsigned long long g_pyr_ts[2 * 16 * 8];      // steps 16 .. 31 (never defined in the library build)
@@ -273,10 +278,17 @@ __device__ unsigned long long g_pyr_ts[2 * 16 * 8];      // steps 16 .. 31 (neve
 #define PYR_TS(i)
 #define PYR_TS_FLUSH(k_)
 #endif
+#ifndef DH_PYR_V3
+#define DH_PYR_V3 0         // (bit-identical, NOT faster: profiles/r06_v_pyr_build_pmc.txt) round 6, third pass (scripts/ubench/pyr_ts.hip: the 64 ds_write_b16 of a step take 470-570 of its ~2 000 cycles).  1 = the MFMA's
+#endif                      // operands are SWAPPED (targets as rows, source pixels as columns): a lane then holds 4 consecutive targets = 4 consecutive
+                            // displacements u of ONE pixel, and with a wave's 16 pixels chosen with equal parity of x1 >> l and its target tiles shifted by
+                            // that parity, u(r = 0) is even: the 4 values are two whole cell pairs -> 2 ds_write_b32 instead of 4 ds_write_b16 per tile,
+                            // 16 pixels of 4 rows on 16 distinct banks without any swizzle.  Same products summed in the same k order: same records.
+                            // Needs DH_PYR_V2 (quad-only swizzle, here none).  0 = rounds 2-6b (variant builds).
 #ifndef DH_PYR_PIPE
 #define DH_PYR_PIPE 0       // (measured SLOWER: 2.44 vs 2.39 ms single, 2.43 vs 2.26 ms dual, profiles/r06_v_pyr_build_pmc.txt) 1 = the scatter of a step is issued between the MFMAs of the next one (ring_level, RING_ITER); 0 = RING_STEP (variant builds)
 #endif
-__device__ __forceinline__ int ring_f(int up) { return DH_PYR_V2 ? ((up & 7) << 2) : ((up & 3) | ((up & 4) << 2)); }
+__device__ __forceinline__ int ring_f(int up) { return (DH_PYR_V3 && DH_PYR_V2) ? 0 : DH_PYR_V2 ? ((up & 7) << 2) : ((up & 3) | ((up & 4) << 2)); }
 // one 16-byte piece (pixels p0 .. p0 + 3 of cell pair up) of a finished ring row, in HBM order
 __device__ __forceinline__ u32x4 ring_read_piece(const unsigned char* src, int up, int p0) {
   const int f = ring_f(up);
@@ -339,7 +351,7 @@ __device__ __forceinline__ void wait_vm_for(u32x4& a) {
 template <int NTL, int NT, bool DUAL = false>
 __device__ __forceinline__ void ring_level(const half8 (&afrag)[4], const __half* __restrict__ trow0, __half* __restrict__ lbase,
                                            unsigned char* __restrict__ ring, unsigned char* __restrict__ sB,
-                                           int l, int h2, int w2, int by, int bx, int tid_all) {
+                                           int l, int h2, int w2, int by, int bx, int tid_all, const __half* __restrict__ f1e = nullptr) {
   constexpr int NTS = DUAL ? 2 * NT : NT;                               // threads that stage a target row
   const int tid = DUAL ? (tid_all & (NT - 1)) : tid_all;
   const int lane = tid & 63, wave = (tid >> 6) & 3, wt = tid >> 8;      // wave = source row pair, wt = target half (NT = 512)
@@ -351,7 +363,8 @@ __device__ __forceinline__ void ring_level(const half8 (&afrag)[4], const __half
   const int rowbytes = w2 * 128;                                  // one displacement row: w2/2 pairs x 64 px x 4 B
   const int nsteps = h2 + R - 1;
   PYR_TS_DECL(l)
-  const int d = ((by * 8 + yy) >> l) - ybase;                      // this lane's source row offset inside the block
+  const int g4 = lane >> 4, prow3 = 4 * (wave >> 1) + (j >> 2), psel = j & 3, par = wave & 1;
+  const int d = ((by * 8 + (DH_PYR_V3 ? prow3 : yy)) >> l) - ybase;      // this lane's source row offset inside the block
   // byte offset inside a ring row of the value (tile nt, register r) of this lane -- the same at every step -- or -1
   // for the padding columns of a row shorter than 16 targets
   int soff[NTW][4];
@@ -364,6 +377,30 @@ __device__ __forceinline__ void ring_level(const half8 (&afrag)[4], const __half
       const int f = ring_f(up);
       soff[nt][r] = x2 < w2 ? ((up * 64 + (p ^ f)) << 2) + ((u & 1) << 1) : -1;
     }
+  // DH_PYR_V3: this wave's 16 pixels = 4 source rows x the 4 columns x1 whose bit l equals the wave's parity (level 3: any split),
+  // lane i = lane & 15 -> row 4 (wave >> 1) + (i >> 2); products arrive transposed: lane (g = lane >> 4, i) holds targets 4 g + r of pixel i
+  const int x13 = l == 1 ? (psel & 1) + 4 * (psel >> 1) + 2 * par : l == 2 ? psel + 4 * par : 2 * psel + par;
+  const int x1l3 = (bx * 8 + x13) >> l, sig = x1l3 & 1, p3 = prow3 * 8 + x13;
+  half8 pfrag[4];
+  int soffp[NTW][2], taddr[NTW][4];
+  if (DH_PYR_V3) {
+    const __half* prow_ptr = f1e + ((long)(by * 8 + prow3) * (w2 << l) + bx * 8 + x13) * CH;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) pfrag[ks] = *reinterpret_cast<const half8*>(prow_ptr + ks * 32 + g4 * 8);
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+      const int T = ((nt0 + nt) * 16 + j + sig) & (w2 - 1);          // the staged target this lane feeds into row i of the tile
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) taddr[nt][ks] = T * 256 + (((ks * 4 + g4) ^ (T & 15)) << 4);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int c = (nt0 + nt) * 16 + 4 * g4 + 2 * q;               // tile row of the pair's first target (before the parity shift)
+        const int x2 = (c + sig) & (w2 - 1);
+        const int u = wrap(x2 - x1l3, w2);                             // even by construction
+        soffp[nt][q] = c < w2 ? (((u >> 1) * 64 + p3) << 2) : -1;
+      }
+    }
+  }
   // B staging role: piece id = tid + 256*q -> (target id>>4, quad id&15), q < NTL.  Target rows are fetched THREE steps
   // ahead into registers.  (A __syncthreads() would drain vmcnt and with it the prefetch: the LDS traffic of a step only
   // needs lgkmcnt(0) + s_barrier.)
@@ -413,18 +450,26 @@ __device__ __forceinline__ void ring_level(const half8 (&afrag)[4], const __half
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {        /* the tiles' accumulation chains interleaved */       \
       half8 b[NTW];                                                                                                  \
       _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt)                                                             \
-        b[nt] = *reinterpret_cast<const half8*>(sB + ((nt0 + nt) * 16 + j) * 256 + (((ks * 4 + (lane >> 4)) ^ j) << 4)); \
+        b[nt] = *reinterpret_cast<const half8*>(sB + (DH_PYR_V3 ? taddr[nt][ks] : ((nt0 + nt) * 16 + j) * 256 + (((ks * 4 + (lane >> 4)) ^ j) << 4))); \
       _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt)                                                             \
-        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag[ks], b[nt], acc[nt], 0, 0, 0);                        \
+        acc[nt] = DH_PYR_V3 ? __builtin_amdgcn_mfma_f32_16x16x32_f16(b[nt], pfrag[ks], acc[nt], 0, 0, 0)             \
+                            : __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag[ks], b[nt], acc[nt], 0, 0, 0);            \
     }                                                                                                                \
     }                                                                                                                \
     PYR_TS(4)                                                                                                        \
     if (DH_PYR_ABL & 2) { _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt) asm volatile("" ::"v"(acc[nt])); }      \
     if (vok && has_tiles && !(DH_PYR_ABL & 2)) {                                                                     \
+      if (DH_PYR_V3) {                                                                                               \
+        _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt)                                                           \
+          _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                              \
+            if (NTL > 1 || soffp[nt][q] >= 0)                                                                        \
+              *reinterpret_cast<uint32_t*>(rslot + soffp[nt][q]) = pack_h2_scaled(acc[nt][2 * q], acc[nt][2 * q + 1]); \
+      } else {                                                                                                       \
       _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt)                                                             \
         _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                                \
           if (NTL > 1 || soff[nt][r] >= 0)                                                                           \
             *reinterpret_cast<__half*>(rslot + soff[nt][r]) = __float2half(acc[nt][r] * 0.0625f);                    \
+      }                                                                                                              \
     }                                                                                                                \
     PYR_TS(5)                                                                                                        \
     RING_BARRIER();                         /* scatter complete */                                                  \
@@ -647,10 +692,11 @@ __global__ __launch_bounds__(DUAL ? 2 * NT : NT, TM ? (NT == 512 ? 4 : 2) : 1) v
   if constexpr (TM && W == 64)          // (before the row-pair fragments below are loaded: its own A fragments take 32 / 64 registers)
     ring_level0_tm<NT>(f1T + (idx1 ? (long)idx1[e] : (long)e) * f1_stride_e, bbase + (long)D.tgt_off[0] * CH,
                        obase + D.lev_off[0] + (long)sb * D.blk_elems[0], ring, sB, h, by, bx, tid);
+  const __half* const f1e = f1T + (idx1 ? (long)idx1[e] : (long)e) * f1_stride_e;
   half8 afrag[4];
   {
     const int p = wave * 16 + (lane & 15);
-    const __half* row = f1T + (idx1 ? (long)idx1[e] : (long)e) * f1_stride_e + ((long)(by * 8 + (p >> 3)) * W + bx * 8 + (p & 7)) * CH;
+    const __half* row = f1e + ((long)(by * 8 + (p >> 3)) * W + bx * 8 + (p & 7)) * CH;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) afrag[ks] = *reinterpret_cast<const half8*>(row + ks * 32 + (lane >> 4) * 8);
   }
@@ -659,7 +705,7 @@ __global__ __launch_bounds__(DUAL ? 2 * NT : NT, TM ? (NT == 512 ? 4 : 2) : 1) v
     constexpr int w2 = W >> (l_);                                                                                    \
     constexpr int NTL = w2 >= 16 ? w2 / 16 : 1;                                                                      \
     ring_level<NTL, NT, DUAL>(afrag, bbase + (long)D.tgt_off[l_] * CH, obase + D.lev_off[l_] + (long)sb * D.blk_elems[l_], \
-                    ring, sB, l_, h >> (l_), w2, by, bx, tid);                                                       \
+                    ring, sB, l_, h >> (l_), w2, by, bx, tid, f1e);                                                  \
   }
   if constexpr (!(TM && W == 64)) {
     RING_LEVEL(0)

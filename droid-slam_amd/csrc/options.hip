@@ -28,8 +28,8 @@ Options& opts() {
     v.ba_strict = env_int("DH_BA_STRICT", 1);
     v.pyr_build_waves = env_int("DH_PYR_BUILD_WAVES", 8);
     v.pyr_build_tm = env_int("DH_PYR_BUILD_TM", 0);
-    v.pyr_build_xcd = env_int("DH_PYR_BUILD_XCD", 1);
-    v.pyr_build_dual = env_int("DH_PYR_BUILD_DUAL", 0);
+    v.pyr_build_xcd = env_int("DH_PYR_BUILD_XCD", 0);
+    v.pyr_build_dual = env_int("DH_PYR_BUILD_DUAL", 1);
     v.lookup_mode = env_int("DH_LOOKUP_MODE", 0);
     v.lookup_fused = env_int("DH_LOOKUP_FUSED", 1);
     v.lookup_mix = env_int("DH_LOOKUP_MIX", 1);
