@@ -1369,6 +1369,7 @@ namespace {
 int launch_ring(const __half* f1T, const __half* f2T, __half* pyramid, const PyrDims& D, long s1, long s2, int E, int w,
                 const int64_t* idx1, const int64_t* idx2, hipStream_t st) {
   const size_t lds = (size_t)w * 1024 + (size_t)(w > 16 ? w : 16) * 256;       // row ring + one staged target row
+  const size_t lds_pad = getenv("DH_PYR_LDS_PAD") ? (size_t)atoi(getenv("DH_PYR_LDS_PAD")) : 0;      // (measurement: forces fewer workgroups per CU)
   if (w == 64 && opts().pyr_build_dual && !opts().pyr_build_tm && opts().pyr_build_waves == 8) {
     const int xe2 = opts().pyr_build_xcd && (long)D.nblk * E < (1L << 30) ? (E / 8) * 8 : 0;
     DH_LDS_OPTIN((&pyr_build_ring_kernel<64, 512, false, true>), 160 * 1024);
@@ -1385,8 +1386,8 @@ int launch_ring(const __half* f1T, const __half* f2T, __half* pyramid, const Pyr
     DH_LDS_OPTIN((&pyr_build_ring_kernel<64, 256, true>), 80 * 1024);
     hipLaunchKernelGGL((pyr_build_ring_kernel<64, 256, true>), grid, dim3(256), lds, st, f1T, f2T, pyramid, D, s1, s2, idx1, idx2, xe);
   } else if (w == 64 && opts().pyr_build_waves == 8) {
-    DH_LDS_OPTIN((&pyr_build_ring_kernel<64, 512>), 80 * 1024);
-    hipLaunchKernelGGL((pyr_build_ring_kernel<64, 512>), grid, dim3(512), lds, st, f1T, f2T, pyramid, D, s1, s2, idx1, idx2, xe);
+    DH_LDS_OPTIN((&pyr_build_ring_kernel<64, 512>), 160 * 1024);
+    hipLaunchKernelGGL((pyr_build_ring_kernel<64, 512>), grid, dim3(512), lds + lds_pad, st, f1T, f2T, pyramid, D, s1, s2, idx1, idx2, xe);
   } else if (w == 64) {
     DH_LDS_OPTIN((&pyr_build_ring_kernel<64>), 80 * 1024);
     hipLaunchKernelGGL(pyr_build_ring_kernel<64>, grid, dim3(256), lds, st, f1T, f2T, pyramid, D, s1, s2, idx1, idx2, xe);
