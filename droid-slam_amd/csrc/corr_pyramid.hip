@@ -1369,7 +1369,7 @@ namespace {
 int launch_ring(const __half* f1T, const __half* f2T, __half* pyramid, const PyrDims& D, long s1, long s2, int E, int w,
                 const int64_t* idx1, const int64_t* idx2, hipStream_t st) {
   const size_t lds = (size_t)w * 1024 + (size_t)(w > 16 ? w : 16) * 256;       // row ring + one staged target row
-  const size_t lds_pad = getenv("DH_PYR_LDS_PAD") ? (size_t)atoi(getenv("DH_PYR_LDS_PAD")) : 0;      // (measurement: forces fewer workgroups per CU)
+  const size_t lds_pad = (size_t)opts().pyr_lds_pad;        // (measurement only, DH_PYR_LDS_PAD: extra LDS bytes = fewer workgroups per CU)
   if (w == 64 && opts().pyr_build_dual && !opts().pyr_build_tm && opts().pyr_build_waves == 8) {
     const int xe2 = opts().pyr_build_xcd && (long)D.nblk * E < (1L << 30) ? (E / 8) * 8 : 0;
     DH_LDS_OPTIN((&pyr_build_ring_kernel<64, 512, false, true>), 160 * 1024);
