@@ -34,6 +34,10 @@
 #include "common.h"
 
 namespace {
+#ifndef DH_CONV_NT
+#define DH_CONV_NT 0        // 1 = the staged epilogues' output stores carry the non-temporal hint (variant builds for A/B runs)
+#endif
+typedef unsigned int u32x4_cnt __attribute__((ext_vector_type(4)));
 using namespace dh;
 
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
@@ -347,7 +351,11 @@ __device__ __forceinline__ void staged_tile_store(const ConvParams& P, __half* _
       }
       v = uint4{o.x, o.y, o.z, o.w};
     }
+#if DH_CONV_NT
+    __builtin_nontemporal_store(__builtin_bit_cast(u32x4_cnt, v), reinterpret_cast<u32x4_cnt*>(reinterpret_cast<__half*>(P.out) + pix * P.out_stride + co));
+#else
     *reinterpret_cast<uint4*>(reinterpret_cast<__half*>(P.out) + pix * P.out_stride + co) = v;
+#endif
     if constexpr (KEEP) *reinterpret_cast<uint4*>(sT + row * ELD + c8) = v;      // (a thread overwrites only the piece it has just read)
   }
 }

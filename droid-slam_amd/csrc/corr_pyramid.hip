@@ -278,6 +278,9 @@ __device__ unsigned long long g_pyr_ts[2 * 16 * 8];      // steps 16 .. 31 (neve
 #define PYR_TS(i)
 #define PYR_TS_FLUSH(k_)
 #endif
+#ifndef DH_PYR_NT
+#define DH_PYR_NT 1         // (shipped: -3 % same-box, r6ze) 1 = the record stores of the ring build carry the non-temporal hint (variant builds; measured: see profiles/r06_v_pyr_build_pmc.txt)
+#endif
 #ifndef DH_PYR_V3
 #define DH_PYR_V3 0         // (bit-identical, NOT faster: profiles/r06_v_pyr_build_pmc.txt) round 6, third pass (scripts/ubench/pyr_ts.hip: the 64 ds_write_b16 of a step take 470-570 of its ~2 000 cycles).  1 = the MFMA's
 #endif                      // operands are SWAPPED (targets as rows, source pixels as columns): a lane then holds 4 consecutive targets = 4 consecutive
@@ -316,6 +319,8 @@ __device__ __forceinline__ void gstore16_async(__half* p, const u32x4& v) {
   if (v[0] == 0x7fc07fc1u) *reinterpret_cast<u32x4*>(p) = v;      // (never true: keeps the read-out alive, drops the store)
 #elif DH_PYR_ASM & 2
   asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#elif DH_PYR_NT
+  __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));      // the records are read back much later (the lookups of the following iterations)
 #else
   *reinterpret_cast<u32x4*>(p) = v;
 #endif
