@@ -74,6 +74,7 @@ struct ConvParams {
   // glo_red[image][c] += sum over the tile's pixels of sigmoid(glo_wt . net' + glo_bias)[c] * net'[c] on the new hidden state that is
   // still in LDS (what glo_reduce_kernel computes from HBM at the start of the next iteration: 3.2 GB of reads at 4096 edges)
   const __half* glo_wt; const float* glo_bias; float* glo_red;
+  int nt_out;             // 1: the staged epilogue stores its tile with the non-temporal hint (write-dominated launches: the stem, the upmask head)
   int xcd_tiles;          // > 0: 1-D grid, workgroup id -> (pixel tile, cout tile) through xcd_decode(); = pixel tiles per XCD
   int ny;                 // cout tiles
 #ifdef DH_ABLATION
@@ -351,11 +352,17 @@ __device__ __forceinline__ void staged_tile_store(const ConvParams& P, __half* _
       }
       v = uint4{o.x, o.y, o.z, o.w};
     }
-#if DH_CONV_NT
-    __builtin_nontemporal_store(__builtin_bit_cast(u32x4_cnt, v), reinterpret_cast<u32x4_cnt*>(reinterpret_cast<__half*>(P.out) + pix * P.out_stride + co));
-#else
-    *reinterpret_cast<uint4*>(reinterpret_cast<__half*>(P.out) + pix * P.out_stride + co) = v;
-#endif
+    // (round 6: -6 % on the stem, which writes 3.2 GB and reads 0.1 GB; neutral on the MFMA-bound layers, slightly negative on small launches
+    //  whose output the next kernel finds in L2 -- hence per launch; -DDH_CONV_NT=1 forces it everywhere for A/B runs)
+    // (as inline asm: LLVM merges an if / else of two stores of the same value into ONE plain store and drops the hint)
+    if (DH_CONV_NT) {
+      __builtin_nontemporal_store(__builtin_bit_cast(u32x4_cnt, v), reinterpret_cast<u32x4_cnt*>(reinterpret_cast<__half*>(P.out) + pix * P.out_stride + co));
+    } else if (P.nt_out) {
+      const __half* optr = reinterpret_cast<const __half*>(P.out) + pix * P.out_stride + co;
+      asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(optr), "v"(__builtin_bit_cast(u32x4_cnt, v)) : "memory");
+    } else {
+      *reinterpret_cast<uint4*>(reinterpret_cast<__half*>(P.out) + pix * P.out_stride + co) = v;
+    }
     if constexpr (KEEP) *reinterpret_cast<uint4*>(sT + row * ELD + c8) = v;      // (a thread overwrites only the piece it has just read)
   }
 }
@@ -2732,6 +2739,12 @@ bool dma_ok(const ConvParams& P) {
 }
 
 // 7x7 on 4 real input channels: weights_halo = [128][7][8][4] (droid_amd.update.pack_conv_7x7_c4)
+// write-dominated launches (option conv_nt_out, default on): outputs of 64 MB and more leave with the non-temporal hint
+inline ConvParams with_nt_out(const ConvParams& P) {
+  ConvParams q = P;
+  q.nt_out = (opts().conv_nt_out && !P.out_f32 && (long)P.N * P.H * P.W * P.out_stride * 2 >= (64L << 20)) ? 1 : 0;
+  return q;
+}
 bool c7_ok(const ConvParams& P) {
   if (!opts().conv_halo || P.cinit || !P.wt_halo || P.KH != 7 || P.KW != 7 || P.nseg != 1 || P.segC[0] != 8) return false;
   if (P.W != 64 || P.H % 4 || P.CoutPad != 128 || P.Cout != 128 || P.epi != EPI_RELU) return false;
@@ -3143,10 +3156,10 @@ extern "C" int dh_conv2d_nhwc_f16_ex3(const void* const* inputs, const int* in_c
     constexpr int lds = (128 + 64) * K1_LD * 2 + 128 * (64 + 8) * 2;
     if (P.epi == EPI_LINEAR) {
       DH_LDS_OPTIN((&conv1x1_c128_kernel<EPI_LINEAR, 128>), 80 * 1024);
-      hipLaunchKernelGGL((conv1x1_c128_kernel<EPI_LINEAR, 128>), grid, dim3(256), lds, st, P);
+      hipLaunchKernelGGL((conv1x1_c128_kernel<EPI_LINEAR, 128>), grid, dim3(256), lds, st, with_nt_out(P));
     } else {
       DH_LDS_OPTIN((&conv1x1_c128_kernel<EPI_RELU, 128>), 80 * 1024);
-      hipLaunchKernelGGL((conv1x1_c128_kernel<EPI_RELU, 128>), grid, dim3(256), lds, st, P);
+      hipLaunchKernelGGL((conv1x1_c128_kernel<EPI_RELU, 128>), grid, dim3(256), lds, st, with_nt_out(P));
     }
     DH_LAUNCH_CHECK();
     return DH_OK;
@@ -3155,10 +3168,10 @@ extern "C" int dh_conv2d_nhwc_f16_ex3(const void* const* inputs, const int* in_c
     const dim3 grid((unsigned)((long)P.N * P.H * P.W / BM));
     if (P.epi == EPI_LINEAR) {
       DH_LDS_OPTIN((&conv1x1_c128_kernel<EPI_LINEAR>), 160 * 1024);
-      hipLaunchKernelGGL((conv1x1_c128_kernel<EPI_LINEAR>), grid, dim3(512), K1_LDS_BYTES, st, P);
+      hipLaunchKernelGGL((conv1x1_c128_kernel<EPI_LINEAR>), grid, dim3(512), K1_LDS_BYTES, st, with_nt_out(P));
     } else {
       DH_LDS_OPTIN((&conv1x1_c128_kernel<EPI_RELU>), 160 * 1024);
-      hipLaunchKernelGGL((conv1x1_c128_kernel<EPI_RELU>), grid, dim3(512), K1_LDS_BYTES, st, P);
+      hipLaunchKernelGGL((conv1x1_c128_kernel<EPI_RELU>), grid, dim3(512), K1_LDS_BYTES, st, with_nt_out(P));
     }
     DH_LAUNCH_CHECK();
     return DH_OK;
@@ -3184,13 +3197,13 @@ extern "C" int dh_conv2d_nhwc_f16_ex3(const void* const* inputs, const int* in_c
     return DH_OK;
   }
   if (c7_ok(P) && opts().conv_c7_split) {                    // 64-cout halves, four workgroups per CU
-    hipLaunchKernelGGL((conv7x7_c4_kernel<EPI_RELU, 64>), dim3((unsigned)((long)P.N * P.H * P.W / BM) * 2), dim3(256), C7_LDS64_BYTES, st, P);
+    hipLaunchKernelGGL((conv7x7_c4_kernel<EPI_RELU, 64>), dim3((unsigned)((long)P.N * P.H * P.W / BM) * 2), dim3(256), C7_LDS64_BYTES, st, with_nt_out(P));
     DH_LAUNCH_CHECK();
     return DH_OK;
   }
   if (c7_ok(P)) {
     DH_LDS_OPTIN((&conv7x7_c4_kernel<EPI_RELU>), 80 * 1024);
-    hipLaunchKernelGGL((conv7x7_c4_kernel<EPI_RELU>), dim3((unsigned)((long)P.N * P.H * P.W / BM)), dim3(512), C7_LDS_BYTES, st, P);
+    hipLaunchKernelGGL((conv7x7_c4_kernel<EPI_RELU>), dim3((unsigned)((long)P.N * P.H * P.W / BM)), dim3(512), C7_LDS_BYTES, st, with_nt_out(P));
     DH_LAUNCH_CHECK();
     return DH_OK;
   }

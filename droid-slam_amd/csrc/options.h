@@ -21,6 +21,7 @@ struct Options {
   int pyr_build_xcd;    // DH_PYR_BUILD_XCD (0): the row-ring build's workgroups of one edge on ONE XCD: fabric reads 11.1 -> 0.9 GB per 256 edges, time 0 .. +7 % (same-line reads queue on one L2; profiles/r06_v_pyr_build_pmc.txt); same records
   int pyr_build_dual;   // DH_PYR_BUILD_DUAL (1): w = 64, one workgroup of 16 waves builds two adjacent source blocks from one staged copy of each target row (row fetches halved: -5 %); same records
   int pyr_lds_pad;      // DH_PYR_LDS_PAD (0): measurement only -- extra dynamic LDS bytes for the 8-wave row-ring build (4096 = one workgroup per CU: +20 %)
+  int conv_nt_out;      // DH_CONV_NT_OUT (1): the stem's and the upmask head's output stores (>= 64 MB) carry the non-temporal hint (-6 % on the stem); same results
   int lookup_mode;      // DH_LOOKUP_MODE (0): pyramid lookup variant: 1 = nt tap loads; 2 / 3 = timing ablations (no stores / no loads, wrong results); fused kernel: also 5 (a quarter of the MFMAs) and 6 = synchronous twin (every tap batch waited for at issue; same results, used by the tests)
   int lookup_fused;     // DH_LOOKUP_FUSED (1): read by the host side (droid_amd.factor_graph, bench.py): lookup and the correlation encoder's first layer in one kernel (dh_corr_pyramid_lookup_corr0); 0 = dh_corr_pyramid_lookup + dh_corr0_nchw_f16
   int lookup_fill;      // DH_LOOKUP_FILL (0): fused lookup refills its tap registers 0 = by half level (two batches of 4 window rows), 1 = window row by window row (-DDH_ABLATION builds); same results

@@ -31,6 +31,7 @@ Options& opts() {
     v.pyr_build_xcd = env_int("DH_PYR_BUILD_XCD", 0);
     v.pyr_build_dual = env_int("DH_PYR_BUILD_DUAL", 1);
     v.pyr_lds_pad = env_int("DH_PYR_LDS_PAD", 0);
+    v.conv_nt_out = env_int("DH_CONV_NT_OUT", 1);
     v.lookup_mode = env_int("DH_LOOKUP_MODE", 0);
     v.lookup_fused = env_int("DH_LOOKUP_FUSED", 1);
     v.lookup_mix = env_int("DH_LOOKUP_MIX", 1);
@@ -98,6 +99,7 @@ static int* slot(const char* name) {
   if (!strcmp(name, "pyr_build_xcd")) return &o.pyr_build_xcd;
   if (!strcmp(name, "pyr_build_dual")) return &o.pyr_build_dual;
   if (!strcmp(name, "pyr_lds_pad")) return &o.pyr_lds_pad;
+  if (!strcmp(name, "conv_nt_out")) return &o.conv_nt_out;
   if (!strcmp(name, "lookup_mode")) return &o.lookup_mode;
   if (!strcmp(name, "lookup_fused")) return &o.lookup_fused;
   if (!strcmp(name, "lookup_mix")) return &o.lookup_mix;

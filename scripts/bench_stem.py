@@ -3,7 +3,7 @@
 (scripts/pmc_stem.sh).    python scripts/bench_stem.py [--edges 4096] [--reps 5]   (DH_CONV_C7_SPLIT / _PP / _W16 select the variants)"""
 import argparse, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "droid-slam_amd")]
+sys.path[:0] = [ROOT] + ([os.path.join(ROOT, "droid-slam_amd", os.environ["DH_LIB_DIR"])] if os.environ.get("DH_LIB_DIR") else []) + [os.path.join(ROOT, "droid-slam_amd")]
 import torch
 import droid_backends as db
 from droid_amd.update import UpdateModule, EPI_RELU
