@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """A/B of the wave roles of the pyramid build kernel on one MI355X (round 6): bit-equality of the records and the time of the build
 kernel alone (frame-level build of E edges into an arena: dh_corr_pyramid_build_indexed), alternating between the variants.
-usage: python scripts/bench_pyr_build.py [edges=256] [rounds=5] [frames=64] [only=substring of the variant names]"""
+usage: python scripts/bench_pyr_build.py [edges=256] [rounds=5] [frames=64] [only=substring of the variant names] [pattern=random|graph|bytarget]
+(bit-equality and the checksum only up to 256 edges; DH_LIB_DIR=variant_x loads a variant build of the library)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT] + ([os.path.join(ROOT, "droid-slam_amd", os.environ["DH_LIB_DIR"])] if os.environ.get("DH_LIB_DIR") else []) + [os.path.join(ROOT, "droid-slam_amd")]
