@@ -1085,6 +1085,26 @@ def test_conv7x7_on_four_channels_and_global_context_kernels(db):
         both.append(o)
     db.set_option("conv_c7_split", saved)
     assert torch.equal(both[0], both[1]) and torch.equal(both[0], out if saved == 0 else both[saved])
+    # round 6: outputs of 64 MB and more leave the stem and the 1x1 128 -> 576 upmask head with NON-TEMPORAL stores (option conv_nt_out;
+    # inline-asm stores the compiler does not track): the same bytes as the plain stores, also right before the kernel ends
+    saved_nt = db.get_option("conv_nt_out")
+    xb = torch.zeros(96, 48, W, 8, device="cuda", dtype=torch.float16)              # 96 x 48 x 64 x 128 x 2 B = 75.5 MB of output
+    xb[..., :4] = (4 * torch.randn(96, 48, W, 4, device="cuda")).half()
+    a128 = torch.relu(torch.randn(24, 48, W, 128, device="cuda")).half()            # 24 x 48 x 64 x 576 x 2 B = 85 MB
+    w576 = torch.randn(576, 128, 1, 1, device="cuda") / 11.0
+    wp576, bp576 = pack_conv(w576, torch.randn(576, device="cuda"))
+    outs = []
+    for v in (0, 1):
+        db.set_option("conv_nt_out", v)
+        o7 = torch.full((96, 48, W, 128), -7.0, device="cuda", dtype=torch.float16)
+        db.conv2d_nhwc([xb], wp, pack_conv_7x7_c4(wgt), bp, 7, 7, 128, EPI_RELU, o7, 128, None, None, None, None)
+        o1 = torch.full((24, 48, W, 576), -7.0, device="cuda", dtype=torch.float16)
+        db.conv2d_nhwc([a128], wp576, None, bp576, 1, 1, 576, 0, o1, 576, None, None, None, None)
+        torch.cuda.synchronize()
+        outs.append((o7, o1))
+    db.set_option("conv_nt_out", saved_nt)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[1][0].min()) >= 0.0 and not bool((outs[1][1] == -7.0).all())
     # the persistent form (option conv_c7_pp: one 16-wave workgroup per CU, two wave groups alternating between multiplying a tile and
     # parking / storing the previous one): EQUAL -- 6 tiles (two per workgroup), 2 101 tiles (odd; eight or nine per workgroup), 1 tile
     # ... and the form with sixteen 32 px x 64 cout waves per workgroup (option conv_c7_w16): EQUAL as well
