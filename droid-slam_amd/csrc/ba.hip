@@ -1839,11 +1839,37 @@ int run_finish(const BaLayout& L, char* ws, float* poses, float* disps, const in
 }  // namespace
 
 namespace {
-// default (DH_BA_STRICT=1): one stream synchronisation behind the call's last launch, flagged arguments (meta[2]: an edge
-// outside the frame buffer, eta without one row per depth block) are reported as DH_ERR_ARG.  The flagged call has
-// applied no update either way.
+// default (DH_BA_STRICT=1): flagged arguments (meta[2]: an edge outside the frame buffer, eta without one row per depth block) are
+// reported as DH_ERR_ARG.  The flagged call has applied no update either way.
+// Round 6: the flags are final after the call's FIRST kernel (ba_prep_kernel is the only single-process writer of meta[2]), so they are
+// copied to pinned host memory right behind it (strict_arm) and the call ends by waiting for THAT copy (an event), not for the stream:
+// the host gets its answer ~0.1 ms into the call's 3.5 ms of device work and enqueues the caller's next launches under the solve.  With the
+// stream synchronisation at the end (rounds 1-5) the device idled 0.33 ms per update iteration while the launch queue refilled
+// (profiles/r06_y_step_timeline.txt).  One probe per host thread; a call that was not armed falls back to the synchronisation.
+struct StrictProbe { int* host = nullptr; hipEvent_t ev = nullptr; bool armed = false; };
+thread_local StrictProbe t_probe;
+
+void strict_arm(const BaLayout& L, char* ws, hipStream_t st) {
+  StrictProbe& p = t_probe;
+  p.armed = false;
+  if (opts().ba_strict != 1) return;        // 0: no check at all; 2: rounds 1-5, the check behind a stream synchronisation (A/B runs)
+  if (!p.host) {
+    if (hipHostMalloc(reinterpret_cast<void**>(&p.host), 64, hipHostMallocDefault) != hipSuccess) { p.host = nullptr; return; }
+    if (hipEventCreateWithFlags(&p.ev, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(p.host); p.host = nullptr; p.ev = nullptr; return; }
+  }
+  if (hipMemcpyAsync(p.host, ws + L.meta, 4 * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return;
+  if (hipEventRecord(p.ev, st) != hipSuccess) return;
+  p.armed = true;
+}
+
 int strict_check(const BaLayout& L, char* ws, hipStream_t st) {
   if (!opts().ba_strict) return DH_OK;
+  StrictProbe& p = t_probe;
+  if (p.armed) {
+    p.armed = false;
+    if (hipEventSynchronize(p.ev) != hipSuccess) return DH_ERR_LAUNCH;
+    return p.host[2] ? DH_ERR_ARG : DH_OK;
+  }
   int flags[4] = {0, 0, 0, 0};
   if (hipMemcpyAsync(flags, ws + L.meta, sizeof(flags), hipMemcpyDeviceToHost, st) != hipSuccess) return DH_ERR_LAUNCH;
   if (hipStreamSynchronize(st) != hipSuccess) return DH_ERR_LAUNCH;
@@ -1881,6 +1907,7 @@ static int ba_build_impl(int strict, const float* poses, const float* disps, con
   hipStream_t st = (hipStream_t)stream;
   rc = run_prep(L, ws, ii, jj, n_edges, num_frames, t0, t1, motion_only ? -1 : n_eta_rows, st);
   if (rc != DH_OK) return rc;
+  if (strict) strict_arm(L, ws, st);
   rc = run_build(L, ws, poses, disps, intrinsics, disps_sens, targets, weights, eta, n_eta_rows, alpha, ii, jj,
                  num_frames, n_edges, ht * wd, wd, t0, motion_only, st);
   if (Hsys_out) *Hsys_out = (double*)(ws + L.H);
@@ -2053,6 +2080,7 @@ extern "C" int dh_ba_ex(float* poses, float* disps, const float* intrinsics, con
   hipStream_t st = (hipStream_t)stream;
   rc = run_prep(L, ws, ii, jj, n_edges, num_frames, t0, t1, motion_only ? -1 : n_eta_rows, st);
   if (rc != DH_OK) return rc;
+  strict_arm(L, ws, st);
   for (int it = 0; it < iterations; ++it) {
     rc = run_build(L, ws, poses, disps, intrinsics, disps_sens, targets, weights, eta, n_eta_rows, alpha, ii, jj,
                    num_frames, n_edges, HW, wd, t0, motion_only, st);

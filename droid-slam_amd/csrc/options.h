@@ -42,7 +42,7 @@ struct Options {
   int eta_fused;        // DH_ETA_FUSED (1): host side (UpdateModule): GraphAgg's eta head as the fused second layer of agg.conv2's launch (EPI_HEADS0 with an output pointer + dh_heads_gather_ex mode 1) instead of a 3x3 convolution with one output channel
   int conv_halo4;       // DH_CONV_HALO4 (0): -DDH_ABLATION builds only: the second kernel with four 64 x 128 waves per workgroup
   int conv_abl;         // DH_CONV_ABL (0): -DDH_ABLATION builds only: timing-ablation mask of conv3x3_halo2_kernel (wrong results)
-  int ba_strict;        // DH_BA_STRICT (1): dh_ba / dh_ba_build synchronise and return DH_ERR_ARG on bad indices / eta rows; 0 = asynchronous, such calls apply no update
+  int ba_strict;        // DH_BA_STRICT (1): dh_ba / dh_ba_ex / dh_ba_build return DH_ERR_ARG on bad indices / eta rows; the host waits for the argument check (the call's first kernel), not for the solve; 2 = the check behind a stream synchronisation (rounds 1-5); 0 = asynchronous, no signal -- a flagged call applies no update in any mode
 };
 
 Options& opts();

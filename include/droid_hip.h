@@ -47,10 +47,12 @@ const char* dh_status_string(int status);
 /* Process-wide switches (A/B measurements and the fallbacks the parity tests exercise).  Initialised from the
  * environment variables DH_<NAME> once, when the library is loaded; nothing on a launch path reads the environment.
  * names: "debug", "chol_lookahead", "conv_epi_staged", "conv_halo", "conv_halo2", "conv_dma", "dma_var",
- * "pyr_build_chunk", "ba_strict" (ON by default: dh_ba / dh_ba_ex / dh_ba_build synchronise the stream once, after their
- * last launch, and return DH_ERR_ARG when an edge index lies outside the frame buffer or eta does not have one row per
- * depth block -- the reference would read out of bounds / fail its broadcast, src/droid_kernels.cu:1407; in either mode
- * such a call applies NO update.  0 = fully asynchronous call, no signal to the caller).
+ * "pyr_build_chunk", "ba_strict" (1 by default: dh_ba / dh_ba_ex / dh_ba_build return DH_ERR_ARG when an edge index lies
+ * outside the frame buffer or eta does not have one row per depth block -- the reference would read out of bounds / fail
+ * its broadcast, src/droid_kernels.cu:1407.  The flags are final after the call's first kernel: the call returns once THAT
+ * kernel has run (an event behind a copy to pinned memory), with the rest of its work still queued on the stream -- like any
+ * other entry point it does NOT synchronise the stream.  2 = the check behind a stream synchronisation after the last launch
+ * (rounds 1-5); 0 = fully asynchronous call, no signal to the caller.  In every mode a flagged call applies NO update).
  * Returns DH_ERR_ARG for an unknown name. */
 int dh_set_option(const char* name, int value);
 int dh_get_option(const char* name, int* value);
