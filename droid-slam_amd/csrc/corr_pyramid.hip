@@ -255,8 +255,8 @@ __global__ __launch_bounds__(256) void pyr_build_kernel(const __half* __restrict
 #define DH_PYR_ABL 0        // timing ablations of the ring build (WRONG results; never in a shipped build): 1 = no record stores, 2 = no scatter into the ring,
 #endif                      // 4 = no B-fragment reads / MFMAs, 8 = no global loads of the target rows, 16 = no LDS writes of them
 #ifndef DH_PYR_V2
-#define DH_PYR_V2 1         // round 6, second pass (profiles/r06_v_pyr_build_pmc.txt: the SIMDs ISSUE 89 % of the kernel's time -- the build is bound by its
-#endif                      // instruction count, 124 per wave and step).  1 = (a) the ring's bank swizzle moves whole 16-byte quads only (bits 2-4 of the
+#define DH_PYR_V2 1         // round 6, second pass (profiles/r06_v_pyr_build_pmc.txt: 124 instructions per wave and step, 56 of them scalar; trimming them to
+#endif                      // 97 bought 5 % -- the kernel is not issue-bound either).  1 = (a) the ring's bank swizzle moves whole 16-byte quads only (bits 2-4 of the
                             // pixel index instead of bits 0, 1, 4), so a finished row leaves LDS with ONE ds_read_b128 per lane and no 12-instruction
                             // dword rotation; (b) the next target row's address is kept as a pointer that wraps instead of a `% h2` per fetch (22
                             // scalar instructions).  Same MFMAs, same rounding, same records.  0 = rounds 2-6a (variant builds, for A/B runs).
@@ -264,7 +264,6 @@ __device__ __forceinline__ uint32_t pack_h2_scaled(float a, float b) {      // {
   const __half2 h = __halves2half2(__float2half(a * 0.0625f), __float2half(b * 0.0625f));
   return __builtin_bit_cast(uint32_t, h);
 }
-// dword swizzle of the ring: pixel p of cell pair `up` lives at dword up * 64 + (p ^ ring_f(up))
 #ifdef DH_PYR_TS            // scripts/ubench/pyr_ts.hip: phase timestamps (s_memtime) of two waves of ONE workgroup (blockIdx = (5, DH_PYR_TS)) at level 0,
 __device__ unsigned long long g_pyr_ts[2 * 16 * 8];      // steps 16 .. 31 (never defined in the library build)
 #define PYR_TS_DECL(l_)                                                                                              \
@@ -279,7 +278,7 @@ __device__ unsigned long long g_pyr_ts[2 * 16 * 8];      // steps 16 .. 31 (neve
 #define PYR_TS_FLUSH(k_)
 #endif
 #ifndef DH_PYR_NT
-#define DH_PYR_NT 1         // (shipped: -3 % same-box, r6ze) 1 = the record stores of the ring build carry the non-temporal hint (variant builds; measured: see profiles/r06_v_pyr_build_pmc.txt)
+#define DH_PYR_NT 1         // 1 (shipped: -3 % same-box, profiles/r06_v_pyr_build_pmc.txt item 8) = the record stores of the ring build carry the non-temporal hint; 0 = plain stores (variant builds)
 #endif
 #ifndef DH_PYR_V3
 #define DH_PYR_V3 0         // (bit-identical, NOT faster: profiles/r06_v_pyr_build_pmc.txt) round 6, third pass (scripts/ubench/pyr_ts.hip: the 64 ds_write_b16 of a step take 470-570 of its ~2 000 cycles).  1 = the MFMA's
@@ -291,6 +290,7 @@ __device__ unsigned long long g_pyr_ts[2 * 16 * 8];      // steps 16 .. 31 (neve
 #ifndef DH_PYR_PIPE
 #define DH_PYR_PIPE 0       // (measured SLOWER: 2.44 vs 2.39 ms single, 2.43 vs 2.26 ms dual, profiles/r06_v_pyr_build_pmc.txt) 1 = the scatter of a step is issued between the MFMAs of the next one (ring_level, RING_ITER); 0 = RING_STEP (variant builds)
 #endif
+// dword swizzle of the ring: pixel p of cell pair `up` lives at dword up * 64 + (p ^ ring_f(up))
 __device__ __forceinline__ int ring_f(int up) { return (DH_PYR_V3 && DH_PYR_V2) ? 0 : DH_PYR_V2 ? ((up & 7) << 2) : ((up & 3) | ((up & 4) << 2)); }
 // one 16-byte piece (pixels p0 .. p0 + 3 of cell pair up) of a finished ring row, in HBM order
 __device__ __forceinline__ u32x4 ring_read_piece(const unsigned char* src, int up, int p0) {
