@@ -291,10 +291,23 @@ __device__ unsigned long long g_pyr_ts[2 * 16 * 8];      // steps 16 .. 31 (neve
 #define DH_PYR_PIPE 0       // (measured SLOWER: 2.44 vs 2.39 ms single, 2.43 vs 2.26 ms dual, profiles/r06_v_pyr_build_pmc.txt) 1 = the scatter of a step is issued between the MFMAs of the next one (ring_level, RING_ITER); 0 = RING_STEP (variant builds)
 #endif
 // dword swizzle of the ring: pixel p of cell pair `up` lives at dword up * 64 + (p ^ ring_f(up))
-__device__ __forceinline__ int ring_f(int up) { return (DH_PYR_V3 && DH_PYR_V2) ? 0 : DH_PYR_V2 ? ((up & 7) << 2) : ((up & 3) | ((up & 4) << 2)); }
+#ifndef DH_PYR_SWZ
+#define DH_PYR_SWZ 0        // 1 (variant builds) = rounds 2-5's conflict-free dword swizzle (bits 0, 1, 4) kept for the scatter, the read-out as FOUR ds_read_b32
+#endif                      // at pre-rotated addresses instead of one ds_read_b128 + 12 v_cndmask (V2's quad swizzle costs 111 M bank-conflict cycles per launch)
+__device__ __forceinline__ int ring_f(int up) { return (DH_PYR_V3 && DH_PYR_V2) ? 0 : (DH_PYR_V2 && !DH_PYR_SWZ) ? ((up & 7) << 2) : ((up & 3) | ((up & 4) << 2)); }
 // one 16-byte piece (pixels p0 .. p0 + 3 of cell pair up) of a finished ring row, in HBM order
 __device__ __forceinline__ u32x4 ring_read_piece(const unsigned char* src, int up, int p0) {
   const int f = ring_f(up);
+  if (DH_PYR_SWZ) {
+    const unsigned char* q = src + ((up * 64 + (p0 ^ (f & 16))) << 2);
+    const int sw = f & 3;
+    u32x4 o;
+    o[0] = *reinterpret_cast<const uint32_t*>(q + ((0 ^ sw) << 2));
+    o[1] = *reinterpret_cast<const uint32_t*>(q + ((1 ^ sw) << 2));
+    o[2] = *reinterpret_cast<const uint32_t*>(q + ((2 ^ sw) << 2));
+    o[3] = *reinterpret_cast<const uint32_t*>(q + ((3 ^ sw) << 2));
+    return o;
+  }
   if (DH_PYR_V2) return *reinterpret_cast<const u32x4*>(src + ((up * 64 + (p0 ^ f)) << 2));
   const uint4 c = *reinterpret_cast<const uint4*>(src + ((up * 64 + (p0 ^ (f & 16))) << 2));
   const int sw = f & 3;               /* out[i] = in[i ^ sw] */
